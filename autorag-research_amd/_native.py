@@ -1,0 +1,124 @@
+"""ctypes binding of libmi355dr.so (the C ABI in include/mi355dr.h).
+
+There is deliberately NO CPU fallback here: if the shared library is missing or no MI355X is
+visible, every entry point raises.  The CPU oracle lives in oracle/ and is test infrastructure.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from pathlib import Path
+
+import numpy as np
+
+_PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = _PKG_DIR / "libmi355dr.so"
+
+_lib: ctypes.CDLL | None = None
+
+# every symbol include/mi355dr.h declares (checked by tests/test_abi_symbols.py)
+ABI_SYMBOLS = [
+    "mi355dr_create", "mi355dr_destroy", "mi355dr_last_error", "mi355dr_version", "mi355dr_reserve",
+    "mi355dr_add_rows", "mi355dr_add_rows_device", "mi355dr_size", "mi355dr_dim", "mi355dr_get_rows",
+    "mi355dr_search", "mi355dr_search_device", "mi355dr_add_multivec", "mi355dr_size_multivec",
+    "mi355dr_search_maxsim", "mi355dr_merge_topk_device", "mi355dr_set_option", "mi355dr_get_stat",
+    "mi355dr_reset_stats", "mi355dr_timer_start", "mi355dr_timer_stop", "mi355dr_synchronize",
+    "mi355dr_dev_alloc", "mi355dr_dev_free", "mi355dr_dev_upload", "mi355dr_dev_download",
+    "mi355dr_debug_screen_dense", "mi355dr_debug_rescore",
+]
+
+
+class NativeError(RuntimeError):
+    """A libmi355dr call failed (code + the library's last_error text)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libmi355dr error {code}: {message}")
+        self.code = code
+
+
+def load() -> ctypes.CDLL:
+    """Load libmi355dr.so and declare argument types.  Raises if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the search path."
+        )
+    L = ctypes.CDLL(str(LIB_PATH), mode=getattr(os, "RTLD_NOW", 2))
+    vp, c_int, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+    f32p, f64p = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)
+    i64p, i32p = ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32)
+    L.mi355dr_create.restype = c_int
+    L.mi355dr_create.argtypes = [ctypes.POINTER(vp), c_int, c_int, c_int]
+    L.mi355dr_destroy.restype = None
+    L.mi355dr_destroy.argtypes = [vp]
+    L.mi355dr_last_error.restype = ctypes.c_char_p
+    L.mi355dr_last_error.argtypes = [vp]
+    L.mi355dr_version.restype = c_int
+    L.mi355dr_reserve.restype = c_int
+    L.mi355dr_reserve.argtypes = [vp, i64]
+    L.mi355dr_add_rows.restype = c_int
+    L.mi355dr_add_rows.argtypes = [vp, f32p, i64]
+    L.mi355dr_add_rows_device.restype = c_int
+    L.mi355dr_add_rows_device.argtypes = [vp, vp, i64]
+    L.mi355dr_size.restype = i64
+    L.mi355dr_size.argtypes = [vp]
+    L.mi355dr_dim.restype = c_int
+    L.mi355dr_dim.argtypes = [vp]
+    L.mi355dr_get_rows.restype = c_int
+    L.mi355dr_get_rows.argtypes = [vp, i64, i64, f32p]
+    L.mi355dr_search.restype = c_int
+    L.mi355dr_search.argtypes = [vp, f32p, c_int, c_int, f64p, i64p]
+    L.mi355dr_search_device.restype = c_int
+    L.mi355dr_search_device.argtypes = [vp, vp, c_int, c_int, vp, vp, vp]
+    L.mi355dr_add_multivec.restype = c_int
+    L.mi355dr_add_multivec.argtypes = [vp, f32p, i64p, i64]
+    L.mi355dr_size_multivec.restype = i64
+    L.mi355dr_size_multivec.argtypes = [vp]
+    L.mi355dr_search_maxsim.restype = c_int
+    L.mi355dr_search_maxsim.argtypes = [vp, f32p, i32p, c_int, c_int, f32p, i64p]
+    L.mi355dr_merge_topk_device.restype = c_int
+    L.mi355dr_merge_topk_device.argtypes = [vp, vp, vp, c_int, c_int, c_int, vp, vp, vp]
+    L.mi355dr_set_option.restype = c_int
+    L.mi355dr_set_option.argtypes = [vp, ctypes.c_char_p, i64]
+    L.mi355dr_get_stat.restype = c_int
+    L.mi355dr_get_stat.argtypes = [vp, ctypes.c_char_p, i64p]
+    L.mi355dr_reset_stats.restype = c_int
+    L.mi355dr_reset_stats.argtypes = [vp]
+    L.mi355dr_timer_start.restype = c_int
+    L.mi355dr_timer_start.argtypes = [vp]
+    L.mi355dr_timer_stop.restype = c_int
+    L.mi355dr_timer_stop.argtypes = [vp, f64p]
+    L.mi355dr_synchronize.restype = c_int
+    L.mi355dr_synchronize.argtypes = [vp]
+    L.mi355dr_dev_alloc.restype = c_int
+    L.mi355dr_dev_alloc.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
+    L.mi355dr_dev_free.restype = c_int
+    L.mi355dr_dev_free.argtypes = [vp, vp]
+    L.mi355dr_dev_upload.restype = c_int
+    L.mi355dr_dev_upload.argtypes = [vp, vp, vp, ctypes.c_size_t]
+    L.mi355dr_dev_download.restype = c_int
+    L.mi355dr_dev_download.argtypes = [vp, vp, vp, ctypes.c_size_t]
+    L.mi355dr_debug_screen_dense.restype = c_int
+    L.mi355dr_debug_screen_dense.argtypes = [vp, f32p, c_int, i64, i64, f32p]
+    L.mi355dr_debug_rescore.restype = c_int
+    L.mi355dr_debug_rescore.argtypes = [vp, f32p, c_int, i32p, i64p, i64, f32p, f64p]
+    _lib = L
+    return L
+
+
+def check(handle, rc: int) -> None:
+    if rc != 0:
+        msg = load().mi355dr_last_error(handle)
+        raise NativeError(rc, msg.decode("utf-8", "replace") if msg else "")
+
+
+def f32c(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def ptr(a: np.ndarray, ct):
+    return a.ctypes.data_as(ctypes.POINTER(ct))

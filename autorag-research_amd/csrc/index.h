@@ -1,0 +1,94 @@
+// index.h -- the opaque handle behind mi355dr_index and the host-side error helpers (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "dev_common.h"
+#include "mi355dr.h"
+
+namespace mi355 {
+struct EventPair {
+    hipEvent_t a, b;
+};
+struct MultiVecStore;  // mi355dr_maxsim.hip
+}  // namespace mi355
+
+struct mi355dr_index {
+    int device = 0, dim = 0, dpad = 0, metric = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::string err;
+
+    // corpus (single-vector)
+    int64_t n = 0, cap_rows = 0;
+    float* rows = nullptr;
+    uint16_t* shadow = nullptr;
+    float* nrm2 = nullptr;
+    int32_t* irr_rows = nullptr;
+    int* irr_count = nullptr;
+    int irr_n = 0;
+
+    // per-search state (sized for one block of kQBlockMax queries)
+    bool qstate_ready = false;
+    mi355::QueryState st{};
+    float* qdev = nullptr;       // [kQBlockMax, dim]
+    int32_t* cand_row = nullptr; // [kQBlockMax, cap]
+    float* cand_val = nullptr;
+    int* qlist_dev = nullptr;    // [kQBlockMax]
+    int* status_or_dev = nullptr;
+    int* status_host = nullptr;  // pinned [kQBlockMax + 1]
+    double* out_dist_dev = nullptr;  // [kQBlockMax, kKMax]
+    int64_t* out_rows_dev = nullptr;
+    unsigned long long* stat_dev = nullptr;  // [2]: candidates, rescored
+
+    // options
+    int path = 0;  // MI355DR_PATH_AUTO
+    int64_t row_offset = 0;
+    int profile = 0;
+    int64_t chunk0_rows = 1024;
+    int64_t chunk_growth = 7;
+    int cap = mi355::kCandCap;
+
+    // stats
+    int64_t s_screen_launches = 0, s_screen_ns = 0, s_screen_rows = 0, s_fallback_queries = 0, s_chunks = 0,
+            s_passes = 0, s_candidates = 0, s_rescored = 0;
+    std::vector<mi355::EventPair> ev_pool, ev_pending;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+
+    // multi-vector store (MaxSim), owned by mi355dr_maxsim.hip
+    mi355::MultiVecStore* mv = nullptr;
+};
+
+
+namespace mi355 {
+
+int fail(mi355dr_index* idx, int code, const std::string& msg);  // mi355dr.hip
+void multivec_destroy(mi355dr_index* idx);                       // mi355dr_maxsim.hip
+
+#define HIPCHECK(idx, expr)                                                                              \
+    do {                                                                                                 \
+        hipError_t e__ = (expr);                                                                         \
+        if (e__ != hipSuccess) {                                                                         \
+            char buf__[512];                                                                             \
+            snprintf(buf__, sizeof(buf__), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, \
+                     __LINE__);                                                                          \
+            return mi355::fail(idx, e__ == hipErrorOutOfMemory ? MI355DR_E_NOMEM : MI355DR_E_HIP, buf__); \
+        }                                                                                                \
+    } while (0)
+
+#define CHECK(expr)                          \
+    do {                                     \
+        int rc__ = (expr);                   \
+        if (rc__ != MI355DR_OK) return rc__; \
+    } while (0)
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+}  // namespace mi355

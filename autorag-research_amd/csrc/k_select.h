@@ -1,0 +1,331 @@
+// k_select.h -- exact re-score + select kernels (the part of `ORDER BY distance LIMIT k` that decides).
+//   k_prune        per query: fold the candidates appended since the last prune into the kept exact
+//                  top-k.  Screen candidates are first cut with a rigorous bound, then re-scored with the
+//                  exact fp32 chain (bit-identical to oracle.c), converted to pgvector's double distance
+//                  and sorted by the total order (distance asc, NaN last, row asc).
+//   k_emit_irregular  append the (rare) rows the bf16 screen cannot see (zero / non-finite / extreme norm)
+//   k_finalize     write [B,k] outputs, OR the per-query status bits into one word
+//   k_merge_topk   multi-GPU: [world,B,k] gathered shard results -> global [B,k] under the same order
+// Reference: replaces the top-N heapsort behind base.py:409-415 and the score conversion inputs of
+// orm/service/retrieval_pipeline.py:504-524.
+#pragma once
+#include "dev_common.h"
+#include "k_prep.h"
+
+namespace mi355 {
+
+// ---- bitonic sorts over LDS arrays (n = power of two, all threads of the block participate) ----
+__device__ __forceinline__ void bitonic_desc_f32(float* v, int n) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const bool desc = ((i & k) == 0);
+                    const float a = v[i], b = v[p];
+                    if (desc ? (a < b) : (a > b)) {
+                        v[i] = b;
+                        v[p] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ bool key_before(uint64_t k1, int32_t r1, uint64_t k2, int32_t r2) {
+    return k1 < k2 || (k1 == k2 && r1 < r2);
+}
+
+__device__ __forceinline__ void bitonic_asc_key_row(uint64_t* key, int32_t* row, int n) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const bool asc = ((i & k) == 0);
+                    const uint64_t ka = key[i], kb = key[p];
+                    const int32_t ra = row[i], rb = row[p];
+                    const bool a_after_b = key_before(kb, rb, ka, ra);
+                    if (asc ? a_after_b : key_before(ka, ra, kb, rb)) {
+                        key[i] = kb;
+                        key[p] = ka;
+                        row[i] = rb;
+                        row[p] = ra;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+struct PruneArgs {
+    const float* rows;   // [n, d] fp32 corpus
+    const float* nrm2;   // [n]
+    const float* q;      // [B, d] fp32 queries
+    QueryState st;
+    int32_t* cand_row;   // [Bpad, cap]
+    float* cand_val;     // [Bpad, cap]  screen: t (NaN = "no bound, always re-score"); exact: the fp32 dot
+    const int* qlist;    // optional compact list of query indices (nullptr: blockIdx.x)
+    unsigned long long* stat_cand;
+    unsigned long long* stat_resc;
+    int cap, d, k, metric;
+    int exact;           // 0: screen candidates (re-score), 1: cand_val already holds the exact dot
+    float E;             // screen bound
+};
+
+constexpr int kPruneThreads = 256;
+// dynamic LDS: SK[kSortMax] u64 | SR[kSortMax] i32 | X = max(Lf[kSortMax] f32, 4 stage tiles) | R[cap] i32 | qs[d] f32
+__host__ __device__ inline size_t prune_lds_bytes(int d, int cap) {
+    size_t x = (size_t)4 * kStageFloats * sizeof(float);
+    size_t lf = (size_t)kSortMax * sizeof(float);
+    if (lf > x) x = lf;
+    return (size_t)kSortMax * 8 + (size_t)kSortMax * 4 + x + (size_t)cap * 4 + (size_t)d * 4 + 64;
+}
+
+__global__ __launch_bounds__(kPruneThreads) void k_prune(PruneArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t* SK = (uint64_t*)smem;
+    int32_t* SR = (int32_t*)(smem + (size_t)kSortMax * 8);
+    char* X = smem + (size_t)kSortMax * 12;
+    size_t xbytes = (size_t)4 * kStageFloats * sizeof(float);
+    if ((size_t)kSortMax * sizeof(float) > xbytes) xbytes = (size_t)kSortMax * sizeof(float);
+    float* Lf = (float*)X;
+    float* tiles = (float*)X;
+    int32_t* R = (int32_t*)(X + xbytes);
+    float* qs = (float*)(X + xbytes + (size_t)a.cap * 4);
+    // two scalars at the very end of the dynamic region (no static LDS: keeps the carve 16-B aligned)
+    int& s_nres = *(int*)(X + xbytes + (size_t)a.cap * 4 + (size_t)a.d * 4);
+    float& s_cut = *(float*)(X + xbytes + (size_t)a.cap * 4 + (size_t)a.d * 4 + 4);
+
+    const int q = a.qlist ? a.qlist[blockIdx.x] : blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int raw_cnt = a.st.cnt[q];
+    const int n_best = a.st.best_n[q];
+    if (raw_cnt == 0) return;  // nothing new; kept list and thresholds stay as they are
+    if (raw_cnt > a.cap) {     // overflow: do not commit; the query is recomputed by the guaranteed path
+        if (tid == 0) {
+            a.st.status[q] |= kStOverflow;
+            a.st.cnt[q] = 0;
+        }
+        return;
+    }
+    const int n_new = raw_cnt;
+    const int32_t* crow = a.cand_row + (int64_t)q * a.cap;
+    const float* cval = a.cand_val + (int64_t)q * a.cap;
+    uint64_t* bkey = a.st.best_key + (int64_t)q * kKMax;
+    int32_t* brow = a.st.best_row + (int64_t)q * kKMax;
+    const float nq = a.st.qn[q];
+    if (tid == 0) {
+        s_nres = 0;
+        atomicAdd(a.stat_cand, (unsigned long long)n_new);
+    }
+
+    int n_res;
+    if (!a.exact) {
+        // ---- phase 1: k-th largest LOWER bound of the exact similarity over (kept U new)
+        const int nL = n_best + n_new;
+        const int nLp = next_pow2(nL);
+        for (int i = tid; i < nLp; i += kPruneThreads) {
+            float lb = -__builtin_inff();
+            if (i < n_best) {
+                const uint64_t kk = bkey[i];
+                if (kk != kKeyNaN) lb = (float)(1.0 - key_to_dist(kk)) - 1e-6f;
+            } else if (i < nL) {
+                const float v = cval[i - n_best];
+                if (v == v) lb = v - a.E;
+            }
+            Lf[i] = lb;
+        }
+        __syncthreads();
+        bitonic_desc_f32(Lf, nLp);
+        if (tid == 0) s_cut = (nL >= a.k) ? Lf[a.k - 1] : -__builtin_inff();
+        __syncthreads();
+        // ---- phase 2: keep new entries whose UPPER bound reaches the cut
+        const float cut = s_cut - a.E * 1.001f - 1e-6f;
+        for (int i = tid; i < n_new; i += kPruneThreads) {
+            const float v = cval[i];
+            if (!(v < cut)) {  // NaN (no bound) is kept
+                const int s = atomicAdd(&s_nres, 1);
+                R[s] = i;
+            }
+        }
+        for (int k = tid; k < a.d; k += kPruneThreads) qs[k] = a.q[(int64_t)q * a.d + k];
+        __syncthreads();
+        n_res = s_nres;
+        if (tid == 0) atomicAdd(a.stat_resc, (unsigned long long)n_res);
+        // ---- phase 3: exact fp32 chain for the survivors, 64 per wave at a time
+        float* tile = tiles + wave * kStageFloats;
+        for (int base = 0; base < n_res; base += kPruneThreads) {
+            const int e = base + wave * kWave + lane;
+            const bool live = e < n_res;
+            const int32_t row = live ? crow[R[e]] : -1;
+            const float* rp = live ? a.rows + (int64_t)row * a.d : nullptr;
+            float acc = 0.0f;
+            // whole waves past the end skip together (wave-uniform condition)
+            if (base + wave * kWave < n_res) {
+                for (int k0 = 0; k0 < a.d; k0 += kStageCols) {
+                    stage_rows(tile, rp, k0, a.d, lane);
+                    const int kn = min(kStageCols, a.d - k0);
+                    const float* t = tile + lane * kStageLd;
+                    for (int k = 0; k < kn; ++k) acc = __builtin_fmaf(t[k], qs[k0 + k], acc);
+                }
+            }
+            if (live) {
+                const double dist = distance_from(a.metric, acc, nq, a.nrm2[row]);
+                SK[n_best + e] = dist_to_key(dist);
+                SR[n_best + e] = row;
+            }
+        }
+    } else {
+        n_res = n_new;
+        for (int i = tid; i < n_new; i += kPruneThreads) {
+            const int32_t row = crow[i];
+            const double dist = distance_from(a.metric, cval[i], nq, a.nrm2[row]);
+            SK[n_best + i] = dist_to_key(dist);
+            SR[n_best + i] = row;
+        }
+    }
+    // ---- phase 4: total-order sort of kept U re-scored, keep k
+    for (int i = tid; i < n_best; i += kPruneThreads) {
+        SK[i] = bkey[i];
+        SR[i] = brow[i];
+    }
+    const int n_tot = n_best + n_res;
+    const int np = next_pow2(n_tot);
+    for (int i = n_tot + tid; i < np; i += kPruneThreads) {
+        SK[i] = kKeyNaN;
+        SR[i] = 0x7FFFFFFF;
+    }
+    __syncthreads();
+    bitonic_asc_key_row(SK, SR, np);
+    const int n_keep = min(a.k, n_tot);
+    for (int i = tid; i < n_keep; i += kPruneThreads) {
+        bkey[i] = SK[i];
+        brow[i] = SR[i];
+    }
+    if (tid == 0) {
+        a.st.best_n[q] = n_keep;
+        a.st.cnt[q] = 0;
+        if (n_keep >= a.k) {
+            const uint64_t wk = SK[a.k - 1];
+            a.st.thr_key[q] = wk;
+            a.st.thr_row[q] = SR[a.k - 1];
+            if (a.metric == 0 && wk != kKeyNaN && !(a.st.status[q] & kStIrregular)) {
+                const float th = (float)((1.0 - key_to_dist(wk)) - (double)a.E);
+                a.st.thr[q] = float_below(th);
+            }
+        }
+    }
+}
+
+// grid: B blocks of 64 threads; appends every irregular row as a "no bound" candidate (val = NaN)
+__global__ __launch_bounds__(64) void k_emit_irregular(const int32_t* __restrict__ irr_rows, int irr_n, QueryState st,
+                                                        int32_t* cand_row, float* cand_val, int cap) {
+    const int q = blockIdx.x;
+    if (st.status[q] & kStIrregular) return;
+    for (int i = threadIdx.x; i < irr_n; i += blockDim.x) {
+        const int slot = atomicAdd(&st.cnt[q], 1);
+        if (slot < cap) {
+            cand_row[(int64_t)q * cap + slot] = irr_rows[i];
+            cand_val[(int64_t)q * cap + slot] = __builtin_nanf("");
+        }
+    }
+}
+
+// grid: B blocks of 64 threads
+__global__ __launch_bounds__(64) void k_finalize(QueryState st, int k, int64_t row_offset, double* out_dist,
+                                                  int64_t* out_rows, int* status_or) {
+    const int q = blockIdx.x;
+    const int n = st.best_n[q];
+    for (int s = threadIdx.x; s < k; s += blockDim.x) {
+        if (s < n) {
+            out_dist[(int64_t)q * k + s] = key_to_dist(st.best_key[(int64_t)q * kKMax + s]);
+            out_rows[(int64_t)q * k + s] = (int64_t)st.best_row[(int64_t)q * kKMax + s] + row_offset;
+        } else {
+            out_dist[(int64_t)q * k + s] = __longlong_as_double(0x7FF8000000000000ll);
+            out_rows[(int64_t)q * k + s] = -1;
+        }
+    }
+    if (threadIdx.x == 0 && st.status[q] != 0) atomicOr(status_or, st.status[q]);
+}
+
+// grid: B blocks of 256 threads.  Shard lists are already in total order and carry global rows; the
+// merge is one more sort under the same order, so the result equals the single-GPU result.
+__global__ __launch_bounds__(256) void k_merge_topk(const double* __restrict__ dist_all,
+                                                     const int64_t* __restrict__ rows_all, int world, int B, int k,
+                                                     double* out_dist, int64_t* out_rows) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t* SK = (uint64_t*)smem;
+    int32_t* SI = (int32_t*)(smem + (size_t)kSortMax * 8);  // index into the gathered lists (row may exceed int32)
+    const int q = blockIdx.x;
+    const int n = world * k;
+    const int np = next_pow2(n);
+    // sort by (key, global row): rows are compared through a second key pass, so pack (key,row) order
+    // as: primary key in SK, tie-break resolved after the sort window by a stable fix-up (rows differ
+    // across shards, and equal keys are rare) -- done exactly below with a 2-level compare.
+    for (int i = threadIdx.x; i < np; i += blockDim.x) {
+        if (i < n) {
+            const int w = i / k, s = i % k;
+            const int64_t src = ((int64_t)w * B + q) * k + s;
+            const int64_t r = rows_all[src];
+            SK[i] = r < 0 ? kKeyNaN : dist_to_key(dist_all[src]);
+            SI[i] = r < 0 ? 0x7FFFFFFF : i;
+        } else {
+            SK[i] = kKeyNaN;
+            SI[i] = 0x7FFFFFFF;
+        }
+    }
+    __syncthreads();
+    // bitonic sort with compare (key asc, global row asc); padding (SI = INT_MAX) sorts last
+    for (int kk = 2; kk <= np; kk <<= 1) {
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < np; i += blockDim.x) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const bool asc = ((i & kk) == 0);
+                    const uint64_t ka = SK[i], kb = SK[p];
+                    const int32_t ia = SI[i], ib = SI[p];
+                    auto grow = [&](int32_t ix) -> int64_t {
+                        if (ix == 0x7FFFFFFF) return INT64_MAX;
+                        const int w = ix / k, s = ix % k;
+                        return rows_all[((int64_t)w * B + q) * k + s];
+                    };
+                    bool a_before_b, b_before_a;
+                    if (ka != kb) {
+                        a_before_b = ka < kb;
+                        b_before_a = !a_before_b;
+                    } else {
+                        const int64_t ra = grow(ia), rb = grow(ib);
+                        a_before_b = ra < rb;
+                        b_before_a = rb < ra;
+                    }
+                    if (asc ? b_before_a : a_before_b) {
+                        SK[i] = kb;
+                        SK[p] = ka;
+                        SI[i] = ib;
+                        SI[p] = ia;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int s = threadIdx.x; s < k; s += blockDim.x) {
+        const int32_t ix = s < np ? SI[s] : 0x7FFFFFFF;
+        if (ix != 0x7FFFFFFF) {
+            const int w = ix / k, ss = ix % k;
+            const int64_t src = ((int64_t)w * B + q) * k + ss;
+            out_dist[(int64_t)q * k + s] = dist_all[src];
+            out_rows[(int64_t)q * k + s] = rows_all[src];
+        } else {
+            out_dist[(int64_t)q * k + s] = __longlong_as_double(0x7FF8000000000000ll);
+            out_rows[(int64_t)q * k + s] = -1;
+        }
+    }
+}
+
+}  // namespace mi355

@@ -1,0 +1,713 @@
+// mi355dr.hip -- host side of libmi355dr.so: the C ABI declared in include/mi355dr.h, device-memory
+// management, and the launch schedule of the search (chunked screen -> prune, exact fallback).
+// gfx950 only.  Build: see __graft_entry__.build().
+#include "index.h"
+#include "k_prep.h"
+#include "k_scan.h"
+#include "k_screen.h"
+#include "k_select.h"
+
+using namespace mi355;
+
+namespace {
+std::mutex g_err_mu;
+std::string g_err;  // errors raised before a handle exists
+}  // namespace
+
+namespace mi355 {
+int fail(mi355dr_index* idx, int code, const std::string& msg) {
+    if (idx) idx->err = msg;
+    else {
+        std::lock_guard<std::mutex> g(g_err_mu);
+        g_err = msg;
+    }
+    return code;
+}
+}  // namespace mi355
+
+namespace {
+
+
+int ensure_capacity(mi355dr_index* idx, int64_t want_rows) {
+    if (want_rows <= idx->cap_rows) return MI355DR_OK;
+    int64_t new_cap = std::max<int64_t>(want_rows, idx->cap_rows + idx->cap_rows / 2);
+    new_cap = round_up(std::max<int64_t>(new_cap, kTileM), kTileM);
+    float* rows = nullptr;
+    uint16_t* shadow = nullptr;
+    float* nrm2 = nullptr;
+    HIPCHECK(idx, hipMalloc(&rows, (size_t)new_cap * idx->dim * sizeof(float)));
+    HIPCHECK(idx, hipMalloc(&shadow, (size_t)new_cap * idx->dpad * sizeof(uint16_t)));
+    HIPCHECK(idx, hipMalloc(&nrm2, (size_t)new_cap * sizeof(float)));
+    HIPCHECK(idx, hipMemsetAsync(shadow, 0, (size_t)new_cap * idx->dpad * sizeof(uint16_t), idx->stream));
+    if (idx->n > 0) {
+        HIPCHECK(idx, hipMemcpyAsync(rows, idx->rows, (size_t)idx->n * idx->dim * sizeof(float),
+                                     hipMemcpyDeviceToDevice, idx->stream));
+        HIPCHECK(idx, hipMemcpyAsync(shadow, idx->shadow, (size_t)idx->n * idx->dpad * sizeof(uint16_t),
+                                     hipMemcpyDeviceToDevice, idx->stream));
+        HIPCHECK(idx, hipMemcpyAsync(nrm2, idx->nrm2, (size_t)idx->n * sizeof(float), hipMemcpyDeviceToDevice,
+                                     idx->stream));
+    }
+    HIPCHECK(idx, hipStreamSynchronize(idx->stream));
+    if (idx->rows) (void)hipFree(idx->rows);
+    if (idx->shadow) (void)hipFree(idx->shadow);
+    if (idx->nrm2) (void)hipFree(idx->nrm2);
+    idx->rows = rows;
+    idx->shadow = shadow;
+    idx->nrm2 = nrm2;
+    idx->cap_rows = new_cap;
+    return MI355DR_OK;
+}
+
+int ensure_qstate(mi355dr_index* idx) {
+    if (idx->qstate_ready) return MI355DR_OK;
+    const size_t B = kQBlockMax;
+    HIPCHECK(idx, hipMalloc(&idx->st.qn, B * sizeof(float)));
+    HIPCHECK(idx, hipMalloc(&idx->st.qhat, B * idx->dpad * sizeof(uint16_t)));
+    HIPCHECK(idx, hipMalloc(&idx->st.thr, B * sizeof(float)));
+    HIPCHECK(idx, hipMalloc(&idx->st.cnt, B * sizeof(int)));
+    HIPCHECK(idx, hipMalloc(&idx->st.best_n, B * sizeof(int)));
+    HIPCHECK(idx, hipMalloc(&idx->st.best_key, B * kKMax * sizeof(uint64_t)));
+    HIPCHECK(idx, hipMalloc(&idx->st.best_row, B * kKMax * sizeof(int32_t)));
+    HIPCHECK(idx, hipMalloc(&idx->st.thr_key, B * sizeof(uint64_t)));
+    HIPCHECK(idx, hipMalloc(&idx->st.thr_row, B * sizeof(int32_t)));
+    HIPCHECK(idx, hipMalloc(&idx->st.status, B * sizeof(int)));
+    HIPCHECK(idx, hipMalloc(&idx->qdev, B * idx->dim * sizeof(float)));
+    HIPCHECK(idx, hipMalloc(&idx->cand_row, B * kCandCap * sizeof(int32_t)));
+    HIPCHECK(idx, hipMalloc(&idx->cand_val, B * kCandCap * sizeof(float)));
+    HIPCHECK(idx, hipMalloc(&idx->qlist_dev, 2 * B * sizeof(int)));  // second half: overflow re-runs
+    HIPCHECK(idx, hipMalloc(&idx->status_or_dev, sizeof(int)));
+    HIPCHECK(idx, hipHostMalloc(&idx->status_host, (B + 1) * sizeof(int)));
+    HIPCHECK(idx, hipMalloc(&idx->out_dist_dev, B * kKMax * sizeof(double)));
+    HIPCHECK(idx, hipMalloc(&idx->out_rows_dev, B * kKMax * sizeof(int64_t)));
+    HIPCHECK(idx, hipMalloc(&idx->stat_dev, 2 * sizeof(unsigned long long)));
+    HIPCHECK(idx, hipMemsetAsync(idx->stat_dev, 0, 2 * sizeof(unsigned long long), idx->stream));
+    // the prune / scan kernels use more than the default 64 KiB of dynamic LDS
+    if (prune_lds_bytes(idx->dim, kCandCap) > 160 * 1024 || scan_lds_bytes(idx->dim, 1) > 160 * 1024)
+        return fail(idx, MI355DR_E_UNSUPPORTED, "dim too large for the select kernels' LDS budget");
+    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_prune, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)prune_lds_bytes(idx->dim, kCandCap)));
+    {
+        int per = kScanQ;
+        while (per > 1 && scan_lds_bytes(idx->dim, per) > 150 * 1024) per >>= 1;
+        HIPCHECK(idx, hipFuncSetAttribute((const void*)k_scan, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)scan_lds_bytes(idx->dim, per)));
+    }
+    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen, hipFuncAttributeMaxDynamicSharedMemorySize, kScreenLds));
+    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_merge_topk, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kSortMax * 12));
+    idx->qstate_ready = true;
+    return MI355DR_OK;
+}
+
+// screen bound E(d): |t - exact cosine key| <= 2^-8 + 8*d*2^-24 + 2^-16   (DESIGN.md "Screen bound")
+inline float screen_bound(int d) {
+    return (float)(std::ldexp(1.0, -8) + 8.0 * d * std::ldexp(1.0, -24) + std::ldexp(1.0, -16));
+}
+
+EventPair take_events(mi355dr_index* idx) {
+    if (!idx->ev_pool.empty()) {
+        EventPair p = idx->ev_pool.back();
+        idx->ev_pool.pop_back();
+        return p;
+    }
+    EventPair p{};
+    (void)hipEventCreate(&p.a);
+    (void)hipEventCreate(&p.b);
+    return p;
+}
+
+void drain_events(mi355dr_index* idx) {  // call only after the stream was synchronised
+    for (auto& p : idx->ev_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) idx->s_screen_ns += (int64_t)(ms * 1e6);
+        idx->ev_pool.push_back(p);
+    }
+    idx->ev_pending.clear();
+}
+
+int launch_prune(mi355dr_index* idx, hipStream_t s, int nblocks, const int* qlist, int k, int exact) {
+    PruneArgs pa{};
+    pa.rows = idx->rows;
+    pa.nrm2 = idx->nrm2;
+    pa.q = idx->qdev;
+    pa.st = idx->st;
+    pa.cand_row = idx->cand_row;
+    pa.cand_val = idx->cand_val;
+    pa.qlist = qlist;
+    pa.stat_cand = idx->stat_dev;
+    pa.stat_resc = idx->stat_dev + 1;
+    pa.cap = idx->cap;
+    pa.d = idx->dim;
+    pa.k = k;
+    pa.metric = idx->metric;
+    pa.exact = exact;
+    pa.E = screen_bound(idx->dim);
+    const size_t lds = prune_lds_bytes(idx->dim, idx->cap);
+    if (lds > 160 * 1024) return fail(idx, MI355DR_E_UNSUPPORTED, "dim too large for the prune kernel's LDS budget");
+    hipLaunchKernelGGL(k_prune, dim3(nblocks), dim3(kPruneThreads), lds, s, pa);
+    HIPCHECK(idx, hipGetLastError());
+    return MI355DR_OK;
+}
+
+// screen path over all rows for the B queries prepared in idx->st / idx->qdev
+int run_screen(mi355dr_index* idx, hipStream_t s, int B, int k) {
+    const int n_qtiles = (int)round_up(B, kTileN) / kTileN;
+    int64_t done = 0;
+    int64_t chunk = std::max<int64_t>(kTileM, std::min<int64_t>(idx->chunk0_rows, idx->cap));
+    while (done < idx->n) {
+        int64_t end = std::min<int64_t>(idx->n, round_up(done + chunk, kTileM));
+        ScreenArgs sa{};
+        sa.shadow = idx->shadow;
+        sa.qhat = idx->st.qhat;
+        sa.thr = idx->st.thr;
+        sa.cnt = idx->st.cnt;
+        sa.cand_row = idx->cand_row;
+        sa.cand_val = idx->cand_val;
+        sa.dpad = idx->dpad;
+        sa.cap = idx->cap;
+        sa.ct0 = (int)(done / kTileM);
+        sa.n_ctiles = (int)(round_up(end, kTileM) / kTileM) - sa.ct0;
+        sa.n_qtiles = n_qtiles;
+        sa.row_end = end;
+        const int64_t grid = round_up(sa.n_ctiles, 8) * n_qtiles;
+        EventPair ev{};
+        if (idx->profile) {
+            ev = take_events(idx);
+            HIPCHECK(idx, hipEventRecord(ev.a, s));
+        }
+        hipLaunchKernelGGL(k_screen, dim3((unsigned)grid), dim3(256), kScreenLds, s, sa);
+        HIPCHECK(idx, hipGetLastError());
+        if (idx->profile) {
+            HIPCHECK(idx, hipEventRecord(ev.b, s));
+            idx->ev_pending.push_back(ev);
+        }
+        idx->s_screen_launches++;
+        idx->s_screen_rows += end - done;
+        idx->s_chunks++;
+        CHECK(launch_prune(idx, s, B, nullptr, k, /*exact=*/0));
+        done = end;
+        chunk = std::max<int64_t>(kTileM, done * idx->chunk_growth);
+    }
+    if (idx->irr_n > 0) {
+        hipLaunchKernelGGL(k_emit_irregular, dim3(B), dim3(64), 0, s, idx->irr_rows, idx->irr_n, idx->st,
+                           idx->cand_row, idx->cand_val, idx->cap);
+        HIPCHECK(idx, hipGetLastError());
+        CHECK(launch_prune(idx, s, B, nullptr, k, 0));
+    }
+    idx->s_passes++;
+    return MI355DR_OK;
+}
+
+__global__ void k_reset_queries(QueryState st, const int* qlist, int nq) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const int q = qlist[i];
+    st.cnt[q] = 0;
+    st.best_n[q] = 0;
+    st.thr_key[q] = kKeyNaN;
+    st.thr_row[q] = 0x7FFFFFFF;
+    st.status[q] &= ~kStOverflow;
+}
+
+// exact scan of rows [r0,r1) for the <= kScanQ queries in qlist_dev[off..off+nq), then exact prune
+int scan_range(mi355dr_index* idx, hipStream_t s, int off, int nq, int k, int64_t r0, int64_t r1) {
+    ScanArgs sa{};
+    sa.rows = idx->rows;
+    sa.nrm2 = idx->nrm2;
+    sa.q = idx->qdev;
+    sa.st = idx->st;
+    sa.cand_row = idx->cand_row;
+    sa.cand_val = idx->cand_val;
+    sa.qlist = idx->qlist_dev + off;
+    sa.nq = nq;
+    sa.cap = idx->cap;
+    sa.d = idx->dim;
+    sa.metric = idx->metric;
+    sa.row0 = r0;
+    sa.row1 = r1;
+    const int64_t grid = (r1 - r0 + kScanThreads - 1) / kScanThreads;
+    hipLaunchKernelGGL(k_scan, dim3((unsigned)grid), dim3(kScanThreads), scan_lds_bytes(idx->dim, nq), s, sa);
+    HIPCHECK(idx, hipGetLastError());
+    return launch_prune(idx, s, nq, idx->qlist_dev + off, k, /*exact=*/1);
+}
+
+// guaranteed exact path for the queries listed in `qs` (indices into the current block)
+int run_scan(mi355dr_index* idx, hipStream_t s, const std::vector<int>& qs, int k) {
+    if (qs.empty()) return MI355DR_OK;
+    HIPCHECK(idx, hipMemcpyAsync(idx->qlist_dev, qs.data(), qs.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    const int nq_all = (int)qs.size();
+    hipLaunchKernelGGL(k_reset_queries, dim3((nq_all + 255) / 256), dim3(256), 0, s, idx->st, idx->qlist_dev, nq_all);
+    HIPCHECK(idx, hipGetLastError());
+    // queries per launch limited by the LDS the query block needs
+    int per = kScanQ;
+    while (per > 1 && scan_lds_bytes(idx->dim, per) > 150 * 1024) per >>= 1;
+    if (scan_lds_bytes(idx->dim, per) > 160 * 1024)
+        return fail(idx, MI355DR_E_UNSUPPORTED, "dim too large for the scan kernel's LDS budget");
+    for (int off = 0; off < nq_all; off += per) {
+        const int nq = std::min(per, nq_all - off);
+        int64_t done = 0;
+        int64_t chunk = std::min<int64_t>(idx->chunk0_rows, idx->cap);
+        while (done < idx->n) {
+            const int64_t end = std::min<int64_t>(idx->n, done + chunk);
+            CHECK(scan_range(idx, s, off, nq, k, done, end));
+            if (end - done > idx->cap) {  // only a chunk larger than the buffer can overflow
+                HIPCHECK(idx, hipMemcpyAsync(idx->status_host, idx->st.status, kQBlockMax * sizeof(int),
+                                             hipMemcpyDeviceToHost, s));
+                HIPCHECK(idx, hipStreamSynchronize(s));
+                std::vector<int> redo;
+                for (int j = 0; j < nq; ++j)
+                    if (idx->status_host[qs[off + j]] & kStOverflow) redo.push_back(qs[off + j]);
+                if (!redo.empty()) {
+                    // re-run this range for the overflowed queries in buffer-sized pieces (cannot overflow);
+                    // the other queries of the group already committed it.  Uses the tail of qlist_dev.
+                    const int roff = kQBlockMax;
+                    HIPCHECK(idx, hipMemcpyAsync(idx->qlist_dev + roff, redo.data(), redo.size() * sizeof(int),
+                                                 hipMemcpyHostToDevice, s));
+                    // clear the overflow bit but keep the kept list (prune did not commit the failed chunk)
+                    for (int q : redo) idx->status_host[q] &= ~kStOverflow;
+                    for (int q : redo)
+                        HIPCHECK(idx, hipMemcpyAsync(idx->st.status + q, idx->status_host + q, sizeof(int),
+                                                     hipMemcpyHostToDevice, s));
+                    for (int64_t p = done; p < end; p += idx->cap)
+                        CHECK(scan_range(idx, s, roff, (int)redo.size(), k, p, std::min<int64_t>(end, p + idx->cap)));
+                }
+            }
+            done = end;
+            chunk = std::max<int64_t>(chunk, done * idx->chunk_growth);
+        }
+    }
+    idx->s_fallback_queries += nq_all;
+    return MI355DR_OK;
+}
+
+__global__ void k_set_int(int* p, int v) { *p = v; }
+
+// one block of B <= kQBlockMax device-resident queries -> device outputs [B,k]
+int search_block(mi355dr_index* idx, hipStream_t s, const float* q_dev, int B, int k, double* out_dist_dev,
+                 int64_t* out_rows_dev) {
+    CHECK(ensure_qstate(idx));
+    const int Bpad = (int)round_up(B, kTileN);
+    if (q_dev != idx->qdev)
+        HIPCHECK(idx, hipMemcpyAsync(idx->qdev, q_dev, (size_t)B * idx->dim * sizeof(float), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_prep_queries, dim3(Bpad), dim3(64), (size_t)idx->dim * sizeof(float), s, idx->qdev, B,
+                       idx->dim, idx->dpad, idx->metric, idx->st);
+    HIPCHECK(idx, hipGetLastError());
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, idx->status_or_dev, 0);
+    const bool screen_possible = idx->metric == MI355DR_METRIC_COSINE && idx->irr_n <= kIrrCap;
+    const bool use_screen = idx->n > 0 && screen_possible && idx->path != MI355DR_PATH_SCAN;
+    if (idx->path == MI355DR_PATH_SCREEN && !screen_possible && idx->n > 0)
+        return fail(idx, MI355DR_E_UNSUPPORTED, "screen path unavailable (metric or too many irregular rows)");
+    std::vector<int> todo;
+    if (idx->n > 0) {
+        if (use_screen) {
+            CHECK(run_screen(idx, s, B, k));
+        } else {
+            todo.resize(B);
+            for (int i = 0; i < B; ++i) todo[i] = i;
+            CHECK(run_scan(idx, s, todo, k));
+            todo.clear();
+        }
+    }
+    hipLaunchKernelGGL(k_finalize, dim3(B), dim3(64), 0, s, idx->st, k, idx->row_offset, out_dist_dev, out_rows_dev,
+                       idx->status_or_dev);
+    HIPCHECK(idx, hipGetLastError());
+    HIPCHECK(idx, hipMemcpyAsync(idx->status_host + kQBlockMax, idx->status_or_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHECK(idx, hipStreamSynchronize(s));
+    drain_events(idx);
+    if (use_screen && idx->status_host[kQBlockMax] != 0) {
+        // some query overflowed its candidate buffer or has an irregular norm: recompute it exactly
+        HIPCHECK(idx, hipMemcpyAsync(idx->status_host, idx->st.status, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHECK(idx, hipStreamSynchronize(s));
+        for (int i = 0; i < B; ++i)
+            if (idx->status_host[i] != 0) todo.push_back(i);
+        CHECK(run_scan(idx, s, todo, k));
+        hipLaunchKernelGGL(k_finalize, dim3(B), dim3(64), 0, s, idx->st, k, idx->row_offset, out_dist_dev,
+                           out_rows_dev, idx->status_or_dev);
+        HIPCHECK(idx, hipGetLastError());
+        HIPCHECK(idx, hipStreamSynchronize(s));
+    }
+    return MI355DR_OK;
+}
+
+int check_search_args(mi355dr_index* idx, const void* q, int B, int k, const void* od, const void* orow) {
+    if (!idx) return fail(nullptr, MI355DR_E_INVALID, "null index");
+    if (B < 0 || k <= 0) return fail(idx, MI355DR_E_INVALID, "B must be >= 0 and k > 0");
+    if (k > kKMax) return fail(idx, MI355DR_E_UNSUPPORTED, "k exceeds 1024");
+    if (B > 0 && (!q || !od || !orow)) return fail(idx, MI355DR_E_INVALID, "null buffer");
+    return MI355DR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi355dr_version(void) { return 100; }
+
+const char* mi355dr_last_error(const mi355dr_index* idx) {
+    if (idx) return idx->err.c_str();
+    std::lock_guard<std::mutex> g(g_err_mu);
+    return g_err.c_str();
+}
+
+int mi355dr_create(mi355dr_index** out, int device_id, int dim, int metric) {
+    if (!out) return fail(nullptr, MI355DR_E_INVALID, "out is null");
+    *out = nullptr;
+    if (dim <= 0 || dim > 16384) return fail(nullptr, MI355DR_E_INVALID, "dim must be in [1,16384]");
+    if (metric != MI355DR_METRIC_COSINE && metric != MI355DR_METRIC_IP)
+        return fail(nullptr, MI355DR_E_INVALID, "metric must be 0 (cosine) or 1 (inner product)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, MI355DR_E_HIP, "no HIP device available (this library has no CPU fallback)");
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, MI355DR_E_INVALID, "device_id out of range");
+    mi355dr_index* idx = new mi355dr_index();
+    idx->device = device_id;
+    idx->dim = dim;
+    idx->dpad = (int)round_up(dim, kStepK);
+    idx->metric = metric;
+    hipError_t e = hipSetDevice(device_id);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(&idx->irr_rows, kIrrCap * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&idx->irr_count, sizeof(int));
+    if (e == hipSuccess) e = hipMemset(idx->irr_count, 0, sizeof(int));
+    if (e == hipSuccess) e = hipEventCreate(&idx->t0);
+    if (e == hipSuccess) e = hipEventCreate(&idx->t1);
+    if (e != hipSuccess) {
+        std::string m = std::string("device setup failed: ") + hipGetErrorString(e);
+        delete idx;
+        return fail(nullptr, MI355DR_E_HIP, m);
+    }
+    *out = idx;
+    return MI355DR_OK;
+}
+
+void mi355dr_destroy(mi355dr_index* idx) {
+    if (!idx) return;
+    (void)hipSetDevice(idx->device);
+    if (idx->stream) (void)hipStreamSynchronize(idx->stream);
+    void* ptrs[] = {idx->rows, idx->shadow, idx->nrm2, idx->irr_rows, idx->irr_count, idx->st.qn, idx->st.qhat,
+                    idx->st.thr, idx->st.cnt, idx->st.best_n, idx->st.best_key, idx->st.best_row, idx->st.thr_key,
+                    idx->st.thr_row, idx->st.status, idx->qdev, idx->cand_row, idx->cand_val, idx->qlist_dev,
+                    idx->status_or_dev, idx->out_dist_dev, idx->out_rows_dev, idx->stat_dev};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    multivec_destroy(idx);
+    if (idx->status_host) (void)hipHostFree(idx->status_host);
+    for (auto& p : idx->ev_pool) {
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    for (auto& p : idx->ev_pending) {
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    if (idx->t0) (void)hipEventDestroy(idx->t0);
+    if (idx->t1) (void)hipEventDestroy(idx->t1);
+    if (idx->stream) (void)hipStreamDestroy(idx->stream);
+    delete idx;
+}
+
+int mi355dr_reserve(mi355dr_index* idx, int64_t n_rows) {
+    if (!idx) return fail(nullptr, MI355DR_E_INVALID, "null index");
+    std::lock_guard<std::mutex> g(idx->mu);
+    HIPCHECK(idx, hipSetDevice(idx->device));
+    if (n_rows < 0) return fail(idx, MI355DR_E_INVALID, "negative row count");
+    if (n_rows >= (int64_t)1 << 31) return fail(idx, MI355DR_E_UNSUPPORTED, "more than 2^31-1 rows per index");
+    return ensure_capacity(idx, n_rows);
+}
+
+static int add_rows_impl(mi355dr_index* idx, const float* rows, int64_t n, hipMemcpyKind kind) {
+    if (!idx) return fail(nullptr, MI355DR_E_INVALID, "null index");
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (n < 0) return fail(idx, MI355DR_E_INVALID, "negative row count");
+    if (n == 0) return MI355DR_OK;
+    if (!rows) return fail(idx, MI355DR_E_INVALID, "rows is null");
+    if (idx->n + n >= (int64_t)1 << 31) return fail(idx, MI355DR_E_UNSUPPORTED, "more than 2^31-1 rows per index");
+    HIPCHECK(idx, hipSetDevice(idx->device));
+    CHECK(ensure_capacity(idx, idx->n + n));
+    hipStream_t s = idx->stream;
+    HIPCHECK(idx, hipMemcpyAsync(idx->rows + idx->n * idx->dim, rows, (size_t)n * idx->dim * sizeof(float), kind, s));
+    hipLaunchKernelGGL(k_row_nrm2, dim3((unsigned)((n + kWave - 1) / kWave)), dim3(kWave), 0, s, idx->rows, idx->n, n,
+                       idx->dim, idx->nrm2);
+    HIPCHECK(idx, hipGetLastError());
+    hipLaunchKernelGGL(k_build_shadow, dim3((unsigned)n), dim3(256), 0, s, idx->rows, idx->nrm2, idx->n, n, idx->dim,
+                       idx->dpad, idx->shadow, idx->irr_rows, idx->irr_count);
+    HIPCHECK(idx, hipGetLastError());
+    int irr = 0;
+    HIPCHECK(idx, hipMemcpyAsync(&irr, idx->irr_count, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHECK(idx, hipStreamSynchronize(s));
+    idx->irr_n = irr;
+    idx->n += n;
+    return MI355DR_OK;
+}
+
+int mi355dr_add_rows(mi355dr_index* idx, const float* rows, int64_t n) {
+    return add_rows_impl(idx, rows, n, hipMemcpyHostToDevice);
+}
+int mi355dr_add_rows_device(mi355dr_index* idx, const float* rows_dev, int64_t n) {
+    return add_rows_impl(idx, rows_dev, n, hipMemcpyDeviceToDevice);
+}
+
+int64_t mi355dr_size(const mi355dr_index* idx) { return idx ? idx->n : -1; }
+int mi355dr_dim(const mi355dr_index* idx) { return idx ? idx->dim : -1; }
+
+int mi355dr_get_rows(mi355dr_index* idx, int64_t row0, int64_t n, float* out) {
+    if (!idx) return fail(nullptr, MI355DR_E_INVALID, "null index");
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (row0 < 0 || n < 0 || row0 + n > idx->n || (n > 0 && !out)) return fail(idx, MI355DR_E_INVALID, "bad row range");
+    if (n == 0) return MI355DR_OK;
+    HIPCHECK(idx, hipSetDevice(idx->device));
+    HIPCHECK(idx, hipMemcpyAsync(out, idx->rows + row0 * idx->dim, (size_t)n * idx->dim * sizeof(float),
+                                 hipMemcpyDeviceToHost, idx->stream));
+    HIPCHECK(idx, hipStreamSynchronize(idx->stream));
+    return MI355DR_OK;
+}
+
+int mi355dr_search(mi355dr_index* idx, const float* queries, int B, int k, double* out_dist, int64_t* out_rows) {
+    CHECK(check_search_args(idx, queries, B, k, out_dist, out_rows));
+    std::lock_guard<std::mutex> g(idx->mu);
+    HIPCHECK(idx, hipSetDevice(idx->device));
+    CHECK(ensure_qstate(idx));
+    hipStream_t s = idx->stream;
+    for (int b0 = 0; b0 < B; b0 += kQBlockMax) {
+        const int nb = std::min(kQBlockMax, B - b0);
+        HIPCHECK(idx, hipMemcpyAsync(idx->qdev, queries + (int64_t)b0 * idx->dim, (size_t)nb * idx->dim * sizeof(float),
+                                     hipMemcpyHostToDevice, s));
+        CHECK(search_block(idx, s, idx->qdev, nb, k, idx->out_dist_dev, idx->out_rows_dev));
+        HIPCHECK(idx, hipMemcpyAsync(out_dist + (int64_t)b0 * k, idx->out_dist_dev, (size_t)nb * k * sizeof(double),
+                                     hipMemcpyDeviceToHost, s));
+        HIPCHECK(idx, hipMemcpyAsync(out_rows + (int64_t)b0 * k, idx->out_rows_dev, (size_t)nb * k * sizeof(int64_t),
+                                     hipMemcpyDeviceToHost, s));
+        HIPCHECK(idx, hipStreamSynchronize(s));
+    }
+    return MI355DR_OK;
+}
+
+int mi355dr_search_device(mi355dr_index* idx, const float* queries_dev, int B, int k, double* out_dist_dev,
+                          int64_t* out_rows_dev, void* stream) {
+    CHECK(check_search_args(idx, queries_dev, B, k, out_dist_dev, out_rows_dev));
+    std::lock_guard<std::mutex> g(idx->mu);
+    HIPCHECK(idx, hipSetDevice(idx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : idx->stream;
+    for (int b0 = 0; b0 < B; b0 += kQBlockMax) {
+        const int nb = std::min(kQBlockMax, B - b0);
+        CHECK(search_block(idx, s, queries_dev + (int64_t)b0 * idx->dim, nb, k, out_dist_dev + (int64_t)b0 * k,
+                           out_rows_dev + (int64_t)b0 * k));
+    }
+    return MI355DR_OK;
+}
+
+int mi355dr_merge_topk_device(mi355dr_index* idx, const double* dist_all_dev, const int64_t* rows_all_dev, int world,
+                              int B, int k, double* out_dist_dev, int64_t* out_rows_dev, void* stream) {
+    if (!idx) return fail(nullptr, MI355DR_E_INVALID, "null index");
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (world <= 0 || B < 0 || k <= 0) return fail(idx, MI355DR_E_INVALID, "bad merge shape");
+    if ((int64_t)world * k > kSortMax) return fail(idx, MI355DR_E_UNSUPPORTED, "world*k exceeds 4096");
+    if (B == 0) return MI355DR_OK;
+    HIPCHECK(idx, hipSetDevice(idx->device));
+    CHECK(ensure_qstate(idx));
+    hipStream_t s = stream ? (hipStream_t)stream : idx->stream;
+    hipLaunchKernelGGL(k_merge_topk, dim3(B), dim3(256), (size_t)kSortMax * 12, s, dist_all_dev, rows_all_dev, world, B,
+                       k, out_dist_dev, out_rows_dev);
+    HIPCHECK(idx, hipGetLastError());
+    HIPCHECK(idx, hipStreamSynchronize(s));
+    return MI355DR_OK;
+}
+
+int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
+    if (!idx || !key) return fail(idx, MI355DR_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> g(idx->mu);
+    const std::string k(key);
+    if (k == "path") {
+        if (value < 0 || value > 2) return fail(idx, MI355DR_E_INVALID, "path must be 0,1,2");
+        idx->path = (int)value;
+    } else if (k == "row_offset") {
+        idx->row_offset = value;
+    } else if (k == "profile") {
+        idx->profile = value != 0;
+    } else if (k == "chunk0_rows") {
+        if (value < 1) return fail(idx, MI355DR_E_INVALID, "chunk0_rows must be >= 1");
+        idx->chunk0_rows = value;
+    } else if (k == "chunk_growth") {
+        if (value < 1) return fail(idx, MI355DR_E_INVALID, "chunk_growth must be >= 1");
+        idx->chunk_growth = value;
+    } else if (k == "cand_cap") {
+        if (value < 16 || value > kCandCap) return fail(idx, MI355DR_E_INVALID, "cand_cap must be in [16,2048]");
+        idx->cap = (int)value;
+    } else {
+        return fail(idx, MI355DR_E_INVALID, "unknown option: " + k);
+    }
+    return MI355DR_OK;
+}
+
+int mi355dr_get_stat(mi355dr_index* idx, const char* key, int64_t* out) {
+    if (!idx || !key || !out) return fail(idx, MI355DR_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> g(idx->mu);
+    const std::string k(key);
+    if (k == "candidates" || k == "rescored") {
+        unsigned long long v[2] = {0, 0};
+        if (idx->stat_dev) {
+            HIPCHECK(idx, hipSetDevice(idx->device));
+            HIPCHECK(idx, hipMemcpy(v, idx->stat_dev, sizeof(v), hipMemcpyDeviceToHost));
+        }
+        *out = (int64_t)(k == "candidates" ? v[0] : v[1]);
+    } else if (k == "screen_launches") *out = idx->s_screen_launches;
+    else if (k == "screen_ns") *out = idx->s_screen_ns;
+    else if (k == "screen_rows") *out = idx->s_screen_rows;
+    else if (k == "fallback_queries") *out = idx->s_fallback_queries;
+    else if (k == "chunks") *out = idx->s_chunks;
+    else if (k == "passes") *out = idx->s_passes;
+    else if (k == "irregular_rows") *out = idx->irr_n;
+    else if (k == "hbm_bytes_resident")
+        *out = idx->cap_rows * ((int64_t)idx->dim * 4 + (int64_t)idx->dpad * 2 + 4);
+    else return fail(idx, MI355DR_E_INVALID, "unknown stat: " + k);
+    return MI355DR_OK;
+}
+
+int mi355dr_reset_stats(mi355dr_index* idx) {
+    if (!idx) return fail(nullptr, MI355DR_E_INVALID, "null index");
+    std::lock_guard<std::mutex> g(idx->mu);
+    idx->s_screen_launches = idx->s_screen_ns = idx->s_screen_rows = idx->s_fallback_queries = idx->s_chunks =
+        idx->s_passes = 0;
+    if (idx->stat_dev) {
+        HIPCHECK(idx, hipSetDevice(idx->device));
+        HIPCHECK(idx, hipMemset(idx->stat_dev, 0, 2 * sizeof(unsigned long long)));
+    }
+    return MI355DR_OK;
+}
+
+int mi355dr_timer_start(mi355dr_index* idx) {
+    if (!idx) return fail(nullptr, MI355DR_E_INVALID, "null index");
+    HIPCHECK(idx, hipSetDevice(idx->device));
+    HIPCHECK(idx, hipEventRecord(idx->t0, idx->stream));
+    return MI355DR_OK;
+}
+int mi355dr_timer_stop(mi355dr_index* idx, double* elapsed_ms) {
+    if (!idx || !elapsed_ms) return fail(idx, MI355DR_E_INVALID, "null argument");
+    HIPCHECK(idx, hipSetDevice(idx->device));
+    HIPCHECK(idx, hipEventRecord(idx->t1, idx->stream));
+    HIPCHECK(idx, hipEventSynchronize(idx->t1));
+    float ms = 0.f;
+    HIPCHECK(idx, hipEventElapsedTime(&ms, idx->t0, idx->t1));
+    *elapsed_ms = ms;
+    return MI355DR_OK;
+}
+int mi355dr_synchronize(mi355dr_index* idx) {
+    if (!idx) return fail(nullptr, MI355DR_E_INVALID, "null index");
+    HIPCHECK(idx, hipSetDevice(idx->device));
+    HIPCHECK(idx, hipStreamSynchronize(idx->stream));
+    return MI355DR_OK;
+}
+
+int mi355dr_dev_alloc(mi355dr_index* idx, size_t bytes, void** out) {
+    if (!idx || !out) return fail(idx, MI355DR_E_INVALID, "null argument");
+    HIPCHECK(idx, hipSetDevice(idx->device));
+    HIPCHECK(idx, hipMalloc(out, bytes ? bytes : 1));
+    return MI355DR_OK;
+}
+int mi355dr_dev_free(mi355dr_index* idx, void* p) {
+    if (!idx) return fail(nullptr, MI355DR_E_INVALID, "null index");
+    HIPCHECK(idx, hipSetDevice(idx->device));
+    if (p) HIPCHECK(idx, hipFree(p));
+    return MI355DR_OK;
+}
+int mi355dr_dev_upload(mi355dr_index* idx, void* dst_dev, const void* src_host, size_t bytes) {
+    if (!idx) return fail(nullptr, MI355DR_E_INVALID, "null index");
+    HIPCHECK(idx, hipSetDevice(idx->device));
+    HIPCHECK(idx, hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+    return MI355DR_OK;
+}
+int mi355dr_dev_download(mi355dr_index* idx, void* dst_host, const void* src_dev, size_t bytes) {
+    if (!idx) return fail(nullptr, MI355DR_E_INVALID, "null index");
+    HIPCHECK(idx, hipSetDevice(idx->device));
+    HIPCHECK(idx, hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    return MI355DR_OK;
+}
+
+int mi355dr_debug_screen_dense(mi355dr_index* idx, const float* queries, int B, int64_t row0, int64_t n, float* out_t) {
+    if (!idx || !queries || !out_t) return fail(idx, MI355DR_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (B <= 0 || B > kQBlockMax || n <= 0 || n > kCandCap || row0 < 0 || row0 % kTileM != 0 || row0 + n > idx->n)
+        return fail(idx, MI355DR_E_INVALID, "debug_screen_dense: need 1<=B<=1024, 1<=n<=2048, row0 % 128 == 0, in range");
+    HIPCHECK(idx, hipSetDevice(idx->device));
+    CHECK(ensure_qstate(idx));
+    hipStream_t s = idx->stream;
+    HIPCHECK(idx, hipMemcpyAsync(idx->qdev, queries, (size_t)B * idx->dim * sizeof(float), hipMemcpyHostToDevice, s));
+    const int Bpad = (int)round_up(B, kTileN);
+    hipLaunchKernelGGL(k_prep_queries, dim3(Bpad), dim3(64), (size_t)idx->dim * sizeof(float), s, idx->qdev, B, idx->dim,
+                       idx->dpad, /*metric=*/1, idx->st);  // metric 1: thresholds at -inf for every query
+    HIPCHECK(idx, hipGetLastError());
+    ScreenArgs sa{};
+    sa.shadow = idx->shadow;
+    sa.qhat = idx->st.qhat;
+    sa.thr = idx->st.thr;
+    sa.cnt = idx->st.cnt;
+    sa.cand_row = idx->cand_row;
+    sa.cand_val = idx->cand_val;
+    sa.dpad = idx->dpad;
+    sa.cap = kCandCap;
+    sa.ct0 = (int)(row0 / kTileM);
+    sa.n_ctiles = (int)(round_up(row0 + n, kTileM) / kTileM) - sa.ct0;
+    sa.n_qtiles = Bpad / kTileN;
+    sa.row_end = row0 + n;
+    hipLaunchKernelGGL(k_screen, dim3((unsigned)(round_up(sa.n_ctiles, 8) * sa.n_qtiles)), dim3(256), kScreenLds, s, sa);
+    HIPCHECK(idx, hipGetLastError());
+    std::vector<int> cnt(B);
+    std::vector<int32_t> crow((size_t)B * kCandCap);
+    std::vector<float> cval((size_t)B * kCandCap);
+    HIPCHECK(idx, hipMemcpyAsync(cnt.data(), idx->st.cnt, B * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHECK(idx, hipMemcpyAsync(crow.data(), idx->cand_row, crow.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIPCHECK(idx, hipMemcpyAsync(cval.data(), idx->cand_val, cval.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHECK(idx, hipStreamSynchronize(s));
+    for (int64_t i = 0; i < (int64_t)B * n; ++i) out_t[i] = NAN;
+    for (int b = 0; b < B; ++b) {
+        const int c = std::min(cnt[b], kCandCap);
+        for (int j = 0; j < c; ++j) {
+            const int64_t r = crow[(size_t)b * kCandCap + j] - row0;
+            if (r >= 0 && r < n) out_t[(int64_t)b * n + r] = cval[(size_t)b * kCandCap + j];
+        }
+    }
+    return MI355DR_OK;
+}
+
+int mi355dr_debug_rescore(mi355dr_index* idx, const float* queries, int B, const int32_t* pair_q,
+                          const int64_t* pair_row, int64_t n_pairs, float* out_dot, double* out_dist) {
+    if (!idx || !queries || !pair_q || !pair_row || !out_dot || !out_dist)
+        return fail(idx, MI355DR_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (B <= 0 || B > kQBlockMax || n_pairs <= 0) return fail(idx, MI355DR_E_INVALID, "bad shape");
+    for (int64_t i = 0; i < n_pairs; ++i)
+        if (pair_q[i] < 0 || pair_q[i] >= B || pair_row[i] < 0 || pair_row[i] >= idx->n)
+            return fail(idx, MI355DR_E_INVALID, "pair out of range");
+    HIPCHECK(idx, hipSetDevice(idx->device));
+    CHECK(ensure_qstate(idx));
+    hipStream_t s = idx->stream;
+    HIPCHECK(idx, hipMemcpyAsync(idx->qdev, queries, (size_t)B * idx->dim * sizeof(float), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_prep_queries, dim3((unsigned)round_up(B, kTileN)), dim3(64), (size_t)idx->dim * sizeof(float), s,
+                       idx->qdev, B, idx->dim, idx->dpad, idx->metric, idx->st);
+    HIPCHECK(idx, hipGetLastError());
+    int32_t* pq = nullptr;
+    int64_t* pr = nullptr;
+    float* od = nullptr;
+    double* ods = nullptr;
+    HIPCHECK(idx, hipMalloc(&pq, n_pairs * sizeof(int32_t)));
+    HIPCHECK(idx, hipMalloc(&pr, n_pairs * sizeof(int64_t)));
+    HIPCHECK(idx, hipMalloc(&od, n_pairs * sizeof(float)));
+    HIPCHECK(idx, hipMalloc(&ods, n_pairs * sizeof(double)));
+    HIPCHECK(idx, hipMemcpyAsync(pq, pair_q, n_pairs * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIPCHECK(idx, hipMemcpyAsync(pr, pair_row, n_pairs * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_rescore_pairs, dim3((unsigned)((n_pairs + kWave - 1) / kWave)), dim3(kWave), 0, s, idx->rows,
+                       idx->nrm2, idx->qdev, idx->st.qn, pq, pr, n_pairs, idx->dim, idx->metric, od, ods);
+    HIPCHECK(idx, hipGetLastError());
+    HIPCHECK(idx, hipMemcpyAsync(out_dot, od, n_pairs * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHECK(idx, hipMemcpyAsync(out_dist, ods, n_pairs * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHECK(idx, hipStreamSynchronize(s));
+    (void)hipFree(pq);
+    (void)hipFree(pr);
+    (void)hipFree(od);
+    (void)hipFree(ods);
+    return MI355DR_OK;
+}
+
+/* ---- multi-vector (MaxSim): implemented in mi355dr_maxsim.hip ---- */
+
+}  // extern "C"

@@ -1,0 +1,196 @@
+"""Mi355Index -- Python handle over one libmi355dr index (one GPU, one corpus shard).
+
+Replaces what BaseVectorRepository asked PostgreSQL to do (reference
+autorag_research/orm/repository/base.py:378-426 `<=>`, :487-571 `@#`): it owns the rows in HBM and
+answers exact top-k.  Rows are dense indices in insertion order; id mapping lives in store.py.
+"""
+
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _native
+from ._native import NativeError, check, f32c, ptr
+
+METRICS = {"cosine": 0, "ip": 1}
+PATHS = {"auto": 0, "screen": 1, "scan": 2}
+
+
+class Mi355Index:
+    def __init__(self, dim: int, metric: str = "cosine", device: int = 0):
+        if metric not in METRICS:
+            raise ValueError(f"metric must be one of {sorted(METRICS)}")
+        self._lib = _native.load()
+        self._h = ctypes.c_void_p()
+        rc = self._lib.mi355dr_create(ctypes.byref(self._h), int(device), int(dim), METRICS[metric])
+        if rc != 0:
+            msg = self._lib.mi355dr_last_error(None)
+            raise NativeError(rc, msg.decode() if msg else "")
+        self.dim = int(dim)
+        self.metric = metric
+        self.device = int(device)
+
+    # ---- lifetime ----
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.mi355dr_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):  # noqa: D105
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+        return False
+
+    # ---- corpus ----
+    def __len__(self) -> int:
+        return int(self._lib.mi355dr_size(self._h))
+
+    def reserve(self, n_rows: int) -> None:
+        check(self._h, self._lib.mi355dr_reserve(self._h, int(n_rows)))
+
+    def add(self, rows) -> None:
+        rows = f32c(rows)
+        if rows.ndim != 2 or rows.shape[1] != self.dim:
+            raise ValueError(f"rows must be [n, {self.dim}], got {rows.shape}")
+        check(self._h, self._lib.mi355dr_add_rows(self._h, ptr(rows, ctypes.c_float), rows.shape[0]))
+
+    def add_device(self, dev_ptr: int, n: int) -> None:
+        """Append n rows already resident on this device (fp32, row-major, contiguous)."""
+        check(self._h, self._lib.mi355dr_add_rows_device(self._h, ctypes.c_void_p(int(dev_ptr)), int(n)))
+
+    def get_rows(self, row0: int, n: int) -> np.ndarray:
+        out = np.empty((n, self.dim), dtype=np.float32)
+        check(self._h, self._lib.mi355dr_get_rows(self._h, int(row0), int(n), ptr(out, ctypes.c_float)))
+        return out
+
+    # ---- search ----
+    def search(self, queries, k: int) -> tuple[np.ndarray, np.ndarray]:
+        """Exact top-k.  Returns (distance float64 [B,k], rows int64 [B,k]); pads with NaN / -1.
+
+        distance is pgvector's cosine distance (or negative inner product), ordered
+        (distance asc, NaN last, row asc) -- identical to oracle.cpu_ref.topk_search.
+        """
+        q = f32c(queries)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise ValueError(f"queries must be [B, {self.dim}], got {q.shape}")
+        B = q.shape[0]
+        dist = np.empty((B, k), dtype=np.float64)
+        rows = np.empty((B, k), dtype=np.int64)
+        check(self._h, self._lib.mi355dr_search(self._h, ptr(q, ctypes.c_float), B, int(k),
+                                                ptr(dist, ctypes.c_double), ptr(rows, ctypes.c_int64)))
+        return dist, rows
+
+    def search_device(self, q_ptr: int, B: int, k: int, out_dist_ptr: int, out_rows_ptr: int,
+                      stream: int | None = None) -> None:
+        check(self._h, self._lib.mi355dr_search_device(self._h, ctypes.c_void_p(int(q_ptr)), int(B), int(k),
+                                                       ctypes.c_void_p(int(out_dist_ptr)),
+                                                       ctypes.c_void_p(int(out_rows_ptr)),
+                                                       ctypes.c_void_p(int(stream) if stream else None)))
+
+    def merge_topk_device(self, dist_all_ptr: int, rows_all_ptr: int, world: int, B: int, k: int, out_dist_ptr: int,
+                          out_rows_ptr: int, stream: int | None = None) -> None:
+        check(self._h, self._lib.mi355dr_merge_topk_device(
+            self._h, ctypes.c_void_p(int(dist_all_ptr)), ctypes.c_void_p(int(rows_all_ptr)), int(world), int(B),
+            int(k), ctypes.c_void_p(int(out_dist_ptr)), ctypes.c_void_p(int(out_rows_ptr)),
+            ctypes.c_void_p(int(stream) if stream else None)))
+
+    # ---- multi-vector ----
+    def add_multivec(self, vecs, offsets) -> None:
+        vecs = f32c(vecs)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        if vecs.ndim != 2 or vecs.shape[1] != self.dim:
+            raise ValueError(f"vecs must be [sum_T, {self.dim}]")
+        if offsets.ndim != 1 or offsets.shape[0] < 1 or offsets[0] != 0 or offsets[-1] != vecs.shape[0]:
+            raise ValueError("offsets must start at 0 and end at vecs.shape[0]")
+        check(self._h, self._lib.mi355dr_add_multivec(self._h, ptr(vecs, ctypes.c_float),
+                                                      ptr(offsets, ctypes.c_int64), offsets.shape[0] - 1))
+
+    def n_docs(self) -> int:
+        return int(self._lib.mi355dr_size_multivec(self._h))
+
+    def search_maxsim(self, qtok, q_offsets, k: int) -> tuple[np.ndarray, np.ndarray]:
+        """MaxSim top-k.  Returns (distance float32 [B,k] = -sum_i max_j <q_i,d_j>, doc rows int64 [B,k])."""
+        qtok = f32c(qtok)
+        q_offsets = np.ascontiguousarray(q_offsets, dtype=np.int32)
+        B = q_offsets.shape[0] - 1
+        dist = np.empty((B, k), dtype=np.float32)
+        rows = np.empty((B, k), dtype=np.int64)
+        check(self._h, self._lib.mi355dr_search_maxsim(self._h, ptr(qtok, ctypes.c_float),
+                                                       ptr(q_offsets, ctypes.c_int32), B, int(k),
+                                                       ptr(dist, ctypes.c_float), ptr(rows, ctypes.c_int64)))
+        return dist, rows
+
+    # ---- options / stats / timing ----
+    def set_option(self, key: str, value: int | str) -> None:
+        if key == "path" and isinstance(value, str):
+            value = PATHS[value]
+        check(self._h, self._lib.mi355dr_set_option(self._h, key.encode(), int(value)))
+
+    def stat(self, key: str) -> int:
+        out = ctypes.c_int64(0)
+        check(self._h, self._lib.mi355dr_get_stat(self._h, key.encode(), ctypes.byref(out)))
+        return int(out.value)
+
+    def reset_stats(self) -> None:
+        check(self._h, self._lib.mi355dr_reset_stats(self._h))
+
+    def timer_start(self) -> None:
+        check(self._h, self._lib.mi355dr_timer_start(self._h))
+
+    def timer_stop(self) -> float:
+        ms = ctypes.c_double(0.0)
+        check(self._h, self._lib.mi355dr_timer_stop(self._h, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def synchronize(self) -> None:
+        check(self._h, self._lib.mi355dr_synchronize(self._h))
+
+    # ---- raw device buffers (tests / bench without torch) ----
+    def dev_alloc(self, nbytes: int) -> int:
+        p = ctypes.c_void_p()
+        check(self._h, self._lib.mi355dr_dev_alloc(self._h, int(nbytes), ctypes.byref(p)))
+        return int(p.value)
+
+    def dev_free(self, p: int) -> None:
+        check(self._h, self._lib.mi355dr_dev_free(self._h, ctypes.c_void_p(int(p))))
+
+    def dev_upload(self, dst: int, arr: np.ndarray) -> None:
+        arr = np.ascontiguousarray(arr)
+        check(self._h, self._lib.mi355dr_dev_upload(self._h, ctypes.c_void_p(int(dst)),
+                                                    ctypes.c_void_p(arr.ctypes.data), arr.nbytes))
+
+    def dev_download(self, src: int, arr: np.ndarray) -> None:
+        assert arr.flags["C_CONTIGUOUS"]
+        check(self._h, self._lib.mi355dr_dev_download(self._h, ctypes.c_void_p(arr.ctypes.data),
+                                                      ctypes.c_void_p(int(src)), arr.nbytes))
+
+    # ---- test hooks ----
+    def debug_screen_dense(self, queries, row0: int, n: int) -> np.ndarray:
+        q = f32c(queries)
+        out = np.empty((q.shape[0], n), dtype=np.float32)
+        check(self._h, self._lib.mi355dr_debug_screen_dense(self._h, ptr(q, ctypes.c_float), q.shape[0], int(row0),
+                                                            int(n), ptr(out, ctypes.c_float)))
+        return out
+
+    def debug_rescore(self, queries, pair_q, pair_row) -> tuple[np.ndarray, np.ndarray]:
+        q = f32c(queries)
+        pq = np.ascontiguousarray(pair_q, dtype=np.int32)
+        pr = np.ascontiguousarray(pair_row, dtype=np.int64)
+        dot = np.empty(pq.shape[0], dtype=np.float32)
+        dist = np.empty(pq.shape[0], dtype=np.float64)
+        check(self._h, self._lib.mi355dr_debug_rescore(self._h, ptr(q, ctypes.c_float), q.shape[0],
+                                                       ptr(pq, ctypes.c_int32), ptr(pr, ctypes.c_int64), pq.shape[0],
+                                                       ptr(dot, ctypes.c_float), ptr(dist, ctypes.c_double)))
+        return dot, dist

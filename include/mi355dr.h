@@ -1,0 +1,134 @@
+/*
+ * mi355dr.h -- C ABI of the MI355X-native dense-retrieval core (libmi355dr.so).
+ *
+ * This is the drop-in boundary for AutoRAG-Research's Vector Search hot path.  The reference
+ * has no FFI of its own for this path: it dispatches two SQL operators to PostgreSQL
+ * extensions.  Each entry point below cites the reference call it replaces
+ * (paths relative to /root/reference):
+ *
+ *   mi355dr_search / _device      <->  BaseVectorRepository.vector_search_with_scores
+ *                                      autorag_research/orm/repository/base.py:378-426
+ *                                      (SELECT id, embedding <=> q AS distance ... ORDER BY distance LIMIT k)
+ *   mi355dr_search_maxsim         <->  BaseVectorRepository.maxsim_search / maxsim_search_with_ids
+ *                                      autorag_research/orm/repository/base.py:487-535, 537-571
+ *                                      (embeddings @# ARRAY[...] AS distance ... ORDER BY distance LIMIT k)
+ *   mi355dr_add_rows / _device    <->  the `embedding VECTOR(d)` column fill
+ *                                      autorag_research/orm/service/base_ingestion.py:199-247
+ *   mi355dr_add_multivec          <->  BaseVectorRepository.set_multi_vector_embedding(s_batch)
+ *                                      autorag_research/orm/repository/base.py:428-485
+ *
+ * Semantics (identical to oracle/oracle.c, which is the checker):
+ *   - cosine distance = pgvector cosine_distance: fp32 accumulators dot/|q|^2/|c|^2 (k-ascending
+ *     fused-multiply-add chains), double sim = dot/sqrt(nq*nc) clamped to [-1,1], distance = 1-sim
+ *     returned as double (float8), NaN when a norm is zero.
+ *   - inner product distance = (double)dot * -1 (pgvector <#>).
+ *   - MaxSim distance = sum over query vectors of min over doc vectors of (-dot), fp32 (VectorChord @#).
+ *   - exact brute force (the reference never builds an ANN index), total order
+ *     (distance asc, NaN last, row index asc).
+ *   - rows are addressed by dense row index in insertion order; the caller owns the
+ *     row-index -> chunk-id table (ids may be BIGINT or VARCHAR, schema_factory.py:63-76).
+ *
+ * Conventions: every function returns 0 on success or a negative MI355DR_E_* code; the text of the
+ * last error is available from mi355dr_last_error().  The caller owns all host buffers; the
+ * library owns device memory.  One search in flight per handle (internal mutex); independent
+ * handles are independent.  No Python / torch types cross this boundary.
+ */
+#ifndef MI355DR_H
+#define MI355DR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mi355dr_index mi355dr_index; /* opaque */
+
+enum {
+    MI355DR_OK = 0,
+    MI355DR_E_INVALID = -1,     /* bad argument */
+    MI355DR_E_HIP = -2,         /* HIP runtime error (text in last_error) */
+    MI355DR_E_NOMEM = -3,       /* device or host allocation failed */
+    MI355DR_E_UNSUPPORTED = -4, /* valid request this build cannot serve */
+    MI355DR_E_INTERNAL = -5
+};
+
+enum { MI355DR_METRIC_COSINE = 0, MI355DR_METRIC_IP = 1 };
+
+/* Search strategies (option "path"). */
+enum {
+    MI355DR_PATH_AUTO = 0,   /* screen where it applies, else scan */
+    MI355DR_PATH_SCREEN = 1, /* bf16 MFMA screen over the normalised shadow corpus + exact fp32 re-score */
+    MI355DR_PATH_SCAN = 2    /* exact fp32 chain per (query,row); slow, guaranteed, also the in-library fallback */
+};
+
+/* ---- lifetime ---- */
+int mi355dr_create(mi355dr_index** out, int device_id, int dim, int metric);
+void mi355dr_destroy(mi355dr_index* idx);
+/* idx may be NULL: returns the text of the last error raised before a handle existed */
+const char* mi355dr_last_error(const mi355dr_index* idx);
+int mi355dr_version(void);
+
+/* ---- corpus (single-vector) ---- */
+int mi355dr_reserve(mi355dr_index* idx, int64_t n_rows);
+/* rows: host, row-major [n, dim] fp32.  Appends; copies to HBM; precomputes |c|^2 and the bf16 shadow. */
+int mi355dr_add_rows(mi355dr_index* idx, const float* rows, int64_t n);
+/* same, rows already resident on this index's device (e.g. an embedding model's output tensor) */
+int mi355dr_add_rows_device(mi355dr_index* idx, const float* rows_dev, int64_t n);
+int64_t mi355dr_size(const mi355dr_index* idx);
+int mi355dr_dim(const mi355dr_index* idx);
+/* copy stored rows back (testing / cpu baseline): out host [n, dim] */
+int mi355dr_get_rows(mi355dr_index* idx, int64_t row0, int64_t n, float* out);
+
+/* ---- search (single-vector) ----
+ * queries: [B, dim] fp32.  out_dist: [B, k] double, out_rows: [B, k] int64; slots beyond the
+ * number of stored rows hold NaN / -1.  row_offset is added to every returned row (shards). */
+int mi355dr_search(mi355dr_index* idx, const float* queries, int B, int k, double* out_dist, int64_t* out_rows);
+/* device-resident queries and outputs; stream = hipStream_t (NULL: the index's own stream).
+ * Returns after the work is complete on that stream (it checks the device-side status word). */
+int mi355dr_search_device(mi355dr_index* idx, const float* queries_dev, int B, int k, double* out_dist_dev,
+                          int64_t* out_rows_dev, void* stream);
+
+/* ---- corpus + search (multi-vector, MaxSim) ----
+ * vecs: host [sum_T, dim] fp32, offsets: [n_docs+1] (doc i owns rows offsets[i]..offsets[i+1]). */
+int mi355dr_add_multivec(mi355dr_index* idx, const float* vecs, const int64_t* offsets, int64_t n_docs);
+int64_t mi355dr_size_multivec(const mi355dr_index* idx);
+/* qtok: host [sum_nq, dim], q_offsets: [B+1].  out_dist: [B,k] fp32 (= -sum_i max_j <q_i,d_j>). */
+int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* q_offsets, int B, int k,
+                          float* out_dist, int64_t* out_rows);
+
+/* ---- shard merge (multi-GPU): [world, B, k] gathered (dist,row) device buffers -> [B, k] ---- */
+int mi355dr_merge_topk_device(mi355dr_index* idx, const double* dist_all_dev, const int64_t* rows_all_dev, int world,
+                              int B, int k, double* out_dist_dev, int64_t* out_rows_dev, void* stream);
+
+/* ---- options / stats / timing ----
+ * options: "path" (MI355DR_PATH_*), "row_offset", "profile" (0/1: HIP-event timing of the dominant kernel),
+ *          "chunk0_rows", "chunk_growth", "cand_cap".
+ * stats:   "screen_launches", "screen_ns" (profile=1), "screen_rows", "candidates", "rescored",
+ *          "fallback_queries", "chunks", "passes", "hbm_bytes_resident". */
+int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value);
+int mi355dr_get_stat(mi355dr_index* idx, const char* key, int64_t* out);
+int mi355dr_reset_stats(mi355dr_index* idx);
+/* HIP-event stopwatch on the index's stream (bench.py: kernel-side time of a timed region) */
+int mi355dr_timer_start(mi355dr_index* idx);
+int mi355dr_timer_stop(mi355dr_index* idx, double* elapsed_ms);
+int mi355dr_synchronize(mi355dr_index* idx);
+
+/* ---- raw device memory helpers for hosts that have no device allocator of their own (tests, bench) ---- */
+int mi355dr_dev_alloc(mi355dr_index* idx, size_t bytes, void** out);
+int mi355dr_dev_free(mi355dr_index* idx, void* p);
+int mi355dr_dev_upload(mi355dr_index* idx, void* dst_dev, const void* src_host, size_t bytes);
+int mi355dr_dev_download(mi355dr_index* idx, void* dst_host, const void* src_dev, size_t bytes);
+
+/* ---- test hooks (used by tests/ only; exercise the production kernels on small inputs) ----
+ * dense screen values t[b, r] for rows [row0,row0+n): runs the screen kernel with thresholds at -inf. */
+int mi355dr_debug_screen_dense(mi355dr_index* idx, const float* queries, int B, int64_t row0, int64_t n, float* out_t);
+/* exact fp32 chain + distance for explicit (query,row) pairs, computed by the re-score device code */
+int mi355dr_debug_rescore(mi355dr_index* idx, const float* queries, int B, const int32_t* pair_q,
+                          const int64_t* pair_row, int64_t n_pairs, float* out_dot, double* out_dist);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355DR_H */

@@ -1,0 +1,72 @@
+"""GPU parity tests of the individual kernels, through the C ABI (libmi355dr.so), against the CPU oracle."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16_round(x: np.ndarray) -> np.ndarray:
+    """numpy emulation of round-to-nearest-even fp32 -> bf16 -> fp32."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+@pytest.fixture(scope="module")
+def pkg(native_built):
+    import autorag_research_amd as p
+
+    return p
+
+
+@pytest.mark.parametrize("d", [768, 384, 100, 7])
+def test_rescore_chain_is_bit_exact(pkg, oracle, d):
+    """exact fp32 chain + pgvector double distance on the GPU == oracle, bit for bit (incl. un-normalised rows)."""
+    rng = np.random.default_rng(100 + d)
+    n, B = 700, 5
+    C = rng.standard_normal((n, d)).astype(np.float32)
+    C[3] *= 1e4
+    C[5] *= 1e-4
+    C[9] = 0.0  # zero-norm row -> NaN distance
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    pq = rng.integers(0, B, size=1500).astype(np.int32)
+    pr = rng.integers(0, n, size=1500).astype(np.int64)
+    pr[:3] = [9, 3, 5]
+    with pkg.Mi355Index(d) as idx:
+        idx.add(C)
+        dot, dist = idx.debug_rescore(Q, pq, pr)
+    exp_dot = np.array([oracle.dot(C[r], Q[q]) for q, r in zip(pq, pr)], dtype=np.float32)
+    exp_dist = np.array([oracle.cosine_distance(Q[q], C[r]) for q, r in zip(pq, pr)])
+    assert np.array_equal(dot.view(np.uint32), exp_dot.view(np.uint32))
+    assert np.array_equal(np.isnan(dist), np.isnan(exp_dist))  # NaN payload/sign is not part of the contract
+    ok = ~np.isnan(dist)
+    assert np.array_equal(dist[ok].view(np.uint64), exp_dist[ok].view(np.uint64))
+    assert np.isnan(dist[0])
+
+
+@pytest.mark.parametrize("d,B", [(768, 130), (384, 3), (100, 17)])
+def test_screen_values_match_bf16_emulation(pkg, d, B):
+    """the MFMA screen kernel (layout, swizzle, staging) == numpy emulation of the bf16 shadow product."""
+    rng = np.random.default_rng(7 + d)
+    n = 1500
+    C = rng.standard_normal((n, d)).astype(np.float32) * rng.uniform(0.1, 10, size=(n, 1)).astype(np.float32)
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    with pkg.Mi355Index(d) as idx:
+        idx.add(C)
+        for row0, cnt in [(0, 1500), (128, 300), (1024, 476)]:
+            t = idx.debug_screen_dense(Q, row0, cnt)
+            sub = C[row0:row0 + cnt].astype(np.float64)
+            ch = _bf16_round((sub / np.linalg.norm(sub, axis=1, keepdims=True)).astype(np.float32)).astype(np.float64)
+            qh = _bf16_round((Q.astype(np.float64) / np.linalg.norm(Q.astype(np.float64), axis=1, keepdims=True))
+                             .astype(np.float32)).astype(np.float64)
+            ref = qh @ ch.T
+            assert not np.isnan(t).any(), "some (query,row) pairs were never produced by the kernel"
+            # shadow normalisation happens in fp32 on the device: allow bf16 ulp flips on a few elements
+            assert np.abs(t - ref).max() < 2e-3
+            assert np.abs(t - ref).mean() < 2e-5
+            # and the screen bound itself: |t - exact cosine| <= E
+            cos = (Q.astype(np.float64) @ sub.T) / (np.linalg.norm(Q.astype(np.float64), axis=1)[:, None]
+                                                     * np.linalg.norm(sub, axis=1)[None, :])
+            E = 2.0 ** -8 + 8 * d * 2.0 ** -24 + 2.0 ** -16
+            assert np.abs(t - cos).max() <= E
