@@ -105,18 +105,41 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// stage columns [k0, k0+64) of the 64 rows `rowptr(lane)` (nullptr = slot unused -> zeros)
+// stage columns [k0, k0+64) of the 64 rows `my_row(lane)` (nullptr = slot unused -> zeros).
+// d % 4 == 0 (16-B aligned row pieces): one global_load_dwordx4 per lane covers 4 rows x 256 B per
+// wave instruction, 16 independent loads are issued back to back before the first LDS write, so the
+// HBM latency is paid once per 64-column piece instead of once per row.
 __device__ __forceinline__ void stage_rows(float* tile, const float* my_row, int k0, int d, int lane) {
     wave_sync();  // previous readers of the tile are done
-    for (int s = 0; s < kWave; ++s) {
-        // broadcast slot s's row pointer (two 32-bit halves) to the whole wave
-        unsigned long long p = (unsigned long long)my_row;
-        unsigned lo = __shfl((unsigned)(p & 0xFFFFFFFFull), s, kWave);
-        unsigned hi = __shfl((unsigned)(p >> 32), s, kWave);
-        const float* r = (const float*)(((unsigned long long)hi << 32) | lo);
-        int k = k0 + lane;
-        float v = (r != nullptr && k < d) ? r[k] : 0.0f;
-        tile[s * kStageLd + lane] = v;
+    const unsigned long long p = (unsigned long long)my_row;
+    const unsigned plo = (unsigned)(p & 0xFFFFFFFFull), phi = (unsigned)(p >> 32);
+    if ((d & 3) == 0) {
+        const int sub = lane >> 4;        // row within the group of 4
+        const int c4 = (lane & 15) * 4;   // first of this lane's 4 columns
+        float4 v[16];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int s = g * 4 + sub;
+            const unsigned lo = __shfl(plo, s, kWave), hi = __shfl(phi, s, kWave);
+            const float* r = (const float*)(((unsigned long long)hi << 32) | lo);
+            v[g] = (r != nullptr && k0 + c4 < d) ? *(const float4*)(r + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            float* t = tile + (g * 4 + sub) * kStageLd + c4;
+            t[0] = v[g].x;
+            t[1] = v[g].y;
+            t[2] = v[g].z;
+            t[3] = v[g].w;
+        }
+    } else {
+#pragma unroll 8
+        for (int s = 0; s < kWave; ++s) {
+            const unsigned lo = __shfl(plo, s, kWave), hi = __shfl(phi, s, kWave);
+            const float* r = (const float*)(((unsigned long long)hi << 32) | lo);
+            const int k = k0 + lane;
+            tile[s * kStageLd + lane] = (r != nullptr && k < d) ? r[k] : 0.0f;
+        }
     }
     wave_sync();  // tile visible to every lane of this wave
 }

@@ -52,7 +52,7 @@ struct mi355dr_index {
     int path = 0;  // MI355DR_PATH_AUTO
     int64_t row_offset = 0;
     int profile = 0;
-    int64_t chunk0_rows = 1024;
+    int64_t chunk0_rows = 512;
     int64_t chunk_growth = 7;
     int cap = mi355::kCandCap;
 

@@ -76,29 +76,37 @@ struct PruneArgs {
     float E;             // screen bound
 };
 
-constexpr int kPruneThreads = 256;
-// dynamic LDS: SK[kSortMax] u64 | SR[kSortMax] i32 | X = max(Lf[kSortMax] f32, 4 stage tiles) | R[cap] i32 | qs[d] f32
-__host__ __device__ inline size_t prune_lds_bytes(int d, int cap) {
-    size_t x = (size_t)4 * kStageFloats * sizeof(float);
-    size_t lf = (size_t)kSortMax * sizeof(float);
+// Two instantiations share the code: a small one (1 wave, <= 512 entries, ~26 KiB LDS, 6 workgroups
+// per CU so that a whole 1024-query block is resident at once and the re-score latency overlaps across
+// queries) handles the common case; the large one (4 waves, 4096 entries) is launched right after it
+// and only finds work for queries the small one skipped (first chunk, k > ~400, adversarial data).
+constexpr int kPruneSmallThreads = 64, kPruneSmallSort = 512;
+constexpr int kPruneBigThreads = 256, kPruneBigSort = kSortMax;
+
+// dynamic LDS: SK[SORT] u64 | SR[SORT] i32 | X = max(Lf[SORT] f32, stage tiles) | R[SORT] i32 | qs[d] f32 | 2 scalars
+__host__ __device__ inline size_t prune_lds_bytes(int d, int threads, int sortmax) {
+    size_t x = (size_t)(threads / kWave) * kStageFloats * sizeof(float);
+    size_t lf = (size_t)sortmax * sizeof(float);
     if (lf > x) x = lf;
-    return (size_t)kSortMax * 8 + (size_t)kSortMax * 4 + x + (size_t)cap * 4 + (size_t)d * 4 + 64;
+    return (size_t)sortmax * 8 + (size_t)sortmax * 4 + x + (size_t)sortmax * 4 + (size_t)d * 4 + 64;
 }
 
-__global__ __launch_bounds__(kPruneThreads) void k_prune(PruneArgs a) {
+template <int THREADS, int SORT>
+__global__ __launch_bounds__(THREADS) void k_prune(PruneArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int kWaves = THREADS / kWave;
     uint64_t* SK = (uint64_t*)smem;
-    int32_t* SR = (int32_t*)(smem + (size_t)kSortMax * 8);
-    char* X = smem + (size_t)kSortMax * 12;
-    size_t xbytes = (size_t)4 * kStageFloats * sizeof(float);
-    if ((size_t)kSortMax * sizeof(float) > xbytes) xbytes = (size_t)kSortMax * sizeof(float);
+    int32_t* SR = (int32_t*)(smem + (size_t)SORT * 8);
+    char* X = smem + (size_t)SORT * 12;
+    constexpr size_t xa = (size_t)kWaves * kStageFloats * sizeof(float), xb = (size_t)SORT * sizeof(float);
+    constexpr size_t xbytes = xa > xb ? xa : xb;
     float* Lf = (float*)X;
     float* tiles = (float*)X;
     int32_t* R = (int32_t*)(X + xbytes);
-    float* qs = (float*)(X + xbytes + (size_t)a.cap * 4);
+    float* qs = (float*)(X + xbytes + (size_t)SORT * 4);
     // two scalars at the very end of the dynamic region (no static LDS: keeps the carve 16-B aligned)
-    int& s_nres = *(int*)(X + xbytes + (size_t)a.cap * 4 + (size_t)a.d * 4);
-    float& s_cut = *(float*)(X + xbytes + (size_t)a.cap * 4 + (size_t)a.d * 4 + 4);
+    int& s_nres = *(int*)(X + xbytes + (size_t)SORT * 4 + (size_t)a.d * 4);
+    float& s_cut = *(float*)(X + xbytes + (size_t)SORT * 4 + (size_t)a.d * 4 + 4);
 
     const int q = a.qlist ? a.qlist[blockIdx.x] : blockIdx.x;
     const int tid = threadIdx.x;
@@ -107,12 +115,14 @@ __global__ __launch_bounds__(kPruneThreads) void k_prune(PruneArgs a) {
     const int n_best = a.st.best_n[q];
     if (raw_cnt == 0) return;  // nothing new; kept list and thresholds stay as they are
     if (raw_cnt > a.cap) {     // overflow: do not commit; the query is recomputed by the guaranteed path
+        if (SORT < kPruneBigSort) return;  // let the large instantiation record it
         if (tid == 0) {
             a.st.status[q] |= kStOverflow;
             a.st.cnt[q] = 0;
         }
         return;
     }
+    if (n_best + raw_cnt > SORT) return;  // too many for this instantiation: left for the large one
     const int n_new = raw_cnt;
     const int32_t* crow = a.cand_row + (int64_t)q * a.cap;
     const float* cval = a.cand_val + (int64_t)q * a.cap;
@@ -129,7 +139,7 @@ __global__ __launch_bounds__(kPruneThreads) void k_prune(PruneArgs a) {
         // ---- phase 1: k-th largest LOWER bound of the exact similarity over (kept U new)
         const int nL = n_best + n_new;
         const int nLp = next_pow2(nL);
-        for (int i = tid; i < nLp; i += kPruneThreads) {
+        for (int i = tid; i < nLp; i += THREADS) {
             float lb = -__builtin_inff();
             if (i < n_best) {
                 const uint64_t kk = bkey[i];
@@ -146,20 +156,20 @@ __global__ __launch_bounds__(kPruneThreads) void k_prune(PruneArgs a) {
         __syncthreads();
         // ---- phase 2: keep new entries whose UPPER bound reaches the cut
         const float cut = s_cut - a.E * 1.001f - 1e-6f;
-        for (int i = tid; i < n_new; i += kPruneThreads) {
+        for (int i = tid; i < n_new; i += THREADS) {
             const float v = cval[i];
             if (!(v < cut)) {  // NaN (no bound) is kept
                 const int s = atomicAdd(&s_nres, 1);
                 R[s] = i;
             }
         }
-        for (int k = tid; k < a.d; k += kPruneThreads) qs[k] = a.q[(int64_t)q * a.d + k];
+        for (int k = tid; k < a.d; k += THREADS) qs[k] = a.q[(int64_t)q * a.d + k];
         __syncthreads();
         n_res = s_nres;
         if (tid == 0) atomicAdd(a.stat_resc, (unsigned long long)n_res);
         // ---- phase 3: exact fp32 chain for the survivors, 64 per wave at a time
         float* tile = tiles + wave * kStageFloats;
-        for (int base = 0; base < n_res; base += kPruneThreads) {
+        for (int base = 0; base < n_res; base += THREADS) {
             const int e = base + wave * kWave + lane;
             const bool live = e < n_res;
             const int32_t row = live ? crow[R[e]] : -1;
@@ -182,7 +192,7 @@ __global__ __launch_bounds__(kPruneThreads) void k_prune(PruneArgs a) {
         }
     } else {
         n_res = n_new;
-        for (int i = tid; i < n_new; i += kPruneThreads) {
+        for (int i = tid; i < n_new; i += THREADS) {
             const int32_t row = crow[i];
             const double dist = distance_from(a.metric, cval[i], nq, a.nrm2[row]);
             SK[n_best + i] = dist_to_key(dist);
@@ -190,20 +200,20 @@ __global__ __launch_bounds__(kPruneThreads) void k_prune(PruneArgs a) {
         }
     }
     // ---- phase 4: total-order sort of kept U re-scored, keep k
-    for (int i = tid; i < n_best; i += kPruneThreads) {
+    for (int i = tid; i < n_best; i += THREADS) {
         SK[i] = bkey[i];
         SR[i] = brow[i];
     }
     const int n_tot = n_best + n_res;
     const int np = next_pow2(n_tot);
-    for (int i = n_tot + tid; i < np; i += kPruneThreads) {
+    for (int i = n_tot + tid; i < np; i += THREADS) {
         SK[i] = kKeyNaN;
         SR[i] = 0x7FFFFFFF;
     }
     __syncthreads();
     bitonic_asc_key_row(SK, SR, np);
     const int n_keep = min(a.k, n_tot);
-    for (int i = tid; i < n_keep; i += kPruneThreads) {
+    for (int i = tid; i < n_keep; i += THREADS) {
         bkey[i] = SK[i];
         brow[i] = SR[i];
     }

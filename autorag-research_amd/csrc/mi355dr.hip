@@ -82,10 +82,14 @@ int ensure_qstate(mi355dr_index* idx) {
     HIPCHECK(idx, hipMalloc(&idx->stat_dev, 2 * sizeof(unsigned long long)));
     HIPCHECK(idx, hipMemsetAsync(idx->stat_dev, 0, 2 * sizeof(unsigned long long), idx->stream));
     // the prune / scan kernels use more than the default 64 KiB of dynamic LDS
-    if (prune_lds_bytes(idx->dim, kCandCap) > 160 * 1024 || scan_lds_bytes(idx->dim, 1) > 160 * 1024)
+    if (prune_lds_bytes(idx->dim, kPruneBigThreads, kPruneBigSort) > 160 * 1024 || scan_lds_bytes(idx->dim, 1) > 160 * 1024)
         return fail(idx, MI355DR_E_UNSUPPORTED, "dim too large for the select kernels' LDS budget");
-    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_prune, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)prune_lds_bytes(idx->dim, kCandCap)));
+    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_prune<kPruneBigThreads, kPruneBigSort>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)prune_lds_bytes(idx->dim, kPruneBigThreads, kPruneBigSort)));
+    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_prune<kPruneSmallThreads, kPruneSmallSort>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)prune_lds_bytes(idx->dim, kPruneSmallThreads, kPruneSmallSort)));
     {
         int per = kScanQ;
         while (per > 1 && scan_lds_bytes(idx->dim, per) > 150 * 1024) per >>= 1;
@@ -142,9 +146,12 @@ int launch_prune(mi355dr_index* idx, hipStream_t s, int nblocks, const int* qlis
     pa.metric = idx->metric;
     pa.exact = exact;
     pa.E = screen_bound(idx->dim);
-    const size_t lds = prune_lds_bytes(idx->dim, idx->cap);
-    if (lds > 160 * 1024) return fail(idx, MI355DR_E_UNSUPPORTED, "dim too large for the prune kernel's LDS budget");
-    hipLaunchKernelGGL(k_prune, dim3(nblocks), dim3(kPruneThreads), lds, s, pa);
+    // small instantiation first (common case, whole block resident), then the large one for what it skipped
+    hipLaunchKernelGGL((k_prune<kPruneSmallThreads, kPruneSmallSort>), dim3(nblocks), dim3(kPruneSmallThreads),
+                       prune_lds_bytes(idx->dim, kPruneSmallThreads, kPruneSmallSort), s, pa);
+    HIPCHECK(idx, hipGetLastError());
+    hipLaunchKernelGGL((k_prune<kPruneBigThreads, kPruneBigSort>), dim3(nblocks), dim3(kPruneBigThreads),
+                       prune_lds_bytes(idx->dim, kPruneBigThreads, kPruneBigSort), s, pa);
     HIPCHECK(idx, hipGetLastError());
     return MI355DR_OK;
 }
