@@ -78,7 +78,7 @@ class Mi355Index:
         """Exact top-k.  Returns (distance float64 [B,k], rows int64 [B,k]); pads with NaN / -1.
 
         distance is pgvector's cosine distance (or negative inner product), ordered
-        (distance asc, NaN last, row asc) -- identical to oracle.cpu_ref.topk_search.
+        (distance asc, NaN last, row asc) -- the same contract the CPU checker in oracle/ states.
         """
         q = f32c(queries)
         if q.ndim == 1:

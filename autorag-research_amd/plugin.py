@@ -1,0 +1,13 @@
+"""Entry-point target for `[project.entry-points."autorag_research.pipelines"]`.
+
+The reference's plugin registry (plugin_registry.py:199-255) resolves the entry point to a MODULE and
+copies the YAML files it finds in that module's package (flat or under `retrieval/`) into
+`configs/pipelines/retrieval/` on `autorag-research plugin sync`.  The YAMLs live in ./retrieval/.
+"""
+
+from .pipelines import (  # noqa: F401
+    Mi355ImageVectorSearchPipelineConfig,
+    Mi355ImageVectorSearchRetrievalPipeline,
+    Mi355VectorSearchPipelineConfig,
+    Mi355VectorSearchRetrievalPipeline,
+)

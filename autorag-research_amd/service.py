@@ -1,0 +1,256 @@
+"""Mi355RetrievalService -- host-side mirror of RetrievalPipelineService for the Vector Search path.
+
+Same method names, argument meaning, return shapes and error behaviour as the reference
+(autorag_research/orm/service/retrieval_pipeline.py):
+  vector_search(query_ids, top_k, search_mode)          :467-525  score = 1 - distance | -distance / n_q
+  vector_search_by_embedding(embedding, top_k)          :527-550
+  run_pipeline / run_image_pipeline / _run_pipeline     :184-357  paging, resume-skip, retry, persistence, stats
+  _collect_retrieval_results                            :151-182
+  _make_retrieval_result                                :374-384  {"doc_id","score","content"}
+  find_query_by_text                                    :386-400
+The difference is WHERE the arithmetic runs: the two SQL operators the reference sends to PostgreSQL
+(orm/repository/base.py:409-415 `<=>`, :518-524 `@#`) are answered by libmi355dr on the GPU, and a whole
+list of query ids is scored as ONE block per corpus pass instead of one SQL statement per query.
+"""
+
+from __future__ import annotations
+
+import asyncio
+import logging
+from collections.abc import Awaitable, Callable
+from typing import Any, Literal
+
+import numpy as np
+
+from .index import Mi355Index
+from .store import ChunkTable, InMemoryStore
+
+logger = logging.getLogger("AutoRAG-Research")
+
+RetrievalFunc = Callable[[int | str, int], Awaitable[list[dict[str, Any]]]]
+
+
+class _UnitIndex:
+    """GPU index of one table (chunk / image_chunk): row <-> primary-key mapping + the native handle."""
+
+    def __init__(self, table: ChunkTable, device: int):
+        self.table = table
+        self.single: Mi355Index | None = None
+        self.multi: Mi355Index | None = None
+        self.single_rows: np.ndarray | None = None  # index row -> table position (NULL embeddings skipped)
+        self.multi_rows: np.ndarray | None = None
+        self.device = device
+
+    def ensure_single(self) -> Mi355Index:
+        if self.single is None:
+            emb = self.table.embedding
+            if emb is None:
+                raise ValueError("table has no single-vector embeddings")
+            not_null = ~np.isnan(emb).all(axis=1)  # WHERE embedding IS NOT NULL
+            self.single_rows = np.nonzero(not_null)[0]
+            self.single = Mi355Index(emb.shape[1], "cosine", self.device)
+            self.single.add(emb[not_null] if not not_null.all() else emb)
+        return self.single
+
+    def ensure_multi(self) -> Mi355Index:
+        if self.multi is None:
+            tok, off = self.table.mv_tokens, self.table.mv_offsets
+            if tok is None or off is None:
+                raise ValueError("table has no multi-vector embeddings")
+            self.multi = Mi355Index(tok.shape[1], "cosine", self.device)
+            self.multi.add_multivec(tok, off)
+            self.multi_rows = np.arange(off.shape[0] - 1)
+        return self.multi
+
+    def close(self) -> None:
+        for ix in (self.single, self.multi):
+            if ix is not None:
+                ix.close()
+        self.single = self.multi = None
+
+
+class Mi355RetrievalService:
+    def __init__(self, session_factory: Callable[[], InMemoryStore], schema: Any | None = None, device: int = 0):
+        self.session_factory = session_factory
+        self._schema = schema
+        self._device = device
+        self._units: dict[str, _UnitIndex] = {}
+
+    # ---- plumbing ----
+    def _store(self) -> InMemoryStore:
+        return self.session_factory()
+
+    def _unit(self, unit: str) -> _UnitIndex:
+        if unit not in self._units:
+            store = self._store()
+            self._units[unit] = _UnitIndex(store.image_chunks if unit == "image_chunk" else store.chunks, self._device)
+        return self._units[unit]
+
+    def close(self) -> None:
+        for u in self._units.values():
+            u.close()
+        self._units.clear()
+
+    def get_or_create_pipeline(self, name: str, config: dict[str, Any]) -> tuple[int, bool]:
+        return self._store().get_or_create_pipeline(name, config)
+
+    def find_query_by_text(self, query_text: str):
+        return self._store().find_query_by_text(query_text)
+
+    def _make_retrieval_result(self, table: ChunkTable, pos: int, score: float, with_content: bool) -> dict[str, Any]:
+        return {"doc_id": table.ids[pos], "score": score, "content": table.contents[pos] if with_content else None}
+
+    # ---- the hot path ----
+    def vector_search(self, query_ids: list[int | str], top_k: int = 10,
+                      search_mode: Literal["single", "multi"] = "single", unit: str = "chunk") -> list[list[dict]]:
+        """Top-k for every query id, scored as one block.  Raises ValueError exactly like the reference."""
+        store = self._store()
+        queries = []
+        for qid in query_ids:
+            q = store.get_query(qid)
+            if q is None:
+                raise ValueError(f"Query {qid} not found")  # noqa: TRY003
+            if search_mode == "multi":
+                if q.embeddings is None:
+                    raise ValueError(f"Query {qid} has no multi-vector embeddings")  # noqa: TRY003
+            elif q.embedding is None:
+                msg = f"Query {qid} has no embedding" if unit == "chunk" else f"Query {qid} has no single-vector embedding"
+                raise ValueError(msg)
+            queries.append(q)
+        if not queries:
+            return []
+        if search_mode == "multi":
+            return self.maxsim_search_by_embeddings([q.embeddings for q in queries], top_k, unit)
+        Q = np.stack([q.embedding for q in queries]).astype(np.float32, copy=False)
+        return self._single_block(Q, top_k, unit)
+
+    def _single_block(self, Q: np.ndarray, top_k: int, unit: str) -> list[list[dict]]:
+        u = self._unit(unit)
+        ix = u.ensure_single()
+        dist, rows = ix.search(Q, top_k)
+        out = []
+        for b in range(Q.shape[0]):
+            res = []
+            for dv, r in zip(dist[b], rows[b]):
+                if r < 0:
+                    break
+                # reference: score = 1 - distance (retrieval_pipeline.py:522-524), Python float arithmetic
+                res.append(self._make_retrieval_result(u.table, int(u.single_rows[r]), 1 - float(dv), unit == "chunk"))
+            out.append(res)
+        return out
+
+    def vector_search_by_embedding(self, embedding: list[float], top_k: int = 10, unit: str = "chunk") -> list[dict]:
+        if len(embedding) == 0:  # reference: `if not query_vector: return []` (base.py:403-404)
+            return []
+        return self._single_block(np.asarray(embedding, dtype=np.float32)[None, :], top_k, unit)[0]
+
+    def maxsim_search_by_embeddings(self, query_vectors: list, top_k: int, unit: str = "chunk") -> list[list[dict]]:
+        u = self._unit(unit)
+        ix = u.ensure_multi()
+        mats = [np.asarray(qv, dtype=np.float32).reshape(-1, ix.dim) for qv in query_vectors]
+        lens = [m.shape[0] for m in mats]
+        live = [i for i, n in enumerate(lens) if n > 0]
+        out: list[list[dict]] = [[] for _ in mats]  # reference: `if not query_vectors: return []`
+        if not live:
+            return out
+        qtok = np.concatenate([mats[i] for i in live], axis=0)
+        qoff = np.concatenate([[0], np.cumsum([lens[i] for i in live])]).astype(np.int32)
+        dist, rows = ix.search_maxsim(qtok, qoff, top_k)
+        for j, i in enumerate(live):
+            n_q = max(1, lens[i])
+            res = []
+            for dv, r in zip(dist[j], rows[j]):
+                if r < 0:
+                    break
+                # reference: score = -distance / n_query_vectors (retrieval_pipeline.py:511-514)
+                res.append(self._make_retrieval_result(u.table, int(u.multi_rows[r]), -float(dv) / n_q, unit == "chunk"))
+            out[i] = res
+        return out
+
+    # ---- batch driver (reference _run_pipeline) ----
+    @staticmethod
+    def _collect_retrieval_results(query_ids, results, pipeline_id, failed_queries, result_id_key) -> list[dict]:
+        rows = []
+        for qid, res in zip(query_ids, results, strict=True):
+            if res is None:
+                failed_queries.append(qid)
+                continue
+            for r in res:
+                rows.append({"query_id": qid, "pipeline_id": pipeline_id, result_id_key: r["doc_id"], "rel_score": r["score"]})
+        return rows
+
+    def _run_pipeline(self, retrieval_func: RetrievalFunc | None, pipeline_id: int, unit: str, top_k: int = 10,
+                      batch_size: int = 128, max_concurrency: int = 16, max_retries: int = 3, retry_delay: float = 1.0,
+                      query_limit: int | None = None,
+                      block_func: Callable[[list, int], list[list[dict] | None]] | None = None) -> dict[str, Any]:
+        """Page through queries, skip completed ones, retrieve, persist; returns the reference's stats dict.
+
+        `retrieval_func` is the reference's per-query coroutine contract (retry with exponential backoff,
+        at most `max_concurrency` in flight).  `block_func`, when given, scores a whole page of ids in one
+        GPU block instead (results aligned with the ids, None = failed query).
+        """
+        store = self._store()
+        result_id_key = "image_chunk_id" if unit == "image_chunk" else "chunk_id"
+        configured = store.pipelines.get(pipeline_id, {}).get("config", {}).get("retrieval_unit", "chunk")
+        if configured == "mixed":
+            raise ValueError(f"Pipeline {pipeline_id!r} is configured for mixed results, which cannot be persisted directly.")
+        if configured != unit:
+            raise ValueError(f"Pipeline {pipeline_id!r} is configured for {configured} results; "
+                             f"refusing to persist {unit} results into the same pipeline identity.")
+
+        async def one(qid) -> list[dict] | None:
+            assert retrieval_func is not None
+            delay = retry_delay
+            for attempt in range(max(1, max_retries)):
+                try:
+                    return await retrieval_func(qid, top_k)
+                except Exception:  # noqa: BLE001
+                    if attempt + 1 >= max(1, max_retries):
+                        logger.exception(f"Retrieval failed for query {qid} after {max_retries} attempts")
+                        return None
+                    await asyncio.sleep(min(max(delay, retry_delay), 60))
+                    delay *= 2
+            return None
+
+        async def page(qids) -> list[list[dict] | None]:
+            sem = asyncio.Semaphore(max(1, max_concurrency))
+
+            async def guarded(q):
+                async with sem:
+                    return await one(q)
+
+            return list(await asyncio.gather(*[guarded(q) for q in qids]))
+
+        total_queries = total_results = offset = 0
+        failed: list = []
+        while True:
+            if query_limit is not None and total_queries >= query_limit:
+                break
+            eff = min(batch_size, query_limit - total_queries) if query_limit is not None else batch_size
+            queries = store.get_all_queries(limit=eff, offset=offset)
+            if not queries:
+                break
+            qids = [q.id for q in queries]
+            done = store.completed_query_ids(unit, pipeline_id, qids)
+            qids = [q for q in qids if q not in done]
+            if not qids:
+                offset += batch_size
+                continue
+            results = block_func(qids, top_k) if block_func is not None else asyncio.run(page(qids))
+            rows = self._collect_retrieval_results(qids, results, pipeline_id, failed, result_id_key)
+            if rows:
+                store.bulk_insert(unit, rows)
+                total_results += len(rows)
+            total_queries += len([r for r in results if r is not None])
+            offset += len(queries)
+            logger.info(f"Processed {total_queries} queries, stored {total_results} results")
+        if failed:
+            logger.warning(f"Failed to process {len(failed)} queries after retries: {failed}")
+        return {"pipeline_id": pipeline_id, "total_queries": total_queries, "total_results": total_results,
+                "failed_queries": failed}
+
+    def run_pipeline(self, retrieval_func: RetrievalFunc, pipeline_id: int, **kw) -> dict[str, Any]:
+        return self._run_pipeline(retrieval_func, pipeline_id, "chunk", **kw)
+
+    def run_image_pipeline(self, retrieval_func: RetrievalFunc, pipeline_id: int, **kw) -> dict[str, Any]:
+        return self._run_pipeline(retrieval_func, pipeline_id, "image_chunk", **kw)

@@ -1,0 +1,141 @@
+"""InMemoryStore -- the handful of tables the Vector Search path touches, without PostgreSQL.
+
+The reference keeps these in PostgreSQL (postgresql/db/init/001-schema.sql:98-138 chunk / image_chunk /
+query with `embedding VECTOR(d)` and `embeddings VECTOR(d)[]`; :186-201 the retrieved-result tables
+with PK (query_id, pipeline_id, chunk_id) and `rel_score FLOAT`).  This store holds the same columns as
+numpy arrays so the service/pipeline mirror (service.py, pipelines.py) can run standalone -- on the GPU
+box, in the bench harness and in tests -- and so a DB exporter has a concrete target format
+(INTEGRATION.md).  Primary keys may be int (BIGINT) or str (VARCHAR) as in schema_factory.py:63-76.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any
+
+import numpy as np
+
+
+@dataclass
+class QueryRow:
+    id: int | str
+    contents: str | None = None
+    embedding: np.ndarray | None = None     # [d] fp32 (VECTOR(d)) or None (NULL)
+    embeddings: np.ndarray | None = None    # [n_q, d] fp32 (VECTOR(d)[]) or None
+
+
+@dataclass
+class RetrievalRelation:
+    """Ground truth row (reference 001-schema.sql retrieval_relation: group_index = AND, group_order = OR)."""
+
+    query_id: int | str
+    group_index: int
+    group_order: int
+    chunk_id: int | str | None = None
+    image_chunk_id: int | str | None = None
+    score: int | None = None
+
+
+@dataclass
+class ChunkTable:
+    """chunk or image_chunk: ids, optional contents, single- and/or multi-vector embeddings."""
+
+    ids: list[int | str] = field(default_factory=list)
+    contents: list[str | None] = field(default_factory=list)
+    embedding: np.ndarray | None = None          # [N, d] fp32; rows of NaN = NULL embedding (skipped by SQL)
+    mv_tokens: np.ndarray | None = None          # [sum_T, d] fp32 ragged multi-vector store
+    mv_offsets: np.ndarray | None = None         # [N+1] int64; empty span = NULL embeddings
+
+    def __len__(self) -> int:
+        return len(self.ids)
+
+
+class InMemoryStore:
+    def __init__(self) -> None:
+        self.queries: dict[int | str, QueryRow] = {}
+        self.query_order: list[int | str] = []
+        self.chunks = ChunkTable()
+        self.image_chunks = ChunkTable()
+        self.relations: dict[int | str, list[RetrievalRelation]] = {}
+        self.pipelines: dict[int, dict[str, Any]] = {}
+        self._pipeline_by_name: dict[str, int] = {}
+        # result tables: {(pipeline_id, query_id): [(chunk_id, rel_score), ...]} in insertion order
+        self.chunk_results: dict[tuple[int, int | str], list[tuple[int | str, float]]] = {}
+        self.image_chunk_results: dict[tuple[int, int | str], list[tuple[int | str, float]]] = {}
+
+    # ---- filling ----
+    def add_queries(self, ids, contents=None, embedding=None, embeddings=None) -> None:
+        for i, qid in enumerate(ids):
+            row = QueryRow(
+                id=qid,
+                contents=None if contents is None else contents[i],
+                embedding=None if embedding is None or embedding[i] is None
+                else np.ascontiguousarray(embedding[i], dtype=np.float32),
+                embeddings=None if embeddings is None or embeddings[i] is None
+                else np.ascontiguousarray(embeddings[i], dtype=np.float32),
+            )
+            if qid not in self.queries:
+                self.query_order.append(qid)
+            self.queries[qid] = row
+
+    def _fill(self, table: ChunkTable, ids, contents, embedding, multivec) -> None:
+        table.ids = list(ids)
+        table.contents = list(contents) if contents is not None else [None] * len(table.ids)
+        if embedding is not None:
+            table.embedding = np.ascontiguousarray(embedding, dtype=np.float32)
+            if table.embedding.shape[0] != len(table.ids):
+                raise ValueError("embedding rows != ids")
+        if multivec is not None:
+            toks = [np.ascontiguousarray(m, dtype=np.float32) if m is not None and len(m) else None for m in multivec]
+            if len(toks) != len(table.ids):
+                raise ValueError("multivec docs != ids")
+            d = next((t.shape[1] for t in toks if t is not None), 0)
+            lens = [0 if t is None else t.shape[0] for t in toks]
+            table.mv_offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            table.mv_tokens = (np.concatenate([t for t in toks if t is not None], axis=0)
+                               if any(t is not None for t in toks) else np.zeros((0, d), np.float32))
+
+    def set_chunks(self, ids, contents=None, embedding=None, multivec=None) -> None:
+        self._fill(self.chunks, ids, contents, embedding, multivec)
+
+    def set_image_chunks(self, ids, embedding=None, multivec=None) -> None:
+        self._fill(self.image_chunks, ids, None, embedding, multivec)
+
+    def add_relations(self, rels: list[RetrievalRelation]) -> None:
+        for r in rels:
+            self.relations.setdefault(r.query_id, []).append(r)
+
+    # ---- what the service reads (names follow the reference repositories) ----
+    def get_query(self, qid):
+        return self.queries.get(qid)
+
+    def get_all_queries(self, limit: int, offset: int) -> list[QueryRow]:
+        return [self.queries[q] for q in self.query_order[offset: offset + limit]]
+
+    def find_query_by_text(self, text: str):
+        for qid in self.query_order:
+            if self.queries[qid].contents == text:
+                return self.queries[qid]
+        return None
+
+    # ---- pipelines / results ----
+    def get_or_create_pipeline(self, name: str, config: dict[str, Any]) -> tuple[int, bool]:
+        if name in self._pipeline_by_name:
+            return self._pipeline_by_name[name], False
+        pid = len(self.pipelines) + 1
+        self.pipelines[pid] = {"name": name, "config": dict(config)}
+        self._pipeline_by_name[name] = pid
+        return pid, True
+
+    def results_table(self, unit: str):
+        return self.image_chunk_results if unit == "image_chunk" else self.chunk_results
+
+    def completed_query_ids(self, unit: str, pipeline_id: int, query_ids) -> set:
+        tab = self.results_table(unit)
+        return {q for q in query_ids if tab.get((pipeline_id, q))}
+
+    def bulk_insert(self, unit: str, rows: list[dict[str, Any]]) -> None:
+        tab = self.results_table(unit)
+        key = "image_chunk_id" if unit == "image_chunk" else "chunk_id"
+        for r in rows:
+            tab.setdefault((r["pipeline_id"], r["query_id"]), []).append((r[key], float(r["rel_score"])))

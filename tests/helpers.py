@@ -1,0 +1,96 @@
+"""Shared test helpers: oracle-backed stand-in for the GPU index (CPU tests), golden-input regeneration."""
+
+from __future__ import annotations
+
+import json
+from pathlib import Path
+
+import numpy as np
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+class OracleIndex:
+    """Same surface as autorag_research_amd.index.Mi355Index for what service.py uses, answered by the CPU oracle.
+
+    Test infrastructure: lets the host logic (service / pipelines / sharding) run under `-m "not gpu"`.
+    """
+
+    def __init__(self, dim: int, metric: str = "cosine", device: int = 0):
+        from oracle import cpu_ref
+
+        self._o = cpu_ref
+        self.dim, self.metric, self.device = dim, metric, device
+        self._rows = np.zeros((0, dim), np.float32)
+        self._tok = None
+        self._off = None
+        self.row_offset = 0
+
+    def add(self, rows):
+        self._rows = np.concatenate([self._rows, np.ascontiguousarray(rows, dtype=np.float32)], axis=0)
+
+    def __len__(self):
+        return self._rows.shape[0]
+
+    def search(self, queries, k):
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        d, r = self._o.topk_search(self._rows, q, k, metric=self.metric)
+        r = np.where(r >= 0, r + self.row_offset, r)
+        return d, r
+
+    def add_multivec(self, vecs, offsets):
+        self._tok = np.ascontiguousarray(vecs, dtype=np.float32)
+        self._off = np.ascontiguousarray(offsets, dtype=np.int64)
+
+    def search_maxsim(self, qtok, q_offsets, k):
+        return self._o.maxsim_topk(self._tok, self._off, qtok, q_offsets, k)
+
+    def set_option(self, key, value):
+        if key == "row_offset":
+            self.row_offset = int(value)
+
+    def close(self):
+        pass
+
+
+def service_golden_inputs():
+    """Regenerate the arrays tests/golden/make_golden.py:make_service() used (same rng call order)."""
+    rng = np.random.default_rng(4242)
+    n, d = 300, 32
+    C = rng.standard_normal((n, d)).astype(np.float32)
+    ids = [int(1000 + 3 * i) for i in range(n)]
+    contents = [f"chunk text {i}" for i in range(n)]
+    dm = 8
+    lens = rng.integers(2, 9, size=n)
+    tok = rng.standard_normal((int(lens.sum()), dm)).astype(np.float32)
+    tok /= np.linalg.norm(tok, axis=1, keepdims=True)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    Q = rng.standard_normal((6, d)).astype(np.float32)
+    Qm = []
+    for t in (1, 4, 5, 2, 3, 6):
+        m = rng.standard_normal((t, dm)).astype(np.float32)
+        m /= np.linalg.norm(m, axis=1, keepdims=True)
+        Qm.append(m)
+    multivec = [tok[offsets[i]:offsets[i + 1]] for i in range(n)]
+    return dict(C=C, ids=ids, contents=contents, tok=tok, offsets=offsets, multivec=multivec, Q=Q, Qm=Qm,
+                img_ids=[f"img-{i}" for i in range(n)])
+
+
+def load_service_golden():
+    return json.loads((GOLDEN / "service_golden.json").read_text())
+
+
+def build_golden_stores():
+    """Two stores like the reference's two databases: single-vector (dim 32) and multi-vector (dim 8)."""
+    from autorag_research_amd.store import InMemoryStore
+
+    g = service_golden_inputs()
+    s = InMemoryStore()
+    s.set_chunks(g["ids"], g["contents"], embedding=g["C"], multivec=g["multivec"])
+    s.set_image_chunks(g["img_ids"], embedding=g["C"], multivec=g["multivec"])
+    qids = [f"q{i}" for i in range(6)]
+    s.add_queries(qids, contents=[f"query text {i}" for i in range(6)], embedding=list(g["Q"]), embeddings=g["Qm"])
+    s.add_queries(["q_noemb"], contents=["no embedding"], embedding=[None], embeddings=[None])
+    return s, g
