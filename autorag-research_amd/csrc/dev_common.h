@@ -90,6 +90,53 @@ __device__ __forceinline__ int next_pow2(int x) {
     return p;
 }
 
+// ---- bitonic sorts over LDS arrays (n = power of two, all threads of the block participate) ----
+__device__ __forceinline__ void bitonic_desc_f32(float* v, int n) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const bool desc = ((i & k) == 0);
+                    const float a = v[i], b = v[p];
+                    if (desc ? (a < b) : (a > b)) {
+                        v[i] = b;
+                        v[p] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ bool key_before(uint64_t k1, int32_t r1, uint64_t k2, int32_t r2) {
+    return k1 < k2 || (k1 == k2 && r1 < r2);
+}
+
+__device__ __forceinline__ void bitonic_asc_key_row(uint64_t* key, int32_t* row, int n) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const bool asc = ((i & k) == 0);
+                    const uint64_t ka = key[i], kb = key[p];
+                    const int32_t ra = row[i], rb = row[p];
+                    const bool a_after_b = key_before(kb, rb, ka, ra);
+                    if (asc ? a_after_b : key_before(ka, ra, kb, rb)) {
+                        key[i] = kb;
+                        key[p] = ka;
+                        row[i] = rb;
+                        row[p] = ra;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // ---- one-wave staged fp32 chains ---------------------------------------------------------------
 // 64 lanes own 64 "slots" (rows).  Rows are pulled from global memory 64 columns at a time with
 // row-contiguous (coalesced) loads into a padded LDS tile, then every lane walks its own row of the

@@ -1,0 +1,127 @@
+"""GPU parity: MaxSim (VectorChord `@#`) through the C ABI vs the CPU oracle -- fp32 distances and doc ids bit-exact."""
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg(native_built):
+    import autorag_research_amd as p
+
+    return p
+
+
+def _ragged(rng, n_docs, d, tmin, tmax, unit=True):
+    lens = rng.integers(tmin, tmax + 1, size=n_docs)
+    tok = rng.standard_normal((int(lens.sum()), d)).astype(np.float32)
+    if unit:
+        tok /= np.linalg.norm(tok, axis=1, keepdims=True)
+    return tok, np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+
+
+def _queries(rng, lens, d, unit=True):
+    qs = []
+    for t in lens:
+        m = rng.standard_normal((t, d)).astype(np.float32)
+        if unit and t:
+            m /= np.linalg.norm(m, axis=1, keepdims=True)
+        qs.append(m)
+    qtok = np.concatenate(qs, axis=0) if qs else np.zeros((0, d), np.float32)
+    return qtok, np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+
+
+def _check(idx, oracle, tok, off, qtok, qoff, k):
+    dist, rows = idx.search_maxsim(qtok, qoff, k)
+    rd, rr = oracle.maxsim_topk(tok, off, qtok, qoff, k)
+    assert np.array_equal(rows, rr)
+    assert np.array_equal(np.isnan(dist), np.isnan(rd))
+    ok = ~np.isnan(dist)
+    assert np.array_equal(dist[ok].view(np.uint32), rd[ok].view(np.uint32))
+
+
+def test_golden_inputs(pkg, oracle):
+    g = np.load(GOLDEN / "scores_golden.npz")
+    tok, off, qtok, qoff = g["ms_tok"], g["ms_offsets"], g["ms_qtok"], g["ms_qoff"]
+    with pkg.Mi355Index(tok.shape[1]) as idx:
+        idx.add_multivec(tok, off)
+        assert idx.n_docs() == off.shape[0] - 1
+        _check(idx, oracle, tok, off, qtok, qoff, 5)
+        # and the documented score = -distance / n_q agrees with the reference's float64 helper
+        dist, rows = idx.search_maxsim(qtok, qoff, 5)
+        for b in range(qoff.shape[0] - 1):
+            nq = qoff[b + 1] - qoff[b]
+            assert np.abs(-dist[b].astype(np.float64) / nq - g["ms_scores"][b][rows[b]]).max() <= 1e-6
+
+
+@pytest.mark.parametrize("d,n_docs,tmin,tmax,qlens,k", [
+    (128, 3000, 1, 180, [32, 24, 1, 32, 32, 7], 10),      # ColBERT-like text docs, several queries per launch
+    (128, 60, 1030, 1030, [24, 20], 10),                  # ColPali-like pages: 1030 patches per doc
+    (128, 500, 1, 40, [128, 100], 100),                   # 4 column blocks, k=100
+    (96, 700, 1, 70, [5, 33], 10),                        # dim not a power of two, 2 column blocks
+    (20, 300, 1, 9, [3], 400),                            # dim padded to 24, k > n_docs
+])
+def test_maxsim_matches_oracle(pkg, oracle, d, n_docs, tmin, tmax, qlens, k):
+    rng = np.random.default_rng(d * 1000 + n_docs)
+    tok, off = _ragged(rng, n_docs, d, tmin, tmax)
+    qtok, qoff = _queries(rng, qlens, d)
+    with pkg.Mi355Index(d) as idx:
+        idx.add_multivec(tok, off)
+        _check(idx, oracle, tok, off, qtok, qoff, k)
+
+
+def test_empty_docs_appends_and_unnormalised(pkg, oracle):
+    rng = np.random.default_rng(77)
+    d = 64
+    tok, off = _ragged(rng, 200, d, 0, 12, unit=False)  # some docs have zero vectors (NULL embeddings)
+    assert (np.diff(off) == 0).any()
+    qtok, qoff = _queries(rng, [4, 0, 9], d, unit=False)  # an empty query returns nothing
+    half = 100
+    with pkg.Mi355Index(d) as idx:
+        idx.add_multivec(tok[: off[half]], off[: half + 1])
+        idx.add_multivec(tok[off[half]:], off[half:] - off[half])  # appended in two calls
+        assert idx.n_docs() == 200
+        dist, rows = idx.search_maxsim(qtok, qoff, 20)
+        rd, rr = oracle.maxsim_topk(tok, off, qtok, qoff, 20)
+        assert np.array_equal(rows[[0, 2]], rr[[0, 2]])
+        assert np.array_equal(dist[[0, 2]].view(np.uint32), rd[[0, 2]].view(np.uint32))
+        assert (rows[1] == -1).all()
+
+
+def test_service_and_pipelines_on_gpu_match_reference_dicts(pkg):
+    """the host mirror over the REAL GPU index reproduces the reference's output dicts (service_golden.json)."""
+    import asyncio
+
+    from helpers import build_golden_stores, load_service_golden
+    from autorag_research_amd.pipelines import (Mi355ImageVectorSearchRetrievalPipeline,
+                                                 Mi355VectorSearchRetrievalPipeline)
+    from autorag_research_amd.service import Mi355RetrievalService
+
+    store, g = build_golden_stores()
+    gold = load_service_golden()
+    k = gold["top_k"]
+
+    def same(got, exp):
+        assert [r["doc_id"] for r in got] == [r["doc_id"] for r in exp]
+        assert [r["content"] for r in got] == [r["content"] for r in exp]
+        assert np.allclose([r["score"] for r in got], [r["score"] for r in exp], rtol=0, atol=1e-12)
+
+    s = Mi355RetrievalService(lambda: store)
+    qids = [f"q{i}" for i in range(6)]
+    for got, exp in zip(s.vector_search(qids, k, "single"), gold["service_single"], strict=True):
+        same(got, exp)
+    for got, exp in zip(s.vector_search(qids, k, "multi"), gold["service_multi"], strict=True):
+        same(got, exp)
+    same(s.vector_search_by_embedding([float(x) for x in g["Q"][2]], k), gold["service_by_embedding"])
+    s.close()
+    p = Mi355ImageVectorSearchRetrievalPipeline(lambda: store, "img", search_mode="multi")
+    same(asyncio.run(p._retrieve_by_id("q2", k)), gold["image_pipeline_multi_q2"])
+    stats = p.run(top_k=4)
+    assert stats["total_queries"] == 6 and stats["failed_queries"] == ["q_noemb"]
+    p.close()
+    p1 = Mi355VectorSearchRetrievalPipeline(lambda: store, "txt", search_mode="single")
+    same(asyncio.run(p1._retrieve_by_id("q1", k)), gold["pipeline_single_q1"])
+    p1.close()
