@@ -1,0 +1,98 @@
+"""Row-sharded multi-GPU search: one process per GPU, local exact top-k, one all-gather, one merge.
+
+The reference has no counterpart (its engine is a single PostgreSQL server, SURVEY.md section 2 rows
+32-34); this is the data-parallel form of `ORDER BY distance LIMIT k`: rank r owns a contiguous row range
+and returns GLOBAL row ids (local + row_offset), every rank all-gathers the [B,k] (float8 distance,
+int64 row) lists -- B*k*16 bytes per rank, e.g. 160 KiB at B=1024,k=10 -- and merges world*k -> k under
+the same total order (distance asc, NaN last, row asc), so the result is bit-identical to the
+single-GPU result.  `torch.distributed` is the transport: backend "nccl" is RCCL over xGMI on the GPU
+box (tensors stay on the device and the merge runs in libmi355dr), "gloo" on CPU tests (host merge).
+"""
+
+from __future__ import annotations
+
+from collections.abc import Callable
+from typing import Any
+
+import numpy as np
+
+
+def shard_bounds(n_rows: int, world: int, rank: int, granule: int = 1) -> tuple[int, int]:
+    """Contiguous [lo, hi) of rank's rows; boundaries are multiples of `granule` (except the end)."""
+    units = (n_rows + granule - 1) // granule
+    lo = min(n_rows, units * rank // world * granule)
+    hi = min(n_rows, units * (rank + 1) // world * granule)
+    return lo, hi
+
+
+def merge_topk_host(dist_all: np.ndarray, rows_all: np.ndarray, k: int) -> tuple[np.ndarray, np.ndarray]:
+    """[world,B,k] shard lists -> [B,k] under (distance asc, NaN last, row asc); pads with NaN / -1."""
+    world, B, kk = dist_all.shape
+    d = np.transpose(dist_all, (1, 0, 2)).reshape(B, world * kk)
+    r = np.transpose(rows_all, (1, 0, 2)).reshape(B, world * kk)
+    out_d = np.full((B, k), np.nan)
+    out_r = np.full((B, k), -1, dtype=np.int64)
+    for b in range(B):
+        valid = r[b] >= 0
+        db, rb = d[b][valid], r[b][valid]
+        nan = np.isnan(db)
+        order = np.lexsort((rb, np.where(nan, 0.0, db), nan))[:k]
+        out_d[b, : order.size] = db[order]
+        out_r[b, : order.size] = rb[order]
+    return out_d, out_r
+
+
+class ShardedSearcher:
+    """One rank's view of a row-sharded corpus."""
+
+    def __init__(self, dim: int, metric: str = "cosine", device: int = 0, index_factory: Callable[..., Any] | None = None,
+                 group: Any | None = None):
+        import torch.distributed as dist
+
+        if index_factory is None:
+            from .index import Mi355Index
+
+            index_factory = Mi355Index
+        self._dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.backend = dist.get_backend(group) if dist.is_initialized() else None
+        self.index = index_factory(dim, metric, device)
+        self.device = device
+        self.row_offset = 0
+
+    def add_local(self, rows, global_row0: int) -> None:
+        """Add this rank's rows; `global_row0` is the global index of its first row (set once)."""
+        if len(self.index) == 0:
+            self.row_offset = int(global_row0)
+            self.index.set_option("row_offset", self.row_offset)
+        self.index.add(rows)
+
+    def search(self, queries, k: int) -> tuple[np.ndarray, np.ndarray]:
+        """Every rank passes the same queries; every rank gets the same global [B,k] result."""
+        dist_l, rows_l = self.index.search(queries, k)
+        if self.world == 1:
+            return dist_l, rows_l
+        import torch
+
+        on_gpu = self.backend == "nccl"
+        dev = torch.device("cuda", self.device) if on_gpu else torch.device("cpu")
+        td = torch.from_numpy(np.ascontiguousarray(dist_l)).to(dev)
+        tr = torch.from_numpy(np.ascontiguousarray(rows_l)).to(dev)
+        B = td.shape[0]
+        all_d = torch.empty((self.world, B, k), dtype=torch.float64, device=dev)
+        all_r = torch.empty((self.world, B, k), dtype=torch.int64, device=dev)
+        self._dist.all_gather_into_tensor(all_d.view(-1), td.view(-1), group=self.group)
+        self._dist.all_gather_into_tensor(all_r.view(-1), tr.view(-1), group=self.group)
+        if on_gpu and hasattr(self.index, "merge_topk_device"):
+            out_d = torch.empty((B, k), dtype=torch.float64, device=dev)
+            out_r = torch.empty((B, k), dtype=torch.int64, device=dev)
+            torch.cuda.current_stream().synchronize()
+            self.index.merge_topk_device(all_d.data_ptr(), all_r.data_ptr(), self.world, B, k, out_d.data_ptr(),
+                                         out_r.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            return out_d.cpu().numpy(), out_r.cpu().numpy()
+        return merge_topk_host(all_d.cpu().numpy(), all_r.cpu().numpy(), k)
+
+    def close(self) -> None:
+        self.index.close()

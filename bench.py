@@ -44,8 +44,8 @@ def parse_args():
     ap.add_argument("--chunk0", type=int, default=0, help="override the first (emit-all) chunk size")
     ap.add_argument("--growth", type=int, default=0, help="override the chunk growth factor")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
-    ap.add_argument("--cpu-sample-queries", type=int, default=64)
+    ap.add_argument("--cpu-sample-rows", type=int, default=2_500_000)
+    ap.add_argument("--cpu-sample-queries", type=int, default=1024)
     return ap.parse_args()
 
 
@@ -97,15 +97,20 @@ def main() -> None:
     if args.growth:
         idx.set_option("chunk_growth", args.growth)
     t_build = time.time()
-    keep_sample = None
+    keep_parts = []
+    keep_rows = 0
+    want_sample = rank == 0 and world == 1 and not args.no_cpu_baseline
     for c in range(c_lo, c_hi):
         rows = min(CHUNK_ROWS, n_total - c * CHUNK_ROWS)
         x = gen_chunk(torch, c, rows, d, device)
         torch.cuda.synchronize()
         idx.add_device(x.data_ptr(), rows)
-        if rank == 0 and c == c_lo and not args.no_cpu_baseline:
-            keep_sample = x[: min(rows, args.cpu_sample_rows)].clone()
+        if want_sample and keep_rows < args.cpu_sample_rows:
+            take = min(rows, args.cpu_sample_rows - keep_rows)
+            keep_parts.append(x[:take].cpu().numpy())  # host copy of the first rows for the CPU baseline
+            keep_rows += take
         del x
+    keep_sample = np.concatenate(keep_parts, axis=0) if keep_parts else None
     torch.cuda.synchronize()
     t_build = time.time() - t_build
 
@@ -232,8 +237,8 @@ def main() -> None:
         from oracle import cpu_ref
 
         S = keep_sample.shape[0]
-        nq = args.cpu_sample_queries
-        Cs = keep_sample.cpu().numpy()
+        nq = min(args.cpu_sample_queries, B)
+        Cs = keep_sample
         Qs = qpool[0, :nq].cpu().numpy()
         cpu_ref.topk_search(Cs[:2048], Qs[:8], k)  # warm the library / thread pool
         tc = time.perf_counter()
@@ -241,7 +246,7 @@ def main() -> None:
         tc = time.perf_counter() - tc
         # parity on the very same sample, through the C ABI
         with pkg.Mi355Index(d, "cosine", device=local_rank) as sidx:
-            sidx.add_device(keep_sample.data_ptr(), S)
+            sidx.add(Cs)
             gd, gr = sidx.search(Qs, k)
         parity = bool(np.array_equal(gr, rr) and np.array_equal(gd, rd))
         qps_sample = nq / tc

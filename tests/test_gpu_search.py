@@ -114,3 +114,54 @@ def test_near_ties_stress(pkg, oracle):
     with pkg.Mi355Index(d) as idx:
         idx.add(C)
         _check(idx, oracle, C, Q, 25)
+
+
+def test_merge_topk_device_equals_host_merge(pkg):
+    """the shard-merge kernel == the host merge (total order incl. cross-shard ties, NaN, -1 padding)."""
+    from autorag_research_amd.sharded import merge_topk_host
+
+    rng = np.random.default_rng(5)
+    world, B, k = 4, 37, 10
+    d = np.sort(rng.random((world, B, k)), axis=2)
+    r = rng.integers(0, 10_000_000_000, size=(world, B, k))  # global rows beyond int32
+    d[1, :, 3] = d[0, :, 2]            # cross-shard distance ties -> lower row wins
+    d[2, 5, 7:] = np.nan               # NaN tail on one shard
+    r[3, :, 8:] = -1                   # short shard list
+    d[3, :, 8:] = np.nan
+    with pkg.Mi355Index(8) as idx:
+        pd, pr = idx.dev_alloc(d.nbytes), idx.dev_alloc(r.nbytes)
+        od, orr = idx.dev_alloc(B * k * 8), idx.dev_alloc(B * k * 8)
+        idx.dev_upload(pd, d)
+        idx.dev_upload(pr, r.astype(np.int64))
+        idx.merge_topk_device(pd, pr, world, B, k, od, orr)
+        gd, gr = np.empty((B, k)), np.empty((B, k), dtype=np.int64)
+        idx.dev_download(od, gd)
+        idx.dev_download(orr, gr)
+        for p in (pd, pr, od, orr):
+            idx.dev_free(p)
+    hd, hr = merge_topk_host(d, r.astype(np.int64), k)
+    assert np.array_equal(gr, hr)
+    assert np.array_equal(gd, hd, equal_nan=True)
+
+
+def test_search_device_buffers_and_row_offset(pkg, oracle):
+    """device-resident queries/outputs (the bench path) + shard row offset."""
+    rng = np.random.default_rng(6)
+    n, d, B, k = 4000, 256, 50, 10
+    C = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    with pkg.Mi355Index(d) as idx:
+        pc = idx.dev_alloc(C.nbytes)
+        idx.dev_upload(pc, C)
+        idx.add_device(pc, n)
+        idx.dev_free(pc)
+        idx.set_option("row_offset", 1_000_000)
+        pq, od, orr = idx.dev_alloc(Q.nbytes), idx.dev_alloc(B * k * 8), idx.dev_alloc(B * k * 8)
+        idx.dev_upload(pq, Q)
+        idx.search_device(pq, B, k, od, orr)
+        gd, gr = np.empty((B, k)), np.empty((B, k), dtype=np.int64)
+        idx.dev_download(od, gd)
+        idx.dev_download(orr, gr)
+        assert np.array_equal(idx.get_rows(10, 3), C[10:13])
+    rd, rr = oracle.topk_search(C, Q, k)
+    assert np.array_equal(gr, rr + 1_000_000) and np.array_equal(gd, rd)

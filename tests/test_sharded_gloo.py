@@ -1,0 +1,77 @@
+"""CPU, world_size 2 over gloo: the row-sharded search + all-gather + merge equals the unsharded oracle."""
+
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank: int, world: int, port: int, out_dir: str):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from helpers import OracleIndex
+    from autorag_research_amd.sharded import ShardedSearcher, shard_bounds
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(123)
+    n, d, B, k = 3001, 48, 9, 12
+    C = rng.standard_normal((n, d)).astype(np.float32)
+    C[5] = C[2900]        # a cross-shard exact tie: the lower global row must win on every rank
+    C[17] = 0.0           # NaN distance on shard 0
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    lo, hi = shard_bounds(n, world, rank, granule=250)
+    s = ShardedSearcher(d, "cosine", index_factory=OracleIndex)
+    s.add_local(C[lo:hi], lo)
+    dist_g, rows_g = s.search(Q, k)
+    # k larger than one shard's rows still merges correctly
+    dist_big, rows_big = s.search(Q[:2], 40)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), d=dist_g, r=rows_g, db=dist_big, rb=rows_big, lo=lo, hi=hi)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_search_equals_unsharded(tmp_path, oracle):
+    import torch.multiprocessing as mp
+
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(123)
+    n, d, B, k = 3001, 48, 9, 12
+    C = rng.standard_normal((n, d)).astype(np.float32)
+    C[5] = C[2900]
+    C[17] = 0.0
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    rd, rr = oracle.topk_search(C, Q, k)
+    rdb, rrb = oracle.topk_search(C, Q[:2], 40)
+    outs = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    assert outs[0]["hi"] == outs[1]["lo"] and outs[0]["lo"] == 0 and outs[1]["hi"] == n
+    for o in outs:
+        assert np.array_equal(o["r"], rr) and np.array_equal(o["d"], rd, equal_nan=True)
+        assert np.array_equal(o["rb"], rrb) and np.array_equal(o["db"], rdb, equal_nan=True)
+
+
+def test_merge_and_bounds_unit():
+    from autorag_research_amd.sharded import merge_topk_host, shard_bounds
+
+    assert [shard_bounds(10_000_000, 8, r, 250_000) for r in (0, 7)] == [(0, 1_250_000), (8_750_000, 10_000_000)]
+    assert shard_bounds(5, 8, 7) == (4, 5) and shard_bounds(5, 8, 0) == (0, 0)
+    d = np.array([[[0.1, 0.5, np.nan]], [[0.1, 0.2, np.nan]]])      # world=2, B=1, k=3
+    r = np.array([[[7, 9, 11]], [[3, 4, -1]]])
+    od, orr = merge_topk_host(d, r, 4)
+    assert orr.tolist() == [[3, 7, 4, 9]] and od[0, :4].tolist() == [0.1, 0.1, 0.2, 0.5]
+    od, orr = merge_topk_host(d, r, 6)
+    assert orr.tolist() == [[3, 7, 4, 9, 11, -1]] and np.isnan(od[0, 4]) and np.isnan(od[0, 5])
