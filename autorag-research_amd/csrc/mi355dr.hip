@@ -5,6 +5,7 @@
 #include "k_prep.h"
 #include "k_scan.h"
 #include "k_screen.h"
+#include "k_screen256.h"
 #include "k_select.h"
 
 using namespace mi355;
@@ -31,7 +32,7 @@ namespace {
 int ensure_capacity(mi355dr_index* idx, int64_t want_rows) {
     if (want_rows <= idx->cap_rows) return MI355DR_OK;
     int64_t new_cap = std::max<int64_t>(want_rows, idx->cap_rows + idx->cap_rows / 2);
-    new_cap = round_up(std::max<int64_t>(new_cap, kTileM), kTileM);
+    new_cap = round_up(std::max<int64_t>(new_cap, kT2), kT2);  // whole 256-row screen tiles
     float* rows = nullptr;
     uint16_t* shadow = nullptr;
     float* nrm2 = nullptr;
@@ -97,6 +98,8 @@ int ensure_qstate(mi355dr_index* idx) {
                                           (int)scan_lds_bytes(idx->dim, per)));
     }
     HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen, hipFuncAttributeMaxDynamicSharedMemorySize, kScreenLds));
+    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen256<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kScreen256Lds));
     HIPCHECK(idx, hipFuncSetAttribute((const void*)k_merge_topk, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kSortMax * 12));
     idx->qstate_ready = true;
@@ -156,34 +159,45 @@ int launch_prune(mi355dr_index* idx, hipStream_t s, int nblocks, const int* qlis
     return MI355DR_OK;
 }
 
+// tile edge used for a block of B queries: the 256x256 ping-pong kernel from 129 queries up, else 128x128
+inline int screen_tile(int B) { return B > kTileN ? kT2 : kTileM; }
+
+// launch one screen pass over rows [r0, r_end) (r0 a multiple of the tile edge)
+int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t r_end, int cap) {
+    const int tile = screen_tile(B);
+    ScreenArgs sa{};
+    sa.shadow = idx->shadow;
+    sa.qhat = idx->st.qhat;
+    sa.thr = idx->st.thr;
+    sa.cnt = idx->st.cnt;
+    sa.cand_row = idx->cand_row;
+    sa.cand_val = idx->cand_val;
+    sa.dpad = idx->dpad;
+    sa.cap = cap;
+    sa.ct0 = (int)(r0 / tile);
+    sa.n_ctiles = (int)(round_up(r_end, tile) / tile) - sa.ct0;
+    sa.n_qtiles = (int)(round_up(B, tile) / tile);
+    sa.row_end = r_end;
+    const int64_t grid = round_up(sa.n_ctiles, 8) * sa.n_qtiles;
+    if (tile == kT2) hipLaunchKernelGGL(k_screen256<0>, dim3((unsigned)grid), dim3(512), kScreen256Lds, s, sa);
+    else hipLaunchKernelGGL(k_screen, dim3((unsigned)grid), dim3(256), kScreenLds, s, sa);
+    HIPCHECK(idx, hipGetLastError());
+    return MI355DR_OK;
+}
+
 // screen path over all rows for the B queries prepared in idx->st / idx->qdev
 int run_screen(mi355dr_index* idx, hipStream_t s, int B, int k) {
-    const int n_qtiles = (int)round_up(B, kTileN) / kTileN;
+    const int tile = screen_tile(B);
     int64_t done = 0;
-    int64_t chunk = std::max<int64_t>(kTileM, std::min<int64_t>(idx->chunk0_rows, idx->cap));
+    int64_t chunk = std::max<int64_t>(tile, std::min<int64_t>(idx->chunk0_rows, idx->cap));
     while (done < idx->n) {
-        int64_t end = std::min<int64_t>(idx->n, round_up(done + chunk, kTileM));
-        ScreenArgs sa{};
-        sa.shadow = idx->shadow;
-        sa.qhat = idx->st.qhat;
-        sa.thr = idx->st.thr;
-        sa.cnt = idx->st.cnt;
-        sa.cand_row = idx->cand_row;
-        sa.cand_val = idx->cand_val;
-        sa.dpad = idx->dpad;
-        sa.cap = idx->cap;
-        sa.ct0 = (int)(done / kTileM);
-        sa.n_ctiles = (int)(round_up(end, kTileM) / kTileM) - sa.ct0;
-        sa.n_qtiles = n_qtiles;
-        sa.row_end = end;
-        const int64_t grid = round_up(sa.n_ctiles, 8) * n_qtiles;
+        const int64_t end = std::min<int64_t>(idx->n, round_up(done + chunk, tile));
         EventPair ev{};
         if (idx->profile) {
             ev = take_events(idx);
             HIPCHECK(idx, hipEventRecord(ev.a, s));
         }
-        hipLaunchKernelGGL(k_screen, dim3((unsigned)grid), dim3(256), kScreenLds, s, sa);
-        HIPCHECK(idx, hipGetLastError());
+        CHECK(launch_screen(idx, s, B, done, end, idx->cap));
         if (idx->profile) {
             HIPCHECK(idx, hipEventRecord(ev.b, s));
             idx->ev_pending.push_back(ev);
@@ -193,7 +207,7 @@ int run_screen(mi355dr_index* idx, hipStream_t s, int B, int k) {
         idx->s_chunks++;
         CHECK(launch_prune(idx, s, B, nullptr, k, /*exact=*/0));
         done = end;
-        chunk = std::max<int64_t>(kTileM, done * idx->chunk_growth);
+        chunk = std::max<int64_t>(tile, done * idx->chunk_growth);
     }
     if (idx->irr_n > 0) {
         hipLaunchKernelGGL(k_emit_irregular, dim3(B), dim3(64), 0, s, idx->irr_rows, idx->irr_n, idx->st,
@@ -293,7 +307,7 @@ __global__ void k_set_int(int* p, int v) { *p = v; }
 int search_block(mi355dr_index* idx, hipStream_t s, const float* q_dev, int B, int k, double* out_dist_dev,
                  int64_t* out_rows_dev) {
     CHECK(ensure_qstate(idx));
-    const int Bpad = (int)round_up(B, kTileN);
+    const int Bpad = (int)round_up(B, screen_tile(B));
     if (q_dev != idx->qdev)
         HIPCHECK(idx, hipMemcpyAsync(idx->qdev, q_dev, (size_t)B * idx->dim * sizeof(float), hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(k_prep_queries, dim3(Bpad), dim3(64), (size_t)idx->dim * sizeof(float), s, idx->qdev, B,
@@ -633,31 +647,18 @@ int mi355dr_dev_download(mi355dr_index* idx, void* dst_host, const void* src_dev
 int mi355dr_debug_screen_dense(mi355dr_index* idx, const float* queries, int B, int64_t row0, int64_t n, float* out_t) {
     if (!idx || !queries || !out_t) return fail(idx, MI355DR_E_INVALID, "null argument");
     std::lock_guard<std::mutex> g(idx->mu);
-    if (B <= 0 || B > kQBlockMax || n <= 0 || n > kCandCap || row0 < 0 || row0 % kTileM != 0 || row0 + n > idx->n)
-        return fail(idx, MI355DR_E_INVALID, "debug_screen_dense: need 1<=B<=1024, 1<=n<=2048, row0 % 128 == 0, in range");
+    if (B <= 0 || B > kQBlockMax || n <= 0 || n > kCandCap || row0 < 0 || row0 % screen_tile(B) != 0 || row0 + n > idx->n)
+        return fail(idx, MI355DR_E_INVALID,
+                    "debug_screen_dense: need 1<=B<=1024, 1<=n<=2048, row0 a multiple of the tile (128; 256 if B>128)");
     HIPCHECK(idx, hipSetDevice(idx->device));
     CHECK(ensure_qstate(idx));
     hipStream_t s = idx->stream;
     HIPCHECK(idx, hipMemcpyAsync(idx->qdev, queries, (size_t)B * idx->dim * sizeof(float), hipMemcpyHostToDevice, s));
-    const int Bpad = (int)round_up(B, kTileN);
+    const int Bpad = (int)round_up(B, screen_tile(B));
     hipLaunchKernelGGL(k_prep_queries, dim3(Bpad), dim3(64), (size_t)idx->dim * sizeof(float), s, idx->qdev, B, idx->dim,
                        idx->dpad, /*metric=*/1, idx->st);  // metric 1: thresholds at -inf for every query
     HIPCHECK(idx, hipGetLastError());
-    ScreenArgs sa{};
-    sa.shadow = idx->shadow;
-    sa.qhat = idx->st.qhat;
-    sa.thr = idx->st.thr;
-    sa.cnt = idx->st.cnt;
-    sa.cand_row = idx->cand_row;
-    sa.cand_val = idx->cand_val;
-    sa.dpad = idx->dpad;
-    sa.cap = kCandCap;
-    sa.ct0 = (int)(row0 / kTileM);
-    sa.n_ctiles = (int)(round_up(row0 + n, kTileM) / kTileM) - sa.ct0;
-    sa.n_qtiles = Bpad / kTileN;
-    sa.row_end = row0 + n;
-    hipLaunchKernelGGL(k_screen, dim3((unsigned)(round_up(sa.n_ctiles, 8) * sa.n_qtiles)), dim3(256), kScreenLds, s, sa);
-    HIPCHECK(idx, hipGetLastError());
+    CHECK(launch_screen(idx, s, B, row0, row0 + n, kCandCap));
     std::vector<int> cnt(B);
     std::vector<int32_t> crow((size_t)B * kCandCap);
     std::vector<float> cval((size_t)B * kCandCap);
@@ -689,8 +690,8 @@ int mi355dr_debug_rescore(mi355dr_index* idx, const float* queries, int B, const
     CHECK(ensure_qstate(idx));
     hipStream_t s = idx->stream;
     HIPCHECK(idx, hipMemcpyAsync(idx->qdev, queries, (size_t)B * idx->dim * sizeof(float), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_prep_queries, dim3((unsigned)round_up(B, kTileN)), dim3(64), (size_t)idx->dim * sizeof(float), s,
-                       idx->qdev, B, idx->dim, idx->dpad, idx->metric, idx->st);
+    hipLaunchKernelGGL(k_prep_queries, dim3((unsigned)round_up(B, screen_tile(B))), dim3(64),
+                       (size_t)idx->dim * sizeof(float), s, idx->qdev, B, idx->dim, idx->dpad, idx->metric, idx->st);
     HIPCHECK(idx, hipGetLastError());
     int32_t* pq = nullptr;
     int64_t* pr = nullptr;

@@ -170,7 +170,7 @@ def main() -> None:
     cand = idx.stat("candidates")
     resc = idx.stat("rescored")
     dpad = (d + 63) // 64 * 64
-    Bpad = (B + 127) // 128 * 128
+    Bpad = (B + 255) // 256 * 256 if B > 128 else 128
     flops = 2.0 * Bpad * screen_rows * dpad          # MFMA flops actually issued by k_screen
     alg_flops = 2.0 * B * screen_rows * d             # algorithmic: 2*B*N*d per pass
     alg_bytes = float(screen_rows) * d * 4            # algorithmic HBM bytes: N*d*4 per pass
@@ -178,7 +178,7 @@ def main() -> None:
     screen_s = screen_ns * 1e-9
     roof = {
         "bound": "mfma",
-        "kernel": "k_screen",
+        "kernel": "k_screen256" if B > 128 else "k_screen",
         "achieved": round(alg_flops / screen_s / 1e12, 2) if screen_s > 0 else None,
         "peak": MFMA_BF16_PEAK_TF,
         "unit": "TFLOP/s",

@@ -54,7 +54,7 @@ def test_screen_values_match_bf16_emulation(pkg, d, B):
     Q = rng.standard_normal((B, d)).astype(np.float32)
     with pkg.Mi355Index(d) as idx:
         idx.add(C)
-        for row0, cnt in [(0, 1500), (128, 300), (1024, 476)]:
+        for row0, cnt in [(0, 1500), (256, 300), (1024, 476)]:
             t = idx.debug_screen_dense(Q, row0, cnt)
             sub = C[row0:row0 + cnt].astype(np.float64)
             ch = _bf16_round((sub / np.linalg.norm(sub, axis=1, keepdims=True)).astype(np.float32)).astype(np.float64)

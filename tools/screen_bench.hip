@@ -1,0 +1,186 @@
+// tools/screen_bench.hip -- developer micro-benchmark of the screen kernels (not part of the library).
+// Builds: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -Iautorag-research_amd/csrc tools/screen_bench.hip -o gpurun_out/screen_bench
+// Runs each variant on synthetic bf16 rows: (1) pure compute (thresholds = +inf), (2) with a finite
+// threshold, comparing the appended candidate sets between variants.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "dev_common.h"
+#include "k_screen.h"
+#include "k_screen256.h"
+
+using namespace mi355;
+
+#define CK(x)                                                                              \
+    do {                                                                                   \
+        hipError_t e = (x);                                                                \
+        if (e != hipSuccess) {                                                             \
+            fprintf(stderr, "%s failed: %s (%d)\n", #x, hipGetErrorString(e), __LINE__);   \
+            exit(1);                                                                       \
+        }                                                                                  \
+    } while (0)
+
+__device__ inline uint32_t hash32(uint64_t x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return (uint32_t)x;
+}
+// rows ~ N(0, 1/d) per element (sum of 4 uniforms), bf16
+__global__ void k_fill(uint16_t* p, int64_t rows, int dpad, int d, uint64_t seed) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * dpad) return;
+    const int k = (int)(i % dpad);
+    float v = 0.f;
+    if (k < d) {
+        uint32_t h = hash32(i * 4 + seed), h2 = hash32(i * 4 + 1 + seed);
+        float u = ((h & 0xFFFF) + (h >> 16) + (h2 & 0xFFFF) + (h2 >> 16)) * (1.0f / 65536.0f) - 2.0f;  // var 1/3
+        v = u * sqrtf(3.0f / d);
+    }
+    p[i] = f32_to_bf16_rn(v);
+}
+__global__ void k_fillf(float* p, int n, float v) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+struct Cand {
+    int q, row;
+    float v;
+    bool operator<(const Cand& o) const { return q != o.q ? q < o.q : row < o.row; }
+};
+
+int main(int argc, char** argv) {
+    const int64_t N = argc > 1 ? atoll(argv[1]) : (1 << 20);
+    const int B = argc > 2 ? atoi(argv[2]) : 1024;
+    const int d = argc > 3 ? atoi(argv[3]) : 768;
+    const int reps = argc > 4 ? atoi(argv[4]) : 5;
+    const int only = argc > 5 ? atoi(argv[5]) : 0;  // run a single variant (profiling)
+    const int dpad = (d + 63) / 64 * 64;
+    const int64_t Npad = (N + 255) / 256 * 256;
+    const int Bpad = (B + 255) / 256 * 256;
+    const int cap = 2048;
+    uint16_t *shadow, *qhat;
+    float *thr, *cval;
+    int *cnt;
+    int32_t* crow;
+    CK(hipMalloc(&shadow, (size_t)Npad * dpad * 2));
+    CK(hipMalloc(&qhat, (size_t)Bpad * dpad * 2));
+    CK(hipMalloc(&thr, Bpad * 4));
+    CK(hipMalloc(&cnt, Bpad * 4));
+    CK(hipMalloc(&crow, (size_t)Bpad * cap * 4));
+    CK(hipMalloc(&cval, (size_t)Bpad * cap * 4));
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)((Npad * dpad + 255) / 256)), dim3(256), 0, 0, shadow, Npad, dpad, d, 1234ull);
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)(((int64_t)Bpad * dpad + 255) / 256)), dim3(256), 0, 0, qhat, (int64_t)Bpad, dpad, d, 99ull);
+    CK(hipDeviceSynchronize());
+    CK(hipFuncSetAttribute((const void*)k_screen, hipFuncAttributeMaxDynamicSharedMemorySize, kScreenLds));
+    CK(hipFuncSetAttribute((const void*)k_screen256<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
+    CK(hipFuncSetAttribute((const void*)k_screen256<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
+    CK(hipFuncSetAttribute((const void*)k_screen256<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
+    CK(hipFuncSetAttribute((const void*)k_screen256<3>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
+    CK(hipFuncSetAttribute((const void*)k_screen256<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+
+    auto launch = [&](int variant) {
+        ScreenArgs sa{};
+        sa.shadow = shadow;
+        sa.qhat = qhat;
+        sa.thr = thr;
+        sa.cnt = cnt;
+        sa.cand_row = crow;
+        sa.cand_val = cval;
+        sa.dpad = dpad;
+        sa.cap = cap;
+        sa.ct0 = 0;
+        sa.row_end = N;
+        if (variant == 128) {
+            sa.n_ctiles = (int)((N + 127) / 128);
+            sa.n_qtiles = (B + 127) / 128;
+            const int64_t grid = (int64_t)((sa.n_ctiles + 7) / 8 * 8) * sa.n_qtiles;
+            hipLaunchKernelGGL(k_screen, dim3((unsigned)grid), dim3(256), kScreenLds, 0, sa);
+        } else {
+            sa.n_ctiles = (int)((N + 255) / 256);
+            sa.n_qtiles = (B + 255) / 256;
+            const int64_t grid = (int64_t)((sa.n_ctiles + 7) / 8 * 8) * sa.n_qtiles;
+            switch (variant - 256) {
+                case 0: hipLaunchKernelGGL(k_screen256<0>, dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa); break;
+                case 1: hipLaunchKernelGGL(k_screen256<1>, dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa); break;
+                case 2: hipLaunchKernelGGL(k_screen256<2>, dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa); break;
+                case 3: hipLaunchKernelGGL(k_screen256<3>, dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa); break;
+                default: hipLaunchKernelGGL(k_screen256<4>, dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa); break;
+            }
+        }
+        CK(hipGetLastError());
+    };
+
+    const double flops = 2.0 * B * (double)N * d;
+    std::vector<std::vector<Cand>> sets;
+    for (int variant : {128, 256, 257, 258, 259}) {
+        if (only && variant != only) continue;
+        // (1) pure compute
+        hipLaunchKernelGGL(k_fillf, dim3((Bpad + 255) / 256), dim3(256), 0, 0, thr, Bpad, INFINITY);
+        launch(variant);
+        CK(hipDeviceSynchronize());
+        float best = 1e30f, sum = 0;
+        for (int r = 0; r < reps; ++r) {
+            CK(hipEventRecord(e0));
+            launch(variant);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            best = std::min(best, ms);
+            sum += ms;
+        }
+        printf("variant %d: N=%lld B=%d d=%d  best %.3f ms  avg %.3f ms  -> %.1f TFLOP/s (best) %.1f (avg)\n", variant,
+               (long long)N, B, d, best, sum / reps, flops / best / 1e9, flops / (sum / reps) / 1e9);
+        // (2) finite threshold: collect candidates
+        const float T0 = 4.6f / sqrtf((float)d);  // ~4.6 sigma
+        hipLaunchKernelGGL(k_fillf, dim3((Bpad + 255) / 256), dim3(256), 0, 0, thr, B, T0);
+        CK(hipMemset(cnt, 0, Bpad * 4));
+        launch(variant);
+        CK(hipDeviceSynchronize());
+        std::vector<int> hc(B);
+        std::vector<int32_t> hr((size_t)B * cap);
+        std::vector<float> hv((size_t)B * cap);
+        CK(hipMemcpy(hc.data(), cnt, B * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hr.data(), crow, hr.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hv.data(), cval, hv.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<Cand> s;
+        long long over = 0;
+        for (int q = 0; q < B; ++q) {
+            if (hc[q] > cap) over++;
+            for (int j = 0; j < std::min(hc[q], cap); ++j) s.push_back({q, hr[(size_t)q * cap + j], hv[(size_t)q * cap + j]});
+        }
+        std::sort(s.begin(), s.end());
+        printf("   threshold %.4f: %zu candidates, %lld overflowed queries\n", T0, s.size(), over);
+        sets.push_back(s);
+    }
+    bool all_same = true;
+    if (only) return 0;
+    for (size_t v = 1; v < sets.size(); ++v) {
+        bool same = sets[0].size() == sets[v].size();
+        double maxdiff = 0;
+        if (same)
+            for (size_t i = 0; i < sets[0].size(); ++i) {
+                if (sets[0][i].q != sets[v][i].q || sets[0][i].row != sets[v][i].row) {
+                    same = false;
+                    break;
+                }
+                maxdiff = std::max(maxdiff, (double)fabsf(sets[0][i].v - sets[v][i].v));
+            }
+        printf("candidate set %zu vs 0: %s (max |dv| %.3g)\n", v, same ? "IDENTICAL" : "DIFFER", maxdiff);
+        all_same = all_same && same;
+    }
+    return all_same ? 0 : 2;
+}
