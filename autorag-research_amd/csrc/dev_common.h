@@ -142,7 +142,8 @@ __device__ __forceinline__ void bitonic_asc_key_row(uint64_t* key, int32_t* row,
 // row-contiguous (coalesced) loads into a padded LDS tile, then every lane walks its own row of the
 // tile in k order, so each lane's accumulator is exactly the k-ascending fmaf chain.
 constexpr int kStageCols = 64;
-constexpr int kStageLd = 65;  // +1 pad: lane l reads word l*65+k -> conflict-free for ds_read_b32
+constexpr int kStageLd = 68;  // row stride in floats: rows stay 16-B aligned and lane l's ds_read_b128 of row l
+                              // lands on 16-B slot (17*l + k/4) mod 16 -> conflict-free within the b128 lane groups
 constexpr int kStageFloats = kWave * kStageLd;
 
 // wave-level LDS hand-off (writes by some lanes -> reads by others of the SAME wave)
@@ -152,43 +153,95 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// stage columns [k0, k0+64) of the 64 rows `my_row(lane)` (nullptr = slot unused -> zeros).
-// d % 4 == 0 (16-B aligned row pieces): one global_load_dwordx4 per lane covers 4 rows x 256 B per
-// wave instruction, 16 independent loads are issued back to back before the first LDS write, so the
-// HBM latency is paid once per 64-column piece instead of once per row.
-__device__ __forceinline__ void stage_rows(float* tile, const float* my_row, int k0, int d, int lane) {
+// One 64-column piece of the 64 rows, held in registers between issue and commit so the HBM/L2 latency
+// of piece p+1 (and p+2) overlaps the chain over piece p.
+struct StagePiece {
+    float4 v[16];
+};
+
+// d % 4 == 0: lane (sub = lane>>4, c4 = 4*(lane&15)) loads 16 B of row 4g+sub for g = 0..15 -- one
+// global_load_dwordx4 covers 4 rows x 256 B, all 16 loads are independent and issued back to back.
+__device__ __forceinline__ void stage_issue(StagePiece& p, const float* my_row, int k0, int d, int lane) {
+    const unsigned long long a = (unsigned long long)my_row;
+    const unsigned plo = (unsigned)(a & 0xFFFFFFFFull), phi = (unsigned)(a >> 32);
+    const int sub = lane >> 4, c4 = (lane & 15) * 4;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const int s = g * 4 + sub;
+        const unsigned lo = __shfl(plo, s, kWave), hi = __shfl(phi, s, kWave);
+        const float* r = (const float*)(((unsigned long long)hi << 32) | lo);
+        p.v[g] = (r != nullptr && k0 + c4 < d) ? *(const float4*)(r + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+__device__ __forceinline__ void stage_commit(float* tile, const StagePiece& p, int lane) {
     wave_sync();  // previous readers of the tile are done
-    const unsigned long long p = (unsigned long long)my_row;
-    const unsigned plo = (unsigned)(p & 0xFFFFFFFFull), phi = (unsigned)(p >> 32);
+    const int sub = lane >> 4, c4 = (lane & 15) * 4;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) *(float4*)(tile + (g * 4 + sub) * kStageLd + c4) = p.v[g];
+    wave_sync();  // tile visible to every lane of this wave
+}
+
+// generic (any d) one-shot staging: scalar loads when rows are not 16-B aligned
+__device__ __forceinline__ void stage_rows(float* tile, const float* my_row, int k0, int d, int lane) {
     if ((d & 3) == 0) {
-        const int sub = lane >> 4;        // row within the group of 4
-        const int c4 = (lane & 15) * 4;   // first of this lane's 4 columns
-        float4 v[16];
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const int s = g * 4 + sub;
-            const unsigned lo = __shfl(plo, s, kWave), hi = __shfl(phi, s, kWave);
-            const float* r = (const float*)(((unsigned long long)hi << 32) | lo);
-            v[g] = (r != nullptr && k0 + c4 < d) ? *(const float4*)(r + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            float* t = tile + (g * 4 + sub) * kStageLd + c4;
-            t[0] = v[g].x;
-            t[1] = v[g].y;
-            t[2] = v[g].z;
-            t[3] = v[g].w;
+        StagePiece p;
+        stage_issue(p, my_row, k0, d, lane);
+        stage_commit(tile, p, lane);
+        return;
+    }
+    wave_sync();
+    const unsigned long long a = (unsigned long long)my_row;
+    const unsigned plo = (unsigned)(a & 0xFFFFFFFFull), phi = (unsigned)(a >> 32);
+#pragma unroll 8
+    for (int s = 0; s < kWave; ++s) {
+        const unsigned lo = __shfl(plo, s, kWave), hi = __shfl(phi, s, kWave);
+        const float* r = (const float*)(((unsigned long long)hi << 32) | lo);
+        const int k = k0 + lane;
+        tile[s * kStageLd + lane] = (r != nullptr && k < d) ? r[k] : 0.0f;
+    }
+    wave_sync();
+}
+
+// acc = k-ascending fmaf chain over columns [0,kn) of this lane's tile row against qv[0..kn) (qv in LDS, 16-B aligned)
+__device__ __forceinline__ float chain_piece(const float* tile, int lane, const float* qv, int kn, float acc) {
+    const float* t = tile + lane * kStageLd;
+    int k = 0;
+    for (; k + 4 <= kn; k += 4) {
+        const float4 tv = *(const float4*)(t + k);
+        const float4 q4 = *(const float4*)(qv + k);
+        acc = __builtin_fmaf(tv.x, q4.x, acc);
+        acc = __builtin_fmaf(tv.y, q4.y, acc);
+        acc = __builtin_fmaf(tv.z, q4.z, acc);
+        acc = __builtin_fmaf(tv.w, q4.w, acc);
+    }
+    for (; k < kn; ++k) acc = __builtin_fmaf(t[k], qv[k], acc);
+    return acc;
+}
+
+// full chain <row, qv> for this lane's row (nullptr = idle slot); rows prefetched two pieces ahead when d%4==0
+__device__ __forceinline__ float staged_dot(float* tile, const float* my_row, const float* qv, int d, int lane) {
+    float acc = 0.0f;
+    if ((d & 3) == 0) {
+        StagePiece p0, p1;
+        stage_issue(p0, my_row, 0, d, lane);
+        if (kStageCols < d) stage_issue(p1, my_row, kStageCols, d, lane);
+        for (int k0 = 0; k0 < d; k0 += 2 * kStageCols) {
+            stage_commit(tile, p0, lane);
+            if (k0 + 2 * kStageCols < d) stage_issue(p0, my_row, k0 + 2 * kStageCols, d, lane);
+            acc = chain_piece(tile, lane, qv + k0, min(kStageCols, d - k0), acc);
+            if (k0 + kStageCols < d) {
+                stage_commit(tile, p1, lane);
+                if (k0 + 3 * kStageCols < d) stage_issue(p1, my_row, k0 + 3 * kStageCols, d, lane);
+                acc = chain_piece(tile, lane, qv + k0 + kStageCols, min(kStageCols, d - k0 - kStageCols), acc);
+            }
         }
     } else {
-#pragma unroll 8
-        for (int s = 0; s < kWave; ++s) {
-            const unsigned lo = __shfl(plo, s, kWave), hi = __shfl(phi, s, kWave);
-            const float* r = (const float*)(((unsigned long long)hi << 32) | lo);
-            const int k = k0 + lane;
-            tile[s * kStageLd + lane] = (r != nullptr && k < d) ? r[k] : 0.0f;
+        for (int k0 = 0; k0 < d; k0 += kStageCols) {
+            stage_rows(tile, my_row, k0, d, lane);
+            acc = chain_piece(tile, lane, qv + k0, min(kStageCols, d - k0), acc);
         }
     }
-    wave_sync();  // tile visible to every lane of this wave
+    return acc;
 }
 
 }  // namespace mi355

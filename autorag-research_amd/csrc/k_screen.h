@@ -51,6 +51,8 @@ struct ScreenArgs {
     int n_ctiles;   // corpus tiles in this chunk
     int n_qtiles;   // query tiles
     int64_t row_end;  // rows >= row_end are not part of this chunk (tile padding)
+    int64_t row0;     // first row of this chunk
+    int emit_all;     // first chunk: every (query,row) is a candidate -> direct store at slot row-row0, no atomics
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
@@ -152,6 +154,25 @@ __global__ __launch_bounds__(256, 2) void k_screen(ScreenArgs a) {
 
     // ---- fused epilogue: threshold test, rare append
     // C/D layout of the 32x32 MFMA: column (query) = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (a.emit_all) {  // wave-uniform: the first chunk keeps everything, slot = row - row0 (counts set by the host)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = q0 + 64 * wc + 32 * j + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int64_t rbase = tile_row0 + 64 * wr + 32 * i + 4 * (lane >> 5);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (row < a.row_end) {
+                        a.cand_row[(int64_t)q * a.cap + (row - a.row0)] = (int32_t)row;
+                        a.cand_val[(int64_t)q * a.cap + (row - a.row0)] = acc[i][j][r];
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int q = q0 + 64 * wc + 32 * j + (lane & 31);

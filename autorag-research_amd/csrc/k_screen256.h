@@ -198,6 +198,27 @@ __global__ __launch_bounds__(512, 2) void k_screen256(ScreenArgs a) {
 #undef MI355_WAIT_VM
 
     // ---- fused epilogue (same rule as k_screen): column (query) = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
+    if (a.emit_all) {  // first chunk: keep everything, slot = row - row0, no atomics
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = q0 + 64 * wc + 32 * j + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    const int64_t rbase = tile_row0 + 128 * wr + 64 * i + 32 * rb + 4 * (lane >> 5);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
+                        if (row < a.row_end) {
+                            a.cand_row[(int64_t)q * a.cap + (row - a.row0)] = (int32_t)row;
+                            a.cand_val[(int64_t)q * a.cap + (row - a.row0)] = acc[i][rb][j][r];
+                        }
+                    }
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int q = q0 + 64 * wc + 32 * j + (lane & 31);

@@ -128,14 +128,7 @@ __global__ __launch_bounds__(THREADS) void k_prune(PruneArgs a) {
             const float* rp = live ? a.rows + (int64_t)row * a.d : nullptr;
             float acc = 0.0f;
             // whole waves past the end skip together (wave-uniform condition)
-            if (base + wave * kWave < n_res) {
-                for (int k0 = 0; k0 < a.d; k0 += kStageCols) {
-                    stage_rows(tile, rp, k0, a.d, lane);
-                    const int kn = min(kStageCols, a.d - k0);
-                    const float* t = tile + lane * kStageLd;
-                    for (int k = 0; k < kn; ++k) acc = __builtin_fmaf(t[k], qs[k0 + k], acc);
-                }
-            }
+            if (base + wave * kWave < n_res) acc = staged_dot(tile, rp, qs, a.d, lane);
             if (live) {
                 const double dist = distance_from(a.metric, acc, nq, a.nrm2[row]);
                 SK[n_best + e] = dist_to_key(dist);
@@ -185,11 +178,13 @@ __global__ __launch_bounds__(THREADS) void k_prune(PruneArgs a) {
 }
 
 // grid: B blocks of 64 threads; appends every irregular row as a "no bound" candidate (val = NaN)
+// rows below `skip_below` were already kept by the emit-all first chunk (their NaN screen value = "no bound")
 __global__ __launch_bounds__(64) void k_emit_irregular(const int32_t* __restrict__ irr_rows, int irr_n, QueryState st,
-                                                        int32_t* cand_row, float* cand_val, int cap) {
+                                                        int32_t* cand_row, float* cand_val, int cap, int skip_below) {
     const int q = blockIdx.x;
     if (st.status[q] & kStIrregular) return;
     for (int i = threadIdx.x; i < irr_n; i += blockDim.x) {
+        if (irr_rows[i] < skip_below) continue;
         const int slot = atomicAdd(&st.cnt[q], 1);
         if (slot < cap) {
             cand_row[(int64_t)q * cap + slot] = irr_rows[i];

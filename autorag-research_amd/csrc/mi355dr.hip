@@ -163,7 +163,12 @@ int launch_prune(mi355dr_index* idx, hipStream_t s, int nblocks, const int* qlis
 inline int screen_tile(int B) { return B > kTileN ? kT2 : kTileM; }
 
 // launch one screen pass over rows [r0, r_end) (r0 a multiple of the tile edge)
-int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t r_end, int cap) {
+__global__ void k_set_counts(int* cnt, int n, int v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) cnt[i] = v;
+}
+
+int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t r_end, int cap, bool emit_all) {
     const int tile = screen_tile(B);
     ScreenArgs sa{};
     sa.shadow = idx->shadow;
@@ -178,10 +183,16 @@ int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t 
     sa.n_ctiles = (int)(round_up(r_end, tile) / tile) - sa.ct0;
     sa.n_qtiles = (int)(round_up(B, tile) / tile);
     sa.row_end = r_end;
+    sa.row0 = r0;
+    sa.emit_all = emit_all ? 1 : 0;
     const int64_t grid = round_up(sa.n_ctiles, 8) * sa.n_qtiles;
     if (tile == kT2) hipLaunchKernelGGL(k_screen256<0>, dim3((unsigned)grid), dim3(512), kScreen256Lds, s, sa);
     else hipLaunchKernelGGL(k_screen, dim3((unsigned)grid), dim3(256), kScreenLds, s, sa);
     HIPCHECK(idx, hipGetLastError());
+    if (emit_all) {  // every row of the chunk was stored at slot row-r0 for every query
+        hipLaunchKernelGGL(k_set_counts, dim3((B + 255) / 256), dim3(256), 0, s, idx->st.cnt, B, (int)(r_end - r0));
+        HIPCHECK(idx, hipGetLastError());
+    }
     return MI355DR_OK;
 }
 
@@ -189,15 +200,19 @@ int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t 
 int run_screen(mi355dr_index* idx, hipStream_t s, int B, int k) {
     const int tile = screen_tile(B);
     int64_t done = 0;
+    int64_t kept_all_below = 0;  // rows the emit-all first chunk already turned into candidates
     int64_t chunk = std::max<int64_t>(tile, std::min<int64_t>(idx->chunk0_rows, idx->cap));
     while (done < idx->n) {
         const int64_t end = std::min<int64_t>(idx->n, round_up(done + chunk, tile));
+        const bool emit_all = done == 0 && end <= idx->cap;
+        if (emit_all) kept_all_below = end;
         EventPair ev{};
         if (idx->profile) {
             ev = take_events(idx);
             HIPCHECK(idx, hipEventRecord(ev.a, s));
         }
-        CHECK(launch_screen(idx, s, B, done, end, idx->cap));
+        // the first chunk has no threshold yet: it keeps every row (direct stores) as long as it fits the buffer
+        CHECK(launch_screen(idx, s, B, done, end, idx->cap, emit_all));
         if (idx->profile) {
             HIPCHECK(idx, hipEventRecord(ev.b, s));
             idx->ev_pending.push_back(ev);
@@ -211,7 +226,7 @@ int run_screen(mi355dr_index* idx, hipStream_t s, int B, int k) {
     }
     if (idx->irr_n > 0) {
         hipLaunchKernelGGL(k_emit_irregular, dim3(B), dim3(64), 0, s, idx->irr_rows, idx->irr_n, idx->st,
-                           idx->cand_row, idx->cand_val, idx->cap);
+                           idx->cand_row, idx->cand_val, idx->cap, (int)kept_all_below);
         HIPCHECK(idx, hipGetLastError());
         CHECK(launch_prune(idx, s, B, nullptr, k, 0));
     }
@@ -658,7 +673,7 @@ int mi355dr_debug_screen_dense(mi355dr_index* idx, const float* queries, int B, 
     hipLaunchKernelGGL(k_prep_queries, dim3(Bpad), dim3(64), (size_t)idx->dim * sizeof(float), s, idx->qdev, B, idx->dim,
                        idx->dpad, /*metric=*/1, idx->st);  // metric 1: thresholds at -inf for every query
     HIPCHECK(idx, hipGetLastError());
-    CHECK(launch_screen(idx, s, B, row0, row0 + n, kCandCap));
+    CHECK(launch_screen(idx, s, B, row0, row0 + n, kCandCap, /*emit_all=*/false));
     std::vector<int> cnt(B);
     std::vector<int32_t> crow((size_t)B * kCandCap);
     std::vector<float> cval((size_t)B * kCandCap);
