@@ -158,20 +158,29 @@ __device__ __forceinline__ void wave_sync() {
 struct StagePiece {
     float4 v[16];
 };
+// The 16 row pointers this lane loads from (rows 4g + (lane>>4), g = 0..15): fetched from the owning lanes
+// once per batch of 64 rows, reused for every 64-column piece.
+struct StageRows {
+    const float* r[16];
+};
+__device__ __forceinline__ void stage_rows_init(StageRows& sr, const float* my_row, int lane) {
+    const unsigned long long a = (unsigned long long)my_row;
+    const unsigned plo = (unsigned)(a & 0xFFFFFFFFull), phi = (unsigned)(a >> 32);
+    const int sub = lane >> 4;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const unsigned lo = __shfl(plo, g * 4 + sub, kWave), hi = __shfl(phi, g * 4 + sub, kWave);
+        sr.r[g] = (const float*)(((unsigned long long)hi << 32) | lo);
+    }
+}
 
 // d % 4 == 0: lane (sub = lane>>4, c4 = 4*(lane&15)) loads 16 B of row 4g+sub for g = 0..15 -- one
 // global_load_dwordx4 covers 4 rows x 256 B, all 16 loads are independent and issued back to back.
-__device__ __forceinline__ void stage_issue(StagePiece& p, const float* my_row, int k0, int d, int lane) {
-    const unsigned long long a = (unsigned long long)my_row;
-    const unsigned plo = (unsigned)(a & 0xFFFFFFFFull), phi = (unsigned)(a >> 32);
-    const int sub = lane >> 4, c4 = (lane & 15) * 4;
+__device__ __forceinline__ void stage_issue(StagePiece& p, const StageRows& sr, int k0, int d, int lane) {
+    const int c4 = (lane & 15) * 4;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-        const int s = g * 4 + sub;
-        const unsigned lo = __shfl(plo, s, kWave), hi = __shfl(phi, s, kWave);
-        const float* r = (const float*)(((unsigned long long)hi << 32) | lo);
-        p.v[g] = (r != nullptr && k0 + c4 < d) ? *(const float4*)(r + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int g = 0; g < 16; ++g)
+        p.v[g] = (sr.r[g] != nullptr && k0 + c4 < d) ? *(const float4*)(sr.r[g] + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 __device__ __forceinline__ void stage_commit(float* tile, const StagePiece& p, int lane) {
     wave_sync();  // previous readers of the tile are done
@@ -184,8 +193,10 @@ __device__ __forceinline__ void stage_commit(float* tile, const StagePiece& p, i
 // generic (any d) one-shot staging: scalar loads when rows are not 16-B aligned
 __device__ __forceinline__ void stage_rows(float* tile, const float* my_row, int k0, int d, int lane) {
     if ((d & 3) == 0) {
+        StageRows sr;
         StagePiece p;
-        stage_issue(p, my_row, k0, d, lane);
+        stage_rows_init(sr, my_row, lane);
+        stage_issue(p, sr, k0, d, lane);
         stage_commit(tile, p, lane);
         return;
     }
@@ -205,6 +216,22 @@ __device__ __forceinline__ void stage_rows(float* tile, const float* my_row, int
 // acc = k-ascending fmaf chain over columns [0,kn) of this lane's tile row against qv[0..kn) (qv in LDS, 16-B aligned)
 __device__ __forceinline__ float chain_piece(const float* tile, int lane, const float* qv, int kn, float acc) {
     const float* t = tile + lane * kStageLd;
+    if (kn == kStageCols) {  // full piece: all 32 ds_read_b128 issued up front, then the 64-step chain
+        float4 tv[16], q4[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            tv[i] = *(const float4*)(t + 4 * i);
+            q4[i] = *(const float4*)(qv + 4 * i);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            acc = __builtin_fmaf(tv[i].x, q4[i].x, acc);
+            acc = __builtin_fmaf(tv[i].y, q4[i].y, acc);
+            acc = __builtin_fmaf(tv[i].z, q4[i].z, acc);
+            acc = __builtin_fmaf(tv[i].w, q4[i].w, acc);
+        }
+        return acc;
+    }
     int k = 0;
     for (; k + 4 <= kn; k += 4) {
         const float4 tv = *(const float4*)(t + k);
@@ -222,16 +249,18 @@ __device__ __forceinline__ float chain_piece(const float* tile, int lane, const 
 __device__ __forceinline__ float staged_dot(float* tile, const float* my_row, const float* qv, int d, int lane) {
     float acc = 0.0f;
     if ((d & 3) == 0) {
+        StageRows sr;
         StagePiece p0, p1;
-        stage_issue(p0, my_row, 0, d, lane);
-        if (kStageCols < d) stage_issue(p1, my_row, kStageCols, d, lane);
+        stage_rows_init(sr, my_row, lane);
+        stage_issue(p0, sr, 0, d, lane);
+        if (kStageCols < d) stage_issue(p1, sr, kStageCols, d, lane);
         for (int k0 = 0; k0 < d; k0 += 2 * kStageCols) {
             stage_commit(tile, p0, lane);
-            if (k0 + 2 * kStageCols < d) stage_issue(p0, my_row, k0 + 2 * kStageCols, d, lane);
+            if (k0 + 2 * kStageCols < d) stage_issue(p0, sr, k0 + 2 * kStageCols, d, lane);
             acc = chain_piece(tile, lane, qv + k0, min(kStageCols, d - k0), acc);
             if (k0 + kStageCols < d) {
                 stage_commit(tile, p1, lane);
-                if (k0 + 3 * kStageCols < d) stage_issue(p1, my_row, k0 + 3 * kStageCols, d, lane);
+                if (k0 + 3 * kStageCols < d) stage_issue(p1, sr, k0 + 3 * kStageCols, d, lane);
                 acc = chain_piece(tile, lane, qv + k0 + kStageCols, min(kStageCols, d - k0 - kStageCols), acc);
             }
         }

@@ -46,7 +46,7 @@ struct mi355dr_index {
     int* status_host = nullptr;  // pinned [kQBlockMax + 1]
     double* out_dist_dev = nullptr;  // [kQBlockMax, kKMax]
     int64_t* out_rows_dev = nullptr;
-    unsigned long long* stat_dev = nullptr;  // [2]: candidates, rescored
+    unsigned long long* stat_dev = nullptr;  // [2*kQBlockMax]: per query (candidates, re-scored)
 
     // options
     int path = 0;  // MI355DR_PATH_AUTO

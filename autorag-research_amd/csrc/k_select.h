@@ -21,8 +21,7 @@ struct PruneArgs {
     int32_t* cand_row;   // [Bpad, cap]
     float* cand_val;     // [Bpad, cap]  screen: t (NaN = "no bound, always re-score"); exact: the fp32 dot
     const int* qlist;    // optional compact list of query indices (nullptr: blockIdx.x)
-    unsigned long long* stat_cand;
-    unsigned long long* stat_resc;
+    unsigned long long* stat;  // [2*kQBlockMax] per-query counters (candidates, re-scored): no shared atomics
     int cap, d, k, metric;
     int exact;           // 0: screen candidates (re-score), 1: cand_val already holds the exact dot
     float E;             // screen bound
@@ -83,7 +82,7 @@ __global__ __launch_bounds__(THREADS) void k_prune(PruneArgs a) {
     const float nq = a.st.qn[q];
     if (tid == 0) {
         s_nres = 0;
-        atomicAdd(a.stat_cand, (unsigned long long)n_new);
+        a.stat[2 * q] += (unsigned long long)n_new;
     }
 
     int n_res;
@@ -118,7 +117,7 @@ __global__ __launch_bounds__(THREADS) void k_prune(PruneArgs a) {
         for (int k = tid; k < a.d; k += THREADS) qs[k] = a.q[(int64_t)q * a.d + k];
         __syncthreads();
         n_res = s_nres;
-        if (tid == 0) atomicAdd(a.stat_resc, (unsigned long long)n_res);
+        if (tid == 0) a.stat[2 * q + 1] += (unsigned long long)n_res;
         // ---- phase 3: exact fp32 chain for the survivors, 64 per wave at a time
         float* tile = tiles + wave * kStageFloats;
         for (int base = 0; base < n_res; base += THREADS) {

@@ -80,8 +80,8 @@ int ensure_qstate(mi355dr_index* idx) {
     HIPCHECK(idx, hipHostMalloc(&idx->status_host, (B + 1) * sizeof(int)));
     HIPCHECK(idx, hipMalloc(&idx->out_dist_dev, B * kKMax * sizeof(double)));
     HIPCHECK(idx, hipMalloc(&idx->out_rows_dev, B * kKMax * sizeof(int64_t)));
-    HIPCHECK(idx, hipMalloc(&idx->stat_dev, 2 * sizeof(unsigned long long)));
-    HIPCHECK(idx, hipMemsetAsync(idx->stat_dev, 0, 2 * sizeof(unsigned long long), idx->stream));
+    HIPCHECK(idx, hipMalloc(&idx->stat_dev, 2 * B * sizeof(unsigned long long)));
+    HIPCHECK(idx, hipMemsetAsync(idx->stat_dev, 0, 2 * B * sizeof(unsigned long long), idx->stream));
     // the prune / scan kernels use more than the default 64 KiB of dynamic LDS
     if (prune_lds_bytes(idx->dim, kPruneBigThreads, kPruneBigSort) > 160 * 1024 || scan_lds_bytes(idx->dim, 1) > 160 * 1024)
         return fail(idx, MI355DR_E_UNSUPPORTED, "dim too large for the select kernels' LDS budget");
@@ -141,8 +141,7 @@ int launch_prune(mi355dr_index* idx, hipStream_t s, int nblocks, const int* qlis
     pa.cand_row = idx->cand_row;
     pa.cand_val = idx->cand_val;
     pa.qlist = qlist;
-    pa.stat_cand = idx->stat_dev;
-    pa.stat_resc = idx->stat_dev + 1;
+    pa.stat = idx->stat_dev;
     pa.cap = idx->cap;
     pa.d = idx->dim;
     pa.k = k;
@@ -582,8 +581,13 @@ int mi355dr_get_stat(mi355dr_index* idx, const char* key, int64_t* out) {
     if (k == "candidates" || k == "rescored") {
         unsigned long long v[2] = {0, 0};
         if (idx->stat_dev) {
+            std::vector<unsigned long long> per(2 * kQBlockMax);
             HIPCHECK(idx, hipSetDevice(idx->device));
-            HIPCHECK(idx, hipMemcpy(v, idx->stat_dev, sizeof(v), hipMemcpyDeviceToHost));
+            HIPCHECK(idx, hipMemcpy(per.data(), idx->stat_dev, per.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            for (int i = 0; i < kQBlockMax; ++i) {
+                v[0] += per[2 * i];
+                v[1] += per[2 * i + 1];
+            }
         }
         *out = (int64_t)(k == "candidates" ? v[0] : v[1]);
     } else if (k == "screen_launches") *out = idx->s_screen_launches;
@@ -606,7 +610,7 @@ int mi355dr_reset_stats(mi355dr_index* idx) {
         idx->s_passes = 0;
     if (idx->stat_dev) {
         HIPCHECK(idx, hipSetDevice(idx->device));
-        HIPCHECK(idx, hipMemset(idx->stat_dev, 0, 2 * sizeof(unsigned long long)));
+        HIPCHECK(idx, hipMemset(idx->stat_dev, 0, 2 * kQBlockMax * sizeof(unsigned long long)));
     }
     return MI355DR_OK;
 }
