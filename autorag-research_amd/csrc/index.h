@@ -53,7 +53,7 @@ struct mi355dr_index {
     int64_t row_offset = 0;
     int profile = 0;
     int64_t chunk0_rows = 512;
-    int64_t chunk_growth = 7;
+    int64_t chunk_growth = 5;
     int cap = mi355::kCandCap;
 
     // stats

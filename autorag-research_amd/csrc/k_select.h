@@ -211,9 +211,10 @@ __global__ __launch_bounds__(64) void k_finalize(QueryState st, int k, int64_t r
 
 // grid: B blocks of 256 threads.  Shard lists are already in total order and carry global rows; the
 // merge is one more sort under the same order, so the result equals the single-GPU result.
+// rank w's lists start at dist_all + w*rank_stride and rows_all + w*rank_stride (elements), each [B][k]
 __global__ __launch_bounds__(256) void k_merge_topk(const double* __restrict__ dist_all,
-                                                     const int64_t* __restrict__ rows_all, int world, int B, int k,
-                                                     double* out_dist, int64_t* out_rows) {
+                                                     const int64_t* __restrict__ rows_all, int64_t rank_stride, int world,
+                                                     int B, int k, double* out_dist, int64_t* out_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint64_t* SK = (uint64_t*)smem;
     int32_t* SI = (int32_t*)(smem + (size_t)kSortMax * 8);  // index into the gathered lists (row may exceed int32)
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256) void k_merge_topk(const double* __restrict__ d
     for (int i = threadIdx.x; i < np; i += blockDim.x) {
         if (i < n) {
             const int w = i / k, s = i % k;
-            const int64_t src = ((int64_t)w * B + q) * k + s;
+            const int64_t src = (int64_t)w * rank_stride + (int64_t)q * k + s;
             const int64_t r = rows_all[src];
             SK[i] = r < 0 ? kKeyNaN : dist_to_key(dist_all[src]);
             SI[i] = r < 0 ? 0x7FFFFFFF : i;
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256) void k_merge_topk(const double* __restrict__ d
                     auto grow = [&](int32_t ix) -> int64_t {
                         if (ix == 0x7FFFFFFF) return INT64_MAX;
                         const int w = ix / k, s = ix % k;
-                        return rows_all[((int64_t)w * B + q) * k + s];
+                        return rows_all[(int64_t)w * rank_stride + (int64_t)q * k + s];
                     };
                     bool a_before_b, b_before_a;
                     if (ka != kb) {
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(256) void k_merge_topk(const double* __restrict__ d
         const int32_t ix = s < np ? SI[s] : 0x7FFFFFFF;
         if (ix != 0x7FFFFFFF) {
             const int w = ix / k, ss = ix % k;
-            const int64_t src = ((int64_t)w * B + q) * k + ss;
+            const int64_t src = (int64_t)w * rank_stride + (int64_t)q * k + ss;
             out_dist[(int64_t)q * k + s] = dist_all[src];
             out_rows[(int64_t)q * k + s] = rows_all[src];
         } else {

@@ -541,8 +541,41 @@ int mi355dr_merge_topk_device(mi355dr_index* idx, const double* dist_all_dev, co
     HIPCHECK(idx, hipSetDevice(idx->device));
     CHECK(ensure_qstate(idx));
     hipStream_t s = stream ? (hipStream_t)stream : idx->stream;
-    hipLaunchKernelGGL(k_merge_topk, dim3(B), dim3(256), (size_t)kSortMax * 12, s, dist_all_dev, rows_all_dev, world, B,
-                       k, out_dist_dev, out_rows_dev);
+    hipLaunchKernelGGL(k_merge_topk, dim3(B), dim3(256), (size_t)kSortMax * 12, s, dist_all_dev, rows_all_dev,
+                       (int64_t)B * k, world, B, k, out_dist_dev, out_rows_dev);
+    HIPCHECK(idx, hipGetLastError());
+    HIPCHECK(idx, hipStreamSynchronize(s));
+    return MI355DR_OK;
+}
+
+int mi355dr_pack_topk_device(mi355dr_index* idx, const double* dist_dev, const int64_t* rows_dev, int B, int k,
+                             int64_t* packed_dev, void* stream) {
+    if (!idx || !dist_dev || !rows_dev || !packed_dev) return fail(idx, MI355DR_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (B < 0 || k <= 0) return fail(idx, MI355DR_E_INVALID, "bad shape");
+    HIPCHECK(idx, hipSetDevice(idx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : idx->stream;
+    const size_t bytes = (size_t)B * k * 8;
+    if (bytes) {
+        HIPCHECK(idx, hipMemcpyAsync(packed_dev, dist_dev, bytes, hipMemcpyDeviceToDevice, s));
+        HIPCHECK(idx, hipMemcpyAsync(packed_dev + (size_t)B * k, rows_dev, bytes, hipMemcpyDeviceToDevice, s));
+    }
+    return MI355DR_OK;
+}
+
+int mi355dr_merge_topk_packed_device(mi355dr_index* idx, const int64_t* packed_all_dev, int world, int B, int k,
+                                     double* out_dist_dev, int64_t* out_rows_dev, void* stream) {
+    if (!idx) return fail(nullptr, MI355DR_E_INVALID, "null index");
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (world <= 0 || B < 0 || k <= 0) return fail(idx, MI355DR_E_INVALID, "bad merge shape");
+    if ((int64_t)world * k > kSortMax) return fail(idx, MI355DR_E_UNSUPPORTED, "world*k exceeds 4096");
+    if (B == 0) return MI355DR_OK;
+    HIPCHECK(idx, hipSetDevice(idx->device));
+    CHECK(ensure_qstate(idx));
+    hipStream_t s = stream ? (hipStream_t)stream : idx->stream;
+    const int64_t plane = (int64_t)B * k;
+    hipLaunchKernelGGL(k_merge_topk, dim3(B), dim3(256), (size_t)kSortMax * 12, s, (const double*)packed_all_dev,
+                       packed_all_dev + plane, 2 * plane, world, B, k, out_dist_dev, out_rows_dev);
     HIPCHECK(idx, hipGetLastError());
     HIPCHECK(idx, hipStreamSynchronize(s));
     return MI355DR_OK;

@@ -106,6 +106,17 @@ class Mi355Index:
             int(k), ctypes.c_void_p(int(out_dist_ptr)), ctypes.c_void_p(int(out_rows_ptr)),
             ctypes.c_void_p(int(stream) if stream else None)))
 
+    def pack_topk_device(self, dist_ptr: int, rows_ptr: int, B: int, k: int, packed_ptr: int, stream: int | None = None) -> None:
+        check(self._h, self._lib.mi355dr_pack_topk_device(self._h, ctypes.c_void_p(int(dist_ptr)), ctypes.c_void_p(int(rows_ptr)),
+                                                          int(B), int(k), ctypes.c_void_p(int(packed_ptr)),
+                                                          ctypes.c_void_p(int(stream) if stream else None)))
+
+    def merge_topk_packed_device(self, packed_all_ptr: int, world: int, B: int, k: int, out_dist_ptr: int, out_rows_ptr: int,
+                                 stream: int | None = None) -> None:
+        check(self._h, self._lib.mi355dr_merge_topk_packed_device(
+            self._h, ctypes.c_void_p(int(packed_all_ptr)), int(world), int(B), int(k), ctypes.c_void_p(int(out_dist_ptr)),
+            ctypes.c_void_p(int(out_rows_ptr)), ctypes.c_void_p(int(stream) if stream else None)))
+
     # ---- multi-vector ----
     def add_multivec(self, vecs, offsets) -> None:
         vecs = f32c(vecs)

@@ -78,21 +78,20 @@ class ShardedSearcher:
 
         on_gpu = self.backend == "nccl"
         dev = torch.device("cuda", self.device) if on_gpu else torch.device("cpu")
-        td = torch.from_numpy(np.ascontiguousarray(dist_l)).to(dev)
-        tr = torch.from_numpy(np.ascontiguousarray(rows_l)).to(dev)
-        B = td.shape[0]
-        all_d = torch.empty((self.world, B, k), dtype=torch.float64, device=dev)
-        all_r = torch.empty((self.world, B, k), dtype=torch.int64, device=dev)
-        self._dist.all_gather_into_tensor(all_d.view(-1), td.view(-1), group=self.group)
-        self._dist.all_gather_into_tensor(all_r.view(-1), tr.view(-1), group=self.group)
-        if on_gpu and hasattr(self.index, "merge_topk_device"):
+        B = dist_l.shape[0]
+        # one all-gather of the packed [2,B,k] int64 block: plane 0 = float8 distance bits, plane 1 = rows
+        packed = torch.from_numpy(np.stack([np.ascontiguousarray(dist_l).view(np.int64), rows_l])).to(dev)
+        gathered = torch.empty((self.world, 2, B, k), dtype=torch.int64, device=dev)
+        self._dist.all_gather_into_tensor(gathered.view(-1), packed.view(-1), group=self.group)
+        if on_gpu and hasattr(self.index, "merge_topk_packed_device"):
             out_d = torch.empty((B, k), dtype=torch.float64, device=dev)
             out_r = torch.empty((B, k), dtype=torch.int64, device=dev)
             torch.cuda.current_stream().synchronize()
-            self.index.merge_topk_device(all_d.data_ptr(), all_r.data_ptr(), self.world, B, k, out_d.data_ptr(),
-                                         out_r.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            self.index.merge_topk_packed_device(gathered.data_ptr(), self.world, B, k, out_d.data_ptr(),
+                                                out_r.data_ptr(), torch.cuda.current_stream().cuda_stream)
             return out_d.cpu().numpy(), out_r.cpu().numpy()
-        return merge_topk_host(all_d.cpu().numpy(), all_r.cpu().numpy(), k)
+        g = gathered.cpu().numpy()
+        return merge_topk_host(np.ascontiguousarray(g[:, 0]).view(np.float64), np.ascontiguousarray(g[:, 1]), k)
 
     def close(self) -> None:
         self.index.close()

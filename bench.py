@@ -123,8 +123,8 @@ def main() -> None:
     out_dist = torch.empty((B, k), device=device, dtype=torch.float64)
     out_rows = torch.empty((B, k), device=device, dtype=torch.int64)
     if world > 1:
-        all_dist = torch.empty((world, B, k), device=device, dtype=torch.float64)
-        all_rows = torch.empty((world, B, k), device=device, dtype=torch.int64)
+        packed = torch.empty((2, B, k), device=device, dtype=torch.int64)
+        packed_all = torch.empty((world, 2, B, k), device=device, dtype=torch.int64)
         fin_dist = torch.empty((B, k), device=device, dtype=torch.float64)
         fin_rows = torch.empty((B, k), device=device, dtype=torch.int64)
     stream = torch.cuda.current_stream().cuda_stream
@@ -133,10 +133,11 @@ def main() -> None:
         q = qpool[i % n_pool]
         idx.search_device(q.data_ptr(), B, k, out_dist.data_ptr(), out_rows.data_ptr(), stream)
         if world > 1:
-            dist.all_gather_into_tensor(all_dist.view(-1), out_dist.view(-1))
-            dist.all_gather_into_tensor(all_rows.view(-1), out_rows.view(-1))
-            idx.merge_topk_device(all_dist.data_ptr(), all_rows.data_ptr(), world, B, k, fin_dist.data_ptr(),
-                                  fin_rows.data_ptr(), stream)
+            # one all-gather of the packed [2,B,k] (distance bits, rows) block per rank, then the merge kernel
+            idx.pack_topk_device(out_dist.data_ptr(), out_rows.data_ptr(), B, k, packed.data_ptr(), stream)
+            dist.all_gather_into_tensor(packed_all.view(-1), packed.view(-1))
+            idx.merge_topk_packed_device(packed_all.data_ptr(), world, B, k, fin_dist.data_ptr(), fin_rows.data_ptr(),
+                                         stream)
             return fin_dist, fin_rows
         return out_dist, out_rows
 

@@ -102,6 +102,13 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
 int mi355dr_merge_topk_device(mi355dr_index* idx, const double* dist_all_dev, const int64_t* rows_all_dev, int world,
                               int B, int k, double* out_dist_dev, int64_t* out_rows_dev, void* stream);
 
+/* same merge on the PACKED layout one rank produces for a single all-gather: int64 [world][2][B][k], plane 0 = the
+ * float8 distance bit patterns, plane 1 = rows.  mi355dr_pack_topk_device builds one rank's [2][B][k] block. */
+int mi355dr_pack_topk_device(mi355dr_index* idx, const double* dist_dev, const int64_t* rows_dev, int B, int k,
+                             int64_t* packed_dev, void* stream);
+int mi355dr_merge_topk_packed_device(mi355dr_index* idx, const int64_t* packed_all_dev, int world, int B, int k,
+                                     double* out_dist_dev, int64_t* out_rows_dev, void* stream);
+
 /* ---- options / stats / timing ----
  * options: "path" (MI355DR_PATH_*), "row_offset", "profile" (0/1: HIP-event timing of the dominant kernel),
  *          "chunk0_rows", "chunk_growth", "cand_cap".

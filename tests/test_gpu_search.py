@@ -137,11 +137,26 @@ def test_merge_topk_device_equals_host_merge(pkg):
         gd, gr = np.empty((B, k)), np.empty((B, k), dtype=np.int64)
         idx.dev_download(od, gd)
         idx.dev_download(orr, gr)
-        for p in (pd, pr, od, orr):
+        # packed layout [world][2][B][k] (what one all-gather delivers)
+        packed = np.stack([d.view(np.int64), r.astype(np.int64)], axis=1)
+        pp = idx.dev_alloc(packed.nbytes)
+        idx.dev_upload(pp, packed)
+        idx.merge_topk_packed_device(pp, world, B, k, od, orr)
+        gd2, gr2 = np.empty((B, k)), np.empty((B, k), dtype=np.int64)
+        idx.dev_download(od, gd2)
+        idx.dev_download(orr, gr2)
+        # and the packer itself
+        one = idx.dev_alloc(2 * B * k * 8)
+        idx.pack_topk_device(pd, pr, B, k, one)
+        got = np.empty((2, B, k), dtype=np.int64)
+        idx.synchronize()
+        idx.dev_download(one, got)
+        for p in (pd, pr, od, orr, pp, one):
             idx.dev_free(p)
     hd, hr = merge_topk_host(d, r.astype(np.int64), k)
-    assert np.array_equal(gr, hr)
-    assert np.array_equal(gd, hd, equal_nan=True)
+    assert np.array_equal(gr, hr) and np.array_equal(gr2, hr)
+    assert np.array_equal(gd, hd, equal_nan=True) and np.array_equal(gd2, hd, equal_nan=True)
+    assert np.array_equal(got[0], d[0].view(np.int64)) and np.array_equal(got[1], r[0])
 
 
 def test_search_device_buffers_and_row_offset(pkg, oracle):
@@ -165,3 +180,57 @@ def test_search_device_buffers_and_row_offset(pkg, oracle):
         assert np.array_equal(idx.get_rows(10, 3), C[10:13])
     rd, rr = oracle.topk_search(C, Q, k)
     assert np.array_equal(gr, rr + 1_000_000) and np.array_equal(gd, rd)
+
+
+def test_large_corpus_properties(pkg, oracle):
+    """N = 2M x d=768 (6 GB fp32 + 3 GB shadow): size-independent properties + planted answers + oracle spot checks.
+
+    * every query's planted near-duplicates are found, at their exact (oracle) distances;
+    * lists are sorted by (distance, row), rows unique and in range;
+    * block search == one-by-one search (B=1 path) == scan path, bit for bit, on a subset;
+    * idempotence: searching twice gives the same bits.
+    """
+    rng = np.random.default_rng(2026)
+    n, d, B, k = 2_000_000, 768, 300, 10
+    chunk = 250_000
+    planted = {}
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    with pkg.Mi355Index(d) as idx:
+        idx.reserve(n)
+        for c in range(n // chunk):
+            X = np.random.default_rng(1234 + c).standard_normal((chunk, d), dtype=np.float32)
+            X /= np.linalg.norm(X, axis=1, keepdims=True)
+            if c in (0, 3, 7):  # plant 3 neighbours per query at known global rows
+                sig = {0: 0.3, 3: 0.6, 7: 1.0}[c]
+                for b in range(B):
+                    pos = 1000 + 37 * b
+                    v = Q[b] / np.linalg.norm(Q[b]) + sig / np.sqrt(d) * rng.standard_normal(d).astype(np.float32)
+                    X[pos] = v.astype(np.float32)
+                    planted.setdefault(b, []).append((c * chunk + pos, X[pos].copy()))
+            idx.add(X)
+        dist, rows = idx.search(Q, k)
+        dist2, rows2 = idx.search(Q, k)
+        assert np.array_equal(rows, rows2) and np.array_equal(dist, dist2)
+        assert rows.min() >= 0 and rows.max() < n
+        assert all(len(set(r)) == k for r in rows)
+        assert (np.diff(dist, axis=1) >= 0).all()
+        for b in range(B):
+            for grow, vec in planted[b]:
+                j = np.nonzero(rows[b] == grow)[0]
+                assert j.size == 1, (b, grow)
+                assert dist[b, j[0]] == oracle.cosine_distance(Q[b], vec)
+            assert set(rows[b][:3]) == {g for g, _ in planted[b]}  # sigma = 0.3/0.6/1.0 neighbours outrank random rows
+        sub = [0, 17, 299]
+        for b in sub:
+            d1, r1 = idx.search(Q[b], k)
+            assert np.array_equal(r1[0], rows[b]) and np.array_equal(d1[0], dist[b])
+        idx.set_option("path", "scan")
+        ds, rs = idx.search(Q[sub], k)
+        assert np.array_equal(rs, rows[sub]) and np.array_equal(ds, dist[sub])
+        # oracle on a 300k-row slice containing the first planted chunk: same ids/distances as a GPU index of that slice
+        sl = idx.get_rows(0, 300_000)
+    rd, rr = oracle.topk_search(sl, Q[:16], k)
+    with pkg.Mi355Index(d) as small:
+        small.add(sl)
+        gd, gr = small.search(Q[:16], k)
+    assert np.array_equal(gr, rr) and np.array_equal(gd, rd)
