@@ -177,6 +177,13 @@ def main() -> None:
     alg_bytes = float(screen_rows) * d * 4            # algorithmic HBM bytes: N*d*4 per pass
     shadow_bytes = float(screen_rows) * dpad * 2      # bytes the screen really streams (bf16 shadow)
     screen_s = screen_ns * 1e-9
+    # HBM traffic of the dominant kernel from the committed PMC pass of this same command (rocprofv3 cannot run
+    # inside the timed region): bytes per screened row x rows per launch.  See tools/collect_traffic.sh.
+    traffic = None
+    tfile = ROOT / "profiles" / "r01_traffic.json"
+    if tfile.exists() and B > 128 and d == 768 and launches:
+        per_row = json.loads(tfile.read_text())["hbm_read_bytes_per_screened_row"]
+        traffic = round(per_row * screen_rows / launches)
     roof = {
         "bound": "mfma",
         "kernel": "k_screen256" if B > 128 else "k_screen",
@@ -184,7 +191,9 @@ def main() -> None:
         "peak": MFMA_BF16_PEAK_TF,
         "unit": "TFLOP/s",
         "frac": round(alg_flops / screen_s / 1e12 / MFMA_BF16_PEAK_TF, 4) if screen_s > 0 else None,
-        "traffic": None,
+        "traffic": traffic,
+        "traffic_unit": "HBM read bytes per launch (PMC FETCH_SIZE, gfx950-corrected), vs algorithmic "
+                        f"{round(alg_bytes / max(launches, 1))}",
         "launches": launches,
         "avg_launch_ms": round(screen_s * 1e3 / max(launches, 1), 4),
         "kernel_ms_per_step": round(screen_s * 1e3 / max(args.steps, 1), 3),
