@@ -323,26 +323,46 @@ int orc_maxsim_topk(const float* tok, const int64_t* offsets, int64_t n_docs, in
     nthreads = threads > 0 ? threads : omp_get_max_threads();
 #endif
     (void)threads;
-#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+    /* per-thread partial lists over a slice of the documents, merged per query (same total order) */
+    double* pd = (double*)malloc(sizeof(double) * (size_t)nthreads * k);
+    int64_t* pr = (int64_t*)malloc(sizeof(int64_t) * (size_t)nthreads * k);
+    int* plen = (int*)malloc(sizeof(int) * (size_t)nthreads);
+    double* td = (double*)malloc(sizeof(double) * (size_t)k);
+    if (!pd || !pr || !plen || !td) return -2;
     for (int b = 0; b < B; ++b) {
-        orc_pin_thread();
-        double* td = (double*)malloc(sizeof(double) * (size_t)k);
-        orc_topk fin = {td, out_rows + (size_t)b * k, k, 0};
         for (int s = 0; s < k; ++s) {
             out_rows[(size_t)b * k + s] = -1;
             out_dist[(size_t)b * k + s] = NAN;
         }
         const float* q = qtok + (int64_t)q_off[b] * d;
-        int nq = q_off[b + 1] - q_off[b];
-        for (int64_t doc = 0; doc < n_docs; ++doc) {
-            int64_t T = offsets[doc + 1] - offsets[doc];
-            if (T <= 0) continue;
-            float dist = orc_maxsim_distance(tok + offsets[doc] * (int64_t)d, T, q, nq, d);
-            orc_topk_push(&fin, (double)dist, doc);
+        const int nq = q_off[b + 1] - q_off[b];
+        for (int t = 0; t < nthreads; ++t) plen[t] = 0;
+#pragma omp parallel num_threads(nthreads)
+        {
+            orc_pin_thread();
+            int tid = 0, nt = 1;
+#ifdef _OPENMP
+            tid = omp_get_thread_num();
+            nt = omp_get_num_threads();
+#endif
+            orc_topk part = {pd + (size_t)tid * k, pr + (size_t)tid * k, k, 0};
+            for (int64_t doc = n_docs * tid / nt; doc < n_docs * (tid + 1) / nt; ++doc) {
+                const int64_t T = offsets[doc + 1] - offsets[doc];
+                if (T <= 0) continue;
+                const float dist = orc_maxsim_distance(tok + offsets[doc] * (int64_t)d, T, q, nq, d);
+                orc_topk_push(&part, (double)dist, doc);
+            }
+            plen[tid] = part.len;
         }
+        orc_topk fin = {td, out_rows + (size_t)b * k, k, 0};
+        for (int t = 0; t < nthreads; ++t)
+            for (int s = 0; s < plen[t]; ++s) orc_topk_push(&fin, pd[(size_t)t * k + s], pr[(size_t)t * k + s]);
         for (int s = 0; s < fin.len; ++s) out_dist[(size_t)b * k + s] = (float)td[s];
-        free(td);
     }
+    free(pd);
+    free(pr);
+    free(plen);
+    free(td);
     return 0;
 }
 
