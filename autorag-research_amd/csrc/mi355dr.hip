@@ -544,8 +544,7 @@ int mi355dr_merge_topk_device(mi355dr_index* idx, const double* dist_all_dev, co
     hipLaunchKernelGGL(k_merge_topk, dim3(B), dim3(256), (size_t)kSortMax * 12, s, dist_all_dev, rows_all_dev,
                        (int64_t)B * k, world, B, k, out_dist_dev, out_rows_dev);
     HIPCHECK(idx, hipGetLastError());
-    HIPCHECK(idx, hipStreamSynchronize(s));
-    return MI355DR_OK;
+    return MI355DR_OK;  // asynchronous on `s`
 }
 
 int mi355dr_pack_topk_device(mi355dr_index* idx, const double* dist_dev, const int64_t* rows_dev, int B, int k,
@@ -577,8 +576,7 @@ int mi355dr_merge_topk_packed_device(mi355dr_index* idx, const int64_t* packed_a
     hipLaunchKernelGGL(k_merge_topk, dim3(B), dim3(256), (size_t)kSortMax * 12, s, (const double*)packed_all_dev,
                        packed_all_dev + plane, 2 * plane, world, B, k, out_dist_dev, out_rows_dev);
     HIPCHECK(idx, hipGetLastError());
-    HIPCHECK(idx, hipStreamSynchronize(s));
-    return MI355DR_OK;
+    return MI355DR_OK;  // asynchronous on `s`
 }
 
 int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {

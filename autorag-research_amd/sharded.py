@@ -89,7 +89,7 @@ class ShardedSearcher:
             torch.cuda.current_stream().synchronize()
             self.index.merge_topk_packed_device(gathered.data_ptr(), self.world, B, k, out_d.data_ptr(),
                                                 out_r.data_ptr(), torch.cuda.current_stream().cuda_stream)
-            return out_d.cpu().numpy(), out_r.cpu().numpy()
+            return out_d.cpu().numpy(), out_r.cpu().numpy()  # .cpu() synchronises the stream the merge ran on
         g = gathered.cpu().numpy()
         return merge_topk_host(np.ascontiguousarray(g[:, 0]).view(np.float64), np.ascontiguousarray(g[:, 1]), k)
 

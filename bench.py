@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument("--docs", type=int, default=50_000, help="maxsim: documents (tokens/doc ~ U{32..180}, d=128)")
     ap.add_argument("--chunk0", type=int, default=0, help="override the first (emit-all) chunk size")
     ap.add_argument("--growth", type=int, default=0, help="override the chunk growth factor")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the all-gather + merge path even at world size 1 (exercises the multi-GPU code on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=2_500_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=1024)
@@ -142,10 +144,13 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist  # noqa: PLC0415
 
-        dist.init_process_group(backend="nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
 
     n_total, d, B, k = args.rows, args.dim, args.block, args.k
     n_chunks = (n_total + CHUNK_ROWS - 1) // CHUNK_ROWS
@@ -187,10 +192,12 @@ def main() -> None:
     n_pool = 10
     qpool = torch.randn((n_pool, B, d), generator=gq, device=device, dtype=torch.float32)
     qpool /= qpool.norm(dim=2, keepdim=True)
-    out_dist = torch.empty((B, k), device=device, dtype=torch.float64)
-    out_rows = torch.empty((B, k), device=device, dtype=torch.int64)
-    if world > 1:
-        packed = torch.empty((2, B, k), device=device, dtype=torch.int64)
+    # the shard result is written straight into the packed [2,B,k] block one all-gather sends:
+    # plane 0 = float8 distance bits, plane 1 = global rows
+    packed = torch.empty((2, B, k), device=device, dtype=torch.int64)
+    out_dist = packed[0].view(torch.float64)
+    out_rows = packed[1]
+    if use_dist:
         packed_all = torch.empty((world, 2, B, k), device=device, dtype=torch.int64)
         fin_dist = torch.empty((B, k), device=device, dtype=torch.float64)
         fin_rows = torch.empty((B, k), device=device, dtype=torch.int64)
@@ -199,9 +206,8 @@ def main() -> None:
     def step(i: int):
         q = qpool[i % n_pool]
         idx.search_device(q.data_ptr(), B, k, out_dist.data_ptr(), out_rows.data_ptr(), stream)
-        if world > 1:
+        if use_dist:
             # one all-gather of the packed [2,B,k] (distance bits, rows) block per rank, then the merge kernel
-            idx.pack_topk_device(out_dist.data_ptr(), out_rows.data_ptr(), B, k, packed.data_ptr(), stream)
             dist.all_gather_into_tensor(packed_all.view(-1), packed.view(-1))
             idx.merge_topk_packed_device(packed_all.data_ptr(), world, B, k, fin_dist.data_ptr(), fin_rows.data_ptr(),
                                          stream)
@@ -211,7 +217,7 @@ def main() -> None:
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     idx.reset_stats()
     idx.set_option("profile", 1)
@@ -220,12 +226,12 @@ def main() -> None:
     for i in range(args.steps):
         res = step(args.warmup + i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     idx.set_option("profile", 0)
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -343,7 +349,7 @@ def main() -> None:
         assert rr_.min() >= 0 and rr_.max() < n_total
         print(json.dumps(result))
     idx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

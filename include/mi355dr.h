@@ -98,7 +98,9 @@ int64_t mi355dr_size_multivec(const mi355dr_index* idx);
 int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* q_offsets, int B, int k,
                           float* out_dist, int64_t* out_rows);
 
-/* ---- shard merge (multi-GPU): [world, B, k] gathered (dist,row) device buffers -> [B, k] ---- */
+/* ---- shard merge (multi-GPU): [world, B, k] gathered (dist,row) device buffers -> [B, k] ----
+ * The merge functions only enqueue work on `stream` (NULL: the index's stream); synchronise that stream (or call
+ * mi355dr_synchronize for the index stream) before reading the outputs on the host. */
 int mi355dr_merge_topk_device(mi355dr_index* idx, const double* dist_all_dev, const int64_t* rows_all_dev, int world,
                               int B, int k, double* out_dist_dev, int64_t* out_rows_dev, void* stream);
 

@@ -134,6 +134,7 @@ def test_merge_topk_device_equals_host_merge(pkg):
         idx.dev_upload(pd, d)
         idx.dev_upload(pr, r.astype(np.int64))
         idx.merge_topk_device(pd, pr, world, B, k, od, orr)
+        idx.synchronize()
         gd, gr = np.empty((B, k)), np.empty((B, k), dtype=np.int64)
         idx.dev_download(od, gd)
         idx.dev_download(orr, gr)
@@ -142,6 +143,7 @@ def test_merge_topk_device_equals_host_merge(pkg):
         pp = idx.dev_alloc(packed.nbytes)
         idx.dev_upload(pp, packed)
         idx.merge_topk_packed_device(pp, world, B, k, od, orr)
+        idx.synchronize()
         gd2, gr2 = np.empty((B, k)), np.empty((B, k), dtype=np.int64)
         idx.dev_download(od, gd2)
         idx.dev_download(orr, gr2)
