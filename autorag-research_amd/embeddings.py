@@ -189,6 +189,59 @@ class TorchEncoderEmbeddings(Embeddings):
         return self._forward([text])[0].cpu().tolist()
 
 
+class TorchLateInteractionEmbeddings(MultiVectorBaseEmbedding):
+    """Multi-vector text encoder on PyTorch-ROCm (ColBERT-style: per-token projection + L2 norm).
+
+    `model(input_ids, attention_mask)` -> [B,T,H] (or an object with `.last_hidden_state`); `proj` is an optional
+    torch module H -> dim (ColBERT/ColPali use 128).  Padding tokens are dropped, so each text yields its own
+    number of vectors -- the ragged `VECTOR(d)[]` shape of the reference (embeddings/colpali.py:120-133).
+    """
+
+    def __init__(self, model: Any, tokenizer: Any, proj: Any | None = None, device: str = "cuda:0",
+                 batch_size: int = 64, max_length: int = 180, model_name: str = "late-interaction"):
+        import torch
+
+        self._torch = torch
+        self.model = model.to(device).eval()
+        self.proj = proj.to(device).eval() if proj is not None else None
+        self.tokenizer = tokenizer
+        self.device = device
+        self.embed_batch_size = batch_size
+        self.max_length = max_length
+        self.model_name = model_name
+
+    def _forward(self, texts: list[str]) -> list[MultiVectorEmbedding]:
+        torch = self._torch
+        enc = self.tokenizer(texts, padding=True, truncation=True, max_length=self.max_length, return_tensors="pt")
+        enc = {k: v.to(self.device) for k, v in enc.items()}
+        with torch.no_grad():
+            out = self.model(**enc)
+            h = out.last_hidden_state if hasattr(out, "last_hidden_state") else out
+            if self.proj is not None:
+                h = self.proj(h)
+            h = torch.nn.functional.normalize(h.float(), dim=-1)
+        mask = enc["attention_mask"].bool()
+        return [h[i][mask[i]].cpu().tolist() for i in range(h.shape[0])]
+
+    def embed_query(self, query: str) -> MultiVectorEmbedding:
+        return self._forward([query])[0]
+
+    async def aembed_query(self, query: str) -> MultiVectorEmbedding:
+        return await asyncio.to_thread(self.embed_query, query)
+
+    def embed_text(self, text: str) -> MultiVectorEmbedding:
+        return self._forward([text])[0]
+
+    async def aembed_text(self, text: str) -> MultiVectorEmbedding:
+        return await asyncio.to_thread(self.embed_text, text)
+
+    def embed_documents(self, texts: list[str]) -> list[MultiVectorEmbedding]:
+        out: list[MultiVectorEmbedding] = []
+        for i in range(0, len(texts), self.embed_batch_size):
+            out.extend(self._forward(texts[i: i + self.embed_batch_size]))
+        return out
+
+
 # ---- loader (reference injection.py) -------------------------------------------------------------------
 
 _CONFIG_DIRS = [Path(__file__).resolve().parent / "configs" / "embedding"]

@@ -236,3 +236,18 @@ def test_large_corpus_properties(pkg, oracle):
         small.add(sl)
         gd, gr = small.search(Q[:16], k)
     assert np.array_equal(gr, rr) and np.array_equal(gd, rd)
+
+
+def test_multi_block_queries_and_large_k(pkg, oracle):
+    """B > 1024 is processed in internal blocks; k up to 1024 is served (kept lists, sorts, merges at their limits)."""
+    rng = np.random.default_rng(44)
+    n, d = 3000, 64
+    C = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((1100, d)).astype(np.float32)
+    with pkg.Mi355Index(d) as idx:
+        idx.add(C)
+        _check(idx, oracle, C, Q, 5)            # two internal blocks (1024 + 76)
+        _check(idx, oracle, C, Q[:9], 1024)     # k = 1024
+        _check(idx, oracle, C, Q[:3], 700)
+        with pytest.raises(pkg.NativeError):
+            idx.search(Q[:1], 1025)             # beyond kKMax: refused loudly, not truncated
