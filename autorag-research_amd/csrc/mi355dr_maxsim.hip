@@ -26,7 +26,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kMsCols = 128;        // query-token columns per launch (4 column blocks of 32)
 constexpr int kMsBlkRows = 32;
 constexpr int kMsThreads = 256;     // 4 waves = 4 docs per workgroup
-constexpr int kSegSort = kSortMax;  // select: entries per segment
+constexpr int kSegSort = kSortMax;  // select: largest segment (entries sorted per workgroup)
 
 struct MultiVecStore {
     int64_t n_docs = 0;
@@ -69,8 +69,45 @@ struct MsArgs {
     int q_len[4];           // real token count of each query
 };
 
+// Column order inside every group of 8 dims, for BOTH stored token rows and the staged query rows:
+// position j holds original column kPerm[j] = {0,4,2,6,1,5,3,7}[j].  A lane of the lower half (k-slot 0 of the
+// 32x32x2 MFMA) reads positions 0..3 = columns (0,4,2,6), a lane of the upper half positions 4..7 = (1,5,3,7),
+// so issuing the MFMAs on components x, z, y, w walks k = (0|1), (2|3), (4|5), (6|7): ascending, no lane swaps.
+__host__ __device__ inline int ms_perm(int j) {
+    constexpr int P[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+    return (j & ~7) | P[j & 7];
+}
+
+__device__ __forceinline__ void ms_load_piece(float4 (&a)[16], const float* row, int chunk, int dpad) {
+    // this lane's 4 floats of every 8-dim group of dims [128*chunk, +128); groups past dpad read as zero
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int k0 = chunk * 128 + i * 8;
+        a[i] = k0 < dpad ? *(const float4*)(row + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+__device__ __forceinline__ void ms_compute_piece(f32x16 (&acc)[4], const float4 (&a)[16], const float* qs, int ld, int ncb,
+                                                 int col, int half, int chunk, int dpad) {
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        if (cb >= ncb) break;
+        const float* brow = qs + (cb * 32 + col) * ld + 4 * half + chunk * 128;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (chunk * 128 + i * 8 >= dpad) break;
+            const float4 bv = *(const float4*)(brow + i * 8);
+            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, bv.x, acc[cb], 0, 0, 0);
+            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, bv.z, acc[cb], 0, 0, 0);
+            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, bv.y, acc[cb], 0, 0, 0);
+            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, bv.w, acc[cb], 0, 0, 0);
+        }
+    }
+}
+
 // B fragments: LDS image [col][dpad + 4] floats (the +4 pad makes the 16-lane groups of ds_read_b128 hit 16
-// distinct 16-B slots)
+// distinct 16-B slots).  The doc-token piece (32 rows x 128 dims = 16 float4 per lane) is register-resident
+// and reused for every query column block; the next piece is prefetched while the current one is consumed.
 __global__ __launch_bounds__(kMsThreads) void k_maxsim(MsArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* qs = (float*)smem;
@@ -91,50 +128,42 @@ __global__ __launch_bounds__(kMsThreads) void k_maxsim(MsArgs a) {
     int ncb = 0;   // column blocks in use
     for (int qi = 0; qi < a.nq_launch; ++qi) ncb = max(ncb, (a.q_col0[qi] + a.q_len[qi] + 31) / 32);
 
-    for (int64_t blk = b0; blk < b1; ++blk) {
-        const float* arow = a.tok + (blk * kMsBlkRows + col) * (int64_t)a.dpad + 4 * half;
-        for (int cb = 0; cb < ncb; ++cb) {
-            const float* brow = qs + (cb * 32 + col) * ld + 4 * half;
-            f32x16 acc;
+    const int nchunk = (a.dpad + 127) / 128;
+    const int64_t npieces = (b1 - b0) * nchunk;
+    f32x16 acc[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            for (int k0 = 0; k0 < a.dpad; k0 += 8) {
-                float4 av = *(const float4*)(arow + k0);
-                float4 bv = *(const float4*)(brow + k0);
-                // lower half holds k0..k0+3, upper half k0+4..k0+7; after the swaps register X pairs
-                // (k0,k0+1), Z (k0+2,k0+3), Y (k0+4,k0+5), W (k0+6,k0+7) across the two halves
-                {
-                    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(av.x), __float_as_uint(av.y), false, false);
-                    av.x = __uint_as_float(r[0]);
-                    av.y = __uint_as_float(r[1]);
-                    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(av.z), __float_as_uint(av.w), false, false);
-                    av.z = __uint_as_float(r[0]);
-                    av.w = __uint_as_float(r[1]);
-                    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(bv.x), __float_as_uint(bv.y), false, false);
-                    bv.x = __uint_as_float(r[0]);
-                    bv.y = __uint_as_float(r[1]);
-                    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(bv.z), __float_as_uint(bv.w), false, false);
-                    bv.z = __uint_as_float(r[0]);
-                    bv.w = __uint_as_float(r[1]);
-                }
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
-            }
-            // block max per column: 16 rows in this lane, the other 16 in lane^32
-            float m = acc[0];
+    for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+        for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
+    float4 pa[16], pb[16];
+    auto row_of = [&](int64_t p) { return a.tok + ((b0 + p / nchunk) * kMsBlkRows + col) * (int64_t)a.dpad + 4 * half; };
+    auto finish_block = [&]() {  // block max per column: 16 rows in this lane, the other 16 in lane^32
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            if (cb >= ncb) break;
+            float m = acc[cb][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[cb][r]);
             m = fmaxf(m, __shfl_xor(m, 32, kWave));
+            run[cb] = fmaxf(run[cb], m);
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (c == cb) run[c] = fmaxf(run[c], m);
+            for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
+        }
+    };
+    if (npieces > 0) ms_load_piece(pa, row_of(0), 0, a.dpad);
+    for (int64_t p = 0; p < npieces; p += 2) {
+        if (p + 1 < npieces) ms_load_piece(pb, row_of(p + 1), (int)((p + 1) % nchunk), a.dpad);
+        ms_compute_piece(acc, pa, qs, ld, ncb, col, half, (int)(p % nchunk), a.dpad);
+        if ((p + 1) % nchunk == 0) finish_block();
+        if (p + 1 < npieces) {
+            if (p + 2 < npieces) ms_load_piece(pa, row_of(p + 2), (int)((p + 2) % nchunk), a.dpad);
+            ms_compute_piece(acc, pb, qs, ld, ncb, col, half, (int)((p + 1) % nchunk), a.dpad);
+            if ((p + 2) % nchunk == 0) finish_block();
         }
     }
     // per query: distance = sum over its tokens (in order) of -(max dot); empty docs are skipped by the select
     for (int qi = 0; qi < a.nq_launch; ++qi) {
-        float acc = 0.0f;
+        float accd = 0.0f;
         for (int j = 0; j < a.q_len[qi]; ++j) {
             const int c = a.q_col0[qi] + j;
             float v = 0.0f;
@@ -142,9 +171,9 @@ __global__ __launch_bounds__(kMsThreads) void k_maxsim(MsArgs a) {
             for (int cbi = 0; cbi < 4; ++cbi)
                 if (cbi == (c >> 5)) v = run[cbi];
             v = __shfl(v, c & 31, kWave);
-            acc = acc + (-v);
+            accd = accd + (-v);
         }
-        if (lane == 0) a.dist[(int64_t)qi * a.n_docs + doc] = acc;
+        if (lane == 0) a.dist[(int64_t)qi * a.n_docs + doc] = accd;
     }
 }
 
@@ -166,12 +195,12 @@ __device__ __forceinline__ float key_to_f32(uint64_t k) {
 // first stage reads distances (and skips empty docs), later stages read (key,row) partials.
 __global__ __launch_bounds__(256) void k_topk_segments(const float* dist, const int64_t* blk_off,
                                                         const uint64_t* key_in, const int32_t* row_in, int64_t n_in,
-                                                        int k, uint64_t* key_out, int32_t* row_out) {
+                                                        int k, int seg, uint64_t* key_out, int32_t* row_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint64_t* SK = (uint64_t*)smem;
     int32_t* SR = (int32_t*)(smem + (size_t)kSegSort * 8);
-    const int64_t base = (int64_t)blockIdx.x * kSegSort;
-    for (int i = threadIdx.x; i < kSegSort; i += blockDim.x) {
+    const int64_t base = (int64_t)blockIdx.x * seg;
+    for (int i = threadIdx.x; i < seg; i += blockDim.x) {
         const int64_t g = base + i;
         uint64_t key = kKeyNaN;
         int32_t row = 0x7FFFFFFF;
@@ -190,7 +219,7 @@ __global__ __launch_bounds__(256) void k_topk_segments(const float* dist, const 
         SR[i] = row;
     }
     __syncthreads();
-    bitonic_asc_key_row(SK, SR, kSegSort);
+    bitonic_asc_key_row(SK, SR, seg);
     for (int i = threadIdx.x; i < k; i += blockDim.x) {
         key_out[(int64_t)blockIdx.x * k + i] = SK[i];
         row_out[(int64_t)blockIdx.x * k + i] = SR[i];
@@ -264,7 +293,12 @@ int mi355dr_add_multivec(mi355dr_index* idx, const float* vecs, const int64_t* o
         const int64_t nb = (T + kMsBlkRows - 1) / kMsBlkRows;
         for (int64_t r = 0; r < nb * kMsBlkRows; ++r) {
             const int64_t src = offsets[i] + std::min<int64_t>(r, T - 1);
-            std::memcpy(&img[(size_t)(blk * kMsBlkRows + r) * dp], vecs + src * d, (size_t)d * sizeof(float));
+            float* dst = &img[(size_t)(blk * kMsBlkRows + r) * dp];
+            const float* sv = vecs + src * d;
+            for (int j = 0; j < dp; ++j) {  // stored position j holds column ms_perm(j) (zero beyond dim)
+                const int c = ms_perm(j);
+                dst[j] = c < d ? sv[c] : 0.0f;
+            }
         }
         blk += nb;
         m->blk_off_host.push_back(m->n_blocks + blk);
@@ -319,7 +353,11 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
         HIPCHECK(idx, hipMalloc(&m->dist, (size_t)4 * m->cap_docs * sizeof(float)));
         m->dist_cap_docs = m->cap_docs;
     }
-    const int64_t nseg0 = (m->n_docs + kSegSort - 1) / kSegSort;
+    // segment size: small segments = many workgroups; it must hold k and shrink the list by >= 4x per stage
+    int seg = 512;
+    while (seg < 4 * k) seg <<= 1;
+    if (seg > kSegSort) seg = kSegSort;
+    const int64_t nseg0 = (m->n_docs + seg - 1) / seg;
     if (m->part_cap < nseg0 * kKMax) {
         for (int i = 0; i < 2; ++i) {
             if (m->pk[i]) (void)hipFree(m->pk[i]);
@@ -348,8 +386,14 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
             if (col + need > kMsCols) break;
             a.q_col0[nql] = col;
             a.q_len[nql] = nq;
-            for (int j = 0; j < nq; ++j)
-                std::memcpy(&qimg[(size_t)(col + j) * dp], qtok + (int64_t)(q_offsets[b] + j) * d, (size_t)d * sizeof(float));
+            for (int j = 0; j < nq; ++j) {
+                float* dst = &qimg[(size_t)(col + j) * dp];
+                const float* sv = qtok + (int64_t)(q_offsets[b] + j) * d;
+                for (int c = 0; c < dp; ++c) {
+                    const int oc = ms_perm(c);
+                    dst[c] = oc < d ? sv[oc] : 0.0f;
+                }
+            }
             col += need;
             ++nql;
             ++b;
@@ -365,11 +409,11 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
             int cur = 0;
             bool first_stage = true;
             while (true) {
-                const int64_t nseg = (n_in + kSegSort - 1) / kSegSort;
+                const int64_t nseg = (n_in + seg - 1) / seg;
                 hipLaunchKernelGGL(k_topk_segments, dim3((unsigned)nseg), dim3(256), (size_t)kSegSort * 12, s,
                                    first_stage ? m->dist + (int64_t)qi * m->n_docs : nullptr, m->blk_off,
                                    first_stage ? nullptr : m->pk[cur ^ 1], first_stage ? nullptr : m->pr[cur ^ 1], n_in,
-                                   k, m->pk[cur], m->pr[cur]);
+                                   k, seg, m->pk[cur], m->pr[cur]);
                 HIPCHECK(idx, hipGetLastError());
                 first_stage = false;
                 if (nseg == 1) break;
