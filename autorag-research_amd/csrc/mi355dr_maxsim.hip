@@ -25,7 +25,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kMsCols = 128;        // query-token columns per launch (4 column blocks of 32)
 constexpr int kMsBlkRows = 32;
-constexpr int kMsThreads = 256;     // 4 waves = 4 docs per workgroup
+constexpr int kMsThreads = 256;     // 4 waves
+constexpr int kMsDocsPerWave = 4;   // docs a wave walks per workgroup (amortises staging the query block in LDS)
 constexpr int kSegSort = kSortMax;  // select: largest segment (entries sorted per workgroup)
 
 struct MultiVecStore {
@@ -108,7 +109,7 @@ __device__ __forceinline__ void ms_compute_piece(f32x16 (&acc)[4], const float4 
 // B fragments: LDS image [col][dpad + 4] floats (the +4 pad makes the 16-lane groups of ds_read_b128 hit 16
 // distinct 16-B slots).  The doc-token piece (32 rows x 128 dims = 16 float4 per lane) is register-resident
 // and reused for every query column block; the next piece is prefetched while the current one is consumed.
-__global__ __launch_bounds__(kMsThreads) void k_maxsim(MsArgs a) {
+__global__ __launch_bounds__(kMsThreads, 2) void k_maxsim(MsArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* qs = (float*)smem;
     const int ld = a.dpad + 4;
@@ -118,17 +119,19 @@ __global__ __launch_bounds__(kMsThreads) void k_maxsim(MsArgs a) {
         *(float4*)(qs + c * ld + k4 * 4) = *(const float4*)(a.qtok + (int64_t)c * a.dpad + k4 * 4);
     }
     __syncthreads();
-    const int64_t doc = (int64_t)blockIdx.x * 4 + wave;
-    if (doc >= a.n_docs) return;
-    const int64_t b0 = a.blk_off[doc], b1 = a.blk_off[doc + 1];
     const int half = lane >> 5, col = lane & 31;
+    int ncb = 0;   // column blocks in use
+    for (int qi = 0; qi < a.nq_launch; ++qi) ncb = max(ncb, (a.q_col0[qi] + a.q_len[qi] + 31) / 32);
+    const int nchunk = (a.dpad + 127) / 128;
+    // docs are dealt round-robin to the waves of the grid so long and short docs mix
+    for (int dw = 0; dw < kMsDocsPerWave; ++dw) {
+    const int64_t doc = ((int64_t)dw * gridDim.x + blockIdx.x) * 4 + wave;
+    if (doc >= a.n_docs) break;
+    const int64_t b0 = a.blk_off[doc], b1 = a.blk_off[doc + 1];
     float run[4];  // running max per column block (this lane's column)
 #pragma unroll
     for (int c = 0; c < 4; ++c) run[c] = -__builtin_inff();
-    int ncb = 0;   // column blocks in use
-    for (int qi = 0; qi < a.nq_launch; ++qi) ncb = max(ncb, (a.q_col0[qi] + a.q_len[qi] + 31) / 32);
 
-    const int nchunk = (a.dpad + 127) / 128;
     const int64_t npieces = (b1 - b0) * nchunk;
     f32x16 acc[4];
 #pragma unroll
@@ -175,6 +178,7 @@ __global__ __launch_bounds__(kMsThreads) void k_maxsim(MsArgs a) {
         }
         if (lane == 0) a.dist[(int64_t)qi * a.n_docs + doc] = accd;
     }
+    }  // docs of this wave
 }
 
 // fp32 -> sortable key (distance asc, NaN last)
@@ -400,7 +404,8 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
         }
         a.nq_launch = nql;
         HIPCHECK(idx, hipMemcpyAsync(m->qtok, qimg.data(), qimg.size() * sizeof(float), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_maxsim, dim3((unsigned)((m->n_docs + 3) / 4)), dim3(kMsThreads), lds, s, a);
+        hipLaunchKernelGGL(k_maxsim, dim3((unsigned)((m->n_docs + 4 * kMsDocsPerWave - 1) / (4 * kMsDocsPerWave))),
+                           dim3(kMsThreads), lds, s, a);
         HIPCHECK(idx, hipGetLastError());
         for (int qi = 0; qi < nql; ++qi) {
             if (a.q_len[qi] == 0) continue;  // reference: `if not query_vectors: return []`
