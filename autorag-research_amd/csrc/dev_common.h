@@ -36,7 +36,35 @@ struct QueryState {
     uint64_t* thr_key;  // [Bpad] exact-path threshold (worst kept key) ...
     int32_t* thr_row;   // [Bpad] ... and its row
     int* status;        // [Bpad]
+    // screen bound and int8-screen state
+    float* E;           // [Bpad] rigorous bound on |screen value - exact cosine| for this query (both screen dtypes)
+    float* sc;          // [Bpad] int8 screen: value of one accumulator unit, S_q * S_c  (1 for the bf16 screen)
+    int* thr_i;         // [Bpad] int8 screen: emit iff acc >= thr_i  (conservative integer image of thr)
+    int8_t* qhat8;      // [Bpad, dpad8] int8 quantised normalised queries
 };
+
+// ---- int8 screen quantisation (DESIGN.md "int8 screen bound") ----
+// Normalised rows are quantised with ONE step for the whole corpus, S_c = kI8Z / (127 sqrt(d)): a unit vector's
+// rms component is 1/sqrt(d), so +-127 steps span kI8Z "sigmas" and the rounding residual has norm
+// ~ S_c sqrt(d/12) = kI8Z / (127 sqrt(12)) = 0.01364, independent of d.  Rows whose measured residual norm exceeds
+// kI8ResidualLimit (clipped outlier components) are "loose": they are left out of the int8 shadow and re-scored
+// for every query like irregular rows; if there are more than kIrrCap of them the index keeps the bf16 screen.
+constexpr float kI8Z = 6.0f;
+constexpr float kI8ResidualLimit = 0.0150f;
+__host__ __device__ inline float i8_corpus_step(int d) { return kI8Z / (127.0f * sqrtf((float)d)); }
+// E_q = 1.0001 (e_q + e_lim) + 3 e_q e_lim + 4 d 2^-24 + 2^-16   (e_q = measured residual norm of the query, inflated)
+__host__ __device__ inline float i8_screen_bound(float e_q, int d) {
+    return 1.0001f * (e_q + kI8ResidualLimit) + 3.0f * e_q * kI8ResidualLimit + 4.0f * (float)d * 5.9604645e-8f +
+           1.5258789e-5f;
+}
+// conservative integer threshold: every acc with acc * sc >= thr satisfies acc >= i8_threshold(thr, sc)
+__device__ __forceinline__ int i8_threshold(float thr, float sc) {
+    if (!(sc > 0.0f) || thr != thr) return 0x7FFFFFFF;      // never emits (|acc| < 2^24)
+    const float x = floorf(thr / sc) - 1.0f;
+    if (x <= -2.0e9f) return -0x7FFFFFFF - 1;
+    if (x >= 2.0e9f) return 0x7FFFFFFF;
+    return (int)x;
+}
 
 __device__ __forceinline__ float bits_f(uint32_t u) { return __uint_as_float(u); }
 
@@ -102,6 +130,29 @@ __device__ __forceinline__ void bitonic_desc_f32(float* v, int n) {
                     if (desc ? (a < b) : (a > b)) {
                         v[i] = b;
                         v[p] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// descending sort of (value, payload) pairs
+__device__ __forceinline__ void bitonic_desc_f32_i32(float* v, int32_t* w, int n) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const bool desc = ((i & k) == 0);
+                    const float a = v[i], b = v[p];
+                    if (desc ? (a < b) : (a > b)) {
+                        v[i] = b;
+                        v[p] = a;
+                        const int32_t t = w[i];
+                        w[i] = w[p];
+                        w[p] = t;
                     }
                 }
             }

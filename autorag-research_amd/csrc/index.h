@@ -34,6 +34,13 @@ struct mi355dr_index {
     int32_t* irr_rows = nullptr;
     int* irr_count = nullptr;
     int irr_n = 0;
+    // int8 screen: second shadow, one step for the whole corpus; rows it cannot hold are flagged and listed
+    int dpad8 = 0;
+    int8_t* shadow8 = nullptr;     // [cap_rows, dpad8]
+    uint8_t* flag8 = nullptr;      // [cap_rows]
+    int32_t* irr8_rows = nullptr;  // [kIrrCap] irregular + loose rows
+    int* irr8_count = nullptr;
+    int irr8_n = 0;
 
     // per-search state (sized for one block of kQBlockMax queries)
     bool qstate_ready = false;
@@ -50,6 +57,7 @@ struct mi355dr_index {
 
     // options
     int path = 0;  // MI355DR_PATH_AUTO
+    int screen_dtype = 0;  // MI355DR_SCREEN_AUTO
     int64_t row_offset = 0;
     int profile = 0;
     int64_t chunk0_rows = 512;

@@ -1,7 +1,8 @@
 // k_prep.h -- corpus-side and query-side preparation kernels.
 //   k_row_nrm2      |c|^2 per stored row, exact k-ascending fp32 chain (pgvector's `normb`, oracle.c orc_dot)
 //   k_build_shadow  bf16 shadow row  c_hat = bf16_rn(c / |c|)  streamed by the screen kernel
-//   k_prep_queries  |q|^2, q_hat = bf16_rn(q / |q|), per-query search state reset
+//   k_build_shadow8 int8 shadow row  round(c / |c| / S_c)  (+ loose-row detection) for the int8 screen
+//   k_prep_queries  |q|^2, q_hat = bf16_rn(q / |q|) and its int8 form, per-query bound, search state reset
 #pragma once
 #include "dev_common.h"
 
@@ -52,9 +53,62 @@ __global__ __launch_bounds__(256) void k_build_shadow(const float* __restrict__ 
 }
 
 
-// grid: Bpad blocks of 64 threads
+// block-wide sum / max over 256 threads (4 waves)
+__device__ __forceinline__ float block256_reduce(float v, bool is_max, float* sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float w = __shfl_xor(v, o);
+        v = is_max ? fmaxf(v, w) : v + w;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return is_max ? fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3])) : (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// grid: n blocks of 256 threads (one row each).  c8 = clamp(round(c_hat / S_c), +-127); the residual norm
+// |c_hat - S_c c8| is measured (inflated by 1e-3 for its own rounding): a row above kI8ResidualLimit, or an
+// irregular one, gets an all-zero int8 row, flag 1, and a slot in irr8_rows (re-scored for every query).
+__global__ __launch_bounds__(256) void k_build_shadow8(const float* __restrict__ rows, const float* __restrict__ nrm2,
+                                                        int64_t row0, int64_t n, int d, int dpad8, float step,
+                                                        int8_t* __restrict__ shadow8, uint8_t* __restrict__ flag8,
+                                                        int32_t* __restrict__ irr8_rows, int* __restrict__ irr8_count) {
+    __shared__ float sh[4];
+    const int64_t i = row0 + blockIdx.x;
+    if (i >= row0 + n) return;
+    const float n2 = nrm2[i];
+    const bool regular = norm_is_regular(n2);
+    const float rc = regular ? 1.0f / sqrtf(n2) : 0.0f;
+    const float inv_step = 1.0f / step;
+    const float* r = rows + i * (int64_t)d;
+    int8_t* s = shadow8 + i * (int64_t)dpad8;
+    float e2 = 0.0f;
+    for (int k = threadIdx.x; k < d; k += blockDim.x) {
+        const float ch = r[k] * rc;
+        const float qv = fminf(fmaxf(rintf(ch * inv_step), -127.0f), 127.0f);
+        const float e = __builtin_fmaf(-step, qv, ch);
+        e2 = __builtin_fmaf(e, e, e2);
+    }
+    e2 = block256_reduce(e2, false, sh);
+    const bool loose = !regular || !(sqrtf(e2) * 1.001f <= kI8ResidualLimit);
+    for (int k = threadIdx.x; k < dpad8; k += blockDim.x) {
+        int8_t v = 0;
+        if (k < d && !loose) v = (int8_t)fminf(fmaxf(rintf(r[k] * rc * inv_step), -127.0f), 127.0f);
+        s[k] = v;
+    }
+    if (threadIdx.x == 0) {
+        flag8[i] = loose ? 1 : 0;
+        if (loose) {
+            const int slot = atomicAdd(irr8_count, 1);
+            if (slot < kIrrCap) irr8_rows[slot] = (int32_t)i;
+        }
+    }
+}
+
+// grid: Bpad blocks of 64 threads.  i8_step > 0: also prepare the int8 screen (qhat8, sc, thr_i, E from the
+// measured query residual); otherwise E = bf16_bound for every query.
 __global__ __launch_bounds__(64) void k_prep_queries(const float* __restrict__ q, int B, int d, int dpad, int metric,
-                                                      QueryState st) {
+                                                      QueryState st, int dpad8, float i8_step, float bf16_bound) {
     extern __shared__ float qs[];  // [d]
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
@@ -69,7 +123,12 @@ __global__ __launch_bounds__(64) void k_prep_queries(const float* __restrict__ q
             st.thr_key[b] = 0;
             st.thr_row[b] = -1;
             st.status[b] = 0;
+            st.E[b] = bf16_bound;
+            st.sc[b] = 1.0f;
+            st.thr_i[b] = 0x7FFFFFFF;
         }
+        if (i8_step > 0.0f)
+            for (int k = lane; k < dpad8; k += kWave) st.qhat8[(int64_t)b * dpad8 + k] = 0;
         return;
     }
     const float* qr = q + (int64_t)b * d;
@@ -81,9 +140,38 @@ __global__ __launch_bounds__(64) void k_prep_queries(const float* __restrict__ q
     const bool regular = norm_is_regular(acc);
     const float rq = regular ? 1.0f / sqrtf(acc) : 0.0f;
     for (int k = lane; k < dpad; k += kWave) qh[k] = (k < d && regular) ? f32_to_bf16_rn(qs[k] * rq) : (uint16_t)0;
+    float E = bf16_bound, sc = 1.0f;
+    if (i8_step > 0.0f) {
+        // per-query step S_q = max|q_hat| / 127, residual norm measured like the corpus side
+        float mx = 0.0f;
+        for (int k = lane; k < d; k += kWave) mx = fmaxf(mx, fabsf(qs[k] * rq));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        const float sq = mx / 127.0f;
+        const float inv = sq > 0.0f ? 1.0f / sq : 0.0f;
+        float e2 = 0.0f;
+        int8_t* q8 = st.qhat8 + (int64_t)b * dpad8;
+        for (int k = lane; k < dpad8; k += kWave) {
+            float qv = 0.0f;
+            if (k < d && regular) {
+                const float qh_f = qs[k] * rq;
+                qv = fminf(fmaxf(rintf(qh_f * inv), -127.0f), 127.0f);
+                const float e = __builtin_fmaf(-sq, qv, qh_f);
+                e2 = __builtin_fmaf(e, e, e2);
+            }
+            q8[k] = (int8_t)qv;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) e2 += __shfl_xor(e2, o);
+        E = i8_screen_bound(sqrtf(e2) * 1.001f, d);
+        sc = sq * i8_step;
+    }
     if (lane == 0) {
         st.qn[b] = acc;
+        st.E[b] = E;
+        st.sc[b] = sc;
         // cosine screen cannot rank an irregular query: park it (never emits) and flag it for the scan path
+        st.thr_i[b] = (regular || metric != 0) ? (-0x7FFFFFFF - 1) : 0x7FFFFFFF;
         st.thr[b] = (regular || metric != 0) ? -__builtin_inff() : __builtin_inff();
         st.cnt[b] = 0;
         st.best_n[b] = 0;

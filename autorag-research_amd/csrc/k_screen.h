@@ -30,6 +30,8 @@ namespace mi355 {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kTileM = 128;  // corpus rows per workgroup tile
 constexpr int kTileN = 128;  // queries per workgroup tile
@@ -39,13 +41,17 @@ constexpr int kTileBytes = kTileM * kRowB;             // 16 KiB per operand per
 constexpr int kScreenLds = 2 * 2 * kTileBytes;         // 64 KiB: 2 buffers x (A,B)
 
 struct ScreenArgs {
-    const uint16_t* shadow;  // [rows_pad, dpad] bf16
-    const uint16_t* qhat;    // [Bpad, dpad] bf16
-    const float* thr;        // [Bpad]
+    const void* shadow;      // [rows_pad, row_bytes]  bf16 (2 B/element) or int8 shadow rows
+    const void* qhat;        // [Bpad, row_bytes]      same element type
+    const float* thr;        // [Bpad]  bf16 screen: emit iff t >= thr
+    const int* thr_i;        // [Bpad]  int8 screen: emit iff acc >= thr_i
+    const float* sc;         // [Bpad]  int8 screen: candidate value = acc * sc
+    const uint8_t* flag8;    // [rows]  int8 screen: 1 = row is not in the int8 shadow (read by the emit-all epilogue only)
     int* cnt;                // [Bpad]
     int32_t* cand_row;       // [Bpad, cap]
     float* cand_val;         // [Bpad, cap]
-    int dpad;
+    int row_bytes;           // bytes per shadow row (a multiple of 128)
+    int ksteps;              // row_bytes / 128: K steps of 64 bf16 or 128 int8
     int cap;
     int ct0;        // first corpus tile of this chunk
     int n_ctiles;   // corpus tiles in this chunk
@@ -60,6 +66,90 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// one 32x32 MFMA step on 16-byte operand fragments (carried as bf16x8 registers): 16 bf16 k-values (I8 = false)
+// or 32 int8 k-values (I8 = true).
+// The int8 form accumulates exact int32; its accumulator travels in the same f32x16 registers (bit pattern).
+template <bool I8>
+__device__ __forceinline__ f32x16 screen_mfma(bf16x8 fa, bf16x8 fb, f32x16 acc) {
+    if constexpr (I8) {
+        return __builtin_bit_cast(f32x16, __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, fa),
+                                                                                __builtin_bit_cast(i32x4, fb),
+                                                                                __builtin_bit_cast(i32x16, acc), 0, 0, 0));
+    } else {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+    }
+}
+
+// Fused epilogue of one 32x32 accumulator block, shared by both screen kernels.  C/D layout: column (query) =
+// lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5); rbase = first row of the block + 4*(lane>>5).
+template <bool I8>
+__device__ __forceinline__ void screen_emit_block(const ScreenArgs& a, f32x16 acc, int q, int64_t rbase, float th,
+                                                  int thi) {
+    // fast path (almost always): one max over the lane's 16 rows and one compare
+    bool any;
+    if constexpr (I8) {
+        const i32x16 v = __builtin_bit_cast(i32x16, acc);
+        int m = v[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) m = max(m, v[r]);
+        any = m >= thi;
+    } else {
+        float m = acc[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+        any = m >= th;
+    }
+    if (!any) return;
+    // hit path: collect the lane's hits in a mask, reserve all their slots with ONE atomic, then store.
+    // (int8: rows outside the int8 shadow may show up here with a stale 0 -- k_prune drops them.)
+    unsigned mask = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
+        bool hit;
+        if constexpr (I8) hit = __builtin_bit_cast(i32x16, acc)[r] >= thi;
+        else hit = acc[r] >= th;
+        if (hit && row < a.row_end) mask |= 1u << r;
+    }
+    if (mask == 0) return;
+    int slot = atomicAdd(&a.cnt[q], __builtin_popcount(mask));
+    float sc = 1.0f;
+    if constexpr (I8) sc = a.sc[q];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if ((mask >> r) & 1u) {
+            if (slot < a.cap) {
+                float val;
+                if constexpr (I8) val = (float)__builtin_bit_cast(i32x16, acc)[r] * sc;
+                else val = acc[r];
+                a.cand_row[(int64_t)q * a.cap + slot] = (int32_t)(rbase + (r & 3) + 8 * (r >> 2));
+                a.cand_val[(int64_t)q * a.cap + slot] = val;
+            }
+            ++slot;
+        }
+    }
+}
+
+// first chunk: every (query,row) becomes a candidate at slot row-row0 (counts are set by the host)
+template <bool I8>
+__device__ __forceinline__ void screen_emit_all_block(const ScreenArgs& a, f32x16 acc, int q, int64_t rbase, float sc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
+        if (row < a.row_end) {
+            float val;
+            if constexpr (I8) {
+                val = a.flag8[row] ? __builtin_nanf("") : (float)__builtin_bit_cast(i32x16, acc)[r] * sc;
+            } else {
+                val = acc[r];
+            }
+            a.cand_row[(int64_t)q * a.cap + (row - a.row0)] = (int32_t)row;
+            a.cand_val[(int64_t)q * a.cap + (row - a.row0)] = val;
+        }
+    }
+}
+
+template <bool I8>
 __global__ __launch_bounds__(256, 2) void k_screen(ScreenArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -77,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void k_screen(ScreenArgs a) {
     const int q0 = qt * kTileN;
 
     const int wr = wave >> 1, wc = wave & 1;
-    const int64_t row_bytes = (int64_t)a.dpad * 2;
+    const int64_t row_bytes = a.row_bytes;
 
     // ---- staging addresses: this wave issues A-instructions ii = wave*4..+3 and the same B ones
     const char* gA[4];
@@ -112,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void k_screen(ScreenArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int T = a.dpad / kStepK;
+    const int T = a.ksteps;
     // prologue: stage step 0 into buffer 0
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -138,6 +228,10 @@ __global__ __launch_bounds__(256, 2) void k_screen(ScreenArgs a) {
         for (int kk = 0; kk < 4; ++kk) {
             // chunk index (2*kk+g) ^ key == ((g ^ key) ^ (2*kk)) because 2*kk only sets bits 1..2
             const int kx = (2 * kk) << 4;
+            // NOTE: the fragments are typed bf16x8 on purpose (also for int8 data).  With this type the compiler's
+            // waitcnt insertion keeps the LDS-DMA of the NEXT step in flight across these ds_reads; with a plain
+            // uint4 load it conservatively adds s_waitcnt vmcnt(0) here and the double buffering is lost
+            // (tests/test_build_pipeline.py checks the generated code).
             bf16x8 fa[2], fb[2];
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
@@ -147,56 +241,22 @@ __global__ __launch_bounds__(256, 2) void k_screen(ScreenArgs a) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[i][j] = screen_mfma<I8>(fa[i], fb[j], acc[i][j]);
         }
     }
 
     // ---- fused epilogue: threshold test, rare append
-    // C/D layout of the 32x32 MFMA: column (query) = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    if (a.emit_all) {  // wave-uniform: the first chunk keeps everything, slot = row - row0 (counts set by the host)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int q = q0 + 64 * wc + 32 * j + (lane & 31);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int64_t rbase = tile_row0 + 64 * wr + 32 * i + 4 * (lane >> 5);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
-                    if (row < a.row_end) {
-                        a.cand_row[(int64_t)q * a.cap + (row - a.row0)] = (int32_t)row;
-                        a.cand_val[(int64_t)q * a.cap + (row - a.row0)] = acc[i][j][r];
-                    }
-                }
-            }
-        }
-        return;
-    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int q = q0 + 64 * wc + 32 * j + (lane & 31);
         const float th = a.thr[q];
+        const int thi = I8 ? a.thr_i[q] : 0;
+        const float sc = (I8 && a.emit_all) ? a.sc[q] : 1.0f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            float m = acc[i][j][0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
-            if (m >= th) {
-                const int64_t rbase = tile_row0 + 64 * wr + 32 * i + 4 * (lane >> 5);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = acc[i][j][r];
-                    const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
-                    if (v >= th && row < a.row_end) {
-                        const int slot = atomicAdd(&a.cnt[q], 1);
-                        if (slot < a.cap) {
-                            a.cand_row[(int64_t)q * a.cap + slot] = (int32_t)row;
-                            a.cand_val[(int64_t)q * a.cap + slot] = v;
-                        }
-                    }
-                }
-            }
+            const int64_t rbase = tile_row0 + 64 * wr + 32 * i + 4 * (lane >> 5);
+            if (a.emit_all) screen_emit_all_block<I8>(a, acc[i][j], q, rbase, sc);  // wave-uniform branch
+            else screen_emit_block<I8>(a, acc[i][j], q, rbase, th, thi);
         }
     }
 }

@@ -36,7 +36,7 @@ constexpr int kScreen256Lds = 8 * kHalfBytes;   // ring of 8 half-tiles
 
 // ABL: developer ablation switches for tools/screen_bench (0 in the library): bit0 = skip the ds_reads after
 // the first K-tile, bit1 = skip the DMA after the prologue, bit2 = no s_setprio.
-template <int ABL>
+template <int ABL, bool I8>
 __global__ __launch_bounds__(512, 2) void k_screen256(ScreenArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(512, 2) void k_screen256(ScreenArgs a) {
     if (ctl >= a.n_ctiles) return;
     const int64_t tile_row0 = (int64_t)(a.ct0 + ctl) * kT2;
     const int q0 = qt * kT2;
-    const int64_t row_bytes = (int64_t)a.dpad * 2;
+    const int64_t row_bytes = a.row_bytes;
 
     // ---- DMA source pointers: this wave stages local rows [16*wave + 8u, +8) of every half-tile, u = 0,1
     // half-tile types: 0 = A0, 1 = B0, 2 = B1, 3 = A1
@@ -91,9 +91,9 @@ __global__ __launch_bounds__(512, 2) void k_screen256(ScreenArgs a) {
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][rb][j][r] = 0.0f;
-    bf16x8 fa[2][4], fb[4];
+    bf16x8 fa[2][4], fb[4];  // typed bf16x8 also for int8 data: see the NOTE in k_screen.h (waitcnt insertion)
 
-    const int T = a.dpad / kStepK;
+    const int T = a.ksteps;
 
 // stage half-tile type S of K-tile TT into its ring slot (slot = 4*(TT&1) + S)
 #define MI355_STAGE(S, TT)                                                                            \
@@ -108,20 +108,20 @@ __global__ __launch_bounds__(512, 2) void k_screen256(ScreenArgs a) {
         const char* s__ = smem + (4 * ((TT) & 1) + ((I) ? 3 : 0)) * kHalfBytes;                       \
         _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                              \
             _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                          \
-                fa[rb][kk] = __builtin_bit_cast(bf16x8, *(const uint4*)(s__ + (offA[rb] ^ (kk * 32)))); \
+                fa[rb][kk] = __builtin_bit_cast(bf16x8, *(const uint4*)(s__ + (offA[rb] ^ (kk * 32))));                          \
     } while (0)
 #define MI355_LOAD_B(J, TT)                                                                           \
     if (!(ABL & 1) || (TT) == 0) do {                                                                                              \
         const char* s__ = smem + (4 * ((TT) & 1) + 1 + (J)) * kHalfBytes;                             \
         _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                              \
-            fb[kk] = __builtin_bit_cast(bf16x8, *(const uint4*)(s__ + (offB ^ (kk * 32))));           \
+            fb[kk] = __builtin_bit_cast(bf16x8, *(const uint4*)(s__ + (offB ^ (kk * 32))));                                    \
     } while (0)
 #define MI355_MFMA(I, J)                                                                              \
     do {                                                                                              \
         if (!(ABL & 4)) __builtin_amdgcn_s_setprio(1);                                                \
         _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                              \
             _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                          \
-                acc[I][rb][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rb][kk], fb[kk], acc[I][rb][J], 0, 0, 0); \
+                acc[I][rb][J] = screen_mfma<I8>(fa[rb][kk], fb[kk], acc[I][rb][J]);                   \
         if (!(ABL & 4)) __builtin_amdgcn_s_setprio(0);                                                \
     } while (0)
 #define MI355_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
@@ -198,55 +198,20 @@ __global__ __launch_bounds__(512, 2) void k_screen256(ScreenArgs a) {
 #undef MI355_WAIT_VM
 
     // ---- fused epilogue (same rule as k_screen): column (query) = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
-    if (a.emit_all) {  // first chunk: keep everything, slot = row - row0, no atomics
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int q = q0 + 64 * wc + 32 * j + (lane & 31);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb) {
-                    const int64_t rbase = tile_row0 + 128 * wr + 64 * i + 32 * rb + 4 * (lane >> 5);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
-                        if (row < a.row_end) {
-                            a.cand_row[(int64_t)q * a.cap + (row - a.row0)] = (int32_t)row;
-                            a.cand_val[(int64_t)q * a.cap + (row - a.row0)] = acc[i][rb][j][r];
-                        }
-                    }
-                }
-        }
-        return;
-    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int q = q0 + 64 * wc + 32 * j + (lane & 31);
         const float th = a.thr[q];
+        const int thi = I8 ? a.thr_i[q] : 0;
+        const float sc = (I8 && a.emit_all) ? a.sc[q] : 1.0f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
-                float m = acc[i][rb][j][0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[i][rb][j][r]);
-                if (m >= th) {
-                    const int64_t rbase = tile_row0 + 128 * wr + 64 * i + 32 * rb + 4 * (lane >> 5);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float v = acc[i][rb][j][r];
-                        const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
-                        if (v >= th && row < a.row_end) {
-                            const int slot = atomicAdd(&a.cnt[q], 1);
-                            if (slot < a.cap) {
-                                a.cand_row[(int64_t)q * a.cap + slot] = (int32_t)row;
-                                a.cand_val[(int64_t)q * a.cap + slot] = v;
-                            }
-                        }
-                    }
-                }
+                const int64_t rbase = tile_row0 + 128 * wr + 64 * i + 32 * rb + 4 * (lane >> 5);
+                if (a.emit_all) screen_emit_all_block<I8>(a, acc[i][rb][j], q, rbase, sc);  // wave-uniform branch
+                else screen_emit_block<I8>(a, acc[i][rb][j], q, rbase, th, thi);
             }
-        }
     }
 }
 

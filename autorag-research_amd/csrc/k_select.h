@@ -24,14 +24,14 @@ struct PruneArgs {
     unsigned long long* stat;  // [2*kQBlockMax] per-query counters (candidates, re-scored): no shared atomics
     int cap, d, k, metric;
     int exact;           // 0: screen candidates (re-score), 1: cand_val already holds the exact dot
-    float E;             // screen bound
-};
+    const uint8_t* flag8;  // int8 screen only (else nullptr): rows outside the int8 shadow
+};                         // (the screen bound is per query: st.E[q])
 
-// Two instantiations share the code: a small one (1 wave, <= 512 entries, ~26 KiB LDS, 6 workgroups
+// Two instantiations share the code: a small one (1 wave, <= 1024 entries, ~36 KiB LDS, 4 workgroups
 // per CU so that a whole 1024-query block is resident at once and the re-score latency overlaps across
 // queries) handles the common case; the large one (4 waves, 4096 entries) is launched right after it
 // and only finds work for queries the small one skipped (first chunk, k > ~400, adversarial data).
-constexpr int kPruneSmallThreads = 64, kPruneSmallSort = 512;
+constexpr int kPruneSmallThreads = 64, kPruneSmallSort = 1024;
 constexpr int kPruneBigThreads = 256, kPruneBigSort = kSortMax;
 
 // dynamic LDS: SK[SORT] u64 | SR[SORT] i32 | X = max(Lf[SORT] f32, stage tiles) | R[SORT] i32 | qs[d] f32 | 2 scalars
@@ -56,8 +56,7 @@ __global__ __launch_bounds__(THREADS) void k_prune(PruneArgs a) {
     int32_t* R = (int32_t*)(X + xbytes);
     float* qs = (float*)(X + xbytes + (size_t)SORT * 4);
     // two scalars at the very end of the dynamic region (no static LDS: keeps the carve 16-B aligned)
-    int& s_nres = *(int*)(X + xbytes + (size_t)SORT * 4 + (size_t)a.d * 4);
-    float& s_cut = *(float*)(X + xbytes + (size_t)SORT * 4 + (size_t)a.d * 4 + 4);
+    int& s_cnt = *(int*)(X + xbytes + (size_t)SORT * 4 + (size_t)a.d * 4);
 
     const int q = a.qlist ? a.qlist[blockIdx.x] : blockIdx.x;
     const int tid = threadIdx.x;
@@ -80,60 +79,95 @@ __global__ __launch_bounds__(THREADS) void k_prune(PruneArgs a) {
     uint64_t* bkey = a.st.best_key + (int64_t)q * kKMax;
     int32_t* brow = a.st.best_row + (int64_t)q * kKMax;
     const float nq = a.st.qn[q];
-    if (tid == 0) {
-        s_nres = 0;
-        a.stat[2 * q] += (unsigned long long)n_new;
-    }
+    const float E = a.st.E[q];
+    if (tid == 0) a.stat[2 * q] += (unsigned long long)n_new;
 
     int n_res;
+    int n_base = n_best;  // kept entries carried into the final sort (truncated to k after round A)
+    bool kept_loaded = false;
     if (!a.exact) {
-        // ---- phase 1: k-th largest LOWER bound of the exact similarity over (kept U new)
-        const int nL = n_best + n_new;
-        const int nLp = next_pow2(nL);
+        // ---- phase 1: order the new candidates by their screen value, best first.  NaN = "no bound" sorts first;
+        // int8 screen: a finite value on a row outside the int8 shadow is a stale zero -> dropped (that row comes
+        // through k_emit_irregular with NaN instead).
+        const int nLp = next_pow2(n_new);
         for (int i = tid; i < nLp; i += THREADS) {
-            float lb = -__builtin_inff();
-            if (i < n_best) {
-                const uint64_t kk = bkey[i];
-                if (kk != kKeyNaN) lb = (float)(1.0 - key_to_dist(kk)) - 1e-6f;
-            } else if (i < nL) {
-                const float v = cval[i - n_best];
-                if (v == v) lb = v - a.E;
+            float v = -__builtin_inff();
+            if (i < n_new) {
+                v = cval[i];
+                if (v != v) v = __builtin_inff();
+                else if (a.flag8 && a.flag8[crow[i]]) v = -__builtin_inff();
             }
-            Lf[i] = lb;
+            Lf[i] = v;
+            R[i] = i;
         }
+        if (tid == 0) s_cnt = 0;
         __syncthreads();
-        bitonic_desc_f32(Lf, nLp);
-        if (tid == 0) s_cut = (nL >= a.k) ? Lf[a.k - 1] : -__builtin_inff();
-        __syncthreads();
-        // ---- phase 2: keep new entries whose UPPER bound reaches the cut
-        const float cut = s_cut - a.E * 1.001f - 1e-6f;
-        for (int i = tid; i < n_new; i += THREADS) {
-            const float v = cval[i];
-            if (!(v < cut)) {  // NaN (no bound) is kept
-                const int s = atomicAdd(&s_nres, 1);
-                R[s] = i;
-            }
-        }
+        bitonic_desc_f32_i32(Lf, R, nLp);
+        for (int i = tid; i < nLp; i += THREADS)
+            if (Lf[i] > -__builtin_inff() && (i + 1 == nLp || !(Lf[i + 1] > -__builtin_inff()))) s_cnt = i + 1;
         for (int k = tid; k < a.d; k += THREADS) qs[k] = a.q[(int64_t)q * a.d + k];
         __syncthreads();
-        n_res = s_nres;
-        if (tid == 0) a.stat[2 * q + 1] += (unsigned long long)n_res;
-        // ---- phase 3: exact fp32 chain for the survivors, 64 per wave at a time
+        const int n_cand = s_cnt;
+        __syncthreads();  // everyone has read s_cnt (it is reused below) and Lf (overwritten by the stage tiles)
         float* tile = tiles + wave * kStageFloats;
-        for (int base = 0; base < n_res; base += THREADS) {
-            const int e = base + wave * kWave + lane;
-            const bool live = e < n_res;
-            const int32_t row = live ? crow[R[e]] : -1;
-            const float* rp = live ? a.rows + (int64_t)row * a.d : nullptr;
-            float acc = 0.0f;
-            // whole waves past the end skip together (wave-uniform condition)
-            if (base + wave * kWave < n_res) acc = staged_dot(tile, rp, qs, a.d, lane);
-            if (live) {
-                const double dist = distance_from(a.metric, acc, nq, a.nrm2[row]);
-                SK[n_best + e] = dist_to_key(dist);
-                SR[n_best + e] = row;
+        // exact fp32 chain for sorted entries [e0, e1) -> SK/SR slots [dst, dst + e1 - e0)
+        auto rescore = [&](int e0, int e1, int dst) {
+            for (int base = e0; base < e1; base += THREADS) {
+                const int e = base + wave * kWave + lane;
+                const bool live = e < e1;
+                const int32_t row = live ? crow[R[e]] : -1;
+                const float* rp = live ? a.rows + (int64_t)row * a.d : nullptr;
+                float acc = 0.0f;
+                if (base + wave * kWave < e1) acc = staged_dot(tile, rp, qs, a.d, lane);  // wave-uniform condition
+                if (live) {
+                    const double dist = distance_from(a.metric, acc, nq, a.nrm2[row]);
+                    SK[dst + (e - e0)] = dist_to_key(dist);
+                    SR[dst + (e - e0)] = row;
+                }
             }
+        };
+        // ---- phase 2 (round A): re-score the THREADS best-looking candidates
+        const int nA = min(n_cand, THREADS);
+        rescore(0, nA, n_best);
+        int n_pass = nA;
+        if (n_cand > nA) {
+            // ---- phase 3: exact k-th best over (kept U round A) -> cut for the rest.  A candidate with
+            // v + E < cut cannot reach the top-k: its exact similarity is <= v + E.
+            for (int i = tid; i < n_best; i += THREADS) {
+                SK[i] = bkey[i];
+                SR[i] = brow[i];
+            }
+            kept_loaded = true;
+            const int n1 = n_best + nA;
+            const int np1 = next_pow2(n1);
+            for (int i = n1 + tid; i < np1; i += THREADS) {
+                SK[i] = kKeyNaN;
+                SR[i] = 0x7FFFFFFF;
+            }
+            __syncthreads();
+            bitonic_asc_key_row(SK, SR, np1);
+            n_base = min(a.k, n1);
+            float cut = -__builtin_inff();
+            if (n1 >= a.k && a.metric == 0) {
+                const uint64_t wk = SK[a.k - 1];
+                if (wk != kKeyNaN) cut = (float)(1.0 - key_to_dist(wk)) - E * 1.001f - 2e-6f;
+            }
+            if (tid == 0) s_cnt = nA;
+            __syncthreads();
+            // the list is sorted by v: the survivors are a prefix
+            for (int i = nA + tid; i < n_cand; i += THREADS) {
+                const float v = cval[R[i]];
+                if (!(v < cut)) atomicMax(&s_cnt, i + 1);  // NaN passes
+            }
+            __syncthreads();
+            n_pass = s_cnt;
+            // ---- phase 4 (round B): re-score the survivors
+            rescore(nA, n_pass, n_base);
+            n_res = n_pass - nA;
+        } else {
+            n_res = nA;
         }
+        if (tid == 0) a.stat[2 * q + 1] += (unsigned long long)n_pass;
     } else {
         n_res = n_new;
         for (int i = tid; i < n_new; i += THREADS) {
@@ -143,12 +177,13 @@ __global__ __launch_bounds__(THREADS) void k_prune(PruneArgs a) {
             SR[n_best + i] = row;
         }
     }
-    // ---- phase 4: total-order sort of kept U re-scored, keep k
-    for (int i = tid; i < n_best; i += THREADS) {
-        SK[i] = bkey[i];
-        SR[i] = brow[i];
-    }
-    const int n_tot = n_best + n_res;
+    // ---- final: total-order sort of kept U re-scored, keep k
+    if (!kept_loaded)
+        for (int i = tid; i < n_best; i += THREADS) {
+            SK[i] = bkey[i];
+            SR[i] = brow[i];
+        }
+    const int n_tot = n_base + n_res;
     const int np = next_pow2(n_tot);
     for (int i = n_tot + tid; i < np; i += THREADS) {
         SK[i] = kKeyNaN;
@@ -169,8 +204,9 @@ __global__ __launch_bounds__(THREADS) void k_prune(PruneArgs a) {
             a.st.thr_key[q] = wk;
             a.st.thr_row[q] = SR[a.k - 1];
             if (a.metric == 0 && wk != kKeyNaN && !(a.st.status[q] & kStIrregular)) {
-                const float th = (float)((1.0 - key_to_dist(wk)) - (double)a.E);
-                a.st.thr[q] = float_below(th);
+                const float th = float_below((float)((1.0 - key_to_dist(wk)) - (double)E));
+                a.st.thr[q] = th;
+                a.st.thr_i[q] = i8_threshold(th, a.st.sc[q]);
             }
         }
     }

@@ -36,10 +36,16 @@ int ensure_capacity(mi355dr_index* idx, int64_t want_rows) {
     float* rows = nullptr;
     uint16_t* shadow = nullptr;
     float* nrm2 = nullptr;
+    int8_t* shadow8 = nullptr;
+    uint8_t* flag8 = nullptr;
     HIPCHECK(idx, hipMalloc(&rows, (size_t)new_cap * idx->dim * sizeof(float)));
     HIPCHECK(idx, hipMalloc(&shadow, (size_t)new_cap * idx->dpad * sizeof(uint16_t)));
     HIPCHECK(idx, hipMalloc(&nrm2, (size_t)new_cap * sizeof(float)));
+    HIPCHECK(idx, hipMalloc(&shadow8, (size_t)new_cap * idx->dpad8));
+    HIPCHECK(idx, hipMalloc(&flag8, (size_t)new_cap));
     HIPCHECK(idx, hipMemsetAsync(shadow, 0, (size_t)new_cap * idx->dpad * sizeof(uint16_t), idx->stream));
+    HIPCHECK(idx, hipMemsetAsync(shadow8, 0, (size_t)new_cap * idx->dpad8, idx->stream));
+    HIPCHECK(idx, hipMemsetAsync(flag8, 0, (size_t)new_cap, idx->stream));
     if (idx->n > 0) {
         HIPCHECK(idx, hipMemcpyAsync(rows, idx->rows, (size_t)idx->n * idx->dim * sizeof(float),
                                      hipMemcpyDeviceToDevice, idx->stream));
@@ -47,11 +53,18 @@ int ensure_capacity(mi355dr_index* idx, int64_t want_rows) {
                                      hipMemcpyDeviceToDevice, idx->stream));
         HIPCHECK(idx, hipMemcpyAsync(nrm2, idx->nrm2, (size_t)idx->n * sizeof(float), hipMemcpyDeviceToDevice,
                                      idx->stream));
+        HIPCHECK(idx, hipMemcpyAsync(shadow8, idx->shadow8, (size_t)idx->n * idx->dpad8, hipMemcpyDeviceToDevice,
+                                     idx->stream));
+        HIPCHECK(idx, hipMemcpyAsync(flag8, idx->flag8, (size_t)idx->n, hipMemcpyDeviceToDevice, idx->stream));
     }
     HIPCHECK(idx, hipStreamSynchronize(idx->stream));
     if (idx->rows) (void)hipFree(idx->rows);
     if (idx->shadow) (void)hipFree(idx->shadow);
     if (idx->nrm2) (void)hipFree(idx->nrm2);
+    if (idx->shadow8) (void)hipFree(idx->shadow8);
+    if (idx->flag8) (void)hipFree(idx->flag8);
+    idx->shadow8 = shadow8;
+    idx->flag8 = flag8;
     idx->rows = rows;
     idx->shadow = shadow;
     idx->nrm2 = nrm2;
@@ -72,6 +85,10 @@ int ensure_qstate(mi355dr_index* idx) {
     HIPCHECK(idx, hipMalloc(&idx->st.thr_key, B * sizeof(uint64_t)));
     HIPCHECK(idx, hipMalloc(&idx->st.thr_row, B * sizeof(int32_t)));
     HIPCHECK(idx, hipMalloc(&idx->st.status, B * sizeof(int)));
+    HIPCHECK(idx, hipMalloc(&idx->st.E, B * sizeof(float)));
+    HIPCHECK(idx, hipMalloc(&idx->st.sc, B * sizeof(float)));
+    HIPCHECK(idx, hipMalloc(&idx->st.thr_i, B * sizeof(int)));
+    HIPCHECK(idx, hipMalloc(&idx->st.qhat8, B * idx->dpad8));
     HIPCHECK(idx, hipMalloc(&idx->qdev, B * idx->dim * sizeof(float)));
     HIPCHECK(idx, hipMalloc(&idx->cand_row, B * kCandCap * sizeof(int32_t)));
     HIPCHECK(idx, hipMalloc(&idx->cand_val, B * kCandCap * sizeof(float)));
@@ -97,8 +114,11 @@ int ensure_qstate(mi355dr_index* idx) {
         HIPCHECK(idx, hipFuncSetAttribute((const void*)k_scan, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)scan_lds_bytes(idx->dim, per)));
     }
-    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen, hipFuncAttributeMaxDynamicSharedMemorySize, kScreenLds));
-    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen256<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreenLds));
+    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreenLds));
+    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen256<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kScreen256Lds));
+    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen256<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kScreen256Lds));
     HIPCHECK(idx, hipFuncSetAttribute((const void*)k_merge_topk, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kSortMax * 12));
@@ -132,6 +152,12 @@ void drain_events(mi355dr_index* idx) {  // call only after the stream was synch
     idx->ev_pending.clear();
 }
 
+// which screen the next search uses: int8 needs the cosine metric and a corpus that quantised within the limit
+inline bool i8_available(const mi355dr_index* idx) { return idx->irr8_n <= kIrrCap; }
+inline bool use_i8(const mi355dr_index* idx) {
+    return idx->screen_dtype == MI355DR_SCREEN_I8 || (idx->screen_dtype == MI355DR_SCREEN_AUTO && i8_available(idx));
+}
+
 int launch_prune(mi355dr_index* idx, hipStream_t s, int nblocks, const int* qlist, int k, int exact) {
     PruneArgs pa{};
     pa.rows = idx->rows;
@@ -147,13 +173,21 @@ int launch_prune(mi355dr_index* idx, hipStream_t s, int nblocks, const int* qlis
     pa.k = k;
     pa.metric = idx->metric;
     pa.exact = exact;
-    pa.E = screen_bound(idx->dim);
+    pa.flag8 = use_i8(idx) ? idx->flag8 : nullptr;
     // small instantiation first (common case, whole block resident), then the large one for what it skipped
     hipLaunchKernelGGL((k_prune<kPruneSmallThreads, kPruneSmallSort>), dim3(nblocks), dim3(kPruneSmallThreads),
                        prune_lds_bytes(idx->dim, kPruneSmallThreads, kPruneSmallSort), s, pa);
     HIPCHECK(idx, hipGetLastError());
     hipLaunchKernelGGL((k_prune<kPruneBigThreads, kPruneBigSort>), dim3(nblocks), dim3(kPruneBigThreads),
                        prune_lds_bytes(idx->dim, kPruneBigThreads, kPruneBigSort), s, pa);
+    HIPCHECK(idx, hipGetLastError());
+    return MI355DR_OK;
+}
+
+int launch_prep(mi355dr_index* idx, hipStream_t s, int B, int Bpad, int metric) {
+    hipLaunchKernelGGL(k_prep_queries, dim3(Bpad), dim3(64), (size_t)idx->dim * sizeof(float), s, idx->qdev, B, idx->dim,
+                       idx->dpad, metric, idx->st, idx->dpad8, use_i8(idx) ? i8_corpus_step(idx->dim) : 0.0f,
+                       screen_bound(idx->dim));
     HIPCHECK(idx, hipGetLastError());
     return MI355DR_OK;
 }
@@ -169,14 +203,19 @@ __global__ void k_set_counts(int* cnt, int n, int v) {
 
 int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t r_end, int cap, bool emit_all) {
     const int tile = screen_tile(B);
+    const bool i8 = use_i8(idx);
     ScreenArgs sa{};
-    sa.shadow = idx->shadow;
-    sa.qhat = idx->st.qhat;
+    sa.shadow = i8 ? (const void*)idx->shadow8 : (const void*)idx->shadow;
+    sa.qhat = i8 ? (const void*)idx->st.qhat8 : (const void*)idx->st.qhat;
     sa.thr = idx->st.thr;
+    sa.thr_i = idx->st.thr_i;
+    sa.sc = idx->st.sc;
+    sa.flag8 = idx->flag8;
     sa.cnt = idx->st.cnt;
     sa.cand_row = idx->cand_row;
     sa.cand_val = idx->cand_val;
-    sa.dpad = idx->dpad;
+    sa.row_bytes = i8 ? idx->dpad8 : idx->dpad * 2;
+    sa.ksteps = sa.row_bytes / kRowB;
     sa.cap = cap;
     sa.ct0 = (int)(r0 / tile);
     sa.n_ctiles = (int)(round_up(r_end, tile) / tile) - sa.ct0;
@@ -185,8 +224,13 @@ int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t 
     sa.row0 = r0;
     sa.emit_all = emit_all ? 1 : 0;
     const int64_t grid = round_up(sa.n_ctiles, 8) * sa.n_qtiles;
-    if (tile == kT2) hipLaunchKernelGGL(k_screen256<0>, dim3((unsigned)grid), dim3(512), kScreen256Lds, s, sa);
-    else hipLaunchKernelGGL(k_screen, dim3((unsigned)grid), dim3(256), kScreenLds, s, sa);
+    if (tile == kT2) {
+        if (i8) hipLaunchKernelGGL((k_screen256<0, true>), dim3((unsigned)grid), dim3(512), kScreen256Lds, s, sa);
+        else hipLaunchKernelGGL((k_screen256<0, false>), dim3((unsigned)grid), dim3(512), kScreen256Lds, s, sa);
+    } else {
+        if (i8) hipLaunchKernelGGL(k_screen<true>, dim3((unsigned)grid), dim3(256), kScreenLds, s, sa);
+        else hipLaunchKernelGGL(k_screen<false>, dim3((unsigned)grid), dim3(256), kScreenLds, s, sa);
+    }
     HIPCHECK(idx, hipGetLastError());
     if (emit_all) {  // every row of the chunk was stored at slot row-r0 for every query
         hipLaunchKernelGGL(k_set_counts, dim3((B + 255) / 256), dim3(256), 0, s, idx->st.cnt, B, (int)(r_end - r0));
@@ -223,8 +267,10 @@ int run_screen(mi355dr_index* idx, hipStream_t s, int B, int k) {
         done = end;
         chunk = std::max<int64_t>(tile, done * idx->chunk_growth);
     }
-    if (idx->irr_n > 0) {
-        hipLaunchKernelGGL(k_emit_irregular, dim3(B), dim3(64), 0, s, idx->irr_rows, idx->irr_n, idx->st,
+    const bool i8 = use_i8(idx);
+    const int side_n = i8 ? idx->irr8_n : idx->irr_n;  // rows this screen cannot see
+    if (side_n > 0) {
+        hipLaunchKernelGGL(k_emit_irregular, dim3(B), dim3(64), 0, s, i8 ? idx->irr8_rows : idx->irr_rows, side_n, idx->st,
                            idx->cand_row, idx->cand_val, idx->cap, (int)kept_all_below);
         HIPCHECK(idx, hipGetLastError());
         CHECK(launch_prune(idx, s, B, nullptr, k, 0));
@@ -324,11 +370,12 @@ int search_block(mi355dr_index* idx, hipStream_t s, const float* q_dev, int B, i
     const int Bpad = (int)round_up(B, screen_tile(B));
     if (q_dev != idx->qdev)
         HIPCHECK(idx, hipMemcpyAsync(idx->qdev, q_dev, (size_t)B * idx->dim * sizeof(float), hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(k_prep_queries, dim3(Bpad), dim3(64), (size_t)idx->dim * sizeof(float), s, idx->qdev, B,
-                       idx->dim, idx->dpad, idx->metric, idx->st);
-    HIPCHECK(idx, hipGetLastError());
+    CHECK(launch_prep(idx, s, B, Bpad, idx->metric));
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, idx->status_or_dev, 0);
-    const bool screen_possible = idx->metric == MI355DR_METRIC_COSINE && idx->irr_n <= kIrrCap;
+    if (idx->screen_dtype == MI355DR_SCREEN_I8 && !i8_available(idx) && idx->path != MI355DR_PATH_SCAN)
+        return fail(idx, MI355DR_E_UNSUPPORTED, "int8 screen unavailable: too many rows outside the residual limit");
+    const bool screen_possible =
+        idx->metric == MI355DR_METRIC_COSINE && (use_i8(idx) ? i8_available(idx) : idx->irr_n <= kIrrCap);
     const bool use_screen = idx->n > 0 && screen_possible && idx->path != MI355DR_PATH_SCAN;
     if (idx->path == MI355DR_PATH_SCREEN && !screen_possible && idx->n > 0)
         return fail(idx, MI355DR_E_UNSUPPORTED, "screen path unavailable (metric or too many irregular rows)");
@@ -398,12 +445,16 @@ int mi355dr_create(mi355dr_index** out, int device_id, int dim, int metric) {
     idx->device = device_id;
     idx->dim = dim;
     idx->dpad = (int)round_up(dim, kStepK);
+    idx->dpad8 = (int)round_up(dim, kRowB);
     idx->metric = metric;
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc(&idx->irr_rows, kIrrCap * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc(&idx->irr_count, sizeof(int));
     if (e == hipSuccess) e = hipMemset(idx->irr_count, 0, sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&idx->irr8_rows, kIrrCap * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&idx->irr8_count, sizeof(int));
+    if (e == hipSuccess) e = hipMemset(idx->irr8_count, 0, sizeof(int));
     if (e == hipSuccess) e = hipEventCreate(&idx->t0);
     if (e == hipSuccess) e = hipEventCreate(&idx->t1);
     if (e != hipSuccess) {
@@ -419,7 +470,9 @@ void mi355dr_destroy(mi355dr_index* idx) {
     if (!idx) return;
     (void)hipSetDevice(idx->device);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
-    void* ptrs[] = {idx->rows, idx->shadow, idx->nrm2, idx->irr_rows, idx->irr_count, idx->st.qn, idx->st.qhat,
+    void* ptrs[] = {idx->shadow8, idx->flag8, idx->irr8_rows, idx->irr8_count, idx->st.E, idx->st.sc, idx->st.thr_i,
+                    idx->st.qhat8,
+                    idx->rows, idx->shadow, idx->nrm2, idx->irr_rows, idx->irr_count, idx->st.qn, idx->st.qhat,
                     idx->st.thr, idx->st.cnt, idx->st.best_n, idx->st.best_key, idx->st.best_row, idx->st.thr_key,
                     idx->st.thr_row, idx->st.status, idx->qdev, idx->cand_row, idx->cand_val, idx->qlist_dev,
                     idx->status_or_dev, idx->out_dist_dev, idx->out_rows_dev, idx->stat_dev};
@@ -467,10 +520,15 @@ static int add_rows_impl(mi355dr_index* idx, const float* rows, int64_t n, hipMe
     hipLaunchKernelGGL(k_build_shadow, dim3((unsigned)n), dim3(256), 0, s, idx->rows, idx->nrm2, idx->n, n, idx->dim,
                        idx->dpad, idx->shadow, idx->irr_rows, idx->irr_count);
     HIPCHECK(idx, hipGetLastError());
-    int irr = 0;
+    hipLaunchKernelGGL(k_build_shadow8, dim3((unsigned)n), dim3(256), 0, s, idx->rows, idx->nrm2, idx->n, n, idx->dim,
+                       idx->dpad8, i8_corpus_step(idx->dim), idx->shadow8, idx->flag8, idx->irr8_rows, idx->irr8_count);
+    HIPCHECK(idx, hipGetLastError());
+    int irr = 0, irr8 = 0;
     HIPCHECK(idx, hipMemcpyAsync(&irr, idx->irr_count, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHECK(idx, hipMemcpyAsync(&irr8, idx->irr8_count, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHECK(idx, hipStreamSynchronize(s));
     idx->irr_n = irr;
+    idx->irr8_n = irr8;
     idx->n += n;
     return MI355DR_OK;
 }
@@ -586,6 +644,9 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
     if (k == "path") {
         if (value < 0 || value > 2) return fail(idx, MI355DR_E_INVALID, "path must be 0,1,2");
         idx->path = (int)value;
+    } else if (k == "screen_dtype") {
+        if (value < 0 || value > 2) return fail(idx, MI355DR_E_INVALID, "screen_dtype must be 0,1,2");
+        idx->screen_dtype = (int)value;
     } else if (k == "row_offset") {
         idx->row_offset = value;
     } else if (k == "profile") {
@@ -628,8 +689,10 @@ int mi355dr_get_stat(mi355dr_index* idx, const char* key, int64_t* out) {
     else if (k == "chunks") *out = idx->s_chunks;
     else if (k == "passes") *out = idx->s_passes;
     else if (k == "irregular_rows") *out = idx->irr_n;
+    else if (k == "loose_rows") *out = idx->irr8_n;
+    else if (k == "screen_dtype_active") *out = use_i8(idx) ? MI355DR_SCREEN_I8 : MI355DR_SCREEN_BF16;
     else if (k == "hbm_bytes_resident")
-        *out = idx->cap_rows * ((int64_t)idx->dim * 4 + (int64_t)idx->dpad * 2 + 4);
+        *out = idx->cap_rows * ((int64_t)idx->dim * 4 + (int64_t)idx->dpad * 2 + (int64_t)idx->dpad8 + 5);
     else return fail(idx, MI355DR_E_INVALID, "unknown stat: " + k);
     return MI355DR_OK;
 }
@@ -705,9 +768,7 @@ int mi355dr_debug_screen_dense(mi355dr_index* idx, const float* queries, int B, 
     hipStream_t s = idx->stream;
     HIPCHECK(idx, hipMemcpyAsync(idx->qdev, queries, (size_t)B * idx->dim * sizeof(float), hipMemcpyHostToDevice, s));
     const int Bpad = (int)round_up(B, screen_tile(B));
-    hipLaunchKernelGGL(k_prep_queries, dim3(Bpad), dim3(64), (size_t)idx->dim * sizeof(float), s, idx->qdev, B, idx->dim,
-                       idx->dpad, /*metric=*/1, idx->st);  // metric 1: thresholds at -inf for every query
-    HIPCHECK(idx, hipGetLastError());
+    CHECK(launch_prep(idx, s, B, Bpad, /*metric=*/1));  // metric 1: thresholds at -inf for every query
     CHECK(launch_screen(idx, s, B, row0, row0 + n, kCandCap, /*emit_all=*/false));
     std::vector<int> cnt(B);
     std::vector<int32_t> crow((size_t)B * kCandCap);
@@ -715,15 +776,31 @@ int mi355dr_debug_screen_dense(mi355dr_index* idx, const float* queries, int B, 
     HIPCHECK(idx, hipMemcpyAsync(cnt.data(), idx->st.cnt, B * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHECK(idx, hipMemcpyAsync(crow.data(), idx->cand_row, crow.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIPCHECK(idx, hipMemcpyAsync(cval.data(), idx->cand_val, cval.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+    std::vector<uint8_t> flag(n, 0);  // int8 screen: rows outside the shadow carry a stale 0 (k_prune drops them)
+    if (use_i8(idx)) HIPCHECK(idx, hipMemcpyAsync(flag.data(), idx->flag8 + row0, n, hipMemcpyDeviceToHost, s));
     HIPCHECK(idx, hipStreamSynchronize(s));
     for (int64_t i = 0; i < (int64_t)B * n; ++i) out_t[i] = NAN;
     for (int b = 0; b < B; ++b) {
         const int c = std::min(cnt[b], kCandCap);
         for (int j = 0; j < c; ++j) {
             const int64_t r = crow[(size_t)b * kCandCap + j] - row0;
-            if (r >= 0 && r < n) out_t[(int64_t)b * n + r] = cval[(size_t)b * kCandCap + j];
+            if (r >= 0 && r < n && !flag[r]) out_t[(int64_t)b * n + r] = cval[(size_t)b * kCandCap + j];
         }
     }
+    return MI355DR_OK;
+}
+
+int mi355dr_debug_screen_bound(mi355dr_index* idx, const float* queries, int B, float* out_E) {
+    if (!idx || !queries || !out_E) return fail(idx, MI355DR_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (B <= 0 || B > kQBlockMax) return fail(idx, MI355DR_E_INVALID, "need 1<=B<=1024");
+    HIPCHECK(idx, hipSetDevice(idx->device));
+    CHECK(ensure_qstate(idx));
+    hipStream_t s = idx->stream;
+    HIPCHECK(idx, hipMemcpyAsync(idx->qdev, queries, (size_t)B * idx->dim * sizeof(float), hipMemcpyHostToDevice, s));
+    CHECK(launch_prep(idx, s, B, (int)round_up(B, screen_tile(B)), idx->metric));
+    HIPCHECK(idx, hipMemcpyAsync(out_E, idx->st.E, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHECK(idx, hipStreamSynchronize(s));
     return MI355DR_OK;
 }
 
@@ -740,9 +817,7 @@ int mi355dr_debug_rescore(mi355dr_index* idx, const float* queries, int B, const
     CHECK(ensure_qstate(idx));
     hipStream_t s = idx->stream;
     HIPCHECK(idx, hipMemcpyAsync(idx->qdev, queries, (size_t)B * idx->dim * sizeof(float), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_prep_queries, dim3((unsigned)round_up(B, screen_tile(B))), dim3(64),
-                       (size_t)idx->dim * sizeof(float), s, idx->qdev, B, idx->dim, idx->dpad, idx->metric, idx->st);
-    HIPCHECK(idx, hipGetLastError());
+    CHECK(launch_prep(idx, s, B, (int)round_up(B, screen_tile(B)), idx->metric));
     int32_t* pq = nullptr;
     int64_t* pr = nullptr;
     float* od = nullptr;

@@ -16,6 +16,7 @@ from ._native import NativeError, check, f32c, ptr
 
 METRICS = {"cosine": 0, "ip": 1}
 PATHS = {"auto": 0, "screen": 1, "scan": 2}
+SCREEN_DTYPES = {"auto": 0, "bf16": 1, "i8": 2}
 
 
 class Mi355Index:
@@ -147,6 +148,8 @@ class Mi355Index:
     def set_option(self, key: str, value: int | str) -> None:
         if key == "path" and isinstance(value, str):
             value = PATHS[value]
+        if key == "screen_dtype" and isinstance(value, str):
+            value = SCREEN_DTYPES[value]
         check(self._h, self._lib.mi355dr_set_option(self._h, key.encode(), int(value)))
 
     def stat(self, key: str) -> int:
@@ -193,6 +196,14 @@ class Mi355Index:
         out = np.empty((q.shape[0], n), dtype=np.float32)
         check(self._h, self._lib.mi355dr_debug_screen_dense(self._h, ptr(q, ctypes.c_float), q.shape[0], int(row0),
                                                             int(n), ptr(out, ctypes.c_float)))
+        return out
+
+    def debug_screen_bound(self, queries) -> np.ndarray:
+        """Per-query rigorous bound E on |screen value - exact cosine| for the active screen dtype."""
+        q = f32c(queries)
+        out = np.empty(q.shape[0], dtype=np.float32)
+        check(self._h, self._lib.mi355dr_debug_screen_bound(self._h, ptr(q, ctypes.c_float), q.shape[0],
+                                                            ptr(out, ctypes.c_float)))
         return out
 
     def debug_rescore(self, queries, pair_q, pair_row) -> tuple[np.ndarray, np.ndarray]:

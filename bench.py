@@ -30,6 +30,7 @@ import numpy as np  # noqa: E402
 CHUNK_ROWS = 250_000  # generation granule; shard boundaries are multiples of it for world in {1,2,4,8}
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
+MFMA_I8_PEAK_TOPS = 5000.0  # int8 MFMA = 2x the bf16 rate on gfx950 (2xK; the guide's ubench ceiling is 4404)
 
 
 def parse_args():
@@ -46,6 +47,7 @@ def parse_args():
     ap.add_argument("--docs", type=int, default=50_000, help="maxsim: documents (tokens/doc ~ U{32..180}, d=128)")
     ap.add_argument("--chunk0", type=int, default=0, help="override the first (emit-all) chunk size")
     ap.add_argument("--growth", type=int, default=0, help="override the chunk growth factor")
+    ap.add_argument("--screen", choices=["auto", "bf16", "i8"], default="auto", help="screen element type")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the all-gather + merge path even at world size 1 (exercises the multi-GPU code on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -168,6 +170,7 @@ def main() -> None:
         idx.set_option("chunk0_rows", args.chunk0)
     if args.growth:
         idx.set_option("chunk_growth", args.growth)
+    idx.set_option("screen_dtype", args.screen)
     t_build = time.time()
     keep_parts = []
     keep_rows = 0
@@ -243,27 +246,30 @@ def main() -> None:
     fallback = idx.stat("fallback_queries")
     cand = idx.stat("candidates")
     resc = idx.stat("rescored")
-    dpad = (d + 63) // 64 * 64
+    i8 = idx.stat("screen_dtype_active") == 2
+    dpad = (d + 127) // 128 * 128 if i8 else (d + 63) // 64 * 64
     Bpad = (B + 255) // 256 * 256 if B > 128 else 128
+    peak = MFMA_I8_PEAK_TOPS if i8 else MFMA_BF16_PEAK_TF
     flops = 2.0 * Bpad * screen_rows * dpad          # MFMA flops actually issued by k_screen
     alg_flops = 2.0 * B * screen_rows * d             # algorithmic: 2*B*N*d per pass
     alg_bytes = float(screen_rows) * d * 4            # algorithmic HBM bytes: N*d*4 per pass
-    shadow_bytes = float(screen_rows) * dpad * 2      # bytes the screen really streams (bf16 shadow)
+    shadow_bytes = float(screen_rows) * dpad * (1 if i8 else 2)  # bytes the screen really streams (shadow rows)
     screen_s = screen_ns * 1e-9
     # HBM traffic of the dominant kernel from the committed PMC pass of this same command (rocprofv3 cannot run
     # inside the timed region): bytes per screened row x rows per launch.  See tools/collect_traffic.sh.
     traffic = None
-    tfile = ROOT / "profiles" / "r01_traffic.json"
+    tfile = ROOT / "profiles" / ("r01_traffic_i8.json" if i8 else "r01_traffic.json")
     if tfile.exists() and B > 128 and d == 768 and launches:
         per_row = json.loads(tfile.read_text())["hbm_read_bytes_per_screened_row"]
         traffic = round(per_row * screen_rows / launches)
     roof = {
         "bound": "mfma",
-        "kernel": "k_screen256" if B > 128 else "k_screen",
+        "kernel": ("k_screen256" if B > 128 else "k_screen") + ("<int8>" if i8 else "<bf16>"),
+        "op": "int8 multiply-add ops (v_mfma_i32_32x32x32_i8)" if i8 else "bf16 flops (v_mfma_f32_32x32x16_bf16)",
         "achieved": round(alg_flops / screen_s / 1e12, 2) if screen_s > 0 else None,
-        "peak": MFMA_BF16_PEAK_TF,
+        "peak": peak,
         "unit": "TFLOP/s",
-        "frac": round(alg_flops / screen_s / 1e12 / MFMA_BF16_PEAK_TF, 4) if screen_s > 0 else None,
+        "frac": round(alg_flops / screen_s / 1e12 / peak, 4) if screen_s > 0 else None,
         "traffic": traffic,
         "traffic_unit": "HBM read bytes per launch (PMC FETCH_SIZE, gfx950-corrected), vs algorithmic "
                         f"{round(alg_bytes / max(launches, 1))}",
@@ -302,8 +308,9 @@ def main() -> None:
             "k": k,
             "queries_per_step": B,
             "parallelism": f"row-shard x{world}" + (" + all-gather top-k merge" if world > 1 else ""),
-            "arithmetic": "bf16 MFMA screen over a normalised shadow corpus, exact fp32 chain re-score, "
-                          "float8 distance (results bit-exact vs CPU oracle)",
+            "arithmetic": ("int8" if i8 else "bf16") + " MFMA screen over a normalised shadow corpus (rigorous "
+                          "per-query error bound), exact fp32 chain re-score, float8 distance (results bit-exact vs "
+                          "CPU oracle)",
         },
         "roofline": roof,
         "extra": {
@@ -311,6 +318,7 @@ def main() -> None:
             "candidates_per_query_per_step": round(cand / max(args.steps * B, 1), 1),
             "rescored_per_query_per_step": round(resc / max(args.steps * B, 1), 1),
             "fallback_queries": fallback,
+            "loose_rows": idx.stat("loose_rows"),
             "hbm_bytes_resident": idx.stat("hbm_bytes_resident"),
         },
     }

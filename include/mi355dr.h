@@ -63,6 +63,14 @@ enum {
     MI355DR_PATH_SCAN = 2    /* exact fp32 chain per (query,row); slow, guaranteed, also the in-library fallback */
 };
 
+/* Element type of the screen pass (option "screen_dtype").  Both are exact end to end: the screen only
+ * decides which rows are re-scored, under a rigorous per-query bound on |screen value - exact cosine|. */
+enum {
+    MI355DR_SCREEN_AUTO = 0, /* int8 when the corpus quantises within the residual limit, else bf16 */
+    MI355DR_SCREEN_BF16 = 1, /* v_mfma_f32_32x32x16_bf16 over the bf16 shadow (bound ~0.0043 at d=768) */
+    MI355DR_SCREEN_I8 = 2    /* v_mfma_i32_32x32x32_i8 over the int8 shadow (bound ~0.023): half the bytes, twice the rate */
+};
+
 /* ---- lifetime ---- */
 int mi355dr_create(mi355dr_index** out, int device_id, int dim, int metric);
 void mi355dr_destroy(mi355dr_index* idx);
@@ -72,7 +80,7 @@ int mi355dr_version(void);
 
 /* ---- corpus (single-vector) ---- */
 int mi355dr_reserve(mi355dr_index* idx, int64_t n_rows);
-/* rows: host, row-major [n, dim] fp32.  Appends; copies to HBM; precomputes |c|^2 and the bf16 shadow. */
+/* rows: host, row-major [n, dim] fp32.  Appends; copies to HBM; precomputes |c|^2 and the bf16 / int8 shadows. */
 int mi355dr_add_rows(mi355dr_index* idx, const float* rows, int64_t n);
 /* same, rows already resident on this index's device (e.g. an embedding model's output tensor) */
 int mi355dr_add_rows_device(mi355dr_index* idx, const float* rows_dev, int64_t n);
@@ -112,10 +120,12 @@ int mi355dr_merge_topk_packed_device(mi355dr_index* idx, const int64_t* packed_a
                                      double* out_dist_dev, int64_t* out_rows_dev, void* stream);
 
 /* ---- options / stats / timing ----
- * options: "path" (MI355DR_PATH_*), "row_offset", "profile" (0/1: HIP-event timing of the dominant kernel),
- *          "chunk0_rows", "chunk_growth", "cand_cap".
+ * options: "path" (MI355DR_PATH_*), "screen_dtype" (MI355DR_SCREEN_*), "row_offset", "profile" (0/1: HIP-event
+ *          timing of the dominant kernel), "chunk0_rows", "chunk_growth", "cand_cap".
  * stats:   "screen_launches", "screen_ns" (profile=1), "screen_rows", "candidates", "rescored",
- *          "fallback_queries", "chunks", "passes", "hbm_bytes_resident". */
+ *          "fallback_queries", "chunks", "passes", "irregular_rows", "loose_rows" (rows outside the int8 shadow,
+ *          irregular ones included), "screen_dtype_active" (MI355DR_SCREEN_BF16 / _I8: what AUTO resolves to now),
+ *          "hbm_bytes_resident". */
 int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value);
 int mi355dr_get_stat(mi355dr_index* idx, const char* key, int64_t* out);
 int mi355dr_reset_stats(mi355dr_index* idx);
@@ -133,6 +143,8 @@ int mi355dr_dev_download(mi355dr_index* idx, void* dst_host, const void* src_dev
 /* ---- test hooks (used by tests/ only; exercise the production kernels on small inputs) ----
  * dense screen values t[b, r] for rows [row0,row0+n): runs the screen kernel with thresholds at -inf. */
 int mi355dr_debug_screen_dense(mi355dr_index* idx, const float* queries, int B, int64_t row0, int64_t n, float* out_t);
+/* the per-query screen bound E (|screen value - exact cosine| <= E) of the active screen dtype */
+int mi355dr_debug_screen_bound(mi355dr_index* idx, const float* queries, int B, float* out_E);
 /* exact fp32 chain + distance for explicit (query,row) pairs, computed by the re-score device code */
 int mi355dr_debug_rescore(mi355dr_index* idx, const float* queries, int B, const int32_t* pair_q,
                           const int64_t* pair_row, int64_t n_pairs, float* out_dot, double* out_dist);

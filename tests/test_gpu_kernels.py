@@ -53,7 +53,9 @@ def test_screen_values_match_bf16_emulation(pkg, d, B):
     C = rng.standard_normal((n, d)).astype(np.float32) * rng.uniform(0.1, 10, size=(n, 1)).astype(np.float32)
     Q = rng.standard_normal((B, d)).astype(np.float32)
     with pkg.Mi355Index(d) as idx:
+        idx.set_option("screen_dtype", "bf16")
         idx.add(C)
+        assert np.allclose(idx.debug_screen_bound(Q), 2.0 ** -8 + 8 * d * 2.0 ** -24 + 2.0 ** -16, rtol=1e-6)
         for row0, cnt in [(0, 1500), (256, 300), (1024, 476)]:
             t = idx.debug_screen_dense(Q, row0, cnt)
             sub = C[row0:row0 + cnt].astype(np.float64)
@@ -70,3 +72,49 @@ def test_screen_values_match_bf16_emulation(pkg, d, B):
                                                      * np.linalg.norm(sub, axis=1)[None, :])
             E = 2.0 ** -8 + 8 * d * 2.0 ** -24 + 2.0 ** -16
             assert np.abs(t - cos).max() <= E
+
+
+@pytest.mark.parametrize("d,B", [(768, 130), (384, 3), (100, 17), (1000, 40)])
+def test_int8_screen_values_and_bound(pkg, d, B):
+    """the int8 MFMA screen (v_mfma_i32_32x32x32_i8, exact int32 accumulate) == numpy emulation of the quantised
+    product, and |t - exact cosine| <= the per-query bound E the library uses to cut candidates."""
+    rng = np.random.default_rng(17 + d)
+    n = 1500
+    C = rng.standard_normal((n, d)).astype(np.float32) * rng.uniform(0.1, 10, size=(n, 1)).astype(np.float32)
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    Q[0] *= 1e3
+    with pkg.Mi355Index(d) as idx:
+        idx.set_option("screen_dtype", "i8")
+        idx.add(C)
+        assert idx.stat("screen_dtype_active") == 2
+        # the residual norm concentrates with d: at d >= 384 no Gaussian row is loose, at d = 100 about 1 % are
+        # (they are left out of the int8 shadow: NaN here, re-scored for every query in a search)
+        loose = idx.stat("loose_rows")
+        assert loose == 0 if d >= 384 else loose < 60
+        E = idx.debug_screen_bound(Q).astype(np.float64)
+        assert (E > 0.015).all() and (E < 0.035).all()
+        step_c = np.float32(6.0) / (np.float32(127.0) * np.sqrt(np.float32(d)))
+        qh = (Q.astype(np.float64) / np.linalg.norm(Q.astype(np.float64), axis=1, keepdims=True))
+        step_q = np.abs(qh).max(axis=1, keepdims=True) / 127.0
+        q8 = np.clip(np.rint(qh / step_q), -127, 127)
+        for row0, cnt in [(0, 1500), (256, 300), (1024, 476)]:
+            t = idx.debug_screen_dense(Q, row0, cnt).astype(np.float64)
+            sub = C[row0:row0 + cnt].astype(np.float64)
+            ch = sub / np.linalg.norm(sub, axis=1, keepdims=True)
+            c8 = np.clip(np.rint(ch / float(step_c)), -127, 127)
+            ref = (q8 @ c8.T) * step_q * float(step_c)
+            missing = np.isnan(t)
+            assert (missing == missing[0:1]).all(), "a row is either in the int8 shadow for every query or for none"
+            assert missing[0].sum() <= loose, "some (query,row) pairs were never produced by the kernel"
+            keep = ~missing[0]
+            t, ref, sub = t[:, keep], ref[:, keep], sub[keep]
+            # the device normalises in fp32, so a few components round to the neighbouring step: each flip moves
+            # the integer accumulator by <= 127 units
+            unit = step_q * float(step_c)
+            assert (np.abs(t - ref) <= 4 * 127 * unit + 1e-6).all()
+            assert np.abs(t - ref).mean() < 1e-5
+            cos = (Q.astype(np.float64) @ sub.T) / (np.linalg.norm(Q.astype(np.float64), axis=1)[:, None]
+                                                     * np.linalg.norm(sub, axis=1)[None, :])
+            assert (np.abs(t - cos) <= E[:, None]).all()
+            # the bound is not vacuous: typical error is a fair fraction of it
+            assert np.abs(t - cos).max() > 0.05 * E.min()

@@ -23,7 +23,10 @@ def _check(idx, oracle, C, Q, k, metric="cosine"):
     return dist, rows
 
 
-@pytest.mark.parametrize("path", ["scan", "screen", "auto"])
+SCREENS = ["bf16", "i8"]
+
+
+@pytest.mark.parametrize("path", ["scan", "screen:bf16", "screen:i8", "auto"])
 @pytest.mark.parametrize("n,d,B,k", [(5183, 384, 33, 10), (3000, 768, 1, 10), (2500, 768, 130, 100), (999, 100, 7, 5)])
 def test_search_matches_oracle(pkg, oracle, path, n, d, B, k):
     rng = np.random.default_rng(n + d + B)
@@ -31,6 +34,9 @@ def test_search_matches_oracle(pkg, oracle, path, n, d, B, k):
     C *= rng.uniform(0.05, 20.0, size=(n, 1)).astype(np.float32)  # un-normalised corpus
     Q = rng.standard_normal((B, d)).astype(np.float32)
     with pkg.Mi355Index(d) as idx:
+        if ":" in path:
+            path, screen = path.split(":")
+            idx.set_option("screen_dtype", screen)
         idx.set_option("path", path)
         idx.add(C[: n // 2])
         idx.add(C[n // 2:])  # appended in two batches
@@ -57,9 +63,10 @@ def test_ties_duplicates_and_zero_rows(pkg, oracle):
     C = np.concatenate([base, base, base[:10] * 2.0, np.zeros((3, 64), np.float32), base[::-1]])
     Q = np.concatenate([base[:5] + 0.01 * rng.standard_normal((5, 64)).astype(np.float32),
                         np.zeros((1, 64), np.float32)])
-    for path in ("screen", "scan"):
+    for path, screen in (("screen", "bf16"), ("screen", "i8"), ("scan", "auto")):
         with pkg.Mi355Index(64) as idx:
             idx.set_option("path", path)
+            idx.set_option("screen_dtype", screen)
             idx.add(C)
             for k in (1, 4, 50, len(C)):
                 _check(idx, oracle, C, Q, k)
@@ -71,11 +78,13 @@ def test_candidate_overflow_falls_back_exactly(pkg, oracle):
     n, d = 6000, 128
     C = rng.standard_normal((n, d)).astype(np.float32)
     Q = rng.standard_normal((20, d)).astype(np.float32)
-    with pkg.Mi355Index(d) as idx:
-        idx.add(C)
-        idx.set_option("cand_cap", 16)
-        _check(idx, oracle, C, Q, 10)
-        assert idx.stat("fallback_queries") > 0
+    for screen in SCREENS:
+        with pkg.Mi355Index(d) as idx:
+            idx.set_option("screen_dtype", screen)
+            idx.add(C)
+            idx.set_option("cand_cap", 16)
+            _check(idx, oracle, C, Q, 10)
+            assert idx.stat("fallback_queries") > 0
 
 
 def test_adversarial_order_ascending_similarity(pkg, oracle):
@@ -87,9 +96,10 @@ def test_adversarial_order_ascending_similarity(pkg, oracle):
     sims = (C @ q) / np.linalg.norm(C, axis=1)
     C = C[np.argsort(sims)]
     Q = np.stack([q, -q, rng.standard_normal(d).astype(np.float32)])
-    for path in ("screen", "scan"):
+    for path, screen in (("screen", "bf16"), ("screen", "i8"), ("scan", "auto")):
         with pkg.Mi355Index(d) as idx:
             idx.set_option("path", path)
+            idx.set_option("screen_dtype", screen)
             idx.add(C)
             _check(idx, oracle, C, Q, 10)
 
@@ -111,9 +121,40 @@ def test_near_ties_stress(pkg, oracle):
     C = np.tile(c0, (4000, 1))
     C += (rng.standard_normal(C.shape) * 1e-6).astype(np.float32)
     Q = (c0[None, :] + 1e-3 * rng.standard_normal((4, d))).astype(np.float32)
+    for screen in SCREENS:
+        with pkg.Mi355Index(d) as idx:
+            idx.set_option("screen_dtype", screen)
+            idx.add(C)
+            _check(idx, oracle, C, Q, 25)
+
+
+def test_int8_loose_rows_and_auto_fallback(pkg, oracle):
+    """rows with outlier components do not quantise within the residual limit: they stay out of the int8 shadow and
+    are re-scored for every query (results unchanged); with too many of them AUTO keeps the bf16 screen."""
+    rng = np.random.default_rng(123)
+    n, d = 6000, 256
+    C = rng.standard_normal((n, d)).astype(np.float32)
+    spikes = rng.choice(n, size=40, replace=False)
+    C[spikes, rng.integers(0, d, size=40)] += 40.0  # one dominant component (|c_hat_k| ~ 0.9): clipped by the int8 grid
+    Q = rng.standard_normal((12, d)).astype(np.float32)
+    Q[:4] = C[spikes[:4]] + 0.1 * rng.standard_normal((4, d)).astype(np.float32)  # the spiky rows ARE the answers
     with pkg.Mi355Index(d) as idx:
         idx.add(C)
-        _check(idx, oracle, C, Q, 25)
+        assert idx.stat("loose_rows") >= 40 and idx.stat("irregular_rows") == 0
+        assert idx.stat("screen_dtype_active") == 2
+        _, rows = _check(idx, oracle, C, Q, 10)
+        assert all(rows[i, 0] == spikes[i] for i in range(4))
+        assert idx.stat("fallback_queries") == 0
+    C2 = C.copy()
+    C2[:1500, 0] += 40.0  # > 1024 loose rows
+    with pkg.Mi355Index(d) as idx:
+        idx.add(C2)
+        assert idx.stat("loose_rows") > 1024
+        assert idx.stat("screen_dtype_active") == 1  # AUTO resolved to bf16
+        _check(idx, oracle, C2, Q, 10)
+        idx.set_option("screen_dtype", "i8")
+        with pytest.raises(pkg.NativeError):
+            idx.search(Q, 10)
 
 
 def test_merge_topk_device_equals_host_merge(pkg):

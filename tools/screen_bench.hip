@@ -81,12 +81,28 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(k_fill, dim3((unsigned)((Npad * dpad + 255) / 256)), dim3(256), 0, 0, shadow, Npad, dpad, d, 1234ull);
     hipLaunchKernelGGL(k_fill, dim3((unsigned)(((int64_t)Bpad * dpad + 255) / 256)), dim3(256), 0, 0, qhat, (int64_t)Bpad, dpad, d, 99ull);
     CK(hipDeviceSynchronize());
-    CK(hipFuncSetAttribute((const void*)k_screen, hipFuncAttributeMaxDynamicSharedMemorySize, kScreenLds));
-    CK(hipFuncSetAttribute((const void*)k_screen256<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
-    CK(hipFuncSetAttribute((const void*)k_screen256<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
-    CK(hipFuncSetAttribute((const void*)k_screen256<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
-    CK(hipFuncSetAttribute((const void*)k_screen256<3>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
-    CK(hipFuncSetAttribute((const void*)k_screen256<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
+    CK(hipFuncSetAttribute((const void*)k_screen<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreenLds));
+    CK(hipFuncSetAttribute((const void*)k_screen<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreenLds));
+    CK(hipFuncSetAttribute((const void*)k_screen256<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
+    CK(hipFuncSetAttribute((const void*)k_screen256<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
+    CK(hipFuncSetAttribute((const void*)k_screen256<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
+    CK(hipFuncSetAttribute((const void*)k_screen256<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
+    CK(hipFuncSetAttribute((const void*)k_screen256<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
+    CK(hipFuncSetAttribute((const void*)k_screen256<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
+    // int8 variants (1128 / 1256) reuse the same buffers as raw bytes: rows of dpad8 = round_up(d,128) int8;
+    // timing only (the integer thresholds are parked at INT_MAX)
+    const int dpad8 = (d + 127) / 128 * 128;
+    int* thr_i;
+    float* scv;
+    uint8_t* flag8;
+    CK(hipMalloc(&thr_i, Bpad * 4));
+    CK(hipMalloc(&scv, Bpad * 4));
+    CK(hipMalloc(&flag8, Npad));
+    CK(hipMemset(flag8, 0, Npad));
+    {
+        std::vector<int> hi(Bpad, 0x7FFFFFFF);
+        CK(hipMemcpy(thr_i, hi.data(), Bpad * 4, hipMemcpyHostToDevice));
+    }
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
@@ -99,7 +115,13 @@ int main(int argc, char** argv) {
         sa.cnt = cnt;
         sa.cand_row = crow;
         sa.cand_val = cval;
-        sa.dpad = dpad;
+        const bool i8 = variant >= 1000;
+        if (i8) variant -= 1000;
+        sa.thr_i = thr_i;
+        sa.sc = scv;
+        sa.flag8 = flag8;
+        sa.row_bytes = i8 ? dpad8 : dpad * 2;
+        sa.ksteps = sa.row_bytes / 128;
         sa.cap = cap;
         sa.ct0 = 0;
         sa.row_end = N;
@@ -107,17 +129,20 @@ int main(int argc, char** argv) {
             sa.n_ctiles = (int)((N + 127) / 128);
             sa.n_qtiles = (B + 127) / 128;
             const int64_t grid = (int64_t)((sa.n_ctiles + 7) / 8 * 8) * sa.n_qtiles;
-            hipLaunchKernelGGL(k_screen, dim3((unsigned)grid), dim3(256), kScreenLds, 0, sa);
+            if (i8) hipLaunchKernelGGL(k_screen<true>, dim3((unsigned)grid), dim3(256), kScreenLds, 0, sa);
+            else hipLaunchKernelGGL(k_screen<false>, dim3((unsigned)grid), dim3(256), kScreenLds, 0, sa);
         } else {
             sa.n_ctiles = (int)((N + 255) / 256);
             sa.n_qtiles = (B + 255) / 256;
             const int64_t grid = (int64_t)((sa.n_ctiles + 7) / 8 * 8) * sa.n_qtiles;
-            switch (variant - 256) {
-                case 0: hipLaunchKernelGGL(k_screen256<0>, dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa); break;
-                case 1: hipLaunchKernelGGL(k_screen256<1>, dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa); break;
-                case 2: hipLaunchKernelGGL(k_screen256<2>, dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa); break;
-                case 3: hipLaunchKernelGGL(k_screen256<3>, dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa); break;
-                default: hipLaunchKernelGGL(k_screen256<4>, dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa); break;
+            if (i8) {
+                hipLaunchKernelGGL((k_screen256<0, true>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa);
+            } else switch (variant - 256) {
+                case 0: hipLaunchKernelGGL((k_screen256<0, false>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa); break;
+                case 1: hipLaunchKernelGGL((k_screen256<1, false>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa); break;
+                case 2: hipLaunchKernelGGL((k_screen256<2, false>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa); break;
+                case 3: hipLaunchKernelGGL((k_screen256<3, false>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa); break;
+                default: hipLaunchKernelGGL((k_screen256<4, false>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa); break;
             }
         }
         CK(hipGetLastError());
@@ -125,7 +150,7 @@ int main(int argc, char** argv) {
 
     const double flops = 2.0 * B * (double)N * d;
     std::vector<std::vector<Cand>> sets;
-    for (int variant : {128, 256, 257, 258, 259}) {
+    for (int variant : {128, 256, 257, 258, 259, 1128, 1256}) {
         if (only && variant != only) continue;
         // (1) pure compute
         hipLaunchKernelGGL(k_fillf, dim3((Bpad + 255) / 256), dim3(256), 0, 0, thr, Bpad, INFINITY);
@@ -144,6 +169,35 @@ int main(int argc, char** argv) {
         }
         printf("variant %d: N=%lld B=%d d=%d  best %.3f ms  avg %.3f ms  -> %.1f TFLOP/s (best) %.1f (avg)\n", variant,
                (long long)N, B, d, best, sum / reps, flops / best / 1e9, flops / (sum / reps) / 1e9);
+        // (1b) cost of the hit path: same launch at decreasing thresholds (z sigmas of the score distribution)
+        if (getenv("SWEEP")) {
+            for (float z : {4.6f, 4.2f, 3.9f, 3.5f, 3.0f}) {
+                hipLaunchKernelGGL(k_fillf, dim3((Bpad + 255) / 256), dim3(256), 0, 0, thr, B, z / sqrtf((float)d));
+                {   // int8 variants: the harness bytes are uniform in [-128,127] -> acc ~ N(0, d * 5461^2)
+                    std::vector<int> hi(Bpad, 0x7FFFFFFF);
+                    for (int q = 0; q < B; ++q) hi[q] = (int)(z * sqrtf((float)d) * 5461.0f);
+                    CK(hipMemcpy(thr_i, hi.data(), Bpad * 4, hipMemcpyHostToDevice));
+                }
+                float bz = 1e30f;
+                for (int r = 0; r < 3; ++r) {
+                    CK(hipMemset(cnt, 0, Bpad * 4));
+                    CK(hipEventRecord(e0));
+                    launch(variant);
+                    CK(hipEventRecord(e1));
+                    CK(hipEventSynchronize(e1));
+                    float ms;
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    bz = std::min(bz, ms);
+                }
+                std::vector<int> hc(B);
+                CK(hipMemcpy(hc.data(), cnt, B * 4, hipMemcpyDeviceToHost));
+                long long tot = 0;
+                for (int q = 0; q < B; ++q) tot += hc[q];
+                printf("   z=%.1f: %.3f ms, %lld hits (%.2e of pairs)\n", z, bz, tot, (double)tot / ((double)N * B));
+            }
+            std::vector<int> hi(Bpad, 0x7FFFFFFF);
+            CK(hipMemcpy(thr_i, hi.data(), Bpad * 4, hipMemcpyHostToDevice));
+        }
         // (2) finite threshold: collect candidates
         const float T0 = 4.6f / sqrtf((float)d);  // ~4.6 sigma
         hipLaunchKernelGGL(k_fillf, dim3((Bpad + 255) / 256), dim3(256), 0, 0, thr, B, T0);
