@@ -130,6 +130,85 @@ __device__ __forceinline__ void screen_emit_block(const ScreenArgs& a, f32x16 ac
     }
 }
 
+// 32-bit LDS address of a pointer into dynamic shared memory
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(unsigned long)((const __attribute__((address_space(3))) char*)p);
+}
+
+// ---- k_screen256's form of the hit path: a per-WAVE candidate queue in LDS ----
+// Hits are appended with wave-level bookkeeping only (ballot + mbcnt, count in an SGPR): no atomics, and no
+// vector-memory instruction, so the in-flight LDS-DMA prefetch of the next tile is never waited for (vmcnt
+// completes in order: waiting for a global atomic's return would wait for the whole prefetch).  A wave flushes its
+// queue to the global candidate lists between two tiles when it is more than half full, and when the workgroup is done.
+constexpr int kWaveQueueCap = 320;  // entries (q, row, value) per wave; 8 waves x 320 x 12 B = 30 KiB
+
+// flush a wave's queue: one global atomic per entry.  Inlined at ONE site per tile (k_screen256) -- a call would
+// make the register allocator spill the accumulators around it.
+__device__ __forceinline__ void wave_queue_flush(const ScreenArgs& a, const int32_t* que, int n) {
+    const int lane = threadIdx.x & 63;
+    for (int e = lane; e < n; e += kWave) {
+        const int q = que[e];
+        const int slot = atomicAdd(&a.cnt[q], 1);
+        if (slot < a.cap) {
+            a.cand_row[(int64_t)q * a.cap + slot] = que[kWaveQueueCap + e];
+            a.cand_val[(int64_t)q * a.cap + slot] = __int_as_float(que[2 * kWaveQueueCap + e]);
+        }
+    }
+}
+
+template <bool I8>
+__device__ __forceinline__ void screen_queue_block(const ScreenArgs& a, f32x16 acc, int q, int rbase, int row_end,
+                                                   float th, int thi, float sc, int32_t* que, int& que_n) {
+    bool any;
+    if constexpr (I8) {
+        const i32x16 v = __builtin_bit_cast(i32x16, acc);
+        int m = v[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) m = max(m, v[r]);
+        any = m >= thi;
+    } else {
+        float m = acc[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+        any = m >= th;
+    }
+    if (__builtin_amdgcn_ballot_w64(any) == 0) return;  // wave-uniform: almost always taken
+    // The queue is written with inline-asm LDS stores on purpose: for compiler-visible LDS accesses the waitcnt
+    // insertion assumes they may alias the in-flight LDS-DMA and puts s_waitcnt vmcnt(0) in front
+    // (tests/test_build_pipeline.py checks the generated code).
+    const unsigned a_q = lds_addr(que), a_r = a_q + 4u * kWaveQueueCap, a_v = a_q + 8u * kWaveQueueCap;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
+        bool hit;
+        if constexpr (I8) hit = __builtin_bit_cast(i32x16, acc)[r] >= thi;
+        else hit = acc[r] >= th;
+        hit = hit && row < row_end;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
+        if (bal == 0) continue;  // wave-uniform
+        if (hit) {
+            const unsigned e =
+                (unsigned)que_n + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+            float val;
+            if constexpr (I8) val = (float)__builtin_bit_cast(i32x16, acc)[r] * sc;
+            else val = acc[r];
+            if (e < (unsigned)kWaveQueueCap) {
+                asm volatile("ds_write_b32 %0, %1" ::"v"(a_q + 4u * e), "v"(q) : "memory");
+                asm volatile("ds_write_b32 %0, %1" ::"v"(a_r + 4u * e), "v"(row) : "memory");
+                asm volatile("ds_write_b32 %0, %1" ::"v"(a_v + 4u * e), "v"(val) : "memory");
+            } else {  // queue full (a burst of hits inside one tile): direct global append, slow but correct
+                const int slot = atomicAdd(&a.cnt[q], 1);
+                if (slot < a.cap) {
+                    a.cand_row[(int64_t)q * a.cap + slot] = row;
+                    a.cand_val[(int64_t)q * a.cap + slot] = val;
+                }
+            }
+        }
+        que_n += __builtin_popcountll(bal);  // may run past the capacity: the flush clamps
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 // first chunk: every (query,row) becomes a candidate at slot row-row0 (counts are set by the host)
 template <bool I8>
 __device__ __forceinline__ void screen_emit_all_block(const ScreenArgs& a, f32x16 acc, int q, int64_t rbase, float sc) {

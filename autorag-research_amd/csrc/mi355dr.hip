@@ -202,7 +202,8 @@ __global__ void k_set_counts(int* cnt, int n, int v) {
 }
 
 int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t r_end, int cap, bool emit_all) {
-    const int tile = screen_tile(B);
+    // the emit-all first chunk always goes through the 128x128 kernel (k_screen256 has no emit-all epilogue)
+    const int tile = emit_all ? kTileM : screen_tile(B);
     const bool i8 = use_i8(idx);
     ScreenArgs sa{};
     sa.shadow = i8 ? (const void*)idx->shadow8 : (const void*)idx->shadow;
@@ -225,8 +226,9 @@ int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t 
     sa.emit_all = emit_all ? 1 : 0;
     const int64_t grid = round_up(sa.n_ctiles, 8) * sa.n_qtiles;
     if (tile == kT2) {
-        if (i8) hipLaunchKernelGGL((k_screen256<0, true>), dim3((unsigned)grid), dim3(512), kScreen256Lds, s, sa);
-        else hipLaunchKernelGGL((k_screen256<0, false>), dim3((unsigned)grid), dim3(512), kScreen256Lds, s, sa);
+        const unsigned g2 = screen256_grid(sa.n_ctiles, sa.n_qtiles);  // persistent: <= one workgroup per CU
+        if (i8) hipLaunchKernelGGL((k_screen256<0, true>), dim3(g2), dim3(512), kScreen256Lds, s, sa);
+        else hipLaunchKernelGGL((k_screen256<0, false>), dim3(g2), dim3(512), kScreen256Lds, s, sa);
     } else {
         if (i8) hipLaunchKernelGGL(k_screen<true>, dim3((unsigned)grid), dim3(256), kScreenLds, s, sa);
         else hipLaunchKernelGGL(k_screen<false>, dim3((unsigned)grid), dim3(256), kScreenLds, s, sa);

@@ -128,6 +128,22 @@ def test_near_ties_stress(pkg, oracle):
             _check(idx, oracle, C, Q, 25)
 
 
+@pytest.mark.parametrize("screen", SCREENS)
+@pytest.mark.parametrize("n,d,B,k", [(7000, 64, 600, 10), (40000, 128, 257, 7), (2600, 200, 513, 3), (66000, 96, 1024, 10)])
+def test_persistent_screen_shapes(pkg, oracle, screen, n, d, B, k):
+    """k_screen256's persistent walk at its corner shapes: 1-4 query tiles (3 -> 30 workgroups per XCD), one K-step
+    per tile (d <= 64 bf16 / 128 int8), chunks smaller than the grid, ragged last tiles."""
+    rng = np.random.default_rng(n + B)
+    C = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    with pkg.Mi355Index(d) as idx:
+        idx.set_option("screen_dtype", screen)
+        idx.set_option("path", "screen")
+        idx.add(C)
+        _check(idx, oracle, C, Q, k)
+        assert idx.stat("fallback_queries") == 0
+
+
 def test_int8_loose_rows_and_auto_fallback(pkg, oracle):
     """rows with outlier components do not quantise within the residual limit: they stay out of the int8 shadow and
     are re-scored for every query (results unchanged); with too many of them AUTO keeps the bf16 screen."""
