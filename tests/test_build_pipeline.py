@@ -51,7 +51,9 @@ def test_screen256_keeps_dma_in_flight(screen_asm, i8):
     name = f"_ZN5mi35511k_screen256ILi0ELb{int(i8)}EEEvNS_10ScreenArgsE"
     ops = screen_asm[name]
     mf = [i for i, o in enumerate(ops) if o.startswith("v_mfma")]
-    assert len(mf) == 32  # ONE K-step body (4 quadrants x 8 MFMAs) serves every K-step of every tile
+    # one K-step body (4 quadrants x 8 MFMAs) serves every K-step of every tile; the compiler may peel or unroll it
+    assert len(mf) % 32 == 0 and 32 <= len(mf) <= 96
+    copies = len(mf) // 32
     want = "v_mfma_i32_32x32x32_i8" if i8 else "v_mfma_f32_32x32x16_bf16"
     assert all(ops[i].startswith(want) for i in mf)
     # the K-step body: from the first LDS-DMA issue after the prologue's barrier to the last MFMA
@@ -59,8 +61,8 @@ def test_screen256_keeps_dma_in_flight(screen_asm, i8):
     body_start = max(i for i in gl if i < mf[0]) - 1
     body = ops[body_start:mf[-1]]
     assert not any(_is_vm0(o) for o in body), "the K-step waits for ALL outstanding LDS-DMA loads"
-    assert sum(o.startswith("s_waitcnt") and "vmcnt(4)" in o for o in body) == 4
-    assert sum(o.startswith("global_load_lds") for o in body) >= 7  # (the first issue may sit just above the slice)
+    assert sum(o.startswith("s_waitcnt") and "vmcnt(4)" in o for o in body) == 4 * copies
+    assert sum(o.startswith("global_load_lds") for o in body) >= 8 * copies - 1  # (the first issue may sit just above)
     # the hit path's queue stores must not be preceded by a vector-memory wait (the compiler adds one for LDS
     # accesses it can see; they are inline asm for that reason)
     for i, o in enumerate(ops):
