@@ -138,6 +138,34 @@ __device__ __forceinline__ void bitonic_desc_f32(float* v, int n) {
     }
 }
 
+// ---- one-wave selection helpers (k_prune's small form: every lane holds kSelPerLane values in registers) ----
+constexpr int kSelPerLane = 16;
+
+// monotone map float -> uint32 (unsigned compare == float compare, -inf lowest finite image, NaN not expected)
+__device__ __forceinline__ uint32_t f32_order_key(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// number of keys >= x over the whole wave (wave-uniform result): 16 ballots + scalar popcounts, no shuffles
+__device__ __forceinline__ int wave_count_ge(const uint32_t (&key)[kSelPerLane], uint32_t x) {
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < kSelPerLane; ++j) c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(key[j] >= x));
+    return c;
+}
+
+// the n-th largest key of the wave's 64*16 keys (1 <= n <= number of keys): bitwise construction of the largest
+// x with count(key >= x) >= n.  32 rounds of wave_count_ge.
+__device__ __forceinline__ uint32_t wave_nth_largest(const uint32_t (&key)[kSelPerLane], int n) {
+    uint32_t x = 0;
+    for (int b = 31; b >= 0; --b) {
+        const uint32_t t = x | (1u << b);
+        if (wave_count_ge(key, t) >= n) x = t;
+    }
+    return x;
+}
+
 // descending sort of (value, payload) pairs
 __device__ __forceinline__ void bitonic_desc_f32_i32(float* v, int32_t* w, int n) {
     for (int k = 2; k <= n; k <<= 1) {

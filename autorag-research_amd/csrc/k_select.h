@@ -85,6 +85,167 @@ __global__ __launch_bounds__(THREADS) void k_prune(PruneArgs a) {
     int n_res;
     int n_base = n_best;  // kept entries carried into the final sort (truncated to k after round A)
     bool kept_loaded = false;
+    if constexpr (THREADS == kWave) {
+        if (!a.exact) {
+            // ============ one-wave form: selections instead of sorts ============
+            // Every lane keeps 16 candidates' screen values (as order keys) in registers; "the n best" are found by
+            // bisection on the key (32 rounds of ballots), lists are built with ballot + mbcnt.  The three LDS
+            // bitonic sorts of the general form cost 60-100 us per launch at one wave per SIMD; this costs a few.
+            float* tile = tiles;
+            uint32_t key[kSelPerLane];
+            unsigned in_a = 0;  // bit j: candidate j*64+lane went through round A
+#pragma unroll
+            for (int j = 0; j < kSelPerLane; ++j) {
+                const int e = j * kWave + lane;
+                uint32_t kk = 0;  // 0 = no candidate (below every real key)
+                if (e < n_new) {
+                    const float v = cval[e];
+                    if (v != v) kk = 0xFFFFFFFFu;  // "no bound": always re-scored
+                    else if (!(a.flag8 && a.flag8[crow[e]])) kk = f32_order_key(v);  // (else: stale zero of a loose row)
+                }
+                key[j] = kk;
+            }
+            for (int k = lane; k < a.d; k += kWave) qs[k] = a.q[(int64_t)q * a.d + k];
+            const int n_cand = wave_count_ge(key, 1u);
+            // wave-local exact re-score of the candidates listed in R[0..n) -> SK/SR[dst..]
+            auto rescore_list = [&](int n, int dst) {
+                for (int base = 0; base < n; base += kWave) {
+                    const int e = base + lane;
+                    const bool live = e < n;
+                    const int32_t row = live ? crow[R[e]] : -1;
+                    const float* rp = live ? a.rows + (int64_t)row * a.d : nullptr;
+                    const float acc = staged_dot(tile, rp, qs, a.d, lane);
+                    if (live) {
+                        SK[dst + e] = dist_to_key(distance_from(a.metric, acc, nq, a.nrm2[row]));
+                        SR[dst + e] = row;
+                    }
+                }
+            };
+            // list the candidates with (key >= x) && !(in_a), at most `room` of them, into R[0..); marks them in_a if mark
+            auto compact = [&](uint32_t x, int room, bool mark) -> int {
+                int n = 0;
+#pragma unroll
+                for (int j = 0; j < kSelPerLane; ++j) {
+                    const bool want = key[j] >= x && key[j] != 0 && !((in_a >> j) & 1u);
+                    const unsigned long long bal = __builtin_amdgcn_ballot_w64(want);
+                    const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32),
+                                                                       __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+                    if (want && pos < room) {
+                        R[pos] = j * kWave + lane;
+                        if (mark) in_a |= 1u << j;
+                    }
+                    n += __builtin_popcountll(bal);
+                }
+                return min(n, room);
+            };
+            wave_sync();  // qs visible
+            // ---- round A: the best-looking candidates (see the general form below for the reasoning)
+            const int wantA = min(n_cand, min(kWave, max(32, 2 * a.k)));
+            int nA = 0;
+            if (wantA > 0) {
+                const uint32_t xA = wave_nth_largest(key, wantA);
+                nA = compact(xA, kWave, true);
+                wave_sync();
+                rescore_list(nA, n_best);
+            }
+            for (int i = lane; i < n_best; i += kWave) {
+                SK[i] = bkey[i];
+                SR[i] = brow[i];
+            }
+            kept_loaded = true;
+            wave_sync();
+            int n1 = n_best + nA;
+            int nB = 0;
+            if (n_cand > nA) {
+                // ---- cut = (k-th largest exact similarity over kept U round A) - E: as float, rounded down
+                float cut = -__builtin_inff();
+                if (n1 >= a.k && a.metric == 0) {
+                    uint32_t sk[kSelPerLane];
+#pragma unroll
+                    for (int j = 0; j < kSelPerLane; ++j) {
+                        const int e = j * kWave + lane;
+                        uint32_t kk = 0;
+                        if (e < n1 && SK[e] != kKeyNaN) kk = f32_order_key((float)(1.0 - key_to_dist(SK[e])));
+                        sk[j] = kk;
+                    }
+                    if (wave_count_ge(sk, 1u) >= a.k) {
+                        const uint32_t xs = wave_nth_largest(sk, a.k);
+                        const uint32_t ub = (xs & 0x80000000u) ? (xs & 0x7FFFFFFFu) : ~xs;  // invert f32_order_key
+                        cut = __uint_as_float(ub) - E * 1.001f - 2e-6f;
+                    }
+                }
+                // ---- round B: everything that can still reach the top-k (v + E >= exact k-th best)
+                const uint32_t xB = cut == -__builtin_inff() ? 1u : f32_order_key(cut);
+                nB = compact(xB, SORT, false);
+                wave_sync();
+                rescore_list(nB, n1);
+            }
+            if (lane == 0) a.stat[2 * q + 1] += (unsigned long long)(nA + nB);
+            wave_sync();
+            // ---- final: the k best of kept U A U B under (key,row).  Select by similarity (float image of the key,
+            // monotone), then sort only the selected few.
+            const int n_tot = n1 + nB;
+            uint64_t* K2 = (uint64_t*)X;                      // the stage tile is dead now
+            int32_t* R2 = (int32_t*)(X + (size_t)SORT * 8);
+            int n_sel = n_tot;
+            if (n_tot > a.k) {
+                uint32_t sk[kSelPerLane];
+#pragma unroll
+                for (int j = 0; j < kSelPerLane; ++j) {
+                    const int e = j * kWave + lane;
+                    uint32_t kk = 0;
+                    if (e < n_tot) kk = SK[e] == kKeyNaN ? 1u : (f32_order_key((float)(1.0 - key_to_dist(SK[e]))) | 2u);
+                    sk[j] = kk;  // (|2: every real similarity ranks above the NaN class 1, which ranks above "absent" 0)
+                }
+                const uint32_t xs = wave_nth_largest(sk, a.k);
+                n_sel = 0;
+#pragma unroll
+                for (int j = 0; j < kSelPerLane; ++j) {
+                    const bool want = sk[j] >= xs && sk[j] != 0;
+                    const unsigned long long bal = __builtin_amdgcn_ballot_w64(want);
+                    const int pos = n_sel + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32),
+                                                                           __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+                    if (want) {
+                        K2[pos] = SK[j * kWave + lane];
+                        R2[pos] = SR[j * kWave + lane];
+                    }
+                    n_sel += __builtin_popcountll(bal);
+                }
+            } else {
+                for (int i = lane; i < n_tot; i += kWave) {
+                    K2[i] = SK[i];
+                    R2[i] = SR[i];
+                }
+            }
+            const int np = next_pow2(max(n_sel, 1));
+            for (int i = n_sel + lane; i < np; i += kWave) {
+                K2[i] = kKeyNaN;
+                R2[i] = 0x7FFFFFFF;
+            }
+            __syncthreads();
+            bitonic_asc_key_row(K2, R2, np);
+            const int n_keep = min(a.k, n_sel);
+            for (int i = lane; i < n_keep; i += kWave) {
+                bkey[i] = K2[i];
+                brow[i] = R2[i];
+            }
+            if (lane == 0) {
+                a.st.best_n[q] = n_keep;
+                a.st.cnt[q] = 0;
+                if (n_keep >= a.k) {
+                    const uint64_t wk = K2[a.k - 1];
+                    a.st.thr_key[q] = wk;
+                    a.st.thr_row[q] = R2[a.k - 1];
+                    if (a.metric == 0 && wk != kKeyNaN && !(a.st.status[q] & kStIrregular)) {
+                        const float th = float_below((float)((1.0 - key_to_dist(wk)) - (double)E));
+                        a.st.thr[q] = th;
+                        a.st.thr_i[q] = i8_threshold(th, a.st.sc[q]);
+                    }
+                }
+            }
+            return;
+        }
+    }
     if (!a.exact) {
         // ---- phase 1: order the new candidates by their screen value, best first.  NaN = "no bound" sorts first;
         // int8 screen: a finite value on a row outside the int8 shadow is a stale zero -> dropped (that row comes
@@ -126,8 +287,10 @@ __global__ __launch_bounds__(THREADS) void k_prune(PruneArgs a) {
                 }
             }
         };
-        // ---- phase 2 (round A): re-score the THREADS best-looking candidates
-        const int nA = min(n_cand, THREADS);
+        // ---- phase 2 (round A): re-score the best-looking candidates -- enough of them to contain the new top-k with
+        // near certainty (the screen's ACTUAL error is ~10x below its bound, so its order is almost the exact order),
+        // but no more: every row costs d*4 gathered bytes, and the gather is what bounds this kernel
+        const int nA = min(n_cand, min(THREADS, max(32, 2 * a.k)));
         rescore(0, nA, n_best);
         int n_pass = nA;
         if (n_cand > nA) {

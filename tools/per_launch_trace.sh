@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace -f csv -d gpurun_out/kt -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/kt.log 2>&1
+rm -rf gpurun_out/kt; rocprofv3 --kernel-trace -f csv -d gpurun_out/kt -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/kt.log 2>&1
 python - <<'PY'
 import csv,glob
 f=glob.glob('gpurun_out/kt/**/*kernel_trace.csv',recursive=True)[0]
