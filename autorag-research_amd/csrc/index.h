@@ -60,8 +60,8 @@ struct mi355dr_index {
     int screen_dtype = 0;  // MI355DR_SCREEN_AUTO
     int64_t row_offset = 0;
     int profile = 0;
-    int64_t chunk0_rows = 512;
-    int64_t chunk_growth = 5;
+    int64_t chunk0_rows = 1024;
+    int64_t chunk_growth = 3;
     int cap = mi355::kCandCap;
 
     // stats

@@ -195,6 +195,8 @@ int launch_prep(mi355dr_index* idx, hipStream_t s, int B, int Bpad, int metric) 
 // tile edge used for a block of B queries: the 256x256 ping-pong kernel from 129 queries up, else 128x128
 inline int screen_tile(int B) { return B > kTileN ? kT2 : kTileM; }
 
+constexpr int64_t kSmallChunkRows = 16384;
+
 // launch one screen pass over rows [r0, r_end) (r0 a multiple of the tile edge)
 __global__ void k_set_counts(int* cnt, int n, int v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -203,7 +205,9 @@ __global__ void k_set_counts(int* cnt, int n, int v) {
 
 int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t r_end, int cap, bool emit_all) {
     // the emit-all first chunk always goes through the 128x128 kernel (k_screen256 has no emit-all epilogue)
-    const int tile = emit_all ? kTileM : screen_tile(B);
+    // ... and so do chunks of a few thousand rows: their thresholds are still so low that a good part of the tile is a
+    // hit, which the per-lane global append of k_screen handles better than k_screen256's small per-wave queues
+    const int tile = (emit_all || r_end - r0 <= kSmallChunkRows) ? kTileM : screen_tile(B);
     const bool i8 = use_i8(idx);
     ScreenArgs sa{};
     sa.shadow = i8 ? (const void*)idx->shadow8 : (const void*)idx->shadow;
