@@ -16,6 +16,7 @@
 namespace mi355 {
 struct EventPair {
     hipEvent_t a, b;
+    int big;  // 1: the launch went to k_screen256 (the dominant kernel), 0: k_screen
 };
 struct MultiVecStore;  // mi355dr_maxsim.hip
 }  // namespace mi355
@@ -67,6 +68,7 @@ struct mi355dr_index {
     // stats
     int64_t s_screen_launches = 0, s_screen_ns = 0, s_screen_rows = 0, s_fallback_queries = 0, s_chunks = 0,
             s_passes = 0, s_candidates = 0, s_rescored = 0;
+    int64_t s_big_launches = 0, s_big_ns = 0, s_big_rows = 0;  // the k_screen256 share of the three above
     std::vector<mi355::EventPair> ev_pool, ev_pending;
     hipEvent_t t0 = nullptr, t1 = nullptr;
 

@@ -146,7 +146,10 @@ EventPair take_events(mi355dr_index* idx) {
 void drain_events(mi355dr_index* idx) {  // call only after the stream was synchronised
     for (auto& p : idx->ev_pending) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) idx->s_screen_ns += (int64_t)(ms * 1e6);
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            idx->s_screen_ns += (int64_t)(ms * 1e6);
+            if (p.big) idx->s_big_ns += (int64_t)(ms * 1e6);
+        }
         idx->ev_pool.push_back(p);
     }
     idx->ev_pending.clear();
@@ -262,12 +265,18 @@ int run_screen(mi355dr_index* idx, hipStream_t s, int B, int k) {
         }
         // the first chunk has no threshold yet: it keeps every row (direct stores) as long as it fits the buffer
         CHECK(launch_screen(idx, s, B, done, end, idx->cap, emit_all));
+        const bool big = !emit_all && end - done > kSmallChunkRows && screen_tile(B) == kT2;
         if (idx->profile) {
             HIPCHECK(idx, hipEventRecord(ev.b, s));
+            ev.big = big ? 1 : 0;
             idx->ev_pending.push_back(ev);
         }
         idx->s_screen_launches++;
         idx->s_screen_rows += end - done;
+        if (big) {
+            idx->s_big_launches++;
+            idx->s_big_rows += end - done;
+        }
         idx->s_chunks++;
         CHECK(launch_prune(idx, s, B, nullptr, k, /*exact=*/0));
         done = end;
@@ -691,6 +700,9 @@ int mi355dr_get_stat(mi355dr_index* idx, const char* key, int64_t* out) {
     } else if (k == "screen_launches") *out = idx->s_screen_launches;
     else if (k == "screen_ns") *out = idx->s_screen_ns;
     else if (k == "screen_rows") *out = idx->s_screen_rows;
+    else if (k == "screen256_launches") *out = idx->s_big_launches;
+    else if (k == "screen256_ns") *out = idx->s_big_ns;
+    else if (k == "screen256_rows") *out = idx->s_big_rows;
     else if (k == "fallback_queries") *out = idx->s_fallback_queries;
     else if (k == "chunks") *out = idx->s_chunks;
     else if (k == "passes") *out = idx->s_passes;
@@ -707,7 +719,7 @@ int mi355dr_reset_stats(mi355dr_index* idx) {
     if (!idx) return fail(nullptr, MI355DR_E_INVALID, "null index");
     std::lock_guard<std::mutex> g(idx->mu);
     idx->s_screen_launches = idx->s_screen_ns = idx->s_screen_rows = idx->s_fallback_queries = idx->s_chunks =
-        idx->s_passes = 0;
+        idx->s_passes = idx->s_big_launches = idx->s_big_ns = idx->s_big_rows = 0;
     if (idx->stat_dev) {
         HIPCHECK(idx, hipSetDevice(idx->device));
         HIPCHECK(idx, hipMemset(idx->stat_dev, 0, 2 * kQBlockMax * sizeof(unsigned long long)));

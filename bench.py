@@ -240,9 +240,15 @@ def main() -> None:
         elapsed = float(tmax.item())
 
     # ---- dominant-kernel accounting (k_screen), measured with HIP events on the launch stream
-    launches = idx.stat("screen_launches")
-    screen_ns = idx.stat("screen_ns")
-    screen_rows = idx.stat("screen_rows")  # rows screened, summed over launches (= n_local per step)
+    all_launches = idx.stat("screen_launches")
+    all_screen_ns = idx.stat("screen_ns")
+    # the dominant kernel's own launches (k_screen256 for B > 128; the few-thousand-row first chunks go through k_screen)
+    if B > 128:
+        launches = idx.stat("screen256_launches")
+        screen_ns = idx.stat("screen256_ns")
+        screen_rows = idx.stat("screen256_rows")
+    else:
+        launches, screen_ns, screen_rows = all_launches, all_screen_ns, idx.stat("screen_rows")
     fallback = idx.stat("fallback_queries")
     cand = idx.stat("candidates")
     resc = idx.stat("rescored")
@@ -276,6 +282,8 @@ def main() -> None:
         "launches": launches,
         "avg_launch_ms": round(screen_s * 1e3 / max(launches, 1), 4),
         "kernel_ms_per_step": round(screen_s * 1e3 / max(args.steps, 1), 3),
+        "all_screen_kernels_ms_per_step": round(all_screen_ns * 1e-6 / max(args.steps, 1), 3),
+        "all_screen_launches": all_launches,
         "issued_tflops": round(flops / screen_s / 1e12, 2) if screen_s > 0 else None,
         # the north-star's HBM view of the same launches: algorithmic N*d*4 bytes per pass over kernel time
         "hbm_view": {

@@ -122,7 +122,8 @@ int mi355dr_merge_topk_packed_device(mi355dr_index* idx, const int64_t* packed_a
 /* ---- options / stats / timing ----
  * options: "path" (MI355DR_PATH_*), "screen_dtype" (MI355DR_SCREEN_*), "row_offset", "profile" (0/1: HIP-event
  *          timing of the dominant kernel), "chunk0_rows", "chunk_growth", "cand_cap".
- * stats:   "screen_launches", "screen_ns" (profile=1), "screen_rows", "candidates", "rescored",
+ * stats:   "screen_launches", "screen_ns" (profile=1), "screen_rows" (all screen launches) and their k_screen256 share
+ *          "screen256_launches", "screen256_ns", "screen256_rows"; "candidates", "rescored",
  *          "fallback_queries", "chunks", "passes", "irregular_rows", "loose_rows" (rows outside the int8 shadow,
  *          irregular ones included), "screen_dtype_active" (MI355DR_SCREEN_BF16 / _I8: what AUTO resolves to now),
  *          "hbm_bytes_resident". */
