@@ -62,7 +62,9 @@ struct MsArgs {
     const float* tok;
     const int64_t* blk_off;
     const float* qtok;      // [kMsCols, dpad] zero-padded
-    float* dist;            // [nq_launch, n_docs]
+    float* dist;            // [nq_launch, n_items]
+    const int32_t* doc_list;  // optional [n_items]: the docs to score (nullptr: item i = doc i); < 0 or >= n_docs: NaN
+    int64_t n_items;        // work items (= n_docs without a list)
     int64_t n_docs;
     int dpad;
     int nq_launch;          // queries in this launch (<= 4)
@@ -125,8 +127,14 @@ __global__ __launch_bounds__(kMsThreads, 2) void k_maxsim(MsArgs a) {
     const int nchunk = (a.dpad + 127) / 128;
     // docs are dealt round-robin to the waves of the grid so long and short docs mix
     for (int dw = 0; dw < kMsDocsPerWave; ++dw) {
-    const int64_t doc = ((int64_t)dw * gridDim.x + blockIdx.x) * 4 + wave;
-    if (doc >= a.n_docs) break;
+    const int64_t item = ((int64_t)dw * gridDim.x + blockIdx.x) * 4 + wave;
+    if (item >= a.n_items) break;
+    const int64_t doc = a.doc_list ? (int64_t)a.doc_list[item] : item;
+    if (doc < 0 || doc >= a.n_docs) {  // (subset scoring) not a stored doc
+        if (lane == 0)
+            for (int qi = 0; qi < a.nq_launch; ++qi) a.dist[(int64_t)qi * a.n_items + item] = __uint_as_float(0x7FC00000u);
+        continue;
+    }
     const int64_t b0 = a.blk_off[doc], b1 = a.blk_off[doc + 1];
     float run[4];  // running max per column block (this lane's column)
 #pragma unroll
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(kMsThreads, 2) void k_maxsim(MsArgs a) {
             v = __shfl(v, c & 31, kWave);
             accd = accd + (-v);
         }
-        if (lane == 0) a.dist[(int64_t)qi * a.n_docs + doc] = accd;
+        if (lane == 0) a.dist[(int64_t)qi * a.n_items + item] = b1 > b0 ? accd : __uint_as_float(0x7FC00000u);
     }
     }  // docs of this wave
 }
@@ -381,6 +389,8 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
         a.qtok = m->qtok;
         a.dist = m->dist;
         a.n_docs = m->n_docs;
+        a.n_items = m->n_docs;
+        a.doc_list = nullptr;
         a.dpad = dp;
         std::fill(qimg.begin(), qimg.end(), 0.0f);
         int col = 0, nql = 0, first = b;
@@ -435,6 +445,80 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
             HIPCHECK(idx, hipStreamSynchronize(s));
         }
     }
+    return MI355DR_OK;
+}
+
+int mi355dr_maxsim_subset(mi355dr_index* idx, const float* qtok, const int32_t* q_offsets, int B, const int64_t* doc_ids,
+                          int m_ids, float* out_dist) {
+    if (!idx) return fail(nullptr, MI355DR_E_INVALID, "null index");
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (B < 0 || m_ids < 0 || !q_offsets || (B > 0 && m_ids > 0 && (!doc_ids || !out_dist)))
+        return fail(idx, MI355DR_E_INVALID, "bad maxsim_subset arguments");
+    for (int64_t i = 0; i < (int64_t)B * m_ids; ++i) out_dist[i] = NAN;
+    MultiVecStore* m = idx->mv;
+    if (B == 0 || m_ids == 0 || !m || m->n_docs == 0) return MI355DR_OK;
+    for (int b = 0; b < B; ++b) {
+        const int nq = q_offsets[b + 1] - q_offsets[b];
+        if (nq < 0) return fail(idx, MI355DR_E_INVALID, "q_offsets must be non-decreasing");
+        if (nq > kMsCols) return fail(idx, MI355DR_E_UNSUPPORTED, "more than 128 query vectors per query");
+    }
+    HIPCHECK(idx, hipSetDevice(idx->device));
+    hipStream_t s = idx->stream;
+    const int dp = m->dpad, d = idx->dim;
+    const size_t lds = (size_t)kMsCols * (dp + 4) * sizeof(float);
+    if (lds > 160 * 1024) return fail(idx, MI355DR_E_UNSUPPORTED, "dim too large for the MaxSim kernel's LDS budget");
+    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_maxsim, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // per call scratch (candidate lists are small: a few hundred docs per query)
+    int32_t* list_dev = nullptr;
+    float* dist_dev = nullptr;
+    float* q_dev = nullptr;
+    std::vector<int32_t> list((size_t)B * m_ids);
+    for (int64_t i = 0; i < (int64_t)B * m_ids; ++i) {
+        const int64_t v = doc_ids[i] - idx->row_offset;  // ids are global rows, like the search results
+        list[i] = (v >= 0 && v < m->n_docs) ? (int32_t)v : -1;
+    }
+    HIPCHECK(idx, hipMalloc(&list_dev, list.size() * sizeof(int32_t)));
+    HIPCHECK(idx, hipMalloc(&dist_dev, list.size() * sizeof(float)));
+    HIPCHECK(idx, hipMalloc(&q_dev, (size_t)kMsCols * dp * sizeof(float)));
+    HIPCHECK(idx, hipMemcpyAsync(list_dev, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    std::vector<float> qimg((size_t)kMsCols * dp);
+    for (int b = 0; b < B; ++b) {
+        const int nq = q_offsets[b + 1] - q_offsets[b];
+        if (nq == 0) continue;  // reference heaven.py:251-252: no query vectors -> every score 0 (host side)
+        std::fill(qimg.begin(), qimg.end(), 0.0f);
+        for (int j = 0; j < nq; ++j) {
+            float* dst = &qimg[(size_t)j * dp];
+            const float* sv = qtok + (int64_t)(q_offsets[b] + j) * d;
+            for (int c = 0; c < dp; ++c) {
+                const int oc = ms_perm(c);
+                dst[c] = oc < d ? sv[oc] : 0.0f;
+            }
+        }
+        // the staging buffer is reused: the previous launch must have consumed it (stream order + pageable copy)
+        HIPCHECK(idx, hipMemcpyAsync(q_dev, qimg.data(), qimg.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        HIPCHECK(idx, hipStreamSynchronize(s));
+        MsArgs a{};
+        a.tok = m->tok;
+        a.blk_off = m->blk_off;
+        a.qtok = q_dev;
+        a.dist = dist_dev + (int64_t)b * m_ids;
+        a.doc_list = list_dev + (int64_t)b * m_ids;
+        a.n_items = m_ids;
+        a.n_docs = m->n_docs;
+        a.dpad = dp;
+        a.nq_launch = 1;
+        a.q_col0[0] = 0;
+        a.q_len[0] = nq;
+        hipLaunchKernelGGL(k_maxsim, dim3((unsigned)((m_ids + 4 * kMsDocsPerWave - 1) / (4 * kMsDocsPerWave))),
+                           dim3(kMsThreads), lds, s, a);
+        HIPCHECK(idx, hipGetLastError());
+        HIPCHECK(idx, hipMemcpyAsync(out_dist + (int64_t)b * m_ids, dist_dev + (int64_t)b * m_ids, m_ids * sizeof(float),
+                                     hipMemcpyDeviceToHost, s));
+    }
+    HIPCHECK(idx, hipStreamSynchronize(s));
+    (void)hipFree(list_dev);
+    (void)hipFree(dist_dev);
+    (void)hipFree(q_dev);
     return MI355DR_OK;
 }
 

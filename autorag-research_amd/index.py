@@ -144,6 +144,20 @@ class Mi355Index:
                                                        ptr(dist, ctypes.c_float), ptr(rows, ctypes.c_int64)))
         return dist, rows
 
+    def maxsim_subset(self, qtok, q_offsets, doc_ids) -> np.ndarray:
+        """Exact MaxSim distance of each query to its own list of docs: doc_ids [B, m] -> distances [B, m] (NaN = skipped)."""
+        qtok = f32c(qtok).reshape(-1, self.dim)
+        q_offsets = np.ascontiguousarray(q_offsets, dtype=np.int32)
+        ids = np.ascontiguousarray(doc_ids, dtype=np.int64)
+        B = q_offsets.shape[0] - 1
+        if ids.ndim != 2 or ids.shape[0] != B:
+            raise ValueError("doc_ids must be [B, m]")
+        out = np.empty(ids.shape, dtype=np.float32)
+        check(self._h, self._lib.mi355dr_maxsim_subset(self._h, ptr(qtok, ctypes.c_float), ptr(q_offsets, ctypes.c_int32),
+                                                       B, ptr(ids, ctypes.c_int64), ids.shape[1],
+                                                       ptr(out, ctypes.c_float)))
+        return out
+
     # ---- options / stats / timing ----
     def set_option(self, key: str, value: int | str) -> None:
         if key == "path" and isinstance(value, str):

@@ -106,6 +106,13 @@ int64_t mi355dr_size_multivec(const mi355dr_index* idx);
 int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* q_offsets, int B, int k,
                           float* out_dist, int64_t* out_rows);
 
+/* exact MaxSim distance of every query to an explicit list of docs (candidate re-scoring: HEAVEN stage 2,
+ * autorag_research/pipelines/retrieval/heaven.py:244-266 `_score_candidates`, score = -distance / n_q; GQR pools,
+ * gqr_hybrid.py:366-406).  doc_ids: host [B, m] global rows (as returned by the searches; other values are skipped),
+ * out_dist: host [B, m] fp32, NaN for skipped ids, docs without vectors and queries without vectors. */
+int mi355dr_maxsim_subset(mi355dr_index* idx, const float* qtok, const int32_t* q_offsets, int B, const int64_t* doc_ids,
+                          int m, float* out_dist);
+
 /* ---- shard merge (multi-GPU): [world, B, k] gathered (dist,row) device buffers -> [B, k] ----
  * The merge functions only enqueue work on `stream` (NULL: the index's stream); synchronise that stream (or call
  * mi355dr_synchronize for the index stream) before reading the outputs on the host. */

@@ -125,3 +125,43 @@ def test_service_and_pipelines_on_gpu_match_reference_dicts(pkg):
     p1 = Mi355VectorSearchRetrievalPipeline(lambda: store, "txt", search_mode="single")
     same(asyncio.run(p1._retrieve_by_id("q1", k)), gold["pipeline_single_q1"])
     p1.close()
+
+
+def test_maxsim_subset_matches_oracle_and_heaven_golden(pkg, oracle):
+    """candidate re-scoring (HEAVEN stage 2 / GQR pools): exact MaxSim distance for explicit (query, doc) lists ==
+    oracle bit for bit; on the golden inputs -distance/n_q == the reference's HEAVEN `_score_candidates` (float64)."""
+    g = np.load(GOLDEN / "scores_golden.npz")
+    tok, off, qtok, qoff = g["ms_tok"], g["ms_offsets"], g["ms_qtok"], g["ms_qoff"]
+    n_docs, B = off.shape[0] - 1, qoff.shape[0] - 1
+    with pkg.Mi355Index(tok.shape[1]) as idx:
+        idx.add_multivec(tok, off)
+        ids = np.tile(np.arange(n_docs, dtype=np.int64), (B, 1))
+        dist = idx.maxsim_subset(qtok, qoff, ids)
+        for b in range(B):
+            nq = qoff[b + 1] - qoff[b]
+            assert np.abs(-dist[b].astype(np.float64) / nq - g["ms_scores_heaven"][b]).max() <= 1e-6
+    rng = np.random.default_rng(31)
+    d = 96
+    tok, off = _ragged(rng, 700, d, 0, 70, unit=False)  # includes docs without vectors
+    qtok, qoff = _queries(rng, [5, 0, 33, 128, 1], d, unit=False)
+    B, m = 5, 57
+    ids = rng.integers(0, 700, size=(B, m)).astype(np.int64)
+    ids[0, :3] = [-1, 700, 10**12]  # not rows of the store: skipped
+    ids[2, 5] = ids[2, 6]           # duplicates are fine
+    with pkg.Mi355Index(d) as idx:
+        idx.add_multivec(tok[: off[300]], off[:301])
+        idx.add_multivec(tok[off[300]:], off[300:] - off[300])
+        dist = idx.maxsim_subset(qtok, qoff, ids)
+        idx.set_option("row_offset", 5000)  # shard: ids are global rows
+        dist_off = idx.maxsim_subset(qtok, qoff, ids + 5000)
+    assert np.array_equal(dist.view(np.uint32), dist_off.view(np.uint32))
+    for b in range(B):
+        q = qtok[qoff[b]:qoff[b + 1]]
+        for j in range(m):
+            i = ids[b, j]
+            empty = not (0 <= i < 700) or off[i + 1] == off[i] or q.shape[0] == 0
+            if empty:
+                assert np.isnan(dist[b, j]), (b, j)
+            else:
+                exp = np.float32(oracle.maxsim_distance(tok[off[i]:off[i + 1]], q))
+                assert dist[b, j].view(np.uint32) == exp.view(np.uint32), (b, j)
