@@ -662,6 +662,8 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
     } else if (k == "screen_dtype") {
         if (value < 0 || value > 2) return fail(idx, MI355DR_E_INVALID, "screen_dtype must be 0,1,2");
         idx->screen_dtype = (int)value;
+    } else if (k == "maxsim_screen") {
+        idx->maxsim_screen = value != 0;
     } else if (k == "row_offset") {
         idx->row_offset = value;
     } else if (k == "profile") {
@@ -706,6 +708,9 @@ int mi355dr_get_stat(mi355dr_index* idx, const char* key, int64_t* out) {
     else if (k == "fallback_queries") *out = idx->s_fallback_queries;
     else if (k == "chunks") *out = idx->s_chunks;
     else if (k == "passes") *out = idx->s_passes;
+    else if (k == "maxsim_screened") *out = idx->s_ms_screened;
+    else if (k == "maxsim_candidates") *out = idx->s_ms_candidates;
+    else if (k == "maxsim_fallbacks") *out = idx->s_ms_fallbacks;
     else if (k == "irregular_rows") *out = idx->irr_n;
     else if (k == "loose_rows") *out = idx->irr8_n;
     else if (k == "screen_dtype_active") *out = use_i8(idx) ? MI355DR_SCREEN_I8 : MI355DR_SCREEN_BF16;
@@ -720,6 +725,7 @@ int mi355dr_reset_stats(mi355dr_index* idx) {
     std::lock_guard<std::mutex> g(idx->mu);
     idx->s_screen_launches = idx->s_screen_ns = idx->s_screen_rows = idx->s_fallback_queries = idx->s_chunks =
         idx->s_passes = idx->s_big_launches = idx->s_big_ns = idx->s_big_rows = 0;
+    idx->s_ms_screened = idx->s_ms_candidates = idx->s_ms_fallbacks = 0;
     if (idx->stat_dev) {
         HIPCHECK(idx, hipSetDevice(idx->device));
         HIPCHECK(idx, hipMemset(idx->stat_dev, 0, 2 * kQBlockMax * sizeof(unsigned long long)));

@@ -15,6 +15,16 @@
 // (A, doc tokens) and LDS -> VGPR (B, query tokens), and two v_permlane32_swap per 4 MFMAs put k in
 // ascending order.  fp32 MFMA runs at the vector rate (157 TF peak): at one 32-token query per pass the
 // kernel is at the HBM/MFMA balance point (16 flop/B), with more queries per pass it is MFMA-bound.
+//
+// Search = bf16 MFMA screen over every doc (k_maxsim16, HBM-bound on a bf16 copy of the tokens laid out in MFMA
+// fragment order) -> candidates under a rigorous bound -> exact kernel (k_maxsim, doc list) on the candidates ->
+// exact top-k.  Same results as running the exact kernel over every doc (option "maxsim_screen" = 0), which stays
+// the path for stores / queries with non-finite values and for candidate lists that overflow.
+//   bound: every token pair |t_ij - s_ij| <= eps |q_i||d_j|, eps = 2^-8 + 3 d 2^-24 + 2^-16 (bf16 rounding of both
+//   sides + fp32 accumulation + the exact chain's own rounding), so |max_j t_ij - max_j s_ij| <= eps |q_i| Dmax
+//   (Dmax = largest token norm in the store) and |T - S| <= E = (eps + 2 n_q 2^-24) Dmax sum_i |q_i| for the
+//   per-doc sums.  k docs have T >= x_k (k-th best screen score) hence S >= x_k - E; any doc of the exact top-k
+//   (ties included) has S >= that, hence T >= x_k - 2E: the candidate set.
 #include "index.h"
 
 using namespace mi355;
@@ -28,6 +38,8 @@ constexpr int kMsBlkRows = 32;
 constexpr int kMsThreads = 256;     // 4 waves
 constexpr int kMsDocsPerWave = 4;   // docs a wave walks per workgroup (amortises staging the query block in LDS)
 constexpr int kSegSort = kSortMax;  // select: largest segment (entries sorted per workgroup)
+constexpr int kMsListGrid = 256;    // workgroups of a doc-list launch of k_maxsim (4 waves each stride over the list)
+constexpr int kMsCandCap = 8192;    // docs the screen may hand to the exact kernel per query (more: exact full scan)
 
 struct MultiVecStore {
     int64_t n_docs = 0;
@@ -35,6 +47,22 @@ struct MultiVecStore {
     int64_t cap_docs = 0;
     int dpad = 0;                  // dim rounded up to 8
     float* tok = nullptr;          // [cap_blocks*32, dpad]
+    // bf16 copy for the screen, MFMA fragment order: [block][kk][lane][8] with lane = (row = lane&31, half = lane>>5)
+    // holding dims kk*16 + half*8 + 0..7 of token `row` (original column order)
+    int nkk = 0;                   // dim rounded up to 16, / 16
+    uint4* tok16 = nullptr;        // [cap_blocks * nkk * 64]
+    double tok_norm_max = 0.0;     // largest token norm (double, from the fp32 values)
+    bool finite = true;            // every stored value is finite (else: no screen)
+    uint4* qfrag = nullptr;        // [4 * nkk * 64] query fragments of one launch
+    float* dist16 = nullptr;       // [4, cap_docs] screen distances
+    int32_t* cand_list = nullptr;  // [kMsCandCap]
+    float* cand_dist = nullptr;    // [kMsCandCap]
+    int* cand_ctl = nullptr;       // [2]: count, overflow flag
+    int* cand_ctl_host = nullptr;  // pinned [2 * 4]
+    uint32_t* sel[2] = {nullptr, nullptr};  // fast path: per-segment k best screen keys, [4, ceil(cap_docs/1024) * 64]
+    float* two_e_dev = nullptr;    // [4]
+    char* stage_host = nullptr;    // pinned: query image | query fragments | 2E (H2D), results (D2H)
+    size_t stage_bytes = 0;
     int64_t* blk_off = nullptr;    // [cap_docs+1] first block of each doc (device)
     std::vector<int64_t> blk_off_host;
     // search scratch
@@ -51,7 +79,11 @@ struct MultiVecStore {
 void multivec_destroy(mi355dr_index* idx) {
     MultiVecStore* m = idx->mv;
     if (!m) return;
-    void* ptrs[] = {m->tok, m->blk_off, m->qtok, m->dist, m->pk[0], m->pk[1], m->pr[0], m->pr[1], m->out_d, m->out_r};
+    void* ptrs[] = {m->tok, m->blk_off, m->qtok, m->dist, m->pk[0], m->pk[1], m->pr[0], m->pr[1], m->out_d, m->out_r,
+                    m->tok16, m->qfrag, m->dist16, m->cand_list, m->cand_dist, m->cand_ctl, m->sel[0], m->sel[1],
+                    m->two_e_dev};
+    if (m->cand_ctl_host) (void)hipHostFree(m->cand_ctl_host);
+    if (m->stage_host) (void)hipHostFree(m->stage_host);
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete m;
@@ -65,6 +97,9 @@ struct MsArgs {
     float* dist;            // [nq_launch, n_items]
     const int32_t* doc_list;  // optional [n_items]: the docs to score (nullptr: item i = doc i); < 0 or >= n_docs: NaN
     int64_t n_items;        // work items (= n_docs without a list)
+    const int* n_items_dev; // optional: the real number of items (<= n_items, which then only sizes the grid / dist rows)
+    int64_t list_stride;    // > 0: grid.y = query of the launch, each with its own doc_list / dist row (stride) and
+                            //      n_items_dev pair (stride 2); the workgroup scores that query only
     int64_t n_docs;
     int dpad;
     int nq_launch;          // queries in this launch (<= 4)
@@ -116,19 +151,40 @@ __global__ __launch_bounds__(kMsThreads, 2) void k_maxsim(MsArgs a) {
     float* qs = (float*)smem;
     const int ld = a.dpad + 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < kMsCols * (a.dpad / 4); i += kMsThreads) {
+    if (a.list_stride > 0) {  // per-query candidate lists
+        const int y = blockIdx.y;
+        a.doc_list += (int64_t)y * a.list_stride;
+        a.dist += (int64_t)y * a.list_stride;
+        a.n_items_dev += 2 * y;
+        int c0 = a.q_col0[0], ln = a.q_len[0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+            if (i == y) {
+                c0 = a.q_col0[i];
+                ln = a.q_len[i];
+            }
+        a.qtok += (int64_t)c0 * a.dpad;  // this query's columns become column block 0.. (c0 is a multiple of 32)
+        a.q_col0[0] = 0;
+        a.q_len[0] = ln;
+        a.nq_launch = 1;
+    }
+    const int64_t n_items = a.n_items_dev ? min((int64_t)*a.n_items_dev, a.n_items) : a.n_items;
+    if ((int64_t)blockIdx.x * 4 >= n_items) return;  // nothing for this workgroup: skip staging the query block
+    int ncb = 0;   // column blocks in use
+    for (int qi = 0; qi < a.nq_launch; ++qi) ncb = max(ncb, (a.q_col0[qi] + a.q_len[qi] + 31) / 32);
+    for (int i = tid; i < ncb * 32 * (a.dpad / 4); i += kMsThreads) {
         const int c = i / (a.dpad / 4), k4 = i - c * (a.dpad / 4);
         *(float4*)(qs + c * ld + k4 * 4) = *(const float4*)(a.qtok + (int64_t)c * a.dpad + k4 * 4);
     }
     __syncthreads();
     const int half = lane >> 5, col = lane & 31;
-    int ncb = 0;   // column blocks in use
-    for (int qi = 0; qi < a.nq_launch; ++qi) ncb = max(ncb, (a.q_col0[qi] + a.q_len[qi] + 31) / 32);
     const int nchunk = (a.dpad + 127) / 128;
     // docs are dealt round-robin to the waves of the grid so long and short docs mix
-    for (int dw = 0; dw < kMsDocsPerWave; ++dw) {
+    // (with a doc list the grid is small and fixed -- the real list length is only known on the device -- and the
+    // waves stride over the list until it ends)
+    for (int dw = 0; a.doc_list || dw < kMsDocsPerWave; ++dw) {
     const int64_t item = ((int64_t)dw * gridDim.x + blockIdx.x) * 4 + wave;
-    if (item >= a.n_items) break;
+    if (item >= n_items) break;
     const int64_t doc = a.doc_list ? (int64_t)a.doc_list[item] : item;
     if (doc < 0 || doc >= a.n_docs) {  // (subset scoring) not a stored doc
         if (lane == 0)
@@ -189,6 +245,110 @@ __global__ __launch_bounds__(kMsThreads, 2) void k_maxsim(MsArgs a) {
     }  // docs of this wave
 }
 
+// ---- bf16 screen: same walk as k_maxsim, operands are 16-byte MFMA fragments (1 KiB per wave instruction, fully
+// coalesced), v_mfma_f32_32x32x16_bf16, 8 fragments of the doc block in flight while the previous 8 are consumed ----
+typedef __bf16 ms_bf16x8 __attribute__((ext_vector_type(8)));
+
+struct Ms16Args {
+    const uint4* tok16;
+    const int64_t* blk_off;
+    const uint4* qfrag;     // [4][nkk][64]
+    float* dist;            // [nq_launch, n_docs]
+    int64_t n_docs;
+    int nkk;
+    int nq_launch;
+    int q_col0[4];
+    int q_len[4];
+};
+
+__device__ __forceinline__ void ms16_load_piece(uint4 (&a)[8], const uint4* blk, int piece, int nkk, int lane) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int kk = piece * 8 + i;
+        a[i] = kk < nkk ? blk[(int64_t)kk * 64 + lane] : make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
+__device__ __forceinline__ void ms16_compute_piece(f32x16 (&acc)[4], const uint4 (&a)[8], const uint4* qs, int ncb, int piece,
+                                                   int nkk, int lane) {
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        if (cb >= ncb) break;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int kk = piece * 8 + i;
+            if (kk >= nkk) break;
+            const uint4 bv = qs[(cb * nkk + kk) * 64 + lane];
+            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ms_bf16x8, a[i]),
+                                                              __builtin_bit_cast(ms_bf16x8, bv), acc[cb], 0, 0, 0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kMsThreads, 2) void k_maxsim16(Ms16Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4* qs = (uint4*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 4 * a.nkk * 64; i += kMsThreads) qs[i] = a.qfrag[i];
+    __syncthreads();
+    int ncb = 0;
+    for (int qi = 0; qi < a.nq_launch; ++qi) ncb = max(ncb, (a.q_col0[qi] + a.q_len[qi] + 31) / 32);
+    const int npp = (a.nkk + 7) / 8;  // pieces of 8 fragments per block
+    for (int dw = 0; dw < kMsDocsPerWave; ++dw) {
+        const int64_t doc = ((int64_t)dw * gridDim.x + blockIdx.x) * 4 + wave;
+        if (doc >= a.n_docs) break;
+        const int64_t b0 = a.blk_off[doc], b1 = a.blk_off[doc + 1];
+        float run[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) run[c] = -__builtin_inff();
+        const int64_t npieces = (b1 - b0) * npp;
+        f32x16 acc[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
+        uint4 pa[8], pb[8];
+        auto blk_of = [&](int64_t p) { return a.tok16 + (b0 + p / npp) * (int64_t)a.nkk * 64; };
+        auto finish_block = [&]() {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                if (cb >= ncb) break;
+                float m = acc[cb][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[cb][r]);
+                m = fmaxf(m, __shfl_xor(m, 32, kWave));
+                run[cb] = fmaxf(run[cb], m);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
+            }
+        };
+        if (npieces > 0) ms16_load_piece(pa, blk_of(0), 0, a.nkk, lane);
+        for (int64_t p = 0; p < npieces; p += 2) {
+            if (p + 1 < npieces) ms16_load_piece(pb, blk_of(p + 1), (int)((p + 1) % npp), a.nkk, lane);
+            ms16_compute_piece(acc, pa, qs, ncb, (int)(p % npp), a.nkk, lane);
+            if ((p + 1) % npp == 0) finish_block();
+            if (p + 1 < npieces) {
+                if (p + 2 < npieces) ms16_load_piece(pa, blk_of(p + 2), (int)((p + 2) % npp), a.nkk, lane);
+                ms16_compute_piece(acc, pb, qs, ncb, (int)((p + 1) % npp), a.nkk, lane);
+                if ((p + 2) % npp == 0) finish_block();
+            }
+        }
+        for (int qi = 0; qi < a.nq_launch; ++qi) {
+            float accd = 0.0f;
+            for (int j = 0; j < a.q_len[qi]; ++j) {
+                const int c = a.q_col0[qi] + j;
+                float v = 0.0f;
+#pragma unroll
+                for (int cbi = 0; cbi < 4; ++cbi)
+                    if (cbi == (c >> 5)) v = run[cbi];
+                v = __shfl(v, c & 31, kWave);
+                accd = accd + (-v);
+            }
+            if (lane == 0) a.dist[(int64_t)qi * a.n_docs + doc] = b1 > b0 ? accd : __uint_as_float(0x7FC00000u);
+        }
+    }
+}
+
 // fp32 -> sortable key (distance asc, NaN last)
 __device__ __forceinline__ uint64_t f32_to_key(float f) {
     if (f != f) return kKeyNaN;
@@ -205,22 +365,26 @@ __device__ __forceinline__ float key_to_f32(uint64_t k) {
 
 // one workgroup per segment of kSegSort entries: sort by (key,row), write the first k.
 // first stage reads distances (and skips empty docs), later stages read (key,row) partials.
+// row_map / n_in_dev (first stage only): entry g is doc row_map[g], and only the first *n_in_dev entries exist.
 __global__ __launch_bounds__(256) void k_topk_segments(const float* dist, const int64_t* blk_off,
                                                         const uint64_t* key_in, const int32_t* row_in, int64_t n_in,
-                                                        int k, int seg, uint64_t* key_out, int32_t* row_out) {
+                                                        int k, int seg, uint64_t* key_out, int32_t* row_out,
+                                                        const int32_t* row_map, const int* n_in_dev) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint64_t* SK = (uint64_t*)smem;
     int32_t* SR = (int32_t*)(smem + (size_t)kSegSort * 8);
     const int64_t base = (int64_t)blockIdx.x * seg;
+    if (dist && n_in_dev) n_in = min(n_in, (int64_t)*n_in_dev);
     for (int i = threadIdx.x; i < seg; i += blockDim.x) {
         const int64_t g = base + i;
         uint64_t key = kKeyNaN;
         int32_t row = 0x7FFFFFFF;
         if (g < n_in) {
             if (dist) {
-                if (blk_off[g + 1] > blk_off[g]) {  // docs without vectors are not rows of the result
+                const int64_t doc = row_map ? (int64_t)row_map[g] : g;
+                if (blk_off[doc + 1] > blk_off[doc]) {  // docs without vectors are not rows of the result
                     key = f32_to_key(dist[g]);
-                    row = (int32_t)g;
+                    row = (int32_t)doc;
                 }
             } else {
                 key = key_in[g];
@@ -238,6 +402,122 @@ __global__ __launch_bounds__(256) void k_topk_segments(const float* dist, const 
     }
 }
 
+// candidates of one query: every doc whose screen distance is within 2E of the k-th best screen distance
+// (kth_key = last entry of the screen's top-k; NaN key = fewer than k docs with vectors -> every doc is a candidate)
+__global__ void k_ms_candidates(const float* dist16, const int64_t* blk_off, int64_t n_docs, const uint64_t* topk_keys, int k,
+                                float two_e, int32_t* list, int cap, int* ctl) {
+    const int64_t doc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (doc >= n_docs || blk_off[doc + 1] <= blk_off[doc]) return;
+    const uint64_t kth = topk_keys[k - 1];
+    float thr = __builtin_inff();
+    if (kth != kKeyNaN) {
+        thr = key_to_f32(kth) + two_e;
+        thr += fabsf(thr) * 1.2e-7f + 1e-30f;  // round the sum up
+    }
+    if (!(dist16[doc] > thr)) {  // (a NaN screen value stays a candidate)
+        const int slot = atomicAdd(&ctl[0], 1);
+        if (slot < cap) list[slot] = (int32_t)doc;
+        else ctl[1] = 1;
+    }
+}
+
+// ---- fast selection path of the screened search (k <= kMsFastK): all queries of a launch at once (grid.y) ----
+constexpr int kMsFastK = 64;
+constexpr int kMsSelSeg = kWave * kSelPerLane;  // 1024 entries per wave
+
+// One wave per segment of 1024 entries: the k smallest distances of the segment, as order keys (unsorted, padded
+// with 0xFFFFFFFF).  First stage reads screen distances (docs without vectors / NaN rank last), later stages keys.
+// Only VALUES travel: the stages exist to find the k-th best screen distance.
+__global__ __launch_bounds__(kWave) void k_ms_select(const float* dist, const int64_t* blk_off, const uint32_t* key_in,
+                                                     int64_t n_in, int64_t in_stride, int k, uint32_t* key_out,
+                                                     int64_t out_stride) {
+    const int lane = threadIdx.x, y = blockIdx.y;
+    const int64_t base = (int64_t)blockIdx.x * kMsSelSeg;
+    uint32_t inv[kSelPerLane];  // inverted key: the smallest distance has the largest inv; 0 = absent
+#pragma unroll
+    for (int j = 0; j < kSelPerLane; ++j) {
+        const int64_t g = base + j * kWave + lane;
+        uint32_t key = 0xFFFFFFFFu;
+        if (g < n_in) {
+            if (dist) {
+                const float v = dist[(int64_t)y * in_stride + g];
+                if (blk_off[g + 1] > blk_off[g] && v == v) key = f32_order_key(v);
+            } else {
+                key = key_in[(int64_t)y * in_stride + g];
+            }
+        }
+        inv[j] = ~key;
+    }
+    uint32_t* out = key_out + (int64_t)y * out_stride + (int64_t)blockIdx.x * k;
+    for (int i = lane; i < k; i += kWave) out[i] = 0xFFFFFFFFu;
+    const int n_valid = wave_count_ge(inv, 1u);
+    const int kk = min(k, n_valid);
+    if (kk == 0) return;
+    const uint32_t x = wave_nth_largest(inv, kk);
+    int n = 0;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {  // strictly better than the k-th first, then ties up to k
+#pragma unroll
+        for (int j = 0; j < kSelPerLane; ++j) {
+            const bool want = pass == 0 ? inv[j] > x : inv[j] == x;
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(want);
+            const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+            if (want && pos < kk) out[pos] = ~inv[j];
+            n += __builtin_popcountll(bal);
+        }
+    }
+}
+
+// candidates of every query of the launch (grid.y): docs whose screen distance is within 2E of the k-th best one
+__global__ void k_ms_candidates_y(const float* dist16, int64_t dist_stride, const int64_t* blk_off, int64_t n_docs,
+                                  const uint32_t* topk_keys, int64_t key_stride, int k, const float* two_e, int32_t* list,
+                                  int cap, int* ctl) {
+    const int y = blockIdx.y;
+    const int64_t doc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (doc >= n_docs || blk_off[doc + 1] <= blk_off[doc]) return;
+    uint32_t kth = 0;
+    for (int i = 0; i < k; ++i) kth = max(kth, topk_keys[(int64_t)y * key_stride + i]);  // all lanes, L1-resident
+    float thr = __builtin_inff();
+    if (kth != 0xFFFFFFFFu) {
+        const uint32_t ub = (kth & 0x80000000u) ? (kth & 0x7FFFFFFFu) : ~kth;
+        thr = __uint_as_float(ub) + two_e[y];
+        thr += fabsf(thr) * 1.2e-7f + 1e-30f;
+    }
+    if (!(dist16[(int64_t)y * dist_stride + doc] > thr)) {
+        const int slot = atomicAdd(&ctl[2 * y], 1);
+        if (slot < cap) list[(int64_t)y * cap + slot] = (int32_t)doc;
+        else ctl[2 * y + 1] = 1;
+    }
+}
+
+// exact top-k of one query's re-scored candidates (grid.y = query): sort by (distance, doc) in LDS, write the result
+__global__ __launch_bounds__(256) void k_ms_final(const float* cand_dist, const int32_t* cand_list, const int* ctl, int cap,
+                                                   int k, int64_t row_offset, float* out_d, int64_t* out_r) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int y = blockIdx.y;
+    const int n = min(ctl[2 * y], cap);
+    const int np = next_pow2(max(n, 1));
+    uint64_t* SK = (uint64_t*)smem;
+    int32_t* SR = (int32_t*)(smem + (size_t)np * 8);
+    for (int i = threadIdx.x; i < np; i += blockDim.x) {
+        uint64_t key = kKeyNaN;
+        int32_t row = 0x7FFFFFFF;
+        if (i < n) {
+            key = f32_to_key(cand_dist[(int64_t)y * cap + i]);
+            row = cand_list[(int64_t)y * cap + i];
+        }
+        SK[i] = key;
+        SR[i] = row;
+    }
+    __syncthreads();
+    bitonic_asc_key_row(SK, SR, np);
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        const bool ok = i < n && SR[i] != 0x7FFFFFFF;
+        out_d[(int64_t)y * k + i] = ok ? key_to_f32(SK[i]) : __uint_as_float(0x7FC00000u);
+        out_r[(int64_t)y * k + i] = ok ? (int64_t)SR[i] + row_offset : -1;
+    }
+}
+
 __global__ void k_ms_write_out(const uint64_t* key, const int32_t* row, int k, int64_t row_offset, float* out_d,
                                int64_t* out_r) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -251,6 +531,14 @@ __global__ void k_ms_write_out(const uint64_t* key, const int32_t* row, int k, i
 
 namespace {
 
+inline uint16_t host_bf16_rn(float f) {  // round-to-nearest-even; NaN/Inf keep their class (the screen is off for them)
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7F800000u) == 0x7F800000u) return (uint16_t)((u >> 16) | ((u & 0xFFFFu) ? 0x40u : 0u));
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
 int ms_reserve(mi355dr_index* idx, MultiVecStore* m, int64_t want_blocks, int64_t want_docs) {
     if (want_blocks > m->cap_blocks) {
         int64_t nb = std::max<int64_t>(want_blocks, m->cap_blocks + m->cap_blocks / 2);
@@ -261,6 +549,12 @@ int ms_reserve(mi355dr_index* idx, MultiVecStore* m, int64_t want_blocks, int64_
                                     hipMemcpyDeviceToDevice));
         if (m->tok) (void)hipFree(m->tok);
         m->tok = t;
+        uint4* t16 = nullptr;
+        HIPCHECK(idx, hipMalloc(&t16, (size_t)nb * m->nkk * 64 * sizeof(uint4)));
+        if (m->n_blocks > 0)
+            HIPCHECK(idx, hipMemcpy(t16, m->tok16, (size_t)m->n_blocks * m->nkk * 64 * sizeof(uint4), hipMemcpyDeviceToDevice));
+        if (m->tok16) (void)hipFree(m->tok16);
+        m->tok16 = t16;
         m->cap_blocks = nb;
     }
     if (want_docs > m->cap_docs) {
@@ -290,6 +584,7 @@ int mi355dr_add_multivec(mi355dr_index* idx, const float* vecs, const int64_t* o
     if (!idx->mv) {
         idx->mv = new MultiVecStore();
         idx->mv->dpad = (int)round_up(idx->dim, 8);
+        idx->mv->nkk = (int)round_up(idx->dim, 16) / 16;
         idx->mv->blk_off_host.push_back(0);
     }
     MultiVecStore* m = idx->mv;
@@ -315,7 +610,38 @@ int mi355dr_add_multivec(mi355dr_index* idx, const float* vecs, const int64_t* o
         blk += nb;
         m->blk_off_host.push_back(m->n_blocks + blk);
     }
+    // bf16 fragment image of the same padded blocks + the store-wide quantities of the screen bound
+    std::vector<uint16_t> img16((size_t)new_blocks * m->nkk * 64 * 8, 0);
+    blk = 0;
+    for (int64_t i = 0; i < n_docs; ++i) {
+        const int64_t T = offsets[i + 1] - offsets[i];
+        const int64_t nb = (T + kMsBlkRows - 1) / kMsBlkRows;
+        for (int64_t t = 0; t < T; ++t) {
+            const float* sv = vecs + (offsets[i] + t) * d;
+            double n2 = 0.0;
+            for (int c = 0; c < d; ++c) {
+                if (!std::isfinite(sv[c])) m->finite = false;
+                n2 += (double)sv[c] * (double)sv[c];
+            }
+            if (std::isfinite(n2)) m->tok_norm_max = std::max(m->tok_norm_max, std::sqrt(n2));
+        }
+        for (int64_t b = 0; b < nb; ++b)
+            for (int kk = 0; kk < m->nkk; ++kk)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int64_t r = b * kMsBlkRows + (lane & 31);
+                    const float* sv = vecs + (offsets[i] + std::min<int64_t>(r, T - 1)) * d;
+                    uint16_t* dst = &img16[(((size_t)(blk + b) * m->nkk + kk) * 64 + lane) * 8];
+                    for (int j = 0; j < 8; ++j) {
+                        const int c = kk * 16 + (lane >> 5) * 8 + j;
+                        dst[j] = c < d ? host_bf16_rn(sv[c]) : (uint16_t)0;
+                    }
+                }
+        blk += nb;
+    }
     CHECK(ms_reserve(idx, m, m->n_blocks + new_blocks, m->n_docs + n_docs));
+    if (new_blocks > 0)
+        HIPCHECK(idx, hipMemcpy(m->tok16 + (size_t)m->n_blocks * m->nkk * 64, img16.data(), img16.size() * sizeof(uint16_t),
+                                hipMemcpyHostToDevice));
     if (new_blocks > 0)
         HIPCHECK(idx, hipMemcpy(m->tok + (size_t)m->n_blocks * kMsBlkRows * dp, img.data(), img.size() * sizeof(float),
                                 hipMemcpyHostToDevice));
@@ -327,6 +653,40 @@ int mi355dr_add_multivec(mi355dr_index* idx, const float* vecs, const int64_t* o
 }
 
 int64_t mi355dr_size_multivec(const mi355dr_index* idx) { return idx && idx->mv ? idx->mv->n_docs : 0; }
+
+namespace {
+
+// segment-wise top-k of n_in distances (first stage) until one segment is left; returns the buffer index holding it
+int ms_topk(mi355dr_index* idx, MultiVecStore* m, hipStream_t s, const float* dist, int64_t n_in, int k, int seg,
+            const int32_t* row_map, const int* n_in_dev, int* cur_out) {
+    int cur = 0;
+    bool first_stage = true;
+    while (true) {
+        const int64_t nseg = (n_in + seg - 1) / seg;
+        hipLaunchKernelGGL(k_topk_segments, dim3((unsigned)nseg), dim3(256), (size_t)kSegSort * 12, s,
+                           first_stage ? dist : nullptr, m->blk_off, first_stage ? nullptr : m->pk[cur ^ 1],
+                           first_stage ? nullptr : m->pr[cur ^ 1], n_in, k, seg, m->pk[cur], m->pr[cur],
+                           first_stage ? row_map : nullptr, first_stage ? n_in_dev : nullptr);
+        HIPCHECK(idx, hipGetLastError());
+        first_stage = false;
+        if (nseg == 1) break;
+        n_in = nseg * k;
+        cur ^= 1;
+    }
+    *cur_out = cur;
+    return MI355DR_OK;
+}
+
+int ms_emit_result(mi355dr_index* idx, MultiVecStore* m, hipStream_t s, int cur, int k, float* out_dist, int64_t* out_rows) {
+    hipLaunchKernelGGL(k_ms_write_out, dim3((k + 255) / 256), dim3(256), 0, s, m->pk[cur], m->pr[cur], k, idx->row_offset,
+                       m->out_d, m->out_r);
+    HIPCHECK(idx, hipGetLastError());
+    HIPCHECK(idx, hipMemcpyAsync(out_dist, m->out_d, k * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHECK(idx, hipMemcpyAsync(out_rows, m->out_r, k * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    return MI355DR_OK;
+}
+
+}  // namespace
 
 int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* q_offsets, int B, int k,
                           float* out_dist, int64_t* out_rows) {
@@ -348,21 +708,38 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
     }
     HIPCHECK(idx, hipSetDevice(idx->device));
     hipStream_t s = idx->stream;
-    const int dp = m->dpad, d = idx->dim;
+    const int dp = m->dpad, d = idx->dim, nkk = m->nkk;
     const size_t lds = (size_t)kMsCols * (dp + 4) * sizeof(float);
+    const size_t lds16 = (size_t)4 * nkk * 64 * sizeof(uint4);
     if (lds > 160 * 1024) return fail(idx, MI355DR_E_UNSUPPORTED, "dim too large for the MaxSim kernel's LDS budget");
     // scratch
     if (!m->qtok) {
         HIPCHECK(idx, hipMalloc(&m->qtok, (size_t)kMsCols * dp * sizeof(float)));
-        HIPCHECK(idx, hipMalloc(&m->out_d, kKMax * sizeof(float)));
-        HIPCHECK(idx, hipMalloc(&m->out_r, kKMax * sizeof(int64_t)));
+        HIPCHECK(idx, hipMalloc(&m->qfrag, lds16));
+        HIPCHECK(idx, hipMalloc(&m->out_d, 4 * kKMax * sizeof(float)));
+        HIPCHECK(idx, hipMalloc(&m->out_r, 4 * kKMax * sizeof(int64_t)));
+        HIPCHECK(idx, hipMalloc(&m->cand_list, 4 * kMsCandCap * sizeof(int32_t)));
+        HIPCHECK(idx, hipMalloc(&m->cand_dist, 4 * kMsCandCap * sizeof(float)));
+        HIPCHECK(idx, hipMalloc(&m->cand_ctl, 8 * sizeof(int)));
+        HIPCHECK(idx, hipMalloc(&m->two_e_dev, 4 * sizeof(float)));
+        HIPCHECK(idx, hipHostMalloc(&m->cand_ctl_host, 8 * sizeof(int)));
+        HIPCHECK(idx, hipFuncSetAttribute((const void*)k_ms_final, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          kMsCandCap * 12));
         HIPCHECK(idx, hipFuncSetAttribute((const void*)k_maxsim, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (lds16 <= 160 * 1024)
+            HIPCHECK(idx, hipFuncSetAttribute((const void*)k_maxsim16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
         HIPCHECK(idx, hipFuncSetAttribute((const void*)k_topk_segments, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           kSegSort * 12));
     }
     if (m->dist_cap_docs < m->n_docs) {
         if (m->dist) (void)hipFree(m->dist);
+        if (m->dist16) (void)hipFree(m->dist16);
         HIPCHECK(idx, hipMalloc(&m->dist, (size_t)4 * m->cap_docs * sizeof(float)));
+        HIPCHECK(idx, hipMalloc(&m->dist16, (size_t)4 * m->cap_docs * sizeof(float)));
+        for (int i = 0; i < 2; ++i) {
+            if (m->sel[i]) (void)hipFree(m->sel[i]);
+            HIPCHECK(idx, hipMalloc(&m->sel[i], (size_t)4 * ((m->cap_docs + kMsSelSeg - 1) / kMsSelSeg) * kMsFastK * sizeof(uint32_t)));
+        }
         m->dist_cap_docs = m->cap_docs;
     }
     // segment size: small segments = many workgroups; it must hold k and shrink the list by >= 4x per stage
@@ -379,9 +756,42 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
         }
         m->part_cap = nseg0 * kKMax;
     }
-    std::vector<float> qimg((size_t)kMsCols * dp);
+    const unsigned grid_all = (unsigned)((m->n_docs + 4 * kMsDocsPerWave - 1) / (4 * kMsDocsPerWave));
+    const int64_t n_cand_max = std::min<int64_t>(kMsCandCap, m->n_docs);
+    const double eps = std::ldexp(1.0, -8) + 3.0 * d * std::ldexp(1.0, -24) + std::ldexp(1.0, -16);
+    // pinned staging (pageable copies are synchronous and cost ~20 us each)
+    const size_t qimg_n = (size_t)kMsCols * dp, qf16_n = (size_t)4 * nkk * 64 * 8;
+    const size_t need_stage = qimg_n * 4 + qf16_n * 2 + 4 * kKMax * 12 + 64;
+    if (m->stage_bytes < need_stage) {
+        if (m->stage_host) (void)hipHostFree(m->stage_host);
+        HIPCHECK(idx, hipHostMalloc(&m->stage_host, need_stage));
+        m->stage_bytes = need_stage;
+    }
+    float* const qimg_p = (float*)m->stage_host;
+    uint16_t* const qf16_p = (uint16_t*)(m->stage_host + qimg_n * 4);
+    float* const hd = (float*)(m->stage_host + qimg_n * 4 + qf16_n * 2);
+    int64_t* const hr = (int64_t*)(hd + 4 * kKMax + 16);
+    struct Span {  // (keeps the vector-style accessors of the code below)
+        float* p;
+        size_t n;
+        float* begin() { return p; }
+        float* end() { return p + n; }
+        float* data() { return p; }
+        size_t size() const { return n; }
+        float& operator[](size_t i) { return p[i]; }
+    } qimg{qimg_p, qimg_n};
+    struct Span16 {
+        uint16_t* p;
+        size_t n;
+        uint16_t* begin() { return p; }
+        uint16_t* end() { return p + n; }
+        uint16_t* data() { return p; }
+        size_t size() const { return n; }
+        uint16_t& operator[](size_t i) { return p[i]; }
+    } qf16{qf16_p, qf16_n};
     int b = 0;
     while (b < B) {
+        HIPCHECK(idx, hipStreamSynchronize(s));  // the staging buffers are free again
         // pack queries into one launch while their 32-padded token counts fit 128 columns (max 4 queries)
         MsArgs a{};
         a.tok = m->tok;
@@ -391,15 +801,20 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
         a.n_docs = m->n_docs;
         a.n_items = m->n_docs;
         a.doc_list = nullptr;
+        a.n_items_dev = nullptr;
         a.dpad = dp;
         std::fill(qimg.begin(), qimg.end(), 0.0f);
+        std::fill(qf16.begin(), qf16.end(), (uint16_t)0);
         int col = 0, nql = 0, first = b;
+        bool q_finite = true;
+        double two_e[4] = {0, 0, 0, 0};
         while (b < B && nql < 4) {
             const int nq = q_offsets[b + 1] - q_offsets[b];
             const int need = (int)round_up(std::max(nq, 1), 32);
             if (col + need > kMsCols) break;
             a.q_col0[nql] = col;
             a.q_len[nql] = nq;
+            double norm_sum = 0.0;
             for (int j = 0; j < nq; ++j) {
                 float* dst = &qimg[(size_t)(col + j) * dp];
                 const float* sv = qtok + (int64_t)(q_offsets[b] + j) * d;
@@ -407,42 +822,163 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
                     const int oc = ms_perm(c);
                     dst[c] = oc < d ? sv[oc] : 0.0f;
                 }
+                // bf16 fragment of the same column: block cb = (col+j)/32, lane = ((col+j)&31) + 32*half
+                double n2 = 0.0;
+                const int cc = col + j;
+                for (int c = 0; c < d; ++c) {
+                    if (!std::isfinite(sv[c])) q_finite = false;
+                    n2 += (double)sv[c] * (double)sv[c];
+                    const int kk = c / 16, half = (c % 16) / 8, jj = c % 8;
+                    qf16[((((size_t)(cc >> 5) * nkk + kk) * 64) + (cc & 31) + 32 * half) * 8 + jj] = host_bf16_rn(sv[c]);
+                }
+                norm_sum += std::sqrt(n2);
             }
+            two_e[nql] = 2.0 * (eps + 2.0 * nq * std::ldexp(1.0, -24)) * m->tok_norm_max * norm_sum * (1.0 + 1e-6);
             col += need;
             ++nql;
             ++b;
         }
         a.nq_launch = nql;
         HIPCHECK(idx, hipMemcpyAsync(m->qtok, qimg.data(), qimg.size() * sizeof(float), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_maxsim, dim3((unsigned)((m->n_docs + 4 * kMsDocsPerWave - 1) / (4 * kMsDocsPerWave))),
-                           dim3(kMsThreads), lds, s, a);
-        HIPCHECK(idx, hipGetLastError());
-        for (int qi = 0; qi < nql; ++qi) {
-            if (a.q_len[qi] == 0) continue;  // reference: `if not query_vectors: return []`
-            // segment-wise top-k until one segment is left
+        const bool screen = idx->maxsim_screen && m->finite && q_finite && lds16 <= 160 * 1024;
+        if (screen) {
+            HIPCHECK(idx, hipMemcpyAsync(m->qfrag, qf16.data(), qf16.size() * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+            Ms16Args sa{};
+            sa.tok16 = m->tok16;
+            sa.blk_off = m->blk_off;
+            sa.qfrag = m->qfrag;
+            sa.dist = m->dist16;
+            sa.n_docs = m->n_docs;
+            sa.nkk = nkk;
+            sa.nq_launch = nql;
+            for (int qi = 0; qi < 4; ++qi) {
+                sa.q_col0[qi] = a.q_col0[qi];
+                sa.q_len[qi] = a.q_len[qi];
+            }
+            hipLaunchKernelGGL(k_maxsim16, dim3(grid_all), dim3(kMsThreads), lds16, s, sa);
+            HIPCHECK(idx, hipGetLastError());
+        } else {
+            hipLaunchKernelGGL(k_maxsim, dim3(grid_all), dim3(kMsThreads), lds, s, a);
+            HIPCHECK(idx, hipGetLastError());
+        }
+        bool handled[4] = {false, false, false, false};
+        if (screen && k <= kMsFastK) {
+            // ---- fast path: every step handles all queries of the launch at once (grid.y), one host sync per launch
+            const int64_t sel_stride = ((m->cap_docs + kMsSelSeg - 1) / kMsSelSeg) * kMsFastK;
             int64_t n_in = m->n_docs;
             int cur = 0;
             bool first_stage = true;
-            while (true) {
-                const int64_t nseg = (n_in + seg - 1) / seg;
-                hipLaunchKernelGGL(k_topk_segments, dim3((unsigned)nseg), dim3(256), (size_t)kSegSort * 12, s,
-                                   first_stage ? m->dist + (int64_t)qi * m->n_docs : nullptr, m->blk_off,
-                                   first_stage ? nullptr : m->pk[cur ^ 1], first_stage ? nullptr : m->pr[cur ^ 1], n_in,
-                                   k, seg, m->pk[cur], m->pr[cur]);
+            while (true) {  // k best screen distances per 1024-entry segment, until one segment is left
+                const int64_t nseg = (n_in + kMsSelSeg - 1) / kMsSelSeg;
+                hipLaunchKernelGGL(k_ms_select, dim3((unsigned)nseg, nql), dim3(kWave), 0, s,
+                                   first_stage ? m->dist16 : nullptr, m->blk_off, first_stage ? nullptr : m->sel[cur ^ 1], n_in,
+                                   first_stage ? m->n_docs : sel_stride, k, m->sel[cur], sel_stride);
                 HIPCHECK(idx, hipGetLastError());
                 first_stage = false;
                 if (nseg == 1) break;
                 n_in = nseg * k;
                 cur ^= 1;
             }
-            hipLaunchKernelGGL(k_ms_write_out, dim3((k + 255) / 256), dim3(256), 0, s, m->pk[cur], m->pr[cur], k, idx->row_offset,
-                               m->out_d, m->out_r);
+            float te[4];
+            for (int qi = 0; qi < 4; ++qi) {
+                te[qi] = (float)two_e[qi];
+                if ((double)te[qi] < two_e[qi]) te[qi] = std::nextafter(te[qi], INFINITY);
+            }
+            HIPCHECK(idx, hipMemcpyAsync(m->two_e_dev, te, sizeof(te), hipMemcpyHostToDevice, s));
+            HIPCHECK(idx, hipMemsetAsync(m->cand_ctl, 0, 8 * sizeof(int), s));
+            hipLaunchKernelGGL(k_ms_candidates_y, dim3((unsigned)((m->n_docs + 255) / 256), nql), dim3(256), 0, s, m->dist16,
+                               m->n_docs, m->blk_off, m->n_docs, m->sel[cur], sel_stride, k, m->two_e_dev, m->cand_list,
+                               kMsCandCap, m->cand_ctl);
             HIPCHECK(idx, hipGetLastError());
-            HIPCHECK(idx, hipMemcpyAsync(out_dist + (int64_t)(first + qi) * k, m->out_d, k * sizeof(float),
-                                         hipMemcpyDeviceToHost, s));
-            HIPCHECK(idx, hipMemcpyAsync(out_rows + (int64_t)(first + qi) * k, m->out_r, k * sizeof(int64_t),
-                                         hipMemcpyDeviceToHost, s));
+            MsArgs c = a;
+            c.dist = m->cand_dist;
+            c.doc_list = m->cand_list;
+            c.n_items = n_cand_max;
+            c.n_items_dev = m->cand_ctl;
+            c.list_stride = kMsCandCap;
+            hipLaunchKernelGGL(k_maxsim, dim3((unsigned)std::min<int64_t>((n_cand_max + 3) / 4, kMsListGrid), nql),
+                               dim3(kMsThreads), lds, s, c);
+            HIPCHECK(idx, hipGetLastError());
+            hipLaunchKernelGGL(k_ms_final, dim3(1, nql), dim3(256), (size_t)kMsCandCap * 12, s, m->cand_dist, m->cand_list,
+                               m->cand_ctl, kMsCandCap, k, idx->row_offset, m->out_d, m->out_r);
+            HIPCHECK(idx, hipGetLastError());
+            HIPCHECK(idx, hipMemcpyAsync(hd, m->out_d, (size_t)nql * k * sizeof(float), hipMemcpyDeviceToHost, s));
+            HIPCHECK(idx, hipMemcpyAsync(hr, m->out_r, (size_t)nql * k * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+            HIPCHECK(idx, hipMemcpyAsync(m->cand_ctl_host, m->cand_ctl, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
             HIPCHECK(idx, hipStreamSynchronize(s));
+            for (int qi = 0; qi < nql; ++qi) {
+                if (a.q_len[qi] == 0) {
+                    handled[qi] = true;
+                    continue;
+                }
+                if (m->cand_ctl_host[2 * qi + 1] != 0) continue;  // list overflow: exact full scan below
+                handled[qi] = true;
+                idx->s_ms_screened++;
+                idx->s_ms_candidates += m->cand_ctl_host[2 * qi];
+                memcpy(out_dist + (int64_t)(first + qi) * k, &hd[(size_t)qi * k], k * sizeof(float));
+                memcpy(out_rows + (int64_t)(first + qi) * k, &hr[(size_t)qi * k], k * sizeof(int64_t));
+            }
+        }
+        for (int qi = 0; qi < nql; ++qi) {
+            if (a.q_len[qi] == 0 || handled[qi]) continue;  // reference: `if not query_vectors: return []`
+            float* od = out_dist + (int64_t)(first + qi) * k;
+            int64_t* orow = out_rows + (int64_t)(first + qi) * k;
+            int cur = 0;
+            bool done = false;
+            const bool overflowed = screen && k <= kMsFastK;  // the fast path gave this query up
+            if (overflowed) {
+                idx->s_ms_fallbacks++;
+                MsArgs f = a;
+                f.nq_launch = 1;
+                f.q_col0[0] = a.q_col0[qi];
+                f.q_len[0] = a.q_len[qi];
+                hipLaunchKernelGGL(k_maxsim, dim3(grid_all), dim3(kMsThreads), lds, s, f);
+                HIPCHECK(idx, hipGetLastError());
+            } else if (screen) {
+                // screen top-k -> candidates -> exact kernel on the candidates -> exact top-k
+                CHECK(ms_topk(idx, m, s, m->dist16 + (int64_t)qi * m->n_docs, m->n_docs, k, seg, nullptr, nullptr, &cur));
+                HIPCHECK(idx, hipMemsetAsync(m->cand_ctl, 0, 2 * sizeof(int), s));
+                float te = (float)two_e[qi];
+                if ((double)te < two_e[qi]) te = std::nextafter(te, INFINITY);
+                hipLaunchKernelGGL(k_ms_candidates, dim3((unsigned)((m->n_docs + 255) / 256)), dim3(256), 0, s,
+                                   m->dist16 + (int64_t)qi * m->n_docs, m->blk_off, m->n_docs, m->pk[cur], k, te, m->cand_list,
+                                   kMsCandCap, m->cand_ctl);
+                HIPCHECK(idx, hipGetLastError());
+                MsArgs c = a;
+                c.dist = m->cand_dist;
+                c.doc_list = m->cand_list;
+                c.n_items = n_cand_max;
+                c.n_items_dev = m->cand_ctl;
+                c.nq_launch = 1;
+                c.q_col0[0] = a.q_col0[qi];
+                c.q_len[0] = a.q_len[qi];
+                hipLaunchKernelGGL(k_maxsim, dim3((unsigned)std::min<int64_t>((n_cand_max + 3) / 4, kMsListGrid)),
+                                   dim3(kMsThreads), lds, s, c);
+                HIPCHECK(idx, hipGetLastError());
+                CHECK(ms_topk(idx, m, s, m->cand_dist, n_cand_max, k, seg, m->cand_list, m->cand_ctl, &cur));
+                CHECK(ms_emit_result(idx, m, s, cur, k, od, orow));
+                HIPCHECK(idx, hipMemcpyAsync(m->cand_ctl_host, m->cand_ctl, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+                HIPCHECK(idx, hipStreamSynchronize(s));
+                if (m->cand_ctl_host[1] == 0) {
+                    done = true;
+                    idx->s_ms_screened++;
+                    idx->s_ms_candidates += m->cand_ctl_host[0];
+                } else {
+                    idx->s_ms_fallbacks++;  // more candidates than the list holds: this query takes the exact full scan
+                    MsArgs f = a;
+                    f.nq_launch = 1;
+                    f.q_col0[0] = a.q_col0[qi];
+                    f.q_len[0] = a.q_len[qi];
+                    hipLaunchKernelGGL(k_maxsim, dim3(grid_all), dim3(kMsThreads), lds, s, f);
+                    HIPCHECK(idx, hipGetLastError());
+                }
+            }
+            if (!done) {
+                const float* dist_q = screen ? m->dist : m->dist + (int64_t)qi * m->n_docs;
+                CHECK(ms_topk(idx, m, s, dist_q, m->n_docs, k, seg, nullptr, nullptr, &cur));
+                CHECK(ms_emit_result(idx, m, s, cur, k, od, orow));
+                HIPCHECK(idx, hipStreamSynchronize(s));
+            }
         }
     }
     return MI355DR_OK;
@@ -509,8 +1045,8 @@ int mi355dr_maxsim_subset(mi355dr_index* idx, const float* qtok, const int32_t* 
         a.nq_launch = 1;
         a.q_col0[0] = 0;
         a.q_len[0] = nq;
-        hipLaunchKernelGGL(k_maxsim, dim3((unsigned)((m_ids + 4 * kMsDocsPerWave - 1) / (4 * kMsDocsPerWave))),
-                           dim3(kMsThreads), lds, s, a);
+        hipLaunchKernelGGL(k_maxsim, dim3((unsigned)std::min<int64_t>((m_ids + 3) / 4, kMsListGrid)), dim3(kMsThreads), lds,
+                           s, a);
         HIPCHECK(idx, hipGetLastError());
         HIPCHECK(idx, hipMemcpyAsync(out_dist + (int64_t)b * m_ids, dist_dev + (int64_t)b * m_ids, m_ids * sizeof(float),
                                      hipMemcpyDeviceToHost, s));

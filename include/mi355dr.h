@@ -128,11 +128,14 @@ int mi355dr_merge_topk_packed_device(mi355dr_index* idx, const int64_t* packed_a
 
 /* ---- options / stats / timing ----
  * options: "path" (MI355DR_PATH_*), "screen_dtype" (MI355DR_SCREEN_*), "row_offset", "profile" (0/1: HIP-event
- *          timing of the dominant kernel), "chunk0_rows", "chunk_growth", "cand_cap".
+ *          timing of the dominant kernel), "chunk0_rows", "chunk_growth", "cand_cap", "maxsim_screen" (1: bf16 MFMA screen
+ *          over every doc + exact re-score of the candidates [default], 0: exact kernel over every doc; same results).
  * stats:   "screen_launches", "screen_ns" (profile=1), "screen_rows" (all screen launches) and their k_screen256 share
  *          "screen256_launches", "screen256_ns", "screen256_rows"; "candidates", "rescored",
  *          "fallback_queries", "chunks", "passes", "irregular_rows", "loose_rows" (rows outside the int8 shadow,
  *          irregular ones included), "screen_dtype_active" (MI355DR_SCREEN_BF16 / _I8: what AUTO resolves to now),
+ *          "maxsim_screened" (queries served by the MaxSim screen), "maxsim_candidates" (docs re-scored exactly for them),
+ *          "maxsim_fallbacks" (queries re-run by the exact full scan),
  *          "hbm_bytes_resident". */
 int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value);
 int mi355dr_get_stat(mi355dr_index* idx, const char* key, int64_t* out);

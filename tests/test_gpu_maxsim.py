@@ -35,12 +35,17 @@ def _queries(rng, lens, d, unit=True):
 
 
 def _check(idx, oracle, tok, off, qtok, qoff, k):
-    dist, rows = idx.search_maxsim(qtok, qoff, k)
+    """both forms of the search -- bf16 screen + exact re-score of the candidates (default) and the exact kernel over
+    every doc -- must equal the oracle bit for bit"""
     rd, rr = oracle.maxsim_topk(tok, off, qtok, qoff, k)
-    assert np.array_equal(rows, rr)
-    assert np.array_equal(np.isnan(dist), np.isnan(rd))
-    ok = ~np.isnan(dist)
-    assert np.array_equal(dist[ok].view(np.uint32), rd[ok].view(np.uint32))
+    for screen in (1, 0):
+        idx.set_option("maxsim_screen", screen)
+        dist, rows = idx.search_maxsim(qtok, qoff, k)
+        assert np.array_equal(rows, rr), screen
+        assert np.array_equal(np.isnan(dist), np.isnan(rd))
+        ok = ~np.isnan(dist)
+        assert np.array_equal(dist[ok].view(np.uint32), rd[ok].view(np.uint32)), screen
+    idx.set_option("maxsim_screen", 1)
 
 
 def test_golden_inputs(pkg, oracle):
@@ -84,11 +89,48 @@ def test_empty_docs_appends_and_unnormalised(pkg, oracle):
         idx.add_multivec(tok[: off[half]], off[: half + 1])
         idx.add_multivec(tok[off[half]:], off[half:] - off[half])  # appended in two calls
         assert idx.n_docs() == 200
-        dist, rows = idx.search_maxsim(qtok, qoff, 20)
         rd, rr = oracle.maxsim_topk(tok, off, qtok, qoff, 20)
-        assert np.array_equal(rows[[0, 2]], rr[[0, 2]])
-        assert np.array_equal(dist[[0, 2]].view(np.uint32), rd[[0, 2]].view(np.uint32))
-        assert (rows[1] == -1).all()
+        for screen in (1, 0):
+            idx.set_option("maxsim_screen", screen)
+            dist, rows = idx.search_maxsim(qtok, qoff, 20)
+            assert np.array_equal(rows[[0, 2]], rr[[0, 2]])
+            assert np.array_equal(dist[[0, 2]].view(np.uint32), rd[[0, 2]].view(np.uint32))
+            assert (rows[1] == -1).all()
+
+
+def test_maxsim_screen_is_used_and_survives_hard_cases(pkg, oracle):
+    """the screen path really runs (stats), its candidate lists stay small on ordinary data, and the cases it cannot
+    bound or hold fall back to the exact full scan with unchanged results: near-duplicate docs (hundreds of docs within
+    the bound of each other), a candidate overflow, non-finite stored values."""
+    rng = np.random.default_rng(5)
+    d = 128
+    tok, off = _ragged(rng, 20000, d, 4, 40)
+    qtok, qoff = _queries(rng, [32, 16, 32, 8, 32], d)
+    with pkg.Mi355Index(d) as idx:
+        idx.add_multivec(tok, off)
+        idx.reset_stats()
+        _check(idx, oracle, tok, off, qtok, qoff, 10)
+        assert idx.stat("maxsim_screened") == 5 and idx.stat("maxsim_fallbacks") == 0
+        assert idx.stat("maxsim_candidates") < 5 * 2000  # a small fraction of the 20000 docs is re-scored
+    # near-duplicates: 9000 noisy copies of one doc -> every copy is within 2E of the k-th best
+    base_tok, base_off = _ragged(rng, 1, d, 20, 20)
+    reps = 9000
+    tok2 = np.concatenate([base_tok + (1e-4 * rng.standard_normal(base_tok.shape)).astype(np.float32) for _ in range(reps)])
+    off2 = np.arange(0, reps + 1, dtype=np.int64) * 20
+    with pkg.Mi355Index(d) as idx:
+        idx.add_multivec(tok2, off2)
+        idx.reset_stats()
+        _check(idx, oracle, tok2, off2, qtok[:32], qoff[:2], 10)
+        assert idx.stat("maxsim_fallbacks") >= 1  # 9000 candidates > the 8192-entry list: exact full scan took over
+    tok3 = tok.copy()
+    tok3[7, 3] = np.inf
+    with pkg.Mi355Index(d) as idx:
+        idx.add_multivec(tok3, off)
+        idx.reset_stats()
+        dist, rows = idx.search_maxsim(qtok, qoff, 10)
+        assert idx.stat("maxsim_screened") == 0  # a store with non-finite values is never screened
+        rd, rr = oracle.maxsim_topk(tok3, off, qtok, qoff, 10)
+        assert np.array_equal(rows, rr)
 
 
 def test_service_and_pipelines_on_gpu_match_reference_dicts(pkg):
