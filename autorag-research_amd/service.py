@@ -167,6 +167,27 @@ class Mi355RetrievalService:
             out[i] = res
         return out
 
+    def maxsim_score_candidates(self, query_vectors, doc_ids: list, unit: str = "chunk") -> dict:
+        """Late-interaction score of explicit candidates: {doc_id: mean_i max_j <q_i, d_j>} (reference HEAVEN
+        `_score_candidates`, heaven.py:244-266).  Ids unknown to the table or without multi-vector embeddings are left
+        out (as `_fetch_candidate_multi_embeddings` does, heaven.py:224-241); no query vectors -> every score 0.0."""
+        u = self._unit(unit)
+        pos = getattr(u, "_pos_of_id", None)
+        if pos is None:
+            pos = u._pos_of_id = {pk: i for i, pk in enumerate(u.table.ids)}
+        off = u.table.mv_offsets
+        known = [(pk, pos[pk]) for pk in doc_ids if pk in pos and off is not None and off[pos[pk] + 1] > off[pos[pk]]]
+        if not known:
+            return {}
+        q = np.asarray(query_vectors, dtype=np.float32)
+        if q.size == 0:
+            return {pk: 0.0 for pk, _ in known}
+        ix = u.ensure_multi()
+        q = q.reshape(-1, ix.dim)
+        rows = np.array([[p for _, p in known]], dtype=np.int64)
+        dist = ix.maxsim_subset(q, np.array([0, q.shape[0]], dtype=np.int32), rows)[0]
+        return {pk: -float(dv) / q.shape[0] for (pk, _), dv in zip(known, dist) if dv == dv}
+
     # ---- batch driver (reference _run_pipeline) ----
     @staticmethod
     def _collect_retrieval_results(query_ids, results, pipeline_id, failed_queries, result_id_key) -> list[dict]:

@@ -238,6 +238,17 @@ class _FakeChunkRepo:
         dist, rows = cpu_ref.topk_search(self.single, np.asarray(query_vector, dtype=np.float32)[None, :], limit)
         return [(_Obj(id=self.ids[r], contents=self.contents[r]), float(dv)) for dv, r in zip(dist[0], rows[0]) if r >= 0]
 
+    def get_by_ids(self, ids):
+        """BaseRepository.get_by_ids: rows with their multi-vector embeddings (HEAVEN stage 2, heaven.py:224-241)."""
+        pos = {pk: i for i, pk in enumerate(self.ids)}
+        out = []
+        for pk in ids:
+            if pk in pos:
+                i = pos[pk]
+                emb = [[float(x) for x in v] for v in self.tok[self.offsets[i]:self.offsets[i + 1]]]
+                out.append(_Obj(id=pk, contents=self.contents[i], embeddings=emb))
+        return out
+
     def maxsim_search(self, query_vectors, vector_column="embeddings", limit=10):
         if not query_vectors:
             return []
@@ -293,7 +304,7 @@ def make_service() -> dict:
         Qm.append(m)
     queries = {}
     for i in range(6):
-        queries[f"q{i}"] = _Obj(id=f"q{i}", embedding=[float(x) for x in Q[i]],
+        queries[f"q{i}"] = _Obj(id=f"q{i}", contents=f"query text {i}", embedding=[float(x) for x in Q[i]],
                                 embeddings=[[float(x) for x in v] for v in Qm[i]])
     queries["q_noemb"] = _Obj(id="q_noemb", embedding=None, embeddings=None)
     chunk_repo = _FakeChunkRepo(ids, contents, single=C, tok=tok, offsets=offsets)
@@ -323,6 +334,18 @@ def make_service() -> dict:
         _pipe(ImageVectorSearchRetrievalPipeline, "multi")._retrieve_by_id("q2", k))
     out["image_pipeline_single_q2"] = loop.run_until_complete(
         _pipe(ImageVectorSearchRetrievalPipeline, "single")._retrieve_by_id("q2", k))
+    # HEAVEN two-stage flow (pipelines/retrieval/heaven.py:268-311) over the same fake UoW.  nltk is not installed
+    # here: its POS tagger is replaced by a deterministic stand-in (even-length token -> noun), which the test
+    # injects into the MI355X pipeline as well.
+    import autorag_research.pipelines.retrieval.heaven as ref_heaven
+
+    ref_heaven.nltk.pos_tag = lambda toks: [(t, "NN" if len(t) % 2 == 0 else "VB") for t in toks]
+    hp = HEAVENRetrievalPipeline.__new__(HEAVENRetrievalPipeline)
+    hp.stage1_candidate_count, hp.stage2_refine_ratio, hp.stage1_weight, hp.default_key_token_ratio = 40, 0.25, 0.3, 0.5
+    hp._service = svc
+    out["heaven_config"] = {"stage1_candidate_count": 40, "stage2_refine_ratio": 0.25, "stage1_weight": 0.3,
+                            "default_key_token_ratio": 0.5}
+    out["heaven"] = {qid: loop.run_until_complete(hp._retrieve_by_id(qid, k)) for qid in ("q1", "q2", "q5")}
     errs = {}
     for name, fn in {
         "missing": lambda: svc.vector_search(["nope"], 3),

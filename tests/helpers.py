@@ -47,6 +47,18 @@ class OracleIndex:
     def search_maxsim(self, qtok, q_offsets, k):
         return self._o.maxsim_topk(self._tok, self._off, qtok, q_offsets, k)
 
+    def maxsim_subset(self, qtok, q_offsets, doc_ids):
+        q = np.ascontiguousarray(qtok, dtype=np.float32).reshape(-1, self.dim)
+        ids = np.asarray(doc_ids, dtype=np.int64)
+        out = np.full(ids.shape, np.nan, dtype=np.float32)
+        n_docs = self._off.shape[0] - 1
+        for b in range(ids.shape[0]):
+            qb = q[q_offsets[b]:q_offsets[b + 1]]
+            for j, i in enumerate(ids[b]):
+                if 0 <= i < n_docs and self._off[i + 1] > self._off[i] and qb.shape[0]:
+                    out[b, j] = self._o.maxsim_distance(self._tok[self._off[i]:self._off[i + 1]], qb)
+        return out
+
     def set_option(self, key, value):
         if key == "row_offset":
             self.row_offset = int(value)

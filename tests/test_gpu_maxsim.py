@@ -167,6 +167,16 @@ def test_service_and_pipelines_on_gpu_match_reference_dicts(pkg):
     p1 = Mi355VectorSearchRetrievalPipeline(lambda: store, "txt", search_mode="single")
     same(asyncio.run(p1._retrieve_by_id("q1", k)), gold["pipeline_single_q1"])
     p1.close()
+    # HEAVEN: stage 1 (single-vector search) and stage 2 (candidate MaxSim) both on the GPU
+    from autorag_research_amd.heaven import Mi355HEAVENRetrievalPipeline
+
+    ph = Mi355HEAVENRetrievalPipeline(lambda: store, "heaven", **gold["heaven_config"],
+                                      pos_tagger=lambda toks: [(t, "NN" if len(t) % 2 == 0 else "VB") for t in toks])
+    for qid, exp in gold["heaven"].items():
+        got = asyncio.run(ph._retrieve_by_id(qid, k))
+        assert [r["doc_id"] for r in got] == [r["doc_id"] for r in exp]
+        assert np.allclose([r["score"] for r in got], [r["score"] for r in exp], rtol=0, atol=1e-6)
+    ph.close()
 
 
 def test_maxsim_subset_matches_oracle_and_heaven_golden(pkg, oracle):
