@@ -349,6 +349,75 @@ __global__ __launch_bounds__(kMsThreads, 2) void k_maxsim16(Ms16Args a) {
     }
 }
 
+// ---- the same screen for dims <= 128 (8 fragments = ONE piece per 32-token block; the ColBERT / ColPali shape),
+// with the number of column blocks a template parameter: every loop is unrolled at compile time, the query fragments
+// stay in registers, LDS and global addresses are one base register + immediates, and the accumulator of a block
+// starts from the MFMA's inline-zero C operand instead of 16 v_mov. ----
+template <int NCB>
+__global__ __launch_bounds__(kMsThreads, 2) void k_maxsim16_d128(Ms16Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4* qs = (uint4*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < NCB * 8 * 64; i += kMsThreads) qs[i] = a.qfrag[i];
+    __syncthreads();
+    const uint4* const ql = qs + lane;
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int dw = 0; dw < kMsDocsPerWave; ++dw) {
+        const int64_t doc = ((int64_t)dw * gridDim.x + blockIdx.x) * 4 + wave;
+        if (doc >= a.n_docs) break;
+        const int64_t b0 = a.blk_off[doc], b1 = a.blk_off[doc + 1];
+        float run[NCB];
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) run[c] = -__builtin_inff();
+        const uint4* blk = a.tok16 + b0 * (8 * 64) + lane;
+        uint4 pa[8], pb[8];
+        auto load = [&](uint4(&dst)[8], const uint4* src) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dst[i] = src[i * 64];
+        };
+        auto block = [&](const uint4(&fr)[8]) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ms_bf16x8, fr[0]),
+                                                                     __builtin_bit_cast(ms_bf16x8, ql[(cb * 8) * 64]), zero, 0, 0, 0);
+#pragma unroll
+                for (int i = 1; i < 8; ++i)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ms_bf16x8, fr[i]),
+                                                                  __builtin_bit_cast(ms_bf16x8, ql[(cb * 8 + i) * 64]), acc, 0, 0, 0);
+                float m = acc[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+                run[cb] = fmaxf(run[cb], m);  // (the two halves of the wave are combined once per doc, below)
+            }
+        };
+        const int64_t nb = b1 - b0;
+        if (nb > 0) load(pa, blk);
+        for (int64_t p = 0; p < nb; p += 2) {
+            if (p + 1 < nb) load(pb, blk + (p + 1) * (8 * 64));
+            block(pa);
+            if (p + 1 < nb) {
+                if (p + 2 < nb) load(pa, blk + (p + 2) * (8 * 64));
+                block(pb);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) run[c] = fmaxf(run[c], __shfl_xor(run[c], 32, kWave));
+        for (int qi = 0; qi < a.nq_launch; ++qi) {
+            float accd = 0.0f;
+            for (int j = 0; j < a.q_len[qi]; ++j) {
+                const int c = a.q_col0[qi] + j;
+                float v = 0.0f;
+#pragma unroll
+                for (int cbi = 0; cbi < NCB; ++cbi)
+                    if (cbi == (c >> 5)) v = run[cbi];
+                v = __shfl(v, c & 31, kWave);
+                accd = accd + (-v);
+            }
+            if (lane == 0) a.dist[(int64_t)qi * a.n_docs + doc] = nb > 0 ? accd : __uint_as_float(0x7FC00000u);
+        }
+    }
+}
+
 // fp32 -> sortable key (distance asc, NaN last)
 __device__ __forceinline__ uint64_t f32_to_key(float f) {
     if (f != f) return kKeyNaN;
@@ -855,7 +924,18 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
                 sa.q_col0[qi] = a.q_col0[qi];
                 sa.q_len[qi] = a.q_len[qi];
             }
-            hipLaunchKernelGGL(k_maxsim16, dim3(grid_all), dim3(kMsThreads), lds16, s, sa);
+            const int ncb_launch = (col + 31) / 32;
+            if (nkk == 8) {  // dims <= 128: the compile-time-unrolled form, only as many column blocks as the pass has
+                const size_t l16 = (size_t)ncb_launch * 8 * 64 * sizeof(uint4);
+                switch (ncb_launch) {
+                    case 1: hipLaunchKernelGGL(k_maxsim16_d128<1>, dim3(grid_all), dim3(kMsThreads), l16, s, sa); break;
+                    case 2: hipLaunchKernelGGL(k_maxsim16_d128<2>, dim3(grid_all), dim3(kMsThreads), l16, s, sa); break;
+                    case 3: hipLaunchKernelGGL(k_maxsim16_d128<3>, dim3(grid_all), dim3(kMsThreads), l16, s, sa); break;
+                    default: hipLaunchKernelGGL(k_maxsim16_d128<4>, dim3(grid_all), dim3(kMsThreads), l16, s, sa); break;
+                }
+            } else {
+                hipLaunchKernelGGL(k_maxsim16, dim3(grid_all), dim3(kMsThreads), lds16, s, sa);
+            }
             HIPCHECK(idx, hipGetLastError());
         } else {
             hipLaunchKernelGGL(k_maxsim, dim3(grid_all), dim3(kMsThreads), lds, s, a);
