@@ -25,6 +25,16 @@ def shard_bounds(n_rows: int, world: int, rank: int, granule: int = 1) -> tuple[
     return lo, hi
 
 
+def shard_bounds_by_tokens(offsets, world: int, rank: int) -> tuple[int, int]:
+    """Contiguous doc range [lo, hi) of a multi-vector store with about 1/world of the TOKENS (the MaxSim pass streams
+    token rows, so tokens -- not docs -- are the unit of work)."""
+    off = np.asarray(offsets, dtype=np.int64)
+    n_docs, total = off.shape[0] - 1, int(off[-1])
+    cut = lambda r: int(np.searchsorted(off, total * r // world, side="left")) if r < world else n_docs  # noqa: E731
+    lo, hi = min(cut(rank), n_docs), min(cut(rank + 1), n_docs)
+    return lo, max(lo, hi)
+
+
 def merge_topk_host(dist_all: np.ndarray, rows_all: np.ndarray, k: int) -> tuple[np.ndarray, np.ndarray]:
     """[world,B,k] shard lists -> [B,k] under (distance asc, NaN last, row asc); pads with NaN / -1."""
     world, B, kk = dist_all.shape
@@ -92,6 +102,32 @@ class ShardedSearcher:
             return out_d.cpu().numpy(), out_r.cpu().numpy()  # .cpu() synchronises the stream the merge ran on
         g = gathered.cpu().numpy()
         return merge_topk_host(np.ascontiguousarray(g[:, 0]).view(np.float64), np.ascontiguousarray(g[:, 1]), k)
+
+    # ---- multi-vector (MaxSim): docs sharded by cumulative token count, same gather + merge ----
+    def add_local_multivec(self, vecs, offsets, global_doc0: int) -> None:
+        """Add this rank's docs (ragged [sum_T, d] + offsets starting at 0); `global_doc0` = global index of its first doc."""
+        self.row_offset = int(global_doc0)
+        self.index.set_option("row_offset", self.row_offset)
+        self.index.add_multivec(vecs, offsets)
+
+    def search_maxsim(self, qtok, q_offsets, k: int) -> tuple[np.ndarray, np.ndarray]:
+        """Every rank passes the same queries; every rank gets the same global [B,k] (fp32 distance, doc) result."""
+        dist_l, rows_l = self.index.search_maxsim(qtok, q_offsets, k)
+        if self.world == 1:
+            return dist_l, rows_l
+        import torch
+
+        on_gpu = self.backend == "nccl"
+        dev = torch.device("cuda", self.device) if on_gpu else torch.device("cpu")
+        B = dist_l.shape[0]
+        # fp32 -> float8 is exact and order-preserving, so the float8 merge applies unchanged
+        d64 = np.ascontiguousarray(dist_l.astype(np.float64))
+        packed = torch.from_numpy(np.stack([d64.view(np.int64), rows_l])).to(dev)
+        gathered = torch.empty((self.world, 2, B, k), dtype=torch.int64, device=dev)
+        self._dist.all_gather_into_tensor(gathered.view(-1), packed.view(-1), group=self.group)
+        g = gathered.cpu().numpy()
+        out_d, out_r = merge_topk_host(np.ascontiguousarray(g[:, 0]).view(np.float64), np.ascontiguousarray(g[:, 1]), k)
+        return out_d.astype(np.float32), out_r
 
     def close(self) -> None:
         self.index.close()

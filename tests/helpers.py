@@ -45,7 +45,8 @@ class OracleIndex:
         self._off = np.ascontiguousarray(offsets, dtype=np.int64)
 
     def search_maxsim(self, qtok, q_offsets, k):
-        return self._o.maxsim_topk(self._tok, self._off, qtok, q_offsets, k)
+        d, r = self._o.maxsim_topk(self._tok, self._off, qtok, q_offsets, k)
+        return d, np.where(r >= 0, r + self.row_offset, r)
 
     def maxsim_subset(self, qtok, q_offsets, doc_ids):
         q = np.ascontiguousarray(qtok, dtype=np.float32).reshape(-1, self.dim)

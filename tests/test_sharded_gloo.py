@@ -17,6 +17,16 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
+def _maxsim_case():
+    rng = np.random.default_rng(321)
+    lens = rng.integers(0, 30, size=400)  # ragged, some docs without vectors
+    lens[:40] = rng.integers(60, 90, size=40)  # token-heavy head: doc counts and token counts split differently
+    tok = rng.standard_normal((int(lens.sum()), 24)).astype(np.float32)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    qtok = rng.standard_normal((5 + 11, 24)).astype(np.float32)
+    return tok, off, qtok, np.array([0, 5, 16], dtype=np.int32)
+
+
 def _worker(rank: int, world: int, port: int, out_dir: str):
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "tests"))
@@ -39,7 +49,16 @@ def _worker(rank: int, world: int, port: int, out_dir: str):
     dist_g, rows_g = s.search(Q, k)
     # k larger than one shard's rows still merges correctly
     dist_big, rows_big = s.search(Q[:2], 40)
-    np.savez(os.path.join(out_dir, f"r{rank}.npz"), d=dist_g, r=rows_g, db=dist_big, rb=rows_big, lo=lo, hi=hi)
+    # multi-vector store sharded by cumulative token count
+    from autorag_research_amd.sharded import shard_bounds_by_tokens
+
+    tok, off, qtok, qoff = _maxsim_case()
+    dlo, dhi = shard_bounds_by_tokens(off, world, rank)
+    m = ShardedSearcher(tok.shape[1], "cosine", index_factory=OracleIndex)
+    m.add_local_multivec(tok[off[dlo]:off[dhi]], off[dlo:dhi + 1] - off[dlo], dlo)
+    md, mr = m.search_maxsim(qtok, qoff, 9)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), d=dist_g, r=rows_g, db=dist_big, rb=rows_big, lo=lo, hi=hi,
+             md=md, mr=mr, dlo=dlo, dhi=dhi)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -62,10 +81,20 @@ def test_sharded_search_equals_unsharded(tmp_path, oracle):
     for o in outs:
         assert np.array_equal(o["r"], rr) and np.array_equal(o["d"], rd, equal_nan=True)
         assert np.array_equal(o["rb"], rrb) and np.array_equal(o["db"], rdb, equal_nan=True)
+    tok, off, qtok, qoff = _maxsim_case()
+    md, mr = oracle.maxsim_topk(tok, off, qtok, qoff, 9)
+    assert outs[0]["dhi"] == outs[1]["dlo"] and outs[0]["dlo"] == 0 and outs[1]["dhi"] == off.shape[0] - 1
+    assert 0 < outs[0]["dhi"] < 200  # the token-heavy head makes the first shard SHORTER in docs than half
+    for o in outs:
+        assert np.array_equal(o["mr"], mr) and np.array_equal(o["md"].view(np.uint32), md.view(np.uint32))
 
 
 def test_merge_and_bounds_unit():
-    from autorag_research_amd.sharded import merge_topk_host, shard_bounds
+    from autorag_research_amd.sharded import merge_topk_host, shard_bounds, shard_bounds_by_tokens
+
+    off = np.array([0, 10, 10, 30, 100, 100, 120])
+    cuts = [shard_bounds_by_tokens(off, 3, r) for r in range(3)]
+    assert cuts[0][0] == 0 and cuts[-1][1] == 6 and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
 
     assert [shard_bounds(10_000_000, 8, r, 250_000) for r in (0, 7)] == [(0, 1_250_000), (8_750_000, 10_000_000)]
     assert shard_bounds(5, 8, 7) == (4, 5) and shard_bounds(5, 8, 0) == (0, 0)
