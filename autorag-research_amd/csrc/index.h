@@ -59,6 +59,7 @@ struct mi355dr_index {
     // options
     int path = 0;  // MI355DR_PATH_AUTO
     int screen_dtype = 0;  // MI355DR_SCREEN_AUTO
+    int k_now = 10;        // k of the search in progress (the screen element type and the chunk growth depend on it)
     int maxsim_screen = 1; // 1: bf16 MFMA screen + exact re-score of the candidates, 0: exact kernel over every doc
     int64_t row_offset = 0;
     int profile = 0;

@@ -155,10 +155,21 @@ void drain_events(mi355dr_index* idx) {  // call only after the stream was synch
     idx->ev_pending.clear();
 }
 
-// which screen the next search uses: int8 needs the cosine metric and a corpus that quantised within the limit
+// Candidates a chunk appends per query ~ k * (chunk / rows seen before) * inflation, where the inflation is how much
+// the screen's bound widens the tail it has to keep: measured ~3 for the bf16 bound and ~14-16 for the int8 bound on
+// Gaussian data.  The chunk growth is capped so that this stays inside what one prune of the one-wave kernel holds.
+constexpr double kInflationBf16 = 3.0, kInflationI8 = 16.0;
+inline double growth_budget(const mi355dr_index* idx, int k, bool i8) {
+    const int room = k < kPruneSmallSort / 2 ? kPruneSmallSort - k : idx->cap;  // (large k: the general prune, whole buffer)
+    return 0.6 * std::min(room, idx->cap) / ((double)k * (i8 ? kInflationI8 : kInflationBf16));
+}
+
+// which screen the search in progress uses: int8 needs the cosine metric, a corpus that quantised within the limit, and
+// (in AUTO) a k small enough that its wider bound still allows chunks to grow (k <= 24); larger k keeps bf16
 inline bool i8_available(const mi355dr_index* idx) { return idx->irr8_n <= kIrrCap; }
 inline bool use_i8(const mi355dr_index* idx) {
-    return idx->screen_dtype == MI355DR_SCREEN_I8 || (idx->screen_dtype == MI355DR_SCREEN_AUTO && i8_available(idx));
+    if (idx->screen_dtype == MI355DR_SCREEN_I8) return true;
+    return idx->screen_dtype == MI355DR_SCREEN_AUTO && i8_available(idx) && growth_budget(idx, idx->k_now, true) >= 1.5;
 }
 
 int launch_prune(mi355dr_index* idx, hipStream_t s, int nblocks, const int* qlist, int k, int exact) {
@@ -254,6 +265,7 @@ int run_screen(mi355dr_index* idx, hipStream_t s, int B, int k) {
     int64_t done = 0;
     int64_t kept_all_below = 0;  // rows the emit-all first chunk already turned into candidates
     int64_t chunk = std::max<int64_t>(tile, std::min<int64_t>(idx->chunk0_rows, idx->cap));
+    const double growth = std::max(0.25, std::min((double)idx->chunk_growth, growth_budget(idx, k, use_i8(idx))));
     while (done < idx->n) {
         const int64_t end = std::min<int64_t>(idx->n, round_up(done + chunk, tile));
         const bool emit_all = done == 0 && end <= idx->cap;
@@ -280,7 +292,7 @@ int run_screen(mi355dr_index* idx, hipStream_t s, int B, int k) {
         idx->s_chunks++;
         CHECK(launch_prune(idx, s, B, nullptr, k, /*exact=*/0));
         done = end;
-        chunk = std::max<int64_t>(tile, done * idx->chunk_growth);
+        chunk = std::max<int64_t>(tile, (int64_t)((double)done * growth));
     }
     const bool i8 = use_i8(idx);
     const int side_n = i8 ? idx->irr8_n : idx->irr_n;  // rows this screen cannot see
@@ -382,6 +394,7 @@ __global__ void k_set_int(int* p, int v) { *p = v; }
 int search_block(mi355dr_index* idx, hipStream_t s, const float* q_dev, int B, int k, double* out_dist_dev,
                  int64_t* out_rows_dev) {
     CHECK(ensure_qstate(idx));
+    idx->k_now = k;
     const int Bpad = (int)round_up(B, screen_tile(B));
     if (q_dev != idx->qdev)
         HIPCHECK(idx, hipMemcpyAsync(idx->qdev, q_dev, (size_t)B * idx->dim * sizeof(float), hipMemcpyDeviceToDevice, s));

@@ -144,6 +144,22 @@ def test_persistent_screen_shapes(pkg, oracle, screen, n, d, B, k):
         assert idx.stat("fallback_queries") == 0
 
 
+@pytest.mark.parametrize("k,expect_dtype", [(10, 2), (24, 2), (26, 1), (100, 1), (400, 1)])
+def test_schedule_adapts_to_k(pkg, oracle, k, expect_dtype):
+    """the wider int8 bound keeps ~16x k candidates per chunk, the bf16 bound ~3x: AUTO keeps int8 for small k only and
+    the chunk growth shrinks with k, so no query overflows its candidate list (which would cost an exact re-scan)"""
+    rng = np.random.default_rng(1000 + k)
+    n, d, B = 150_000, 128, 300
+    C = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    with pkg.Mi355Index(d) as idx:
+        idx.add(C)
+        idx.reset_stats()
+        _check(idx, oracle, C, Q, k)
+        assert idx.stat("fallback_queries") == 0
+        assert idx.stat("screen_dtype_active") == expect_dtype
+
+
 def test_int8_loose_rows_and_auto_fallback(pkg, oracle):
     """rows with outlier components do not quantise within the residual limit: they stay out of the int8 shadow and
     are re-scored for every query (results unchanged); with too many of them AUTO keeps the bf16 screen."""
