@@ -59,6 +59,12 @@ struct mi355dr_index {
     // options
     int path = 0;  // MI355DR_PATH_AUTO
     int screen_dtype = 0;  // MI355DR_SCREEN_AUTO
+    int retry_level = 0;   // > 0 while overflowed queries are re-screened: bf16 bound, slower chunk growth
+    bool i8_demoted = false;  // AUTO saw the int8 bound overflow on this corpus' score distribution: bf16 from now on
+    float* retry_q = nullptr;      // [kQBlockMax, dim] queries being re-screened
+    double* retry_dist = nullptr;  // [kQBlockMax, kKMax]
+    int64_t* retry_rows = nullptr;
+    int* retry_map = nullptr;      // [kQBlockMax] position of each re-screened query in its block
     int k_now = 10;        // k of the search in progress (the screen element type and the chunk growth depend on it)
     int maxsim_screen = 1; // 1: bf16 MFMA screen + exact re-score of the candidates, 0: exact kernel over every doc
     int64_t row_offset = 0;
@@ -71,6 +77,7 @@ struct mi355dr_index {
     int64_t s_screen_launches = 0, s_screen_ns = 0, s_screen_rows = 0, s_fallback_queries = 0, s_chunks = 0,
             s_passes = 0, s_candidates = 0, s_rescored = 0;
     int64_t s_big_launches = 0, s_big_ns = 0, s_big_rows = 0;  // the k_screen256 share of the three above
+    int64_t s_retry_queries = 0;  // queries whose candidate list overflowed and that were re-screened with the bf16 bound
     int64_t s_ms_screened = 0, s_ms_candidates = 0, s_ms_fallbacks = 0;  // MaxSim: queries screened, docs re-scored, full re-runs
     std::vector<mi355::EventPair> ev_pool, ev_pending;
     hipEvent_t t0 = nullptr, t1 = nullptr;

@@ -168,8 +168,10 @@ inline double growth_budget(const mi355dr_index* idx, int k, bool i8) {
 // (in AUTO) a k small enough that its wider bound still allows chunks to grow (k <= 24); larger k keeps bf16
 inline bool i8_available(const mi355dr_index* idx) { return idx->irr8_n <= kIrrCap; }
 inline bool use_i8(const mi355dr_index* idx) {
+    if (idx->retry_level > 0) return false;  // re-screening overflowed queries: the 5x tighter bf16 bound
     if (idx->screen_dtype == MI355DR_SCREEN_I8) return true;
-    return idx->screen_dtype == MI355DR_SCREEN_AUTO && i8_available(idx) && growth_budget(idx, idx->k_now, true) >= 1.5;
+    return idx->screen_dtype == MI355DR_SCREEN_AUTO && i8_available(idx) && !idx->i8_demoted &&
+           growth_budget(idx, idx->k_now, true) >= 1.5;
 }
 
 int launch_prune(mi355dr_index* idx, hipStream_t s, int nblocks, const int* qlist, int k, int exact) {
@@ -265,7 +267,8 @@ int run_screen(mi355dr_index* idx, hipStream_t s, int B, int k) {
     int64_t done = 0;
     int64_t kept_all_below = 0;  // rows the emit-all first chunk already turned into candidates
     int64_t chunk = std::max<int64_t>(tile, std::min<int64_t>(idx->chunk0_rows, idx->cap));
-    const double growth = std::max(0.25, std::min((double)idx->chunk_growth, growth_budget(idx, k, use_i8(idx))));
+    double growth = std::max(0.25, std::min((double)idx->chunk_growth, growth_budget(idx, k, use_i8(idx))));
+    if (idx->retry_level > 0) growth = std::max(0.25, growth * 0.5);
     while (done < idx->n) {
         const int64_t end = std::min<int64_t>(idx->n, round_up(done + chunk, tile));
         const bool emit_all = done == 0 && end <= idx->cap;
@@ -390,6 +393,20 @@ int run_scan(mi355dr_index* idx, hipStream_t s, const std::vector<int>& qs, int 
 
 __global__ void k_set_int(int* p, int v) { *p = v; }
 
+// rows `map[j]` of src -> row j of dst (d floats each)
+__global__ void k_gather_queries(const float* src, const int* map, int d, float* dst) {
+    const int j = blockIdx.x;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) dst[(int64_t)j * d + c] = src[(int64_t)map[j] * d + c];
+}
+// result j of the re-screened sub-block -> slot map[j] of the block's outputs
+__global__ void k_scatter_results(const double* sd, const int64_t* sr, const int* map, int k, double* od, int64_t* orow) {
+    const int j = blockIdx.x;
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        od[(int64_t)map[j] * k + i] = sd[(int64_t)j * k + i];
+        orow[(int64_t)map[j] * k + i] = sr[(int64_t)j * k + i];
+    }
+}
+
 // one block of B <= kQBlockMax device-resident queries -> device outputs [B,k]
 int search_block(mi355dr_index* idx, hipStream_t s, const float* q_dev, int B, int k, double* out_dist_dev,
                  int64_t* out_rows_dev) {
@@ -425,16 +442,49 @@ int search_block(mi355dr_index* idx, hipStream_t s, const float* q_dev, int B, i
     HIPCHECK(idx, hipStreamSynchronize(s));
     drain_events(idx);
     if (use_screen && idx->status_host[kQBlockMax] != 0) {
-        // some query overflowed its candidate buffer or has an irregular norm: recompute it exactly
+        // some query overflowed its candidate buffer or has an irregular norm
         HIPCHECK(idx, hipMemcpyAsync(idx->status_host, idx->st.status, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHECK(idx, hipStreamSynchronize(s));
-        for (int i = 0; i < B; ++i)
-            if (idx->status_host[i] != 0) todo.push_back(i);
-        CHECK(run_scan(idx, s, todo, k));
-        hipLaunchKernelGGL(k_finalize, dim3(B), dim3(64), 0, s, idx->st, k, idx->row_offset, out_dist_dev,
-                           out_rows_dev, idx->status_or_dev);
-        HIPCHECK(idx, hipGetLastError());
-        HIPCHECK(idx, hipStreamSynchronize(s));
+        std::vector<int> retry;
+        const bool was_i8 = use_i8(idx);
+        for (int i = 0; i < B; ++i) {
+            const int st = idx->status_host[i];
+            if (st == 0) continue;
+            // an overflow at the first attempt is re-screened with the tighter bound and slower growth; whatever
+            // overflows again, and every query the screen cannot rank (irregular norm), is recomputed exactly
+            if (idx->retry_level == 0 && !(st & kStIrregular)) retry.push_back(i);
+            else todo.push_back(i);
+        }
+        if (!todo.empty()) {
+            CHECK(run_scan(idx, s, todo, k));
+            hipLaunchKernelGGL(k_finalize, dim3(B), dim3(64), 0, s, idx->st, k, idx->row_offset, out_dist_dev,
+                               out_rows_dev, idx->status_or_dev);
+            HIPCHECK(idx, hipGetLastError());
+            HIPCHECK(idx, hipStreamSynchronize(s));
+        }
+        if (!retry.empty()) {
+            const int nr = (int)retry.size();
+            idx->s_retry_queries += nr;
+            if (was_i8 && idx->screen_dtype == MI355DR_SCREEN_AUTO && nr * 20 > B) idx->i8_demoted = true;
+            if (!idx->retry_q) {
+                HIPCHECK(idx, hipMalloc(&idx->retry_q, (size_t)kQBlockMax * idx->dim * sizeof(float)));
+                HIPCHECK(idx, hipMalloc(&idx->retry_dist, (size_t)kQBlockMax * kKMax * sizeof(double)));
+                HIPCHECK(idx, hipMalloc(&idx->retry_rows, (size_t)kQBlockMax * kKMax * sizeof(int64_t)));
+                HIPCHECK(idx, hipMalloc(&idx->retry_map, (size_t)kQBlockMax * sizeof(int)));
+            }
+            HIPCHECK(idx, hipMemcpyAsync(idx->retry_map, retry.data(), nr * sizeof(int), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_gather_queries, dim3(nr), dim3(128), 0, s, idx->qdev, idx->retry_map, idx->dim, idx->retry_q);
+            HIPCHECK(idx, hipGetLastError());
+            HIPCHECK(idx, hipStreamSynchronize(s));  // `retry` (pageable) was read by the copy
+            idx->retry_level = 1;
+            const int rc = search_block(idx, s, idx->retry_q, nr, k, idx->retry_dist, idx->retry_rows);
+            idx->retry_level = 0;
+            CHECK(rc);
+            hipLaunchKernelGGL(k_scatter_results, dim3(nr), dim3(128), 0, s, idx->retry_dist, idx->retry_rows, idx->retry_map,
+                               k, out_dist_dev, out_rows_dev);
+            HIPCHECK(idx, hipGetLastError());
+            HIPCHECK(idx, hipStreamSynchronize(s));
+        }
     }
     return MI355DR_OK;
 }
@@ -498,7 +548,7 @@ void mi355dr_destroy(mi355dr_index* idx) {
     if (!idx) return;
     (void)hipSetDevice(idx->device);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
-    void* ptrs[] = {idx->shadow8, idx->flag8, idx->irr8_rows, idx->irr8_count, idx->st.E, idx->st.sc, idx->st.thr_i,
+    void* ptrs[] = {idx->retry_q, idx->retry_dist, idx->retry_rows, idx->retry_map, idx->shadow8, idx->flag8, idx->irr8_rows, idx->irr8_count, idx->st.E, idx->st.sc, idx->st.thr_i,
                     idx->st.qhat8,
                     idx->rows, idx->shadow, idx->nrm2, idx->irr_rows, idx->irr_count, idx->st.qn, idx->st.qhat,
                     idx->st.thr, idx->st.cnt, idx->st.best_n, idx->st.best_key, idx->st.best_row, idx->st.thr_key,
@@ -675,6 +725,7 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
     } else if (k == "screen_dtype") {
         if (value < 0 || value > 2) return fail(idx, MI355DR_E_INVALID, "screen_dtype must be 0,1,2");
         idx->screen_dtype = (int)value;
+        idx->i8_demoted = false;  // (setting the option again re-arms AUTO)
     } else if (k == "maxsim_screen") {
         idx->maxsim_screen = value != 0;
     } else if (k == "row_offset") {
@@ -721,6 +772,8 @@ int mi355dr_get_stat(mi355dr_index* idx, const char* key, int64_t* out) {
     else if (k == "fallback_queries") *out = idx->s_fallback_queries;
     else if (k == "chunks") *out = idx->s_chunks;
     else if (k == "passes") *out = idx->s_passes;
+    else if (k == "retry_queries") *out = idx->s_retry_queries;
+    else if (k == "i8_demoted") *out = idx->i8_demoted ? 1 : 0;
     else if (k == "maxsim_screened") *out = idx->s_ms_screened;
     else if (k == "maxsim_candidates") *out = idx->s_ms_candidates;
     else if (k == "maxsim_fallbacks") *out = idx->s_ms_fallbacks;
@@ -738,7 +791,7 @@ int mi355dr_reset_stats(mi355dr_index* idx) {
     std::lock_guard<std::mutex> g(idx->mu);
     idx->s_screen_launches = idx->s_screen_ns = idx->s_screen_rows = idx->s_fallback_queries = idx->s_chunks =
         idx->s_passes = idx->s_big_launches = idx->s_big_ns = idx->s_big_rows = 0;
-    idx->s_ms_screened = idx->s_ms_candidates = idx->s_ms_fallbacks = 0;
+    idx->s_ms_screened = idx->s_ms_candidates = idx->s_ms_fallbacks = idx->s_retry_queries = 0;
     if (idx->stat_dev) {
         HIPCHECK(idx, hipSetDevice(idx->device));
         HIPCHECK(idx, hipMemset(idx->stat_dev, 0, 2 * kQBlockMax * sizeof(unsigned long long)));

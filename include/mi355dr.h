@@ -132,7 +132,9 @@ int mi355dr_merge_topk_packed_device(mi355dr_index* idx, const int64_t* packed_a
  *          over every doc + exact re-score of the candidates [default], 0: exact kernel over every doc; same results).
  * stats:   "screen_launches", "screen_ns" (profile=1), "screen_rows" (all screen launches) and their k_screen256 share
  *          "screen256_launches", "screen256_ns", "screen256_rows"; "candidates", "rescored",
- *          "fallback_queries", "chunks", "passes", "irregular_rows", "loose_rows" (rows outside the int8 shadow,
+ *          "fallback_queries" (queries recomputed by the exact scan), "retry_queries" (queries whose candidate list
+ *          overflowed and that were re-screened with the bf16 bound and slower chunk growth first), "i8_demoted" (AUTO
+ *          gave up the int8 screen for this index after > 5 % of a block overflowed), "chunks", "passes", "irregular_rows", "loose_rows" (rows outside the int8 shadow,
  *          irregular ones included), "screen_dtype_active" (MI355DR_SCREEN_BF16 / _I8: what AUTO resolves to now),
  *          "maxsim_screened" (queries served by the MaxSim screen), "maxsim_candidates" (docs re-scored exactly for them),
  *          "maxsim_fallbacks" (queries re-run by the exact full scan),

@@ -160,6 +160,39 @@ def test_schedule_adapts_to_k(pkg, oracle, k, expect_dtype):
         assert idx.stat("screen_dtype_active") == expect_dtype
 
 
+def test_overflow_is_rescreened_before_the_exact_scan(pkg, oracle):
+    """a dense neighbourhood (3000 rows within ~0.02 cosine of each other around the query) overflows the candidate
+    list under the int8 bound (2E = 0.046 covers all of them) but not under the bf16 bound (2E = 0.009): those queries
+    are re-screened with bf16, nobody pays the exact scan, results unchanged; AUTO then stays with bf16 for the index"""
+    rng = np.random.default_rng(4)
+    n, d, B, k = 60_000, 256, 64, 10
+    C = rng.standard_normal((n, d)).astype(np.float32)
+    v = rng.standard_normal(d).astype(np.float32)
+    v /= np.linalg.norm(v)
+    # cluster: v + noise of growing size -> cosines to v spread evenly over about [0.975, 0.995]
+    m = 3000
+    amp = np.sqrt(1.0 / np.linspace(0.995, 0.975, m) ** 2 - 1.0).astype(np.float32)
+    noise = rng.standard_normal((m, d)).astype(np.float32)
+    noise -= (noise @ v)[:, None] * v[None, :]
+    noise /= np.linalg.norm(noise, axis=1, keepdims=True)
+    pos = rng.choice(n, size=m, replace=False)
+    C[pos] = v[None, :] + amp[:, None] * noise
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    Q[:8] = v[None, :] + 0.01 * rng.standard_normal((8, d)).astype(np.float32)  # 8 queries look into the cluster
+    with pkg.Mi355Index(d) as idx:
+        idx.add(C)
+        assert idx.stat("screen_dtype_active") == 2
+        idx.reset_stats()
+        _check(idx, oracle, C, Q, k)
+        assert idx.stat("retry_queries") >= 8 and idx.stat("fallback_queries") == 0
+        assert idx.stat("i8_demoted") == 1 and idx.stat("screen_dtype_active") == 1   # 8 of 64 > 5 %
+        idx.reset_stats()
+        _check(idx, oracle, C, Q, k)                                                   # now bf16 from the start
+        assert idx.stat("retry_queries") == 0 and idx.stat("fallback_queries") == 0
+        idx.set_option("screen_dtype", "auto")                                         # re-arms AUTO
+        assert idx.stat("screen_dtype_active") == 2
+
+
 def test_int8_loose_rows_and_auto_fallback(pkg, oracle):
     """rows with outlier components do not quantise within the residual limit: they stay out of the int8 shadow and
     are re-scored for every query (results unchanged); with too many of them AUTO keeps the bf16 screen."""
