@@ -61,10 +61,11 @@ struct mi355dr_index {
     int screen_dtype = 0;  // MI355DR_SCREEN_AUTO
     int retry_level = 0;   // > 0 while overflowed queries are re-screened: bf16 bound, slower chunk growth
     bool i8_demoted = false;  // AUTO saw the int8 bound overflow on this corpus' score distribution: bf16 from now on
-    float* retry_q = nullptr;      // [kQBlockMax, dim] queries being re-screened
-    double* retry_dist = nullptr;  // [kQBlockMax, kKMax]
-    int64_t* retry_rows = nullptr;
-    int* retry_map = nullptr;      // [kQBlockMax] position of each re-screened query in its block
+    // buffers of the sub-block a search at retry level L re-screens (one set per level: the nested call owns the next)
+    float* retry_q[2] = {nullptr, nullptr};      // [kQBlockMax, dim] queries being re-screened
+    double* retry_dist[2] = {nullptr, nullptr};  // [kQBlockMax, kKMax]
+    int64_t* retry_rows[2] = {nullptr, nullptr};
+    int* retry_map[2] = {nullptr, nullptr};      // [kQBlockMax] position of each re-screened query in its block
     int k_now = 10;        // k of the search in progress (the screen element type and the chunk growth depend on it)
     int maxsim_screen = 1; // 1: bf16 MFMA screen + exact re-score of the candidates, 0: exact kernel over every doc
     int64_t row_offset = 0;

@@ -212,6 +212,7 @@ int launch_prep(mi355dr_index* idx, hipStream_t s, int B, int Bpad, int metric) 
 inline int screen_tile(int B) { return B > kTileN ? kT2 : kTileM; }
 
 constexpr int64_t kSmallChunkRows = 16384;
+constexpr int kRetryLevels = 2;  // re-screens of an overflowed query (bf16, growth/2, then growth 0.25) before the exact scan
 
 // launch one screen pass over rows [r0, r_end) (r0 a multiple of the tile edge)
 __global__ void k_set_counts(int* cnt, int n, int v) {
@@ -268,7 +269,8 @@ int run_screen(mi355dr_index* idx, hipStream_t s, int B, int k) {
     int64_t kept_all_below = 0;  // rows the emit-all first chunk already turned into candidates
     int64_t chunk = std::max<int64_t>(tile, std::min<int64_t>(idx->chunk0_rows, idx->cap));
     double growth = std::max(0.25, std::min((double)idx->chunk_growth, growth_budget(idx, k, use_i8(idx))));
-    if (idx->retry_level > 0) growth = std::max(0.25, growth * 0.5);
+    if (idx->retry_level == 1) growth = std::max(0.25, growth * 0.5);
+    if (idx->retry_level >= 2) growth = 0.25;  // (every chunk then holds <= 20 % of the rows: a dense neighbourhood is split up)
     while (done < idx->n) {
         const int64_t end = std::min<int64_t>(idx->n, round_up(done + chunk, tile));
         const bool emit_all = done == 0 && end <= idx->cap;
@@ -452,7 +454,7 @@ int search_block(mi355dr_index* idx, hipStream_t s, const float* q_dev, int B, i
             if (st == 0) continue;
             // an overflow at the first attempt is re-screened with the tighter bound and slower growth; whatever
             // overflows again, and every query the screen cannot rank (irregular norm), is recomputed exactly
-            if (idx->retry_level == 0 && !(st & kStIrregular)) retry.push_back(i);
+            if (idx->retry_level < kRetryLevels && !(st & kStIrregular)) retry.push_back(i);
             else todo.push_back(i);
         }
         if (!todo.empty()) {
@@ -466,22 +468,24 @@ int search_block(mi355dr_index* idx, hipStream_t s, const float* q_dev, int B, i
             const int nr = (int)retry.size();
             idx->s_retry_queries += nr;
             if (was_i8 && idx->screen_dtype == MI355DR_SCREEN_AUTO && nr * 20 > B) idx->i8_demoted = true;
-            if (!idx->retry_q) {
-                HIPCHECK(idx, hipMalloc(&idx->retry_q, (size_t)kQBlockMax * idx->dim * sizeof(float)));
-                HIPCHECK(idx, hipMalloc(&idx->retry_dist, (size_t)kQBlockMax * kKMax * sizeof(double)));
-                HIPCHECK(idx, hipMalloc(&idx->retry_rows, (size_t)kQBlockMax * kKMax * sizeof(int64_t)));
-                HIPCHECK(idx, hipMalloc(&idx->retry_map, (size_t)kQBlockMax * sizeof(int)));
+            const int level = idx->retry_level;  // this call's level; the nested call runs at level + 1
+            if (!idx->retry_q[level]) {
+                HIPCHECK(idx, hipMalloc(&idx->retry_q[level], (size_t)kQBlockMax * idx->dim * sizeof(float)));
+                HIPCHECK(idx, hipMalloc(&idx->retry_dist[level], (size_t)kQBlockMax * kKMax * sizeof(double)));
+                HIPCHECK(idx, hipMalloc(&idx->retry_rows[level], (size_t)kQBlockMax * kKMax * sizeof(int64_t)));
+                HIPCHECK(idx, hipMalloc(&idx->retry_map[level], (size_t)kQBlockMax * sizeof(int)));
             }
-            HIPCHECK(idx, hipMemcpyAsync(idx->retry_map, retry.data(), nr * sizeof(int), hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(k_gather_queries, dim3(nr), dim3(128), 0, s, idx->qdev, idx->retry_map, idx->dim, idx->retry_q);
+            HIPCHECK(idx, hipMemcpyAsync(idx->retry_map[level], retry.data(), nr * sizeof(int), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_gather_queries, dim3(nr), dim3(128), 0, s, idx->qdev, idx->retry_map[level], idx->dim,
+                               idx->retry_q[level]);
             HIPCHECK(idx, hipGetLastError());
             HIPCHECK(idx, hipStreamSynchronize(s));  // `retry` (pageable) was read by the copy
-            idx->retry_level = 1;
-            const int rc = search_block(idx, s, idx->retry_q, nr, k, idx->retry_dist, idx->retry_rows);
-            idx->retry_level = 0;
+            idx->retry_level = level + 1;
+            const int rc = search_block(idx, s, idx->retry_q[level], nr, k, idx->retry_dist[level], idx->retry_rows[level]);
+            idx->retry_level = level;
             CHECK(rc);
-            hipLaunchKernelGGL(k_scatter_results, dim3(nr), dim3(128), 0, s, idx->retry_dist, idx->retry_rows, idx->retry_map,
-                               k, out_dist_dev, out_rows_dev);
+            hipLaunchKernelGGL(k_scatter_results, dim3(nr), dim3(128), 0, s, idx->retry_dist[level], idx->retry_rows[level],
+                               idx->retry_map[level], k, out_dist_dev, out_rows_dev);
             HIPCHECK(idx, hipGetLastError());
             HIPCHECK(idx, hipStreamSynchronize(s));
         }
@@ -548,7 +552,8 @@ void mi355dr_destroy(mi355dr_index* idx) {
     if (!idx) return;
     (void)hipSetDevice(idx->device);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
-    void* ptrs[] = {idx->retry_q, idx->retry_dist, idx->retry_rows, idx->retry_map, idx->shadow8, idx->flag8, idx->irr8_rows, idx->irr8_count, idx->st.E, idx->st.sc, idx->st.thr_i,
+    void* ptrs[] = {idx->retry_q[0], idx->retry_dist[0], idx->retry_rows[0], idx->retry_map[0], idx->retry_q[1],
+                    idx->retry_dist[1], idx->retry_rows[1], idx->retry_map[1], idx->shadow8, idx->flag8, idx->irr8_rows, idx->irr8_count, idx->st.E, idx->st.sc, idx->st.thr_i,
                     idx->st.qhat8,
                     idx->rows, idx->shadow, idx->nrm2, idx->irr_rows, idx->irr_count, idx->st.qn, idx->st.qhat,
                     idx->st.thr, idx->st.cnt, idx->st.best_n, idx->st.best_key, idx->st.best_row, idx->st.thr_key,

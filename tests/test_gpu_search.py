@@ -191,6 +191,20 @@ def test_overflow_is_rescreened_before_the_exact_scan(pkg, oracle):
         assert idx.stat("retry_queries") == 0 and idx.stat("fallback_queries") == 0
         idx.set_option("screen_dtype", "auto")                                         # re-arms AUTO
         assert idx.stat("screen_dtype_active") == 2
+    # a denser neighbourhood (6000 rows within 0.005): re-screening (bf16 at half the growth, then -- if that list
+    # overflows too -- in chunks of <= 20 % of the rows, which splits the neighbourhood up) still avoids the exact scan
+    m2 = 6000
+    amp2 = np.sqrt(1.0 / np.linspace(0.995, 0.990, m2) ** 2 - 1.0).astype(np.float32)
+    noise2 = rng.standard_normal((m2, d)).astype(np.float32)
+    noise2 -= (noise2 @ v)[:, None] * v[None, :]
+    noise2 /= np.linalg.norm(noise2, axis=1, keepdims=True)
+    C2 = rng.standard_normal((n, d)).astype(np.float32)
+    C2[rng.choice(n, size=m2, replace=False)] = v[None, :] + amp2[:, None] * noise2
+    with pkg.Mi355Index(d) as idx:
+        idx.add(C2)
+        idx.reset_stats()
+        _check(idx, oracle, C2, Q, k)
+        assert idx.stat("retry_queries") >= 8 and idx.stat("fallback_queries") == 0
 
 
 def test_int8_loose_rows_and_auto_fallback(pkg, oracle):
