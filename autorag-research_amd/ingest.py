@@ -64,6 +64,32 @@ def embed_all_chunks(store: InMemoryStore, model: Any, batch_size: int = 128, un
     return len(todo)
 
 
+def index_texts_on_device(model: Any, texts: list[str], index: Any, batch_size: int = 1024) -> int:
+    """Encode `texts` and append the vectors to `index` without leaving the GPU.
+
+    `model` is a single-vector encoder with `encode_to_device(texts) -> fp32 [n, d] tensor on the index's device`
+    (TorchEncoderEmbeddings); each batch's tensor is handed to `Mi355Index.add_device` by pointer
+    (mi355dr_add_rows_device: device-to-device copy + norms + shadows on the library's stream).  The reference's path for
+    the same work is model -> `.tolist()` -> per-row SQL UPDATE with a text literal (base_ingestion.py:199-247, 326-495).
+    Returns the number of rows added.
+    """
+    import torch
+
+    done = 0
+    for i in range(0, len(texts), batch_size):
+        v = model.encode_to_device(texts[i: i + batch_size])
+        if v.dtype != torch.float32 or not v.is_contiguous():
+            v = v.float().contiguous()
+        if v.shape[0] == 0:
+            continue
+        if v.shape[1] != index.dim:
+            raise ValueError(f"encoder output dim {v.shape[1]} != index dim {index.dim}")
+        torch.cuda.current_stream(v.device).synchronize()  # the library copies on its own stream
+        index.add_device(v.data_ptr(), v.shape[0])
+        done += v.shape[0]
+    return done
+
+
 def embed_all_queries(store: InMemoryStore, model: Any, batch_size: int = 128) -> int:
     multi = isinstance(model, MultiVectorBaseEmbedding)
     todo = [q for q in store.query_order

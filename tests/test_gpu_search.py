@@ -371,3 +371,30 @@ def test_multi_block_queries_and_large_k(pkg, oracle):
         _check(idx, oracle, C, Q[:3], 700)
         with pytest.raises(pkg.NativeError):
             idx.search(Q[:1], 1025)             # beyond kKMax: refused loudly, not truncated
+
+
+def test_encode_and_index_without_leaving_the_gpu(pkg, oracle):
+    """embed -> index on the device: a (random-init) torch encoder's output tensors go to the index by pointer
+    (mi355dr_add_rows_device); the stored rows are the encoder's rows bit for bit and the search equals the oracle's"""
+    import torch
+
+    from test_embeddings_ingest import _TinyEnc, _TinyTok
+    from autorag_research_amd.embeddings import TorchEncoderEmbeddings
+    from autorag_research_amd.ingest import index_texts_on_device
+
+    rng = np.random.default_rng(12)
+    words = [f"w{i}" for i in range(200)]
+    texts = [" ".join(rng.choice(words, size=int(rng.integers(3, 12)))) for _ in range(1500)]
+    enc = TorchEncoderEmbeddings(_TinyEnc(64), _TinyTok(), pooling="mean", device="cuda:0", batch_size=256)
+    with pkg.Mi355Index(64) as idx:
+        assert index_texts_on_device(enc, texts, idx, batch_size=400) == len(texts)
+        assert len(idx) == len(texts)
+        ref = enc.encode_to_device(texts).cpu().numpy()
+        # batches of 400 vs one pass of 256-row model batches: same rows (row-wise model, deterministic kernels)
+        stored = idx.get_rows(0, len(texts))
+        assert np.allclose(stored, ref, atol=1e-6)
+        q = enc.encode_to_device(texts[:7]).cpu().numpy()
+        dist, rows = idx.search(q, 5)
+        rd, rr = oracle.topk_search(stored, q, 5)
+        assert np.array_equal(rows, rr) and np.array_equal(dist.view(np.uint64), rd.view(np.uint64))
+        assert (rows[:, 0] == np.arange(7)).all() or (dist[:, 0] < 1e-6).all()  # every text finds itself (or a duplicate)
