@@ -134,7 +134,8 @@ int main(int argc, char** argv) {
         } else {
             sa.n_ctiles = (int)((N + 255) / 256);
             sa.n_qtiles = (B + 255) / 256;
-            const int64_t grid = screen256_grid(sa.n_ctiles, sa.n_qtiles);
+            int64_t grid = screen256_grid(sa.n_ctiles, sa.n_qtiles);
+            if (getenv("GRIDDIV")) grid = grid / atoi(getenv("GRIDDIV")) / 8 / sa.n_qtiles * 8 * sa.n_qtiles;  // fewer CUs busy
             if (i8) {
                 hipLaunchKernelGGL((k_screen256<0, true>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa);
             } else switch (variant - 256) {
