@@ -194,8 +194,8 @@ __global__ __launch_bounds__(THREADS) void k_prune(PruneArgs a) {
                 for (int j = 0; j < kSelPerLane; ++j) {
                     const int e = j * kWave + lane;
                     uint32_t kk = 0;
-                    if (e < n_tot) kk = SK[e] == kKeyNaN ? 1u : (f32_order_key((float)(1.0 - key_to_dist(SK[e]))) | 2u);
-                    sk[j] = kk;  // (|2: every real similarity ranks above the NaN class 1, which ranks above "absent" 0)
+                    if (e < n_tot) kk = SK[e] == kKeyNaN ? 1u : f32_order_key((float)(1.0 - key_to_dist(SK[e])));
+                    sk[j] = kk;  // every real similarity (order key >= 0x007FFFFF) ranks above the NaN class 1 and "absent" 0
                 }
                 const uint32_t xs = wave_nth_largest(sk, a.k);
                 n_sel = 0;

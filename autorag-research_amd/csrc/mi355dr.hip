@@ -126,9 +126,11 @@ int ensure_qstate(mi355dr_index* idx) {
     return MI355DR_OK;
 }
 
-// screen bound E(d): |t - exact cosine key| <= 2^-8 + 8*d*2^-24 + 2^-16   (DESIGN.md "Screen bound")
+// bf16 screen bound E(d): |t - exact cosine key| <= 2^-7 + 2^-15 + 8*d*2^-24   (DESIGN.md "Screen bounds").
+// bf16 keeps 8 significand bits: round-to-nearest has unit roundoff 2^-8 PER OPERAND, so a product of two rounded
+// operands is off by up to 2^-7 + 2^-16 (relative), and by Cauchy-Schwarz so is the dot product of unit vectors.
 inline float screen_bound(int d) {
-    return (float)(std::ldexp(1.0, -8) + 8.0 * d * std::ldexp(1.0, -24) + std::ldexp(1.0, -16));
+    return (float)(std::ldexp(1.0, -7) + std::ldexp(1.0, -15) + 8.0 * d * std::ldexp(1.0, -24));
 }
 
 EventPair take_events(mi355dr_index* idx) {
@@ -156,9 +158,9 @@ void drain_events(mi355dr_index* idx) {  // call only after the stream was synch
 }
 
 // Candidates a chunk appends per query ~ k * (chunk / rows seen before) * inflation, where the inflation is how much
-// the screen's bound widens the tail it has to keep: measured ~3 for the bf16 bound and ~14-16 for the int8 bound on
+// the screen's bound widens the tail it has to keep: measured ~4-5 for the bf16 bound and ~14-16 for the int8 bound on
 // Gaussian data.  The chunk growth is capped so that this stays inside what one prune of the one-wave kernel holds.
-constexpr double kInflationBf16 = 3.0, kInflationI8 = 16.0;
+constexpr double kInflationBf16 = 5.0, kInflationI8 = 16.0;
 inline double growth_budget(const mi355dr_index* idx, int k, bool i8) {
     const int room = k < kPruneSmallSort / 2 ? kPruneSmallSort - k : idx->cap;  // (large k: the general prune, whole buffer)
     return 0.6 * std::min(room, idx->cap) / ((double)k * (i8 ? kInflationI8 : kInflationBf16));
@@ -168,7 +170,7 @@ inline double growth_budget(const mi355dr_index* idx, int k, bool i8) {
 // (in AUTO) a k small enough that its wider bound still allows chunks to grow (k <= 24); larger k keeps bf16
 inline bool i8_available(const mi355dr_index* idx) { return idx->irr8_n <= kIrrCap; }
 inline bool use_i8(const mi355dr_index* idx) {
-    if (idx->retry_level > 0) return false;  // re-screening overflowed queries: the 5x tighter bf16 bound
+    if (idx->retry_level > 0) return false;  // re-screening overflowed queries: the ~3x tighter bf16 bound
     if (idx->screen_dtype == MI355DR_SCREEN_I8) return true;
     return idx->screen_dtype == MI355DR_SCREEN_AUTO && i8_available(idx) && !idx->i8_demoted &&
            growth_budget(idx, idx->k_now, true) >= 1.5;

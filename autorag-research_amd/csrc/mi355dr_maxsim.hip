@@ -20,7 +20,7 @@
 // fragment order) -> candidates under a rigorous bound -> exact kernel (k_maxsim, doc list) on the candidates ->
 // exact top-k.  Same results as running the exact kernel over every doc (option "maxsim_screen" = 0), which stays
 // the path for stores / queries with non-finite values and for candidate lists that overflow.
-//   bound: every token pair |t_ij - s_ij| <= eps |q_i||d_j|, eps = 2^-8 + 3 d 2^-24 + 2^-16 (bf16 rounding of both
+//   bound: every token pair |t_ij - s_ij| <= eps |q_i||d_j|, eps = 2^-7 + 2^-15 + 3 d 2^-24 (bf16 rounding of both
 //   sides + fp32 accumulation + the exact chain's own rounding), so |max_j t_ij - max_j s_ij| <= eps |q_i| Dmax
 //   (Dmax = largest token norm in the store) and |T - S| <= E = (eps + 2 n_q 2^-24) Dmax sum_i |q_i| for the
 //   per-doc sums.  k docs have T >= x_k (k-th best screen score) hence S >= x_k - E; any doc of the exact top-k
@@ -827,7 +827,8 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
     }
     const unsigned grid_all = (unsigned)((m->n_docs + 4 * kMsDocsPerWave - 1) / (4 * kMsDocsPerWave));
     const int64_t n_cand_max = std::min<int64_t>(kMsCandCap, m->n_docs);
-    const double eps = std::ldexp(1.0, -8) + 3.0 * d * std::ldexp(1.0, -24) + std::ldexp(1.0, -16);
+    // bf16 round-to-nearest: unit roundoff 2^-8 per operand -> 2^-7 + 2^-16 per product
+    const double eps = std::ldexp(1.0, -7) + std::ldexp(1.0, -15) + 3.0 * d * std::ldexp(1.0, -24);
     // pinned staging (pageable copies are synchronous and cost ~20 us each)
     const size_t qimg_n = (size_t)kMsCols * dp, qf16_n = (size_t)4 * nkk * 64 * 8;
     const size_t need_stage = qimg_n * 4 + qf16_n * 2 + 4 * kKMax * 12 + 64;

@@ -67,7 +67,7 @@ enum {
  * decides which rows are re-scored, under a rigorous per-query bound on |screen value - exact cosine|. */
 enum {
     MI355DR_SCREEN_AUTO = 0, /* int8 when the corpus quantises within the residual limit, else bf16 */
-    MI355DR_SCREEN_BF16 = 1, /* v_mfma_f32_32x32x16_bf16 over the bf16 shadow (bound ~0.0043 at d=768) */
+    MI355DR_SCREEN_BF16 = 1, /* v_mfma_f32_32x32x16_bf16 over the bf16 shadow (bound ~0.0082 at d=768) */
     MI355DR_SCREEN_I8 = 2    /* v_mfma_i32_32x32x32_i8 over the int8 shadow (bound ~0.023): half the bytes, twice the rate */
 };
 

@@ -162,7 +162,7 @@ def test_schedule_adapts_to_k(pkg, oracle, k, expect_dtype):
 
 def test_overflow_is_rescreened_before_the_exact_scan(pkg, oracle):
     """a dense neighbourhood (3000 rows within ~0.02 cosine of each other around the query) overflows the candidate
-    list under the int8 bound (2E = 0.046 covers all of them) but not under the bf16 bound (2E = 0.009): those queries
+    list under the int8 bound (2E = 0.046 covers all of them) but not under the bf16 bound (2E = 0.016): those queries
     are re-screened with bf16, nobody pays the exact scan, results unchanged; AUTO then stays with bf16 for the index"""
     rng = np.random.default_rng(4)
     n, d, B, k = 60_000, 256, 64, 10

@@ -1,0 +1,159 @@
+"""Randomised differential test: libmi355dr (through the Python binding) vs the CPU oracle, bit for bit.
+
+Runs random shapes / data modes / option settings for a wall-clock budget and stops at the first mismatch, printing the
+seed of the failing case.  Test infrastructure (it uses oracle/), meant for a GPU box:
+    python tools/fuzz_parity.py --seconds 300 [--seed 1] [--only single|maxsim]
+"""
+import argparse
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+import autorag_research_amd as pkg  # noqa: E402
+from oracle import cpu_ref  # noqa: E402
+
+
+def corpus(rng, n, d, mode):
+    C = rng.standard_normal((n, d)).astype(np.float32)
+    if mode == "scaled":
+        C *= np.exp(rng.uniform(-6, 6, size=(n, 1))).astype(np.float32)
+    elif mode == "clustered":
+        c = rng.standard_normal((max(1, n // 200), d)).astype(np.float32)
+        C = c[rng.integers(0, c.shape[0], size=n)] + (0.02 * rng.standard_normal((n, d))).astype(np.float32)
+    elif mode == "dups":
+        base = C[: max(1, n // 7)]
+        C = base[rng.integers(0, base.shape[0], size=n)].copy()
+    elif mode == "spiky":
+        idx = rng.choice(n, size=max(1, n // 50), replace=False)
+        C[idx, rng.integers(0, d, size=idx.size)] += 30.0
+    elif mode == "dirty":
+        for v in (0.0, np.nan, np.inf, 1e-25, 1e25):
+            C[rng.integers(0, n)] = v if v == 0.0 else C[rng.integers(0, n)] * 0 + v
+    return C
+
+
+def check_single(rng, case):
+    n = int(rng.choice([1, 7, 300, 4000, 30000, 120000, 250000]))
+    n = max(1, int(n * rng.uniform(0.5, 1.0)))
+    d = int(rng.choice([5, 16, 64, 100, 128, 256, 384, 768, 1000]))
+    Bmax = max(1, int(4e10 / (n * d)))
+    B = int(min(Bmax, rng.choice([1, 3, 33, 128, 129, 300, 777, 1024, 1500])))
+    k = int(rng.choice([1, 3, 10, 24, 25, 64, 100, 300]))
+    mode = str(rng.choice(["gauss", "scaled", "clustered", "dups", "spiky", "dirty"]))
+    metric = "ip" if rng.random() < 0.08 else "cosine"
+    C = corpus(rng, n, d, mode)
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    if mode in ("clustered", "dups") and B > 2:
+        Q[: B // 2] = C[rng.integers(0, n, size=B // 2)] + (0.01 * rng.standard_normal((B // 2, d))).astype(np.float32)
+    opts = {}
+    if rng.random() < 0.5:
+        opts["screen_dtype"] = str(rng.choice(["auto", "bf16", "i8"]))
+    if rng.random() < 0.2:
+        opts["cand_cap"] = int(rng.choice([64, 300, 1024]))
+    if rng.random() < 0.2:
+        opts["chunk_growth"] = int(rng.choice([1, 2, 5, 7]))
+    if rng.random() < 0.2:
+        opts["chunk0_rows"] = int(rng.choice([256, 512, 2048]))
+    desc = f"single n={n} d={d} B={B} k={k} mode={mode} metric={metric} opts={opts}"
+    with pkg.Mi355Index(d, metric) as idx:
+        for key, val in opts.items():
+            idx.set_option(key, val)
+        cut = int(rng.integers(0, n + 1))
+        if cut:
+            idx.add(C[:cut])
+        if cut < n:
+            idx.add(C[cut:])
+        try:
+            dist, rows = idx.search(Q, k)
+        except pkg.NativeError as e:
+            if opts.get("screen_dtype") == "i8" and "int8 screen unavailable" in str(e):
+                return desc + " (i8 unavailable: skipped)"
+            raise
+        stats = {s: idx.stat(s) for s in ("fallback_queries", "retry_queries", "loose_rows", "screen_dtype_active")}
+    rd, rr = cpu_ref.topk_search(C, Q, k, metric=metric)
+    ok = np.array_equal(rows, rr) and np.array_equal(np.isnan(dist), np.isnan(rd))
+    m = ~np.isnan(dist)
+    ok = ok and np.array_equal(dist[m].view(np.uint64), rd[m].view(np.uint64))
+    if not ok:
+        bad = np.argwhere(rows != rr)
+        raise AssertionError(f"MISMATCH {desc} stats={stats} first bad (query,slot)={bad[:3].tolist()}")
+    return desc + f" stats={stats}"
+
+
+def check_maxsim(rng, case):
+    d = int(rng.choice([8, 20, 64, 96, 128, 200]))
+    n_docs = int(rng.choice([1, 40, 700, 5000, 30000]))
+    tmax = int(rng.choice([3, 40, 180, 1100])) if n_docs <= 700 else int(rng.choice([3, 40]))
+    lens = rng.integers(0 if rng.random() < 0.3 else 1, tmax + 1, size=n_docs)
+    unit = rng.random() < 0.6
+    tok = rng.standard_normal((int(lens.sum()), d)).astype(np.float32)
+    if unit and tok.shape[0]:
+        tok /= np.linalg.norm(tok, axis=1, keepdims=True)
+    mode = str(rng.choice(["plain", "dups", "dirty"]))
+    if mode == "dups" and tok.shape[0] > 10:
+        tok[:] = tok[rng.integers(0, max(1, tok.shape[0] // 9), size=tok.shape[0])]
+    if mode == "dirty" and tok.shape[0] > 3:
+        tok[rng.integers(0, tok.shape[0])] = np.inf
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    nq = int(rng.choice([1, 2, 5, 9]))
+    qlens = [int(x) for x in rng.choice([0, 1, 5, 24, 32, 33, 100, 128], size=nq)]
+    qtok = rng.standard_normal((sum(qlens), d)).astype(np.float32)
+    if unit and qtok.shape[0]:
+        qtok /= np.linalg.norm(qtok, axis=1, keepdims=True)
+    qoff = np.concatenate([[0], np.cumsum(qlens)]).astype(np.int32)
+    k = int(rng.choice([1, 10, 64, 65, 200]))
+    screen = int(rng.random() < 0.8)
+    desc = f"maxsim d={d} docs={n_docs} tmax={tmax} qlens={qlens} k={k} unit={unit} mode={mode} screen={screen}"
+    if tok.shape[0] == 0:
+        return desc + " (no tokens: skipped)"
+    with pkg.Mi355Index(d) as idx:
+        idx.set_option("maxsim_screen", screen)
+        idx.add_multivec(tok, off)
+        dist, rows = idx.search_maxsim(qtok, qoff, k)
+        stats = {s: idx.stat(s) for s in ("maxsim_screened", "maxsim_fallbacks")}
+    rd, rr = cpu_ref.maxsim_topk(tok, off, qtok, qoff, k)
+    live = [i for i, t in enumerate(qlens) if t > 0]
+    ok = True
+    for i in range(nq):
+        if i in live:
+            ok = ok and np.array_equal(rows[i], rr[i]) and np.array_equal(np.isnan(dist[i]), np.isnan(rd[i]))
+            m = ~np.isnan(dist[i])
+            ok = ok and np.array_equal(dist[i][m].view(np.uint32), rd[i][m].view(np.uint32))
+        else:
+            ok = ok and (rows[i] == -1).all()
+    if not ok:
+        raise AssertionError(f"MISMATCH {desc} stats={stats}")
+    return desc + f" stats={stats}"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--only", choices=["single", "maxsim"], default=None)
+    ap.add_argument("--verbose", action="store_true")
+    a = ap.parse_args()
+    t0, case, counts = time.time(), 0, {"single": 0, "maxsim": 0}
+    while time.time() - t0 < a.seconds:
+        seed = a.seed * 1_000_003 + case
+        rng = np.random.default_rng(seed)
+        kind = a.only or ("maxsim" if rng.random() < 0.3 else "single")
+        try:
+            msg = (check_maxsim if kind == "maxsim" else check_single)(rng, case)
+        except Exception as e:  # noqa: BLE001
+            print(f"FAILED case {case} seed {seed} kind {kind}: {e}")
+            sys.exit(1)
+        counts[kind] += 1
+        if a.verbose:
+            print(f"ok {case} seed {seed}: {msg}", flush=True)
+        case += 1
+    print(f"fuzz ok: {case} cases in {time.time() - t0:.0f} s ({counts}), seed base {a.seed}")
+
+
+if __name__ == "__main__":
+    main()
