@@ -43,6 +43,17 @@ struct QueryState {
     int8_t* qhat8;      // [Bpad, dpad8] int8 quantised normalised queries
 };
 
+// bf16 value (upper 16 bits) back to fp32
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+// bf16 screen bound from MEASURED residual norms (same algebra as the int8 bound below): q_hat = q16 + e_q, c_hat =
+// c16 + e_c exactly, so |q_hat.c_hat - q16.c16| <= |c16||e_q| + |q16||e_c| + |e_q||e_c| <= 1.0001 (e_q + e_c) + 3 e_q e_c;
+// + 8 d 2^-24 + 2^-16 for the fp32 normalisation, the MFMA's fp32 accumulation and the exact key's own rounding.
+// e_c = the largest residual norm over the stored rows.  Never above the a-priori 2^-7 + 2^-15 + 8 d 2^-24.
+__host__ __device__ inline float bf16_screen_bound(float e_q, float e_c, int d) {
+    return 1.0001f * (e_q + e_c) + 3.0f * e_q * e_c + 8.0f * (float)d * 5.9604645e-8f + 1.5258789e-5f;
+}
+
 // ---- int8 screen quantisation (DESIGN.md "int8 screen bound") ----
 // Normalised rows are quantised with ONE step for the whole corpus, S_c = kI8Z / (127 sqrt(d)): a unit vector's
 // rms component is 1/sqrt(d), so +-127 steps span kI8Z "sigmas" and the rounding residual has norm

@@ -35,6 +35,8 @@ struct mi355dr_index {
     int32_t* irr_rows = nullptr;
     int* irr_count = nullptr;
     int irr_n = 0;
+    unsigned* bf16_res2_dev = nullptr;  // largest squared residual norm |c_hat - bf16(c_hat)|^2 over the rows (float bits)
+    float bf16_ec = 0.00390625f;        // its square root, inflated: the corpus half of the bf16 screen bound
     // int8 screen: second shadow, one step for the whole corpus; rows it cannot hold are flagged and listed
     int dpad8 = 0;
     int8_t* shadow8 = nullptr;     // [cap_rows, dpad8]

@@ -29,11 +29,14 @@ __global__ __launch_bounds__(64) void k_row_nrm2(const float* __restrict__ rows,
 }
 
 // grid: n blocks of 256 threads (one row each).  Irregular rows get an all-NaN shadow row (never
-// emitted by the screen: NaN compares false) and are recorded in irr_rows for the exact side pass.
+// emitted by the screen: NaN compares false) and are recorded in irr_rows for the exact side pass.  The residual norm
+// |c_hat - bf16(c_hat)| of every regular row is measured; res2_max keeps the largest squared one (bit pattern of a
+// non-negative float: unsigned max == float max) -- the corpus half of the bf16 screen bound.
 __global__ __launch_bounds__(256) void k_build_shadow(const float* __restrict__ rows, const float* __restrict__ nrm2,
                                                        int64_t row0, int64_t n, int d, int dpad,
                                                        uint16_t* __restrict__ shadow, int32_t* __restrict__ irr_rows,
-                                                       int* __restrict__ irr_count) {
+                                                       int* __restrict__ irr_count, unsigned* __restrict__ res2_max) {
+    __shared__ float sh[4];
     const int64_t i = row0 + blockIdx.x;
     if (i >= row0 + n) return;
     const float n2 = nrm2[i];
@@ -41,14 +44,31 @@ __global__ __launch_bounds__(256) void k_build_shadow(const float* __restrict__ 
     const float rc = regular ? 1.0f / sqrtf(n2) : 0.0f;
     const float* r = rows + i * (int64_t)d;
     uint16_t* s = shadow + i * (int64_t)dpad;
+    float e2 = 0.0f;
     for (int k = threadIdx.x; k < dpad; k += blockDim.x) {
         uint16_t v = 0;
-        if (k < d) v = regular ? f32_to_bf16_rn(r[k] * rc) : (uint16_t)0x7FC0;  // bf16 quiet NaN
+        if (k < d) {
+            if (regular) {
+                const float ch = r[k] * rc;
+                v = f32_to_bf16_rn(ch);
+                const float e = ch - bf16_bits_to_f32(v);  // exact in fp32
+                e2 = __builtin_fmaf(e, e, e2);
+            } else {
+                v = (uint16_t)0x7FC0;  // bf16 quiet NaN
+            }
+        }
         s[k] = v;
     }
-    if (!regular && threadIdx.x == 0) {
-        int slot = atomicAdd(irr_count, 1);
-        if (slot < kIrrCap) irr_rows[slot] = (int32_t)i;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) e2 += __shfl_xor(e2, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = e2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (regular) atomicMax(res2_max, __float_as_uint((sh[0] + sh[1]) + (sh[2] + sh[3])));
+        else {
+            int slot = atomicAdd(irr_count, 1);
+            if (slot < kIrrCap) irr_rows[slot] = (int32_t)i;
+        }
     }
 }
 
@@ -106,9 +126,10 @@ __global__ __launch_bounds__(256) void k_build_shadow8(const float* __restrict__
 }
 
 // grid: Bpad blocks of 64 threads.  i8_step > 0: also prepare the int8 screen (qhat8, sc, thr_i, E from the
-// measured query residual); otherwise E = bf16_bound for every query.
+// measured query residual); otherwise the bf16 screen: E from the measured query residual and bf16_ec, the largest
+// residual norm of the stored rows.
 __global__ __launch_bounds__(64) void k_prep_queries(const float* __restrict__ q, int B, int d, int dpad, int metric,
-                                                      QueryState st, int dpad8, float i8_step, float bf16_bound) {
+                                                      QueryState st, int dpad8, float i8_step, float bf16_ec) {
     extern __shared__ float qs[];  // [d]
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
@@ -123,7 +144,7 @@ __global__ __launch_bounds__(64) void k_prep_queries(const float* __restrict__ q
             st.thr_key[b] = 0;
             st.thr_row[b] = -1;
             st.status[b] = 0;
-            st.E[b] = bf16_bound;
+            st.E[b] = bf16_screen_bound(0.00390625f, bf16_ec, d);
             st.sc[b] = 1.0f;
             st.thr_i[b] = 0x7FFFFFFF;
         }
@@ -139,8 +160,20 @@ __global__ __launch_bounds__(64) void k_prep_queries(const float* __restrict__ q
     for (int k = 0; k < d; ++k) acc = __builtin_fmaf(qs[k], qs[k], acc);
     const bool regular = norm_is_regular(acc);
     const float rq = regular ? 1.0f / sqrtf(acc) : 0.0f;
-    for (int k = lane; k < dpad; k += kWave) qh[k] = (k < d && regular) ? f32_to_bf16_rn(qs[k] * rq) : (uint16_t)0;
-    float E = bf16_bound, sc = 1.0f;
+    float eq2 = 0.0f;
+    for (int k = lane; k < dpad; k += kWave) {
+        uint16_t v = 0;
+        if (k < d && regular) {
+            const float qh_f = qs[k] * rq;
+            v = f32_to_bf16_rn(qh_f);
+            const float e = qh_f - bf16_bits_to_f32(v);
+            eq2 = __builtin_fmaf(e, e, eq2);
+        }
+        qh[k] = v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) eq2 += __shfl_xor(eq2, o);
+    float E = bf16_screen_bound(sqrtf(eq2) * 1.001f, bf16_ec, d), sc = 1.0f;
     if (i8_step > 0.0f) {
         // per-query step S_q = max|q_hat| / 127, residual norm measured like the corpus side
         float mx = 0.0f;

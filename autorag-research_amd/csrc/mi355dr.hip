@@ -204,8 +204,7 @@ int launch_prune(mi355dr_index* idx, hipStream_t s, int nblocks, const int* qlis
 
 int launch_prep(mi355dr_index* idx, hipStream_t s, int B, int Bpad, int metric) {
     hipLaunchKernelGGL(k_prep_queries, dim3(Bpad), dim3(64), (size_t)idx->dim * sizeof(float), s, idx->qdev, B, idx->dim,
-                       idx->dpad, metric, idx->st, idx->dpad8, use_i8(idx) ? i8_corpus_step(idx->dim) : 0.0f,
-                       screen_bound(idx->dim));
+                       idx->dpad, metric, idx->st, idx->dpad8, use_i8(idx) ? i8_corpus_step(idx->dim) : 0.0f, idx->bf16_ec);
     HIPCHECK(idx, hipGetLastError());
     return MI355DR_OK;
 }
@@ -536,6 +535,8 @@ int mi355dr_create(mi355dr_index** out, int device_id, int dim, int metric) {
     if (e == hipSuccess) e = hipMalloc(&idx->irr_rows, kIrrCap * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc(&idx->irr_count, sizeof(int));
     if (e == hipSuccess) e = hipMemset(idx->irr_count, 0, sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&idx->bf16_res2_dev, sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(idx->bf16_res2_dev, 0, sizeof(unsigned));
     if (e == hipSuccess) e = hipMalloc(&idx->irr8_rows, kIrrCap * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc(&idx->irr8_count, sizeof(int));
     if (e == hipSuccess) e = hipMemset(idx->irr8_count, 0, sizeof(int));
@@ -554,7 +555,7 @@ void mi355dr_destroy(mi355dr_index* idx) {
     if (!idx) return;
     (void)hipSetDevice(idx->device);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
-    void* ptrs[] = {idx->retry_q[0], idx->retry_dist[0], idx->retry_rows[0], idx->retry_map[0], idx->retry_q[1],
+    void* ptrs[] = {idx->bf16_res2_dev, idx->retry_q[0], idx->retry_dist[0], idx->retry_rows[0], idx->retry_map[0], idx->retry_q[1],
                     idx->retry_dist[1], idx->retry_rows[1], idx->retry_map[1], idx->shadow8, idx->flag8, idx->irr8_rows, idx->irr8_count, idx->st.E, idx->st.sc, idx->st.thr_i,
                     idx->st.qhat8,
                     idx->rows, idx->shadow, idx->nrm2, idx->irr_rows, idx->irr_count, idx->st.qn, idx->st.qhat,
@@ -603,7 +604,7 @@ static int add_rows_impl(mi355dr_index* idx, const float* rows, int64_t n, hipMe
                        idx->dim, idx->nrm2);
     HIPCHECK(idx, hipGetLastError());
     hipLaunchKernelGGL(k_build_shadow, dim3((unsigned)n), dim3(256), 0, s, idx->rows, idx->nrm2, idx->n, n, idx->dim,
-                       idx->dpad, idx->shadow, idx->irr_rows, idx->irr_count);
+                       idx->dpad, idx->shadow, idx->irr_rows, idx->irr_count, idx->bf16_res2_dev);
     HIPCHECK(idx, hipGetLastError());
     hipLaunchKernelGGL(k_build_shadow8, dim3((unsigned)n), dim3(256), 0, s, idx->rows, idx->nrm2, idx->n, n, idx->dim,
                        idx->dpad8, i8_corpus_step(idx->dim), idx->shadow8, idx->flag8, idx->irr8_rows, idx->irr8_count);
@@ -611,7 +612,10 @@ static int add_rows_impl(mi355dr_index* idx, const float* rows, int64_t n, hipMe
     int irr = 0, irr8 = 0;
     HIPCHECK(idx, hipMemcpyAsync(&irr, idx->irr_count, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHECK(idx, hipMemcpyAsync(&irr8, idx->irr8_count, sizeof(int), hipMemcpyDeviceToHost, s));
+    float res2 = 0.0f;
+    HIPCHECK(idx, hipMemcpyAsync(&res2, idx->bf16_res2_dev, sizeof(float), hipMemcpyDeviceToHost, s));
     HIPCHECK(idx, hipStreamSynchronize(s));
+    idx->bf16_ec = std::min(std::sqrt(res2) * 1.001f, 0.00390625f * 1.0001f);  // (a-priori cap: 2^-8 |c_hat|)
     idx->irr_n = irr;
     idx->irr8_n = irr8;
     idx->n += n;

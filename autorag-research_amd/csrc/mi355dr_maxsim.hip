@@ -20,7 +20,7 @@
 // fragment order) -> candidates under a rigorous bound -> exact kernel (k_maxsim, doc list) on the candidates ->
 // exact top-k.  Same results as running the exact kernel over every doc (option "maxsim_screen" = 0), which stays
 // the path for stores / queries with non-finite values and for candidate lists that overflow.
-//   bound: every token pair |t_ij - s_ij| <= eps |q_i||d_j|, eps = 2^-7 + 2^-15 + 3 d 2^-24 (bf16 rounding of both
+//   bound (a priori): every token pair |t_ij - s_ij| <= eps |q_i||d_j|, eps = 2^-7 + 2^-15 + 3 d 2^-24 (bf16 rounding of both
 //   sides + fp32 accumulation + the exact chain's own rounding), so |max_j t_ij - max_j s_ij| <= eps |q_i| Dmax
 //   (Dmax = largest token norm in the store) and |T - S| <= E = (eps + 2 n_q 2^-24) Dmax sum_i |q_i| for the
 //   per-doc sums.  k docs have T >= x_k (k-th best screen score) hence S >= x_k - E; any doc of the exact top-k
@@ -52,6 +52,8 @@ struct MultiVecStore {
     int nkk = 0;                   // dim rounded up to 16, / 16
     uint4* tok16 = nullptr;        // [cap_blocks * nkk * 64]
     double tok_norm_max = 0.0;     // largest token norm (double, from the fp32 values)
+    double tok16_norm_max = 0.0;   // largest norm of a bf16-rounded token
+    double tok_res_max = 0.0;      // largest residual norm |d - bf16(d)| of a token
     bool finite = true;            // every stored value is finite (else: no screen)
     uint4* qfrag = nullptr;        // [4 * nkk * 64] query fragments of one launch
     float* dist16 = nullptr;       // [4, cap_docs] screen distances
@@ -600,6 +602,13 @@ __global__ void k_ms_write_out(const uint64_t* key, const int32_t* row, int k, i
 
 namespace {
 
+inline float host_bf16_to_f32(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
 inline uint16_t host_bf16_rn(float f) {  // round-to-nearest-even; NaN/Inf keep their class (the screen is off for them)
     uint32_t u;
     memcpy(&u, &f, 4);
@@ -687,12 +696,19 @@ int mi355dr_add_multivec(mi355dr_index* idx, const float* vecs, const int64_t* o
         const int64_t nb = (T + kMsBlkRows - 1) / kMsBlkRows;
         for (int64_t t = 0; t < T; ++t) {
             const float* sv = vecs + (offsets[i] + t) * d;
-            double n2 = 0.0;
+            double n2 = 0.0, n16 = 0.0, r2 = 0.0;
             for (int c = 0; c < d; ++c) {
                 if (!std::isfinite(sv[c])) m->finite = false;
-                n2 += (double)sv[c] * (double)sv[c];
+                const double x = sv[c], x16 = host_bf16_to_f32(host_bf16_rn(sv[c]));
+                n2 += x * x;
+                n16 += x16 * x16;
+                r2 += (x - x16) * (x - x16);
             }
-            if (std::isfinite(n2)) m->tok_norm_max = std::max(m->tok_norm_max, std::sqrt(n2));
+            if (std::isfinite(n2)) {
+                m->tok_norm_max = std::max(m->tok_norm_max, std::sqrt(n2));
+                m->tok16_norm_max = std::max(m->tok16_norm_max, std::sqrt(n16));
+                m->tok_res_max = std::max(m->tok_res_max, std::sqrt(r2));
+            }
         }
         for (int64_t b = 0; b < nb; ++b)
             for (int kk = 0; kk < m->nkk; ++kk)
@@ -884,7 +900,7 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
             if (col + need > kMsCols) break;
             a.q_col0[nql] = col;
             a.q_len[nql] = nq;
-            double norm_sum = 0.0;
+            double norm_sum = 0.0, res_sum = 0.0;
             for (int j = 0; j < nq; ++j) {
                 float* dst = &qimg[(size_t)(col + j) * dp];
                 const float* sv = qtok + (int64_t)(q_offsets[b] + j) * d;
@@ -893,17 +909,26 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
                     dst[c] = oc < d ? sv[oc] : 0.0f;
                 }
                 // bf16 fragment of the same column: block cb = (col+j)/32, lane = ((col+j)&31) + 32*half
-                double n2 = 0.0;
+                double n2 = 0.0, r2 = 0.0;
                 const int cc = col + j;
                 for (int c = 0; c < d; ++c) {
                     if (!std::isfinite(sv[c])) q_finite = false;
-                    n2 += (double)sv[c] * (double)sv[c];
+                    const uint16_t h = host_bf16_rn(sv[c]);
+                    const double x = sv[c], x16 = host_bf16_to_f32(h);
+                    n2 += x * x;
+                    r2 += (x - x16) * (x - x16);
                     const int kk = c / 16, half = (c % 16) / 8, jj = c % 8;
-                    qf16[((((size_t)(cc >> 5) * nkk + kk) * 64) + (cc & 31) + 32 * half) * 8 + jj] = host_bf16_rn(sv[c]);
+                    qf16[((((size_t)(cc >> 5) * nkk + kk) * 64) + (cc & 31) + 32 * half) * 8 + jj] = h;
                 }
                 norm_sum += std::sqrt(n2);
+                res_sum += std::sqrt(r2);
             }
-            two_e[nql] = 2.0 * (eps + 2.0 * nq * std::ldexp(1.0, -24)) * m->tok_norm_max * norm_sum * (1.0 + 1e-6);
+            // per token pair: |q16.d16 - q.d| <= |r_q||d16| + |q||r_d| with the residuals MEASURED (round-to-nearest leaves
+            // about half of the a-priori 2^-8 |x|), + fp32 accumulation of both dot products and of the per-doc sums
+            const double e_pair = res_sum * m->tok16_norm_max + norm_sum * m->tok_res_max;
+            const double e_acc = (3.0 * d + 2.0 * nq) * std::ldexp(1.0, -24) * m->tok_norm_max * norm_sum;
+            two_e[nql] = 2.0 * std::min(e_pair + e_acc, (eps + 2.0 * nq * std::ldexp(1.0, -24)) * m->tok_norm_max * norm_sum) *
+                         (1.0 + 1e-6);
             col += need;
             ++nql;
             ++b;
