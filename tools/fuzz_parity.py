@@ -43,7 +43,7 @@ def check_single(rng, case):
     d = int(rng.choice([5, 16, 64, 100, 128, 256, 384, 768, 1000]))
     Bmax = max(1, int(4e10 / (n * d)))
     B = int(min(Bmax, rng.choice([1, 3, 33, 128, 129, 300, 777, 1024, 1500])))
-    k = int(rng.choice([1, 3, 10, 24, 25, 64, 100, 300]))
+    k = int(rng.choice([1, 3, 10, 24, 25, 64, 100, 300, 1024]))
     mode = str(rng.choice(["gauss", "scaled", "clustered", "dups", "spiky", "dirty"]))
     metric = "ip" if rng.random() < 0.08 else "cosine"
     C = corpus(rng, n, d, mode)
@@ -59,10 +59,12 @@ def check_single(rng, case):
         opts["chunk_growth"] = int(rng.choice([1, 2, 5, 7]))
     if rng.random() < 0.2:
         opts["chunk0_rows"] = int(rng.choice([256, 512, 2048]))
-    desc = f"single n={n} d={d} B={B} k={k} mode={mode} metric={metric} opts={opts}"
+    row_offset = int(rng.choice([0, 0, 12345, 2**33]))
+    desc = f"single n={n} d={d} B={B} k={k} mode={mode} metric={metric} opts={opts} row_offset={row_offset}"
     with pkg.Mi355Index(d, metric) as idx:
         for key, val in opts.items():
             idx.set_option(key, val)
+        idx.set_option("row_offset", row_offset)
         cut = int(rng.integers(0, n + 1))
         if cut:
             idx.add(C[:cut])
@@ -76,6 +78,7 @@ def check_single(rng, case):
             raise
         stats = {s: idx.stat(s) for s in ("fallback_queries", "retry_queries", "loose_rows", "screen_dtype_active")}
     rd, rr = cpu_ref.topk_search(C, Q, k, metric=metric)
+    rr = np.where(rr >= 0, rr + row_offset, rr)
     ok = np.array_equal(rows, rr) and np.array_equal(np.isnan(dist), np.isnan(rd))
     m = ~np.isnan(dist)
     ok = ok and np.array_equal(dist[m].view(np.uint64), rd[m].view(np.uint64))
@@ -116,6 +119,21 @@ def check_maxsim(rng, case):
         idx.add_multivec(tok, off)
         dist, rows = idx.search_maxsim(qtok, qoff, k)
         stats = {s: idx.stat(s) for s in ("maxsim_screened", "maxsim_fallbacks")}
+        # candidate re-scoring entry point on a random list per query (incl. ids that are not docs)
+        m_ids = int(rng.integers(1, 40))
+        ids = rng.integers(-2, n_docs + 3, size=(nq, m_ids)).astype(np.int64)
+        sub = idx.maxsim_subset(qtok, qoff, ids)
+    for b in range(nq):
+        qb = qtok[qoff[b]:qoff[b + 1]]
+        for j in range(m_ids):
+            i = int(ids[b, j])
+            if 0 <= i < n_docs and off[i + 1] > off[i] and qb.shape[0]:
+                exp = np.float32(cpu_ref.maxsim_distance(tok[off[i]:off[i + 1]], qb))
+                same = (np.isnan(exp) and np.isnan(sub[b, j])) or sub[b, j].view(np.uint32) == exp.view(np.uint32)
+                if not same:
+                    raise AssertionError(f"SUBSET MISMATCH {desc} query {b} doc {i}: {sub[b, j]} vs {exp}")
+            elif not np.isnan(sub[b, j]):
+                raise AssertionError(f"SUBSET MISMATCH {desc} query {b} doc {i}: expected NaN, got {sub[b, j]}")
     rd, rr = cpu_ref.maxsim_topk(tok, off, qtok, qoff, k)
     live = [i for i, t in enumerate(qlens) if t > 0]
     ok = True
