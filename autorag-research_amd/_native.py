@@ -38,6 +38,32 @@ class NativeError(RuntimeError):
         self.code = code
 
 
+def _preload_torch_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 (same
+    sonames as /opt/rocm's).  If libmi355dr.so pulled in the system copies first and torch is imported later, torch
+    comes up with "No HIP GPUs are available"; the other order works (torch's copies are found by soname).  So when
+    torch is installed, its copies are loaded here -- without importing torch -- before libmi355dr.so."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = Path(list(spec.submodule_search_locations)[0]) / "lib"
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        f = libdir / name
+        if f.exists():
+            try:
+                ctypes.CDLL(str(f), mode=getattr(os, "RTLD_NOW", 2) | getattr(os, "RTLD_GLOBAL", 0x100))
+            except OSError:
+                return
+
+
 def load() -> ctypes.CDLL:
     """Load libmi355dr.so and declare argument types.  Raises if it was not built."""
     global _lib
@@ -48,6 +74,7 @@ def load() -> ctypes.CDLL:
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the search path."
         )
+    _preload_torch_hip_runtime()
     L = ctypes.CDLL(str(LIB_PATH), mode=getattr(os, "RTLD_NOW", 2))
     vp, c_int, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
     f32p, f64p = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)
