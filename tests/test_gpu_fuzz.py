@@ -18,8 +18,9 @@ def test_fuzz_slice(native_built, oracle, base):
     for case in range(12):
         seed = base * 1_000_003 + case
         rng = np.random.default_rng(seed)
-        kind = "maxsim" if rng.random() < 0.3 else "single"
+        u = rng.random()
+        kind = "maxsim" if u < 0.3 else "session" if u < 0.45 else "single"
         try:
-            (fz.check_maxsim if kind == "maxsim" else fz.check_single)(rng, case)
+            {"maxsim": fz.check_maxsim, "single": fz.check_single, "session": fz.check_session}[kind](rng, case)
         except AssertionError as e:  # pragma: no cover - a failure names the seed to replay
             raise AssertionError(f"seed {seed} ({kind}): {e}") from e

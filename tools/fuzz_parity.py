@@ -88,6 +88,52 @@ def check_single(rng, case):
     return desc + f" stats={stats}"
 
 
+def check_session(rng, case):
+    """one index, several operations: searches with changing k / B / options interleaved with appends (state carried
+    across calls: thresholds, the int8 demotion flag, retry buffers, reallocation of every shadow)"""
+    d = int(rng.choice([16, 64, 128, 384, 768]))
+    mode = str(rng.choice(["gauss", "clustered", "dups", "spiky", "dirty"]))
+    big = rng.random() < 0.25
+    n0 = int(rng.choice([500_000, 1_000_000]) if big else rng.choice([50, 3000, 40000]))
+    if big:
+        d = min(d, 384)
+    C = corpus(rng, n0, d, mode)
+    metric = "cosine"
+    desc = f"session d={d} mode={mode} n0={n0}"
+    with pkg.Mi355Index(d, metric) as idx:
+        idx.add(C)
+        for step in range(int(rng.integers(3, 7))):
+            op = rng.random()
+            if op < 0.25 and not big:
+                more = corpus(rng, int(rng.integers(1, 5000)), d, str(rng.choice(["gauss", "clustered", "dups"])))
+                idx.add(more)
+                C = np.concatenate([C, more], axis=0)
+                desc += f" | add {more.shape[0]}"
+                continue
+            if op < 0.4:
+                key, val = [("screen_dtype", str(rng.choice(["auto", "bf16"]))), ("path", "auto"),
+                            ("cand_cap", int(rng.choice([128, 2048]))), ("chunk_growth", int(rng.choice([2, 3, 6])))][int(rng.integers(0, 4))]
+                idx.set_option(key, val)
+                desc += f" | {key}={val}"
+                continue
+            B = int(rng.choice([1, 2, 8])) if big else int(rng.choice([1, 5, 64, 130, 400, 1100]))
+            k = int(rng.choice([1, 10, 24, 30, 100]))
+            Q = rng.standard_normal((B, d)).astype(np.float32)
+            if mode in ("clustered", "dups"):
+                Q[: max(1, B // 2)] = C[rng.integers(0, C.shape[0], size=max(1, B // 2))] + (
+                    0.01 * rng.standard_normal((max(1, B // 2), d))).astype(np.float32)
+            desc += f" | search B={B} k={k}"
+            dist, rows = idx.search(Q, k)
+            rd, rr = cpu_ref.topk_search(C, Q, k, metric=metric)
+            ok = np.array_equal(rows, rr) and np.array_equal(np.isnan(dist), np.isnan(rd))
+            m = ~np.isnan(dist)
+            ok = ok and np.array_equal(dist[m].view(np.uint64), rd[m].view(np.uint64))
+            if not ok:
+                st = {s: idx.stat(s) for s in ("fallback_queries", "retry_queries", "loose_rows", "screen_dtype_active", "i8_demoted")}
+                raise AssertionError(f"MISMATCH {desc} stats={st} first bad={np.argwhere(rows != rr)[:3].tolist()}")
+    return desc
+
+
 def check_maxsim(rng, case):
     d = int(rng.choice([8, 20, 64, 96, 128, 200]))
     n_docs = int(rng.choice([1, 40, 700, 5000, 30000]))
@@ -153,16 +199,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--only", choices=["single", "maxsim"], default=None)
+    ap.add_argument("--only", choices=["single", "maxsim", "session"], default=None)
     ap.add_argument("--verbose", action="store_true")
     a = ap.parse_args()
-    t0, case, counts = time.time(), 0, {"single": 0, "maxsim": 0}
+    t0, case, counts = time.time(), 0, {"single": 0, "maxsim": 0, "session": 0}
     while time.time() - t0 < a.seconds:
         seed = a.seed * 1_000_003 + case
         rng = np.random.default_rng(seed)
-        kind = a.only or ("maxsim" if rng.random() < 0.3 else "single")
+        u = rng.random()
+        kind = a.only or ("maxsim" if u < 0.3 else "session" if u < 0.45 else "single")
         try:
-            msg = (check_maxsim if kind == "maxsim" else check_single)(rng, case)
+            msg = {"maxsim": check_maxsim, "single": check_single, "session": check_session}[kind](rng, case)
         except Exception as e:  # noqa: BLE001
             print(f"FAILED case {case} seed {seed} kind {kind}: {e}")
             sys.exit(1)
