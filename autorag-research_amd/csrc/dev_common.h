@@ -98,6 +98,12 @@ __device__ __forceinline__ double distance_from(int metric, float dot, float nq,
     return metric == 0 ? cosine_distance_from(dot, nq, nc) : (double)dot * -1.0;
 }
 
+// "higher is better" image of a distance key, as float (monotone; used only to SELECT, the exact keys decide order):
+// cosine: 1 - distance = the similarity; inner product: -distance = the dot product
+__device__ __forceinline__ float sim_of_dist(int metric, double dist) {
+    return metric == 0 ? (float)(1.0 - dist) : (float)(-dist);
+}
+
 // monotone map double -> uint64 so that unsigned compare == (distance asc, NaN last)
 __device__ __forceinline__ uint64_t dist_to_key(double d) {
     if (d != d) return kKeyNaN;

@@ -35,6 +35,8 @@ struct mi355dr_index {
     int32_t* irr_rows = nullptr;
     int* irr_count = nullptr;
     int irr_n = 0;
+    unsigned* n2max_dev = nullptr;  // largest regular |c|^2 (float bits)
+    float cmax = 0.0f;              // its square root, inflated: inner-product thresholds
     unsigned* bf16_res2_dev = nullptr;  // largest squared residual norm |c_hat - bf16(c_hat)|^2 over the rows (float bits)
     float bf16_ec = 0.00390625f;        // its square root, inflated: the corpus half of the bf16 screen bound
     // int8 screen: second shadow, one step for the whole corpus; rows it cannot hold are flagged and listed

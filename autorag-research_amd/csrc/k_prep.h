@@ -9,8 +9,9 @@
 namespace mi355 {
 
 // grid: ceil(n/64) blocks of 64 threads (one wave, 64 rows)
+// n2max: running maximum of the regular |c|^2 (float bits; inner-product thresholds need the largest row norm)
 __global__ __launch_bounds__(64) void k_row_nrm2(const float* __restrict__ rows, int64_t row0, int64_t n, int d,
-                                                  float* __restrict__ nrm2) {
+                                                  float* __restrict__ nrm2, unsigned* __restrict__ n2max) {
     __shared__ float tile[kStageFloats];
     const int lane = threadIdx.x;
     const int64_t i = row0 + (int64_t)blockIdx.x * kWave + lane;
@@ -26,6 +27,13 @@ __global__ __launch_bounds__(64) void k_row_nrm2(const float* __restrict__ rows,
         __syncthreads();
     }
     if (live) nrm2[i] = acc;
+    float m = (live && norm_is_regular(acc)) ? acc : 0.0f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) {
+        const unsigned v = __float_as_uint(m);
+        if (v > *(volatile unsigned*)n2max) atomicMax(n2max, v);
+    }
 }
 
 // grid: n blocks of 256 threads (one row each).  Irregular rows get an all-NaN shadow row (never
@@ -209,8 +217,9 @@ __global__ __launch_bounds__(64) void k_prep_queries(const float* __restrict__ q
         st.E[b] = E;
         st.sc[b] = sc;
         // cosine screen cannot rank an irregular query: park it (never emits) and flag it for the scan path
-        st.thr_i[b] = (regular || metric != 0) ? (-0x7FFFFFFF - 1) : 0x7FFFFFFF;
-        st.thr[b] = (regular || metric != 0) ? -__builtin_inff() : __builtin_inff();
+        // (metric 2 = test hook: every query screens with thresholds at -inf)
+        st.thr_i[b] = (regular || metric == 2) ? (-0x7FFFFFFF - 1) : 0x7FFFFFFF;
+        st.thr[b] = (regular || metric == 2) ? -__builtin_inff() : __builtin_inff();
         st.cnt[b] = 0;
         st.best_n[b] = 0;
         st.thr_key[b] = kKeyNaN;

@@ -25,6 +25,7 @@ struct PruneArgs {
     int cap, d, k, metric;
     int exact;           // 0: screen candidates (re-score), 1: cand_val already holds the exact dot
     const uint8_t* flag8;  // int8 screen only (else nullptr): rows outside the int8 shadow
+    float cmax;            // inner-product metric: largest stored row norm (inflated); thresholds are cos >= dot_k / (|q| cmax)
 };                         // (the screen bound is per query: st.E[q])
 
 // Two instantiations share the code: a small one (1 wave, <= 1024 entries, ~36 KiB LDS, 4 workgroups
@@ -101,7 +102,18 @@ __global__ __launch_bounds__(THREADS) void k_prune(PruneArgs a) {
                 if (e < n_new) {
                     const float v = cval[e];
                     if (v != v) kk = 0xFFFFFFFFu;  // "no bound": always re-scored
-                    else if (!(a.flag8 && a.flag8[crow[e]])) kk = f32_order_key(v);  // (else: stale zero of a loose row)
+                    else if (!(a.flag8 && a.flag8[crow[e]])) {  // (else: stale zero of a loose row)
+                        if (a.metric == 0) {
+                            kk = f32_order_key(v);
+                        } else {
+                            // inner product: rank by an UPPER bound of the dot product, (v + E) |q| |c| -- the exact dot
+                            // is cos_key * sqrt(nq * nc) with the same fp32 norms the cosine key is defined with
+                            const float vb = v + E;
+                            const float s = sqrtf(nq) * sqrtf(a.nrm2[crow[e]]);
+                            const float ub = vb >= 0.0f ? vb * s * 1.000002f + 1e-30f : vb * s * 0.999998f;
+                            kk = ub == ub ? f32_order_key(ub) : 0xFFFFFFFFu;
+                        }
+                    }
                 }
                 key[j] = kk;
             }
@@ -159,19 +171,20 @@ __global__ __launch_bounds__(THREADS) void k_prune(PruneArgs a) {
             if (n_cand > nA) {
                 // ---- cut = (k-th largest exact similarity over kept U round A) - E: as float, rounded down
                 float cut = -__builtin_inff();
-                if (n1 >= a.k && a.metric == 0) {
+                if (n1 >= a.k) {
                     uint32_t sk[kSelPerLane];
 #pragma unroll
                     for (int j = 0; j < kSelPerLane; ++j) {
                         const int e = j * kWave + lane;
                         uint32_t kk = 0;
-                        if (e < n1 && SK[e] != kKeyNaN) kk = f32_order_key((float)(1.0 - key_to_dist(SK[e])));
+                        if (e < n1 && SK[e] != kKeyNaN) kk = f32_order_key(sim_of_dist(a.metric, key_to_dist(SK[e])));
                         sk[j] = kk;
                     }
                     if (wave_count_ge(sk, 1u) >= a.k) {
                         const uint32_t xs = wave_nth_largest(sk, a.k);
-                        const uint32_t ub = (xs & 0x80000000u) ? (xs & 0x7FFFFFFFu) : ~xs;  // invert f32_order_key
-                        cut = __uint_as_float(ub) - E * 1.001f - 2e-6f;
+                        const float kth = __uint_as_float((xs & 0x80000000u) ? (xs & 0x7FFFFFFFu) : ~xs);  // invert the key
+                        // cosine: candidates carry v, exact <= v + E.  inner product: they carry the upper bound itself.
+                        cut = a.metric == 0 ? kth - E * 1.001f - 2e-6f : kth - fabsf(kth) * 4e-6f - 1e-30f;
                     }
                 }
                 // ---- round B: everything that can still reach the top-k (v + E >= exact k-th best)
@@ -194,7 +207,7 @@ __global__ __launch_bounds__(THREADS) void k_prune(PruneArgs a) {
                 for (int j = 0; j < kSelPerLane; ++j) {
                     const int e = j * kWave + lane;
                     uint32_t kk = 0;
-                    if (e < n_tot) kk = SK[e] == kKeyNaN ? 1u : f32_order_key((float)(1.0 - key_to_dist(SK[e])));
+                    if (e < n_tot) kk = SK[e] == kKeyNaN ? 1u : f32_order_key(sim_of_dist(a.metric, key_to_dist(SK[e])));
                     sk[j] = kk;  // every real similarity (order key >= 0x007FFFFF) ranks above the NaN class 1 and "absent" 0
                 }
                 const uint32_t xs = wave_nth_largest(sk, a.k);
@@ -236,15 +249,35 @@ __global__ __launch_bounds__(THREADS) void k_prune(PruneArgs a) {
                     const uint64_t wk = K2[a.k - 1];
                     a.st.thr_key[q] = wk;
                     a.st.thr_row[q] = R2[a.k - 1];
-                    if (a.metric == 0 && wk != kKeyNaN && !(a.st.status[q] & kStIrregular)) {
-                        const float th = float_below((float)((1.0 - key_to_dist(wk)) - (double)E));
-                        a.st.thr[q] = th;
-                        a.st.thr_i[q] = i8_threshold(th, a.st.sc[q]);
+                    if (wk != kKeyNaN && !(a.st.status[q] & kStIrregular)) {
+                        if (a.metric == 0) {
+                            const float th = float_below((float)((1.0 - key_to_dist(wk)) - (double)E));
+                            a.st.thr[q] = th;
+                            a.st.thr_i[q] = i8_threshold(th, a.st.sc[q]);
+                        } else {
+                            // a row can only beat dot_k > 0 if its cosine is at least dot_k / (|q| cmax)
+                            const double dk = -key_to_dist(wk);
+                            const double den = (double)sqrtf(nq) * (double)a.cmax;
+                            if (dk > 0.0 && den > 0.0 && den < 1e300) {
+                                const float th = float_below((float)(dk / den * (1.0 - 4e-6) - (double)E));
+                                a.st.thr[q] = th;
+                                a.st.thr_i[q] = i8_threshold(th, a.st.sc[q]);
+                            }
+                        }
                     }
                 }
             }
             return;
         }
+    }
+    if (!a.exact && a.metric != 0) {
+        // inner product is screened by the one-wave form only; what it skipped (k > ~500, > 1024 candidates) is
+        // recomputed by the exact scan
+        if (tid == 0) {
+            a.st.status[q] |= kStOverflow;
+            a.st.cnt[q] = 0;
+        }
+        return;
     }
     if (!a.exact) {
         // ---- phase 1: order the new candidates by their screen value, best first.  NaN = "no bound" sorts first;

@@ -192,6 +192,7 @@ int launch_prune(mi355dr_index* idx, hipStream_t s, int nblocks, const int* qlis
     pa.metric = idx->metric;
     pa.exact = exact;
     pa.flag8 = use_i8(idx) ? idx->flag8 : nullptr;
+    pa.cmax = idx->cmax;
     // small instantiation first (common case, whole block resident), then the large one for what it skipped
     hipLaunchKernelGGL((k_prune<kPruneSmallThreads, kPruneSmallSort>), dim3(nblocks), dim3(kPruneSmallThreads),
                        prune_lds_bytes(idx->dim, kPruneSmallThreads, kPruneSmallSort), s, pa);
@@ -422,8 +423,8 @@ int search_block(mi355dr_index* idx, hipStream_t s, const float* q_dev, int B, i
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, idx->status_or_dev, 0);
     if (idx->screen_dtype == MI355DR_SCREEN_I8 && !i8_available(idx) && idx->path != MI355DR_PATH_SCAN)
         return fail(idx, MI355DR_E_UNSUPPORTED, "int8 screen unavailable: too many rows outside the residual limit");
-    const bool screen_possible =
-        idx->metric == MI355DR_METRIC_COSINE && (use_i8(idx) ? i8_available(idx) : idx->irr_n <= kIrrCap);
+    // (inner product rides the same cosine screens: thresholds become cos >= dot_k / (|q| cmax), see k_prune)
+    const bool screen_possible = use_i8(idx) ? i8_available(idx) : idx->irr_n <= kIrrCap;
     const bool use_screen = idx->n > 0 && screen_possible && idx->path != MI355DR_PATH_SCAN;
     if (idx->path == MI355DR_PATH_SCREEN && !screen_possible && idx->n > 0)
         return fail(idx, MI355DR_E_UNSUPPORTED, "screen path unavailable (metric or too many irregular rows)");
@@ -535,6 +536,8 @@ int mi355dr_create(mi355dr_index** out, int device_id, int dim, int metric) {
     if (e == hipSuccess) e = hipMalloc(&idx->irr_rows, kIrrCap * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc(&idx->irr_count, sizeof(int));
     if (e == hipSuccess) e = hipMemset(idx->irr_count, 0, sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&idx->n2max_dev, sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(idx->n2max_dev, 0, sizeof(unsigned));
     if (e == hipSuccess) e = hipMalloc(&idx->bf16_res2_dev, sizeof(unsigned));
     if (e == hipSuccess) e = hipMemset(idx->bf16_res2_dev, 0, sizeof(unsigned));
     if (e == hipSuccess) e = hipMalloc(&idx->irr8_rows, kIrrCap * sizeof(int32_t));
@@ -555,7 +558,7 @@ void mi355dr_destroy(mi355dr_index* idx) {
     if (!idx) return;
     (void)hipSetDevice(idx->device);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
-    void* ptrs[] = {idx->bf16_res2_dev, idx->retry_q[0], idx->retry_dist[0], idx->retry_rows[0], idx->retry_map[0], idx->retry_q[1],
+    void* ptrs[] = {idx->n2max_dev, idx->bf16_res2_dev, idx->retry_q[0], idx->retry_dist[0], idx->retry_rows[0], idx->retry_map[0], idx->retry_q[1],
                     idx->retry_dist[1], idx->retry_rows[1], idx->retry_map[1], idx->shadow8, idx->flag8, idx->irr8_rows, idx->irr8_count, idx->st.E, idx->st.sc, idx->st.thr_i,
                     idx->st.qhat8,
                     idx->rows, idx->shadow, idx->nrm2, idx->irr_rows, idx->irr_count, idx->st.qn, idx->st.qhat,
@@ -601,7 +604,7 @@ static int add_rows_impl(mi355dr_index* idx, const float* rows, int64_t n, hipMe
     hipStream_t s = idx->stream;
     HIPCHECK(idx, hipMemcpyAsync(idx->rows + idx->n * idx->dim, rows, (size_t)n * idx->dim * sizeof(float), kind, s));
     hipLaunchKernelGGL(k_row_nrm2, dim3((unsigned)((n + kWave - 1) / kWave)), dim3(kWave), 0, s, idx->rows, idx->n, n,
-                       idx->dim, idx->nrm2);
+                       idx->dim, idx->nrm2, idx->n2max_dev);
     HIPCHECK(idx, hipGetLastError());
     hipLaunchKernelGGL(k_build_shadow, dim3((unsigned)n), dim3(256), 0, s, idx->rows, idx->nrm2, idx->n, n, idx->dim,
                        idx->dpad, idx->shadow, idx->irr_rows, idx->irr_count, idx->bf16_res2_dev);
@@ -616,6 +619,9 @@ static int add_rows_impl(mi355dr_index* idx, const float* rows, int64_t n, hipMe
     HIPCHECK(idx, hipMemcpyAsync(&res2, idx->bf16_res2_dev, sizeof(float), hipMemcpyDeviceToHost, s));
     HIPCHECK(idx, hipStreamSynchronize(s));
     idx->bf16_ec = std::min(std::sqrt(res2) * 1.001f, 0.00390625f * 1.0001f);  // (a-priori cap: 2^-8 |c_hat|)
+    float n2max = 0.0f;
+    HIPCHECK(idx, hipMemcpy(&n2max, idx->n2max_dev, sizeof(float), hipMemcpyDeviceToHost));
+    idx->cmax = std::sqrt(n2max) * 1.000001f;
     idx->irr_n = irr;
     idx->irr8_n = irr8;
     idx->n += n;
@@ -869,7 +875,7 @@ int mi355dr_debug_screen_dense(mi355dr_index* idx, const float* queries, int B, 
     hipStream_t s = idx->stream;
     HIPCHECK(idx, hipMemcpyAsync(idx->qdev, queries, (size_t)B * idx->dim * sizeof(float), hipMemcpyHostToDevice, s));
     const int Bpad = (int)round_up(B, screen_tile(B));
-    CHECK(launch_prep(idx, s, B, Bpad, /*metric=*/1));  // metric 1: thresholds at -inf for every query
+    CHECK(launch_prep(idx, s, B, Bpad, /*metric=*/2));  // test hook: thresholds at -inf for every query
     CHECK(launch_screen(idx, s, B, row0, row0 + n, kCandCap, /*emit_all=*/false));
     std::vector<int> cnt(B);
     std::vector<int32_t> crow((size_t)B * kCandCap);

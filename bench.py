@@ -48,6 +48,7 @@ def parse_args():
     ap.add_argument("--chunk0", type=int, default=0, help="override the first (emit-all) chunk size")
     ap.add_argument("--growth", type=int, default=0, help="override the chunk growth factor")
     ap.add_argument("--screen", choices=["auto", "bf16", "i8"], default="auto", help="screen element type")
+    ap.add_argument("--metric", choices=["cosine", "ip"], default="cosine", help="cosine (headline) or inner product")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the all-gather + merge path even at world size 1 (exercises the multi-GPU code on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -171,7 +172,7 @@ def main() -> None:
     row_hi = min(n_total, c_hi * CHUNK_ROWS)
     n_local = row_hi - row_lo
 
-    idx = pkg.Mi355Index(d, "cosine", device=local_rank)
+    idx = pkg.Mi355Index(d, args.metric, device=local_rank)
     idx.reserve(n_local)
     idx.set_option("row_offset", row_lo)
     if args.chunk0:
@@ -317,7 +318,7 @@ def main() -> None:
         "data": "synthetic",
         "config": {
             "workload": f"synthetic fp32 d={d} N={n_total} corpus (L2-normalised N(0,1)), {B}-query blocks, "
-                        f"exact cosine top-{k}",
+                        f"exact {'cosine' if args.metric == 'cosine' else 'inner-product'} top-{k}",
             "rows_total": n_total,
             "rows_per_gpu": n_local,
             "dim": d,
@@ -349,10 +350,10 @@ def main() -> None:
         Qs = qpool[0, :nq].cpu().numpy()
         cpu_ref.topk_search(Cs[:2048], Qs[:8], k)  # warm the library / thread pool
         tc = time.perf_counter()
-        rd, rr = cpu_ref.topk_search(Cs, Qs, k)
+        rd, rr = cpu_ref.topk_search(Cs, Qs, k, metric=args.metric)
         tc = time.perf_counter() - tc
         # parity on the very same sample, through the C ABI
-        with pkg.Mi355Index(d, "cosine", device=local_rank) as sidx:
+        with pkg.Mi355Index(d, args.metric, device=local_rank) as sidx:
             sidx.add(Cs)
             gd, gr = sidx.search(Qs, k)
         parity = bool(np.array_equal(gr, rr) and np.array_equal(gd, rd))

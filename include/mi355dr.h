@@ -59,7 +59,7 @@ enum { MI355DR_METRIC_COSINE = 0, MI355DR_METRIC_IP = 1 };
 /* Search strategies (option "path"). */
 enum {
     MI355DR_PATH_AUTO = 0,   /* screen where it applies, else scan */
-    MI355DR_PATH_SCREEN = 1, /* bf16 MFMA screen over the normalised shadow corpus + exact fp32 re-score */
+    MI355DR_PATH_SCREEN = 1, /* MFMA screen over the normalised shadow corpus + exact fp32 re-score (both metrics) */
     MI355DR_PATH_SCAN = 2    /* exact fp32 chain per (query,row); slow, guaranteed, also the in-library fallback */
 };
 

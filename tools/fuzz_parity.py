@@ -18,6 +18,11 @@ import autorag_research_amd as pkg  # noqa: E402
 from oracle import cpu_ref  # noqa: E402
 
 
+import os  # noqa: E402
+
+IP_PROB = float(os.environ.get("FUZZ_IP_PROB", "0.2"))  # share of inner-product cases among the single-vector ones
+
+
 def corpus(rng, n, d, mode):
     C = rng.standard_normal((n, d)).astype(np.float32)
     if mode == "scaled":
@@ -45,7 +50,7 @@ def check_single(rng, case):
     B = int(min(Bmax, rng.choice([1, 3, 33, 128, 129, 300, 777, 1024, 1500])))
     k = int(rng.choice([1, 3, 10, 24, 25, 64, 100, 300, 1024]))
     mode = str(rng.choice(["gauss", "scaled", "clustered", "dups", "spiky", "dirty"]))
-    metric = "ip" if rng.random() < 0.08 else "cosine"
+    metric = "ip" if rng.random() < IP_PROB else "cosine"
     C = corpus(rng, n, d, mode)
     Q = rng.standard_normal((B, d)).astype(np.float32)
     if mode in ("clustered", "dups") and B > 2:
