@@ -22,7 +22,8 @@ ABI_SYMBOLS = [
     "mi355dr_create", "mi355dr_destroy", "mi355dr_last_error", "mi355dr_version", "mi355dr_reserve",
     "mi355dr_add_rows", "mi355dr_add_rows_device", "mi355dr_size", "mi355dr_dim", "mi355dr_get_rows",
     "mi355dr_search", "mi355dr_search_device", "mi355dr_add_multivec", "mi355dr_size_multivec",
-    "mi355dr_search_maxsim", "mi355dr_maxsim_subset", "mi355dr_merge_topk_device", "mi355dr_pack_topk_device",
+    "mi355dr_search_maxsim", "mi355dr_maxsim_subset", "mi355dr_gqr_refine", "mi355dr_gqr_refine_maxsim",
+    "mi355dr_gqr_refine_scores", "mi355dr_merge_topk_device", "mi355dr_pack_topk_device",
     "mi355dr_merge_topk_packed_device", "mi355dr_set_option", "mi355dr_get_stat",
     "mi355dr_reset_stats", "mi355dr_timer_start", "mi355dr_timer_stop", "mi355dr_synchronize",
     "mi355dr_dev_alloc", "mi355dr_dev_free", "mi355dr_dev_upload", "mi355dr_dev_download",
@@ -110,6 +111,14 @@ def load() -> ctypes.CDLL:
     L.mi355dr_search_maxsim.argtypes = [vp, f32p, i32p, c_int, c_int, f32p, i64p]
     L.mi355dr_maxsim_subset.restype = c_int
     L.mi355dr_maxsim_subset.argtypes = [vp, f32p, i32p, c_int, i64p, c_int, f32p]
+    c_double = ctypes.c_double
+    L.mi355dr_gqr_refine.restype = c_int
+    L.mi355dr_gqr_refine.argtypes = [vp, f64p, c_int, i64p, c_int, f64p, c_int, c_double, c_double, c_double, f64p]
+    L.mi355dr_gqr_refine_maxsim.restype = c_int
+    L.mi355dr_gqr_refine_maxsim.argtypes = [vp, f64p, i32p, c_int, i64p, c_int, f64p, c_int, c_double, c_double, c_double,
+                                            f64p]
+    L.mi355dr_gqr_refine_scores.restype = c_int
+    L.mi355dr_gqr_refine_scores.argtypes = [vp, f64p, i32p, c_int, c_int, f64p, c_int, c_double, c_double, c_double, f64p]
     L.mi355dr_merge_topk_device.restype = c_int
     L.mi355dr_merge_topk_device.argtypes = [vp, vp, vp, c_int, c_int, c_int, vp, vp, vp]
     L.mi355dr_pack_topk_device.restype = c_int

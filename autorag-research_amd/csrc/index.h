@@ -96,6 +96,16 @@ namespace mi355 {
 
 int fail(mi355dr_index* idx, int code, const std::string& msg);  // mi355dr.hip
 void multivec_destroy(mi355dr_index* idx);                       // mi355dr_maxsim.hip
+// read-only view of the multi-vector store for kernels outside mi355dr_maxsim.hip (GQR refinement)
+struct MultiVecView {
+    const float* tok;             // [blocks*32, dpad] device
+    const int64_t* blk_off;       // [n_docs+1] device
+    const int64_t* blk_off_host;  // same, host
+    int dpad;
+    int64_t n_docs;
+};
+bool multivec_view(const mi355dr_index* idx, MultiVecView* out);  // false: no store yet
+int multivec_col_perm(int j);  // position j of a stored token row holds original column multivec_col_perm(j)
 
 #define HIPCHECK(idx, expr)                                                                              \
     do {                                                                                                 \

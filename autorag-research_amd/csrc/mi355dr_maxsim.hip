@@ -78,6 +78,17 @@ struct MultiVecStore {
     int64_t dist_cap_docs = 0;
 };
 
+bool multivec_view(const mi355dr_index* idx, MultiVecView* out) {
+    const MultiVecStore* m = idx->mv;
+    if (!m || m->n_docs == 0) return false;
+    out->tok = m->tok;
+    out->blk_off = m->blk_off;
+    out->blk_off_host = m->blk_off_host.data();
+    out->dpad = m->dpad;
+    out->n_docs = m->n_docs;
+    return true;
+}
+
 void multivec_destroy(mi355dr_index* idx) {
     MultiVecStore* m = idx->mv;
     if (!m) return;
@@ -117,6 +128,8 @@ __host__ __device__ inline int ms_perm(int j) {
     constexpr int P[8] = {0, 4, 2, 6, 1, 5, 3, 7};
     return (j & ~7) | P[j & 7];
 }
+
+int multivec_col_perm(int j) { return ms_perm(j); }
 
 __device__ __forceinline__ void ms_load_piece(float4 (&a)[16], const float* row, int chunk, int dpad) {
     // this lane's 4 floats of every 8-dim group of dims [128*chunk, +128); groups past dpad read as zero

@@ -158,6 +158,58 @@ class Mi355Index:
                                                        ptr(out, ctypes.c_float)))
         return out
 
+    # ---- Guided Query Refinement of candidate pools (reference gqr_hybrid.py:306-362) ----
+    @staticmethod
+    def _gqr_pool(pool, comp) -> tuple[np.ndarray, np.ndarray]:
+        pool = np.ascontiguousarray(pool, dtype=np.int64)
+        comp = np.ascontiguousarray(comp, dtype=np.float64)
+        if pool.ndim != 2 or comp.shape != pool.shape:
+            raise ValueError("candidate pool and complementary distribution must both be [B, P]")
+        return pool, comp
+
+    def gqr_refine(self, queries, cand_rows, comp_dist, n_steps: int, learning_rate: float, temperature: float,
+                   mixture_alpha: float) -> np.ndarray:
+        """Refine each query embedding against its candidate rows; returns the refined cosine scores float64 [B, P]
+        (NaN at the -1 padding of a pool)."""
+        pool, comp = self._gqr_pool(cand_rows, comp_dist)
+        q = np.ascontiguousarray(queries, dtype=np.float64).reshape(pool.shape[0], self.dim)
+        out = np.empty(pool.shape, dtype=np.float64)
+        check(self._h, self._lib.mi355dr_gqr_refine(
+            self._h, ptr(q, ctypes.c_double), pool.shape[0], ptr(pool, ctypes.c_int64), pool.shape[1],
+            ptr(comp, ctypes.c_double), int(n_steps), float(learning_rate), float(temperature), float(mixture_alpha),
+            ptr(out, ctypes.c_double)))
+        return out
+
+    def gqr_refine_maxsim(self, qtok, q_offsets, doc_ids, comp_dist, n_steps: int, learning_rate: float,
+                          temperature: float, mixture_alpha: float) -> np.ndarray:
+        """Multi-vector form: refine each query matrix against its candidate docs; refined mean-of-max scores [B, P]."""
+        pool, comp = self._gqr_pool(doc_ids, comp_dist)
+        q = np.ascontiguousarray(qtok, dtype=np.float64).reshape(-1, self.dim)
+        q_offsets = np.ascontiguousarray(q_offsets, dtype=np.int32)
+        if q_offsets.shape[0] != pool.shape[0] + 1 or int(q_offsets[-1]) != q.shape[0]:
+            raise ValueError("q_offsets must be [B+1] and end at the number of query vectors")
+        out = np.empty(pool.shape, dtype=np.float64)
+        check(self._h, self._lib.mi355dr_gqr_refine_maxsim(
+            self._h, ptr(q, ctypes.c_double), ptr(q_offsets, ctypes.c_int32), pool.shape[0], ptr(pool, ctypes.c_int64),
+            pool.shape[1], ptr(comp, ctypes.c_double), int(n_steps), float(learning_rate), float(temperature),
+            float(mixture_alpha), ptr(out, ctypes.c_double)))
+        return out
+
+    def gqr_refine_scores(self, primary_scores, counts, comp_dist, n_steps: int, learning_rate: float,
+                          temperature: float, mixture_alpha: float) -> np.ndarray:
+        """Score-space form (no vectors): the primary scores themselves are refined; [B, P], counts[b] live entries."""
+        z = np.ascontiguousarray(primary_scores, dtype=np.float64)
+        comp = np.ascontiguousarray(comp_dist, dtype=np.float64)
+        counts = np.ascontiguousarray(counts, dtype=np.int32)
+        if z.ndim != 2 or comp.shape != z.shape or counts.shape != (z.shape[0],):
+            raise ValueError("primary_scores / comp_dist must be [B, P] and counts [B]")
+        out = np.empty(z.shape, dtype=np.float64)
+        check(self._h, self._lib.mi355dr_gqr_refine_scores(
+            self._h, ptr(z, ctypes.c_double), ptr(counts, ctypes.c_int32), z.shape[0], z.shape[1],
+            ptr(comp, ctypes.c_double), int(n_steps), float(learning_rate), float(temperature), float(mixture_alpha),
+            ptr(out, ctypes.c_double)))
+        return out
+
     # ---- options / stats / timing ----
     def set_option(self, key: str, value: int | str) -> None:
         if key == "path" and isinstance(value, str):

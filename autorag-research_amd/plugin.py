@@ -5,6 +5,7 @@ copies the YAML files it finds in that module's package (flat or under `retrieva
 `configs/pipelines/retrieval/` on `autorag-research plugin sync`.  The YAMLs live in ./retrieval/.
 """
 
+from .gqr import Mi355GQRHybridPipelineConfig, Mi355GQRHybridRetrievalPipeline  # noqa: F401
 from .heaven import Mi355HEAVENPipelineConfig, Mi355HEAVENRetrievalPipeline  # noqa: F401
 from .pipelines import (  # noqa: F401
     Mi355ImageVectorSearchPipelineConfig,

@@ -90,6 +90,9 @@ class Mi355RetrievalService:
         for u in self._units.values():
             u.close()
         self._units.clear()
+        if getattr(self, "_scratch", None) is not None:
+            self._scratch.close()
+            self._scratch = None
 
     def get_or_create_pipeline(self, name: str, config: dict[str, Any]) -> tuple[int, bool]:
         return self._store().get_or_create_pipeline(name, config)
@@ -187,6 +190,64 @@ class Mi355RetrievalService:
         rows = np.array([[p for _, p in known]], dtype=np.int64)
         dist = ix.maxsim_subset(q, np.array([0, q.shape[0]], dtype=np.int32), rows)[0]
         return {pk: -float(dv) / q.shape[0] for (pk, _), dv in zip(known, dist) if dv == dv}
+
+    # ---- Guided Query Refinement support (reference retrieval_pipeline.py:573-641 + gqr_hybrid.py:306-362) ----
+    def get_query_embedding(self, query_id) -> np.ndarray | None:
+        """Stored single-vector query embedding as float64, None when the query or its embedding is missing (:573-587)."""
+        q = self._store().get_query(query_id)
+        return None if q is None or q.embedding is None else np.asarray(q.embedding, dtype=np.float64)
+
+    def get_query_multi_embedding(self, query_id) -> np.ndarray | None:
+        """Stored multi-vector query embedding [n_q, d] float64, or None (:589-603)."""
+        q = self._store().get_query(query_id)
+        return None if q is None or q.embeddings is None else np.asarray(q.embeddings, dtype=np.float64)
+
+    def _gqr_handle(self) -> Mi355Index:
+        """Any native handle (the score-space refinement needs a device, not an index)."""
+        u = self._unit("chunk")
+        if u.single is not None or u.multi is not None:
+            return u.single if u.single is not None else u.multi
+        if getattr(self, "_scratch", None) is None:
+            self._scratch = Mi355Index(8, "cosine", self._device)
+        return self._scratch
+
+    def chunk_rows_single(self, doc_ids: list) -> np.ndarray | None:
+        """Index rows of chunks, or None when one of them has no stored single-vector embedding (the reference's
+        `len(embedding_ids) == len(candidate_ids)` test, gqr_hybrid.py:454-456)."""
+        u = self._unit("chunk")
+        if u.table.embedding is None:
+            return None
+        u.ensure_single()
+        inv = getattr(u, "_row_of_pos", None)
+        if inv is None:
+            inv = u._row_of_pos = {int(p): r for r, p in enumerate(u.single_rows)}
+            u._pos_of_id = getattr(u, "_pos_of_id", None) or {pk: i for i, pk in enumerate(u.table.ids)}
+        rows = [inv.get(u._pos_of_id.get(pk, -1), -1) for pk in doc_ids]
+        return None if any(r < 0 for r in rows) else np.asarray(rows, dtype=np.int64)
+
+    def chunk_rows_multi(self, doc_ids: list) -> np.ndarray | None:
+        """Same for multi-vector embeddings (gqr_hybrid.py:439-441)."""
+        u = self._unit("chunk")
+        off = u.table.mv_offsets
+        if off is None:
+            return None
+        u.ensure_multi()
+        if getattr(u, "_pos_of_id", None) is None:
+            u._pos_of_id = {pk: i for i, pk in enumerate(u.table.ids)}
+        pos = [u._pos_of_id.get(pk, -1) for pk in doc_ids]
+        if any(p < 0 or off[p + 1] <= off[p] for p in pos):
+            return None
+        return np.asarray(pos, dtype=np.int64)
+
+    def gqr_refine_single(self, queries: np.ndarray, pools: np.ndarray, comp: np.ndarray, **prm) -> np.ndarray:
+        return self._unit("chunk").ensure_single().gqr_refine(queries, pools, comp, **prm)
+
+    def gqr_refine_multi(self, qtok: np.ndarray, q_offsets: np.ndarray, pools: np.ndarray, comp: np.ndarray,
+                         **prm) -> np.ndarray:
+        return self._unit("chunk").ensure_multi().gqr_refine_maxsim(qtok, q_offsets, pools, comp, **prm)
+
+    def gqr_refine_scores(self, primary: np.ndarray, counts: np.ndarray, comp: np.ndarray, **prm) -> np.ndarray:
+        return self._gqr_handle().gqr_refine_scores(primary, counts, comp, **prm)
 
     # ---- batch driver (reference _run_pipeline) ----
     @staticmethod

@@ -113,6 +113,27 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
 int mi355dr_maxsim_subset(mi355dr_index* idx, const float* qtok, const int32_t* q_offsets, int B, const int64_t* doc_ids,
                           int m, float* out_dist);
 
+/* ---- Guided Query Refinement of candidate pools (GQR hybrid pipeline) ----
+ * Replaces the per-query numpy loops of autorag_research/pipelines/retrieval/gqr_hybrid.py: `_optimize_query_embedding`
+ * (:321-340), `_optimize_query_multi_embedding` (:342-362), `_optimize_in_score_space` (:306-319).  Float64 throughout
+ * (the reference's arithmetic type); a block of B queries is one launch, one workgroup per query; the candidate vectors
+ * are the rows already resident in HBM, named by global row id.  Pools: host [B, P], live ids first, -1 padding after
+ * (P <= 2048); comp_dist: host [B, P] complementary distribution (gqr_hybrid.py:436); out_scores: host [B, P], NaN at
+ * padding.  n_steps > 0, learning_rate > 0, temperature > 0, 0 <= mixture_alpha <= 1 (:202-216), else MI355DR_E_INVALID.
+ *   mi355dr_gqr_refine         queries: host [B, dim] float64; candidates = single-vector rows; out = refined cosine
+ *   mi355dr_gqr_refine_maxsim  qtok: host [sum_nq, dim] float64, q_offsets [B+1] (every query >= 1 vector); candidates =
+ *                              multi-vector docs (each must have vectors); out = refined mean-of-max late-interaction score
+ *   mi355dr_gqr_refine_scores  no vectors: primary_scores host [B, P] float64 are the variables, counts[b] live entries */
+int mi355dr_gqr_refine(mi355dr_index* idx, const double* queries, int B, const int64_t* cand_rows, int P,
+                       const double* comp_dist, int n_steps, double learning_rate, double temperature,
+                       double mixture_alpha, double* out_scores);
+int mi355dr_gqr_refine_maxsim(mi355dr_index* idx, const double* qtok, const int32_t* q_offsets, int B,
+                              const int64_t* doc_ids, int P, const double* comp_dist, int n_steps, double learning_rate,
+                              double temperature, double mixture_alpha, double* out_scores);
+int mi355dr_gqr_refine_scores(mi355dr_index* idx, const double* primary_scores, const int32_t* counts, int B, int P,
+                              const double* comp_dist, int n_steps, double learning_rate, double temperature,
+                              double mixture_alpha, double* out_scores);
+
 /* ---- shard merge (multi-GPU): [world, B, k] gathered (dist,row) device buffers -> [B, k] ----
  * The merge functions only enqueue work on `stream` (NULL: the index's stream); synchronise that stream (or call
  * mi355dr_synchronize for the index stream) before reading the outputs on the host. */

@@ -22,6 +22,11 @@ Fixtures written next to this file:
                            and ImageVectorSearchRetrievalPipeline._retrieve_by_id
                            (pipelines/retrieval/image_vector_search.py:65-94) driven over a fake
                            Unit-of-Work whose SQL operators are answered by the CPU oracle.
+  gqr_golden.npz / .json   Guided Query Refinement: outputs of GQRHybridRetrievalPipeline._optimize_query_embedding /
+                           _optimize_query_multi_embedding / _optimize_in_score_space (pipelines/retrieval/
+                           gqr_hybrid.py:306-362) on seeded pools, and of _retrieve_by_id (:472-489) over the fake
+                           Unit-of-Work with recorded child-pipeline results (embedding, multi-vector and score-space
+                           branches of _run_gqr, :415-470).
 """
 
 from __future__ import annotations
@@ -75,7 +80,12 @@ sys.modules["pgvector.sqlalchemy"].Vector = _Vector  # type: ignore[attr-defined
 from autorag_research.evaluation.metrics import retrieval as ref_metrics  # noqa: E402
 from autorag_research.evaluation.metrics.util import calculate_cosine_similarity  # noqa: E402
 from autorag_research.orm.service.retrieval_pipeline import RetrievalPipelineService  # noqa: E402
-from autorag_research.pipelines.retrieval.gqr_hybrid import _cosine_scores, _maxsim_scores  # noqa: E402
+from autorag_research.pipelines.retrieval.gqr_hybrid import (  # noqa: E402
+    GQRHybridRetrievalPipeline,
+    _cosine_scores,
+    _maxsim_scores,
+    _softmax,
+)
 from autorag_research.pipelines.retrieval.heaven import HEAVENRetrievalPipeline  # noqa: E402
 from autorag_research.pipelines.retrieval.image_vector_search import ImageVectorSearchRetrievalPipeline  # noqa: E402
 from autorag_research.pipelines.retrieval.vector_search import VectorSearchRetrievalPipeline  # noqa: E402
@@ -246,7 +256,8 @@ class _FakeChunkRepo:
             if pk in pos:
                 i = pos[pk]
                 emb = [[float(x) for x in v] for v in self.tok[self.offsets[i]:self.offsets[i + 1]]]
-                out.append(_Obj(id=pk, contents=self.contents[i], embeddings=emb))
+                single = None if self.single is None else [float(x) for x in self.single[i]]
+                out.append(_Obj(id=pk, contents=self.contents[i], embeddings=emb, embedding=single))
         return out
 
     def maxsim_search(self, query_vectors, vector_column="embeddings", limit=10):
@@ -284,6 +295,9 @@ class _FakeService(RetrievalPipelineService):
         return self._uow
 
 
+_LAST: dict = {}  # the fake service of make_service(), reused by make_gqr_flow
+
+
 def make_service() -> dict:
     rng = np.random.default_rng(4242)
     n, d = 300, 32
@@ -311,6 +325,7 @@ def make_service() -> dict:
     img_ids = [f"img-{i}" for i in range(n)]  # VARCHAR pks
     img_repo = _FakeChunkRepo(img_ids, [None] * n, single=C, tok=tok, offsets=offsets)
     svc = _FakeService(_FakeUow(queries, chunk_repo, img_repo))
+    _LAST.update(svc=svc, ids=ids)
 
     out = {"seed": 4242, "n": n, "d": d, "dm": dm, "chunk_ids": ids, "image_chunk_ids": img_ids, "top_k": 7}
     k = 7
@@ -362,10 +377,153 @@ def make_service() -> dict:
     return out
 
 
+# --------------------------------------------------------------------------------------
+# 4. Guided Query Refinement
+# --------------------------------------------------------------------------------------
+
+GQR_PARAM_SETS = [  # (n_steps, learning_rate, temperature, mixture_alpha)
+    (25, 0.1, 1.0, 0.5),   # the reference defaults (gqr_hybrid.py:137-140)
+    (3, 0.5, 0.05, 1.0),   # sharp softmax, pure complementary target
+    (40, 1.5, 0.3, 0.25),  # long run, large steps
+]
+
+
+def _gqr(n_steps, lr, temperature, alpha, **kw):
+    p = GQRHybridRetrievalPipeline.__new__(GQRHybridRetrievalPipeline)
+    p.n_steps, p.learning_rate, p.temperature, p.mixture_alpha = n_steps, lr, temperature, alpha
+    p.fetch_k_multiplier, p.candidate_pool_mode, p.scorer_mode = 2, "union", "auto"
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def make_gqr_arrays() -> dict[str, np.ndarray]:
+    rng = np.random.default_rng(31337)
+    out: dict[str, np.ndarray] = {"params": np.array(GQR_PARAM_SETS, dtype=np.float64)}
+    # ---- single-vector pools over a small corpus
+    n, d, P = 80, 48, 40
+    C = rng.standard_normal((n, d)).astype(np.float32)
+    C[5] *= 25.0
+    C[6] *= 1e-3
+    C[7] = 0.0  # zero row: its norm is floored at eps
+    sizes = [1, 7, 20, 40, 33, 12]
+    pools = np.full((len(sizes), P), -1, dtype=np.int64)
+    comp = np.zeros((len(sizes), P))
+    Q = rng.standard_normal((len(sizes), d)).astype(np.float32).astype(np.float64)
+    Q[4] = 0.0  # zero query: scores and gradients vanish
+    for b, m in enumerate(sizes):
+        pools[b, :m] = rng.choice(n, size=m, replace=False)
+        comp[b, :m] = _softmax(rng.standard_normal(m) * 2.0, 1.0)
+    pools[2, :3] = [5, 6, 7]
+    out.update(single_C=C, single_pools=pools, single_comp=comp, single_Q=Q)
+    exp = np.full((len(GQR_PARAM_SETS), len(sizes), P), np.nan)
+    for s_i, prm in enumerate(GQR_PARAM_SETS):
+        p = _gqr(*prm)
+        for b, m in enumerate(sizes):
+            exp[s_i, b, :m] = p._optimize_query_embedding(Q[b], C[pools[b, :m]].astype(np.float64), comp[b, :m])
+    out["single_expected"] = exp
+    # ---- multi-vector pools
+    dm = 16
+    lens = rng.integers(1, 70, size=50)
+    tok = rng.standard_normal((int(lens.sum()), dm)).astype(np.float32)
+    tok /= np.linalg.norm(tok, axis=1, keepdims=True)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    docs = [tok[off[i]:off[i + 1]] for i in range(len(lens))]
+    q_lens = [1, 3, 17, 32]
+    qtok = rng.standard_normal((sum(q_lens), dm)).astype(np.float32)
+    qtok /= np.linalg.norm(qtok, axis=1, keepdims=True)
+    qoff = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
+    Pm = 24
+    msizes = [24, 5, 13, 1]
+    mpools = np.full((len(q_lens), Pm), -1, dtype=np.int64)
+    mcomp = np.zeros((len(q_lens), Pm))
+    for b, m in enumerate(msizes):
+        mpools[b, :m] = rng.choice(len(lens), size=m, replace=False)
+        mcomp[b, :m] = _softmax(rng.standard_normal(m), 0.5)
+    out.update(multi_tok=tok, multi_off=off, multi_qtok=qtok.astype(np.float64), multi_qoff=qoff, multi_pools=mpools,
+               multi_comp=mcomp)
+    mexp = np.full((len(GQR_PARAM_SETS), len(q_lens), Pm), np.nan)
+    for s_i, prm in enumerate(GQR_PARAM_SETS):
+        p = _gqr(*prm)
+        for b, m in enumerate(msizes):
+            mexp[s_i, b, :m] = p._optimize_query_multi_embedding(
+                qtok[qoff[b]:qoff[b + 1]].astype(np.float64), [docs[i].astype(np.float64) for i in mpools[b, :m]],
+                mcomp[b, :m])
+    out["multi_expected"] = mexp
+    # ---- score-space form
+    Ps = 30
+    ssizes = [30, 1, 9, 18]
+    prim = np.zeros((len(ssizes), Ps))
+    scomp = np.zeros((len(ssizes), Ps))
+    for b, m in enumerate(ssizes):
+        prim[b, :m] = rng.standard_normal(m) * (10.0 if b == 3 else 1.0)  # BM25-sized raw scores in one row
+        scomp[b, :m] = _softmax(rng.standard_normal(m), 1.0)
+    out.update(score_primary=prim, score_comp=scomp, score_counts=np.array(ssizes, dtype=np.int32))
+    sexp = np.full((len(GQR_PARAM_SETS), len(ssizes), Ps), np.nan)
+    for s_i, prm in enumerate(GQR_PARAM_SETS):
+        p = _gqr(*prm)
+        for b, m in enumerate(ssizes):
+            sexp[s_i, b, :m] = p._optimize_in_score_space(prim[b, :m], scomp[b, :m])
+    out["score_expected"] = sexp
+    return out
+
+
+class _RecordedChild:
+    """A child retrieval pipeline that answers from a recorded table (what the test replays on the MI355X side)."""
+
+    def __init__(self, name, table, search_mode="single"):
+        self.name, self._table, self.search_mode = name, table, search_mode
+        self._embedding_model = None
+
+    async def _retrieve_by_id(self, query_id, top_k):
+        return [dict(r) for r in self._table[query_id][:top_k]]
+
+
+def make_gqr_flow(svc: "_FakeService", chunk_ids: list) -> dict:
+    """_retrieve_by_id of the reference pipeline over the fake UoW of make_service (same seeds), with a recorded
+    lexical child as the complementary retriever (a BM25 stand-in: arbitrary positive scores, partly disjoint ids)."""
+    rng = np.random.default_rng(99)
+    k = 5
+    loop = asyncio.new_event_loop()
+
+    def primary(mode):
+        p = VectorSearchRetrievalPipeline.__new__(VectorSearchRetrievalPipeline)
+        p.search_mode, p._service, p._embedding_model, p.name = mode, svc, None, f"vs_{mode}"
+        return p
+
+    lexical = {}
+    for qi in range(6):
+        picks = [int(x) for x in rng.choice(len(chunk_ids), size=10, replace=False)]
+        scores = np.sort(rng.gamma(2.0, 4.0, size=10))[::-1]
+        lexical[f"q{qi}"] = [{"doc_id": chunk_ids[i], "score": float(s), "content": f"chunk text {i}"}
+                             for i, s in zip(picks, scores)]
+    # q5's lexical list names a chunk that does not exist: its embedding is missing -> score-space branch
+    lexical["q5"][2]["doc_id"] = 999_999
+    out = {"top_k": k, "lexical": lexical, "cases": []}
+    cases = [
+        ("single_union", "single", "union", "auto", (25, 0.1, 1.0, 0.5), ["q0", "q1", "q2"]),
+        ("single_primary_pool", "single", "primary", "auto", (25, 0.1, 1.0, 0.5), ["q3"]),
+        ("multi_union", "multi", "union", "auto", (10, 0.2, 0.5, 0.7), ["q1", "q4"]),
+        ("multi_primary_forced_single", "multi", "union", "single", (25, 0.1, 1.0, 0.5), ["q2"]),
+        ("score_space_fallback", "single", "union", "auto", (25, 0.1, 1.0, 0.5), ["q5"]),
+    ]
+    for name, mode, pool_mode, scorer, prm, qids in cases:
+        p = _gqr(*prm, candidate_pool_mode=pool_mode, scorer_mode=scorer, _service=svc,
+                 _primary_retrieval_pipeline=primary(mode),
+                 _complementary_retrieval_pipeline=_RecordedChild("lexical", lexical))
+        res = {qid: loop.run_until_complete(p._retrieve_by_id(qid, k)) for qid in qids}
+        out["cases"].append({"name": name, "primary_search_mode": mode, "candidate_pool_mode": pool_mode,
+                             "scorer_mode": scorer, "params": list(prm), "results": res})
+    loop.close()
+    return out
+
+
 def main() -> None:
     (HERE / "metrics_golden.json").write_text(json.dumps(make_metrics(), indent=1))
     np.savez_compressed(HERE / "scores_golden.npz", **make_scores())
     (HERE / "service_golden.json").write_text(json.dumps(make_service(), indent=1))
+    np.savez_compressed(HERE / "gqr_golden.npz", **make_gqr_arrays())
+    (HERE / "gqr_golden.json").write_text(json.dumps(make_gqr_flow(_LAST["svc"], _LAST["ids"]), indent=1))
     print("wrote", sorted(p.name for p in HERE.iterdir()))
 
 

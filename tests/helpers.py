@@ -60,6 +60,43 @@ class OracleIndex:
                     out[b, j] = self._o.maxsim_distance(self._tok[self._off[i]:self._off[i + 1]], qb)
         return out
 
+    # ---- GQR refinement: same surface as Mi355Index.gqr_refine*, answered by oracle/gqr_ref.py ----
+    def gqr_refine(self, queries, cand_rows, comp_dist, n_steps, learning_rate, temperature, mixture_alpha):
+        from oracle import gqr_ref
+
+        pools = np.asarray(cand_rows, dtype=np.int64)
+        out = np.full(pools.shape, np.nan)
+        C = self._rows.astype(np.float64)
+        for b in range(pools.shape[0]):
+            m = int((pools[b] >= 0).sum())
+            out[b, :m] = gqr_ref.refine_single(np.asarray(queries, dtype=np.float64)[b], C[pools[b, :m] - self.row_offset],
+                                               np.asarray(comp_dist)[b, :m], n_steps, learning_rate, temperature,
+                                               mixture_alpha)
+        return out
+
+    def gqr_refine_maxsim(self, qtok, q_offsets, doc_ids, comp_dist, n_steps, learning_rate, temperature, mixture_alpha):
+        from oracle import gqr_ref
+
+        pools = np.asarray(doc_ids, dtype=np.int64)
+        out = np.full(pools.shape, np.nan)
+        q = np.asarray(qtok, dtype=np.float64).reshape(-1, self.dim)
+        for b in range(pools.shape[0]):
+            m = int((pools[b] >= 0).sum())
+            docs = [self._tok[self._off[i]:self._off[i + 1]] for i in pools[b, :m] - self.row_offset]
+            out[b, :m] = gqr_ref.refine_multi(q[q_offsets[b]:q_offsets[b + 1]], docs, np.asarray(comp_dist)[b, :m],
+                                              n_steps, learning_rate, temperature, mixture_alpha)
+        return out
+
+    def gqr_refine_scores(self, primary_scores, counts, comp_dist, n_steps, learning_rate, temperature, mixture_alpha):
+        from oracle import gqr_ref
+
+        z = np.asarray(primary_scores, dtype=np.float64)
+        out = np.full(z.shape, np.nan)
+        for b, m in enumerate(counts):
+            out[b, :m] = gqr_ref.refine_scores(z[b, :m], np.asarray(comp_dist)[b, :m], n_steps, learning_rate,
+                                               temperature, mixture_alpha)
+        return out
+
     def set_option(self, key, value):
         if key == "row_offset":
             self.row_offset = int(value)
@@ -89,6 +126,48 @@ def service_golden_inputs():
     multivec = [tok[offsets[i]:offsets[i + 1]] for i in range(n)]
     return dict(C=C, ids=ids, contents=contents, tok=tok, offsets=offsets, multivec=multivec, Q=Q, Qm=Qm,
                 img_ids=[f"img-{i}" for i in range(n)])
+
+
+def load_gqr_golden():
+    return np.load(GOLDEN / "gqr_golden.npz"), json.loads((GOLDEN / "gqr_golden.json").read_text())
+
+
+class RecordedChild:
+    """A child retrieval pipeline answering from a recorded table (the lexical retriever of gqr_golden.json)."""
+
+    retrieval_unit = "chunk"
+
+    def __init__(self, name, table, search_mode="single"):
+        self.name, self._table, self.search_mode, self._embedding_model = name, table, search_mode, None
+
+    async def _retrieve_by_id(self, query_id, top_k):
+        return [dict(r) for r in self._table[query_id][:top_k]]
+
+
+def check_gqr_flow(store, make_primary, atol=1e-9):
+    """Replay every case of gqr_golden.json through Mi355GQRHybridRetrievalPipeline (per query AND as one block) and
+    compare with the reference's _retrieve_by_id output: same ids in the same order, scores within atol."""
+    import asyncio
+
+    from autorag_research_amd.gqr import Mi355GQRHybridRetrievalPipeline
+
+    _, flow = load_gqr_golden()
+    k = flow["top_k"]
+    for case in flow["cases"]:
+        n_steps, lr, temp, alpha = case["params"]
+        p = Mi355GQRHybridRetrievalPipeline(
+            lambda: store, f"gqr_{case['name']}", make_primary(case["primary_search_mode"]),
+            RecordedChild("lexical", flow["lexical"]), n_steps=int(n_steps), learning_rate=lr, temperature=temp,
+            mixture_alpha=alpha, candidate_pool_mode=case["candidate_pool_mode"], scorer_mode=case["scorer_mode"])
+        qids = list(case["results"])
+        per_query = [asyncio.run(p._retrieve_by_id(q, k)) for q in qids]
+        block = p._retrieve_block(qids, k)
+        for qid, got, got_b in zip(qids, per_query, block):
+            exp = case["results"][qid]
+            for res in (got, got_b):
+                assert [r["doc_id"] for r in res] == [r["doc_id"] for r in exp], (case["name"], qid)
+                assert np.allclose([r["score"] for r in res], [r["score"] for r in exp], rtol=0, atol=atol), (case["name"], qid)
+        p.close()
 
 
 def load_service_golden():

@@ -110,3 +110,33 @@ def test_ragged_maxsim_empty_docs(oracle):
     dist, rows = oracle.maxsim_topk(tok, off, q, np.array([0, 2], np.int32), 5)
     assert set(rows[0][:3]) == {0, 2, 3} and (rows[0][3:] == -1).all()
     assert (np.diff(dist[0][:3]) >= 0).all()
+
+
+def test_gqr_oracle_matches_reference_loops():
+    """oracle/gqr_ref.py vs the reference's _optimize_query_embedding / _optimize_query_multi_embedding /
+    _optimize_in_score_space outputs (tests/golden/gqr_golden.npz, generated by importing gqr_hybrid.py)."""
+    import numpy as np
+
+    from helpers import load_gqr_golden
+    from oracle import gqr_ref as G
+
+    g, _ = load_gqr_golden()
+    C = g["single_C"].astype(np.float64)
+    tok, off, qoff = g["multi_tok"].astype(np.float64), g["multi_off"], g["multi_qoff"]
+    for s, (n, lr, T, a) in enumerate(g["params"]):
+        n = int(n)
+        for b, pool in enumerate(g["single_pools"]):
+            m = int((pool >= 0).sum())
+            got = G.refine_single(g["single_Q"][b], C[pool[:m]], g["single_comp"][b, :m], n, lr, T, a)
+            assert np.allclose(got, g["single_expected"][s, b, :m], rtol=0, atol=1e-12)
+            assert np.isnan(g["single_expected"][s, b, m:]).all()
+        for b, pool in enumerate(g["multi_pools"]):
+            m = int((pool >= 0).sum())
+            docs = [tok[off[i]:off[i + 1]] for i in pool[:m]]
+            got = G.refine_multi(g["multi_qtok"][qoff[b]:qoff[b + 1]], docs, g["multi_comp"][b, :m], n, lr, T, a)
+            assert np.allclose(got, g["multi_expected"][s, b, :m], rtol=0, atol=1e-12)
+        for b, m in enumerate(g["score_counts"]):
+            got = G.refine_scores(g["score_primary"][b, :m], g["score_comp"][b, :m], n, lr, T, a)
+            assert np.allclose(got, g["score_expected"][s, b, :m], rtol=0, atol=1e-12)
+    # the zero query and the zero candidate row of the fixture (norm floors, gqr_hybrid.py:68-73)
+    assert (g["single_expected"][:, 4, :33] == 0).all() and g["single_expected"][0, 2, 2] == 0.0
