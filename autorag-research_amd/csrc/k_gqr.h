@@ -183,7 +183,9 @@ __global__ __launch_bounds__(kGqrThreads) void k_gqr_scores(GqrScoreArgs a) {
 // block repeats the last token (so the FIRST maximum is always a real token, np.argmax's rule), columns are permuted
 // inside groups of 8 and zero-padded to dpad -- the query matrix is handed over in the same column order, and since
 // only scores leave the kernel the permutation never has to be undone.
-constexpr int kGqrQChunk = 16;  // query vectors scored per sweep over a doc's tokens (accumulators in registers)
+constexpr int kGqrQChunk = 16;  // query vectors per MFMA tile (v_mfma_f64_16x16x4_f64: 16 query vectors x 16 tokens)
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 struct GqrMultiArgs {
     const float* tok;        // [blocks*32, dpad]
@@ -199,73 +201,131 @@ struct GqrMultiArgs {
     GqrParams prm;
 };
 
-// dynamic LDS (doubles): Q[nq_pad * dpad] | sc[P] | comp[P] | g[P] | red[4]
+// Q rows sit dpad + 2 doubles apart in LDS: the 16 lanes of an MFMA operand read (ds_read_b128 of 16 different rows,
+// same column) then fall into different banks instead of one
+__host__ __device__ inline int gqr_multi_ld(int dpad) { return dpad + 2; }
+// dynamic LDS (doubles): Q[nq_pad * ld] | sc[P] | comp[P] | g[P] | red[4]
 __host__ __device__ inline size_t gqr_multi_lds(int nq_pad, int dpad, int P) {
-    return ((size_t)nq_pad * dpad + 3 * (size_t)P + 4) * sizeof(double);
+    return ((size_t)nq_pad * gqr_multi_ld(dpad) + 3 * (size_t)P + 4) * sizeof(double);
 }
 
+// two 16-token tiles x 16 query vectors over the whole dimension; KSTEPS > 0: dpad == 16*KSTEPS, everything unrolled
+// and all token loads issued before the first MFMA; KSTEPS == 0: any dpad (multiple of 8)
+template <int KSTEPS>
+__device__ __forceinline__ void gqr_tile_pair(const float* ta, const float* tb, const double* qrow, int kk, int dp,
+                                              f64x4& acc_a, f64x4& acc_b) {
+    if constexpr (KSTEPS > 0) {
+        float4 xa[KSTEPS], xb[KSTEPS];
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            xa[s] = *(const float4*)(ta + 16 * s + 4 * kk);
+            xb[s] = *(const float4*)(tb + 16 * s + 4 * kk);
+        }
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            const double* qp = qrow + 16 * s + 4 * kk;
+            const double q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3];
+            acc_a = __builtin_amdgcn_mfma_f64_16x16x4f64(q0, (double)xa[s].x, acc_a, 0, 0, 0);
+            acc_b = __builtin_amdgcn_mfma_f64_16x16x4f64(q0, (double)xb[s].x, acc_b, 0, 0, 0);
+            acc_a = __builtin_amdgcn_mfma_f64_16x16x4f64(q1, (double)xa[s].y, acc_a, 0, 0, 0);
+            acc_b = __builtin_amdgcn_mfma_f64_16x16x4f64(q1, (double)xb[s].y, acc_b, 0, 0, 0);
+            acc_a = __builtin_amdgcn_mfma_f64_16x16x4f64(q2, (double)xa[s].z, acc_a, 0, 0, 0);
+            acc_b = __builtin_amdgcn_mfma_f64_16x16x4f64(q2, (double)xb[s].z, acc_b, 0, 0, 0);
+            acc_a = __builtin_amdgcn_mfma_f64_16x16x4f64(q3, (double)xa[s].w, acc_a, 0, 0, 0);
+            acc_b = __builtin_amdgcn_mfma_f64_16x16x4f64(q3, (double)xb[s].w, acc_b, 0, 0, 0);
+        }
+    } else {
+        for (int K = 0; K < dp; K += 16) {
+            const int k = K + 4 * kk;
+            float4 xa = make_float4(0.f, 0.f, 0.f, 0.f), xb = xa;
+            double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+            if (k < dp) {  // dpad is a multiple of 8: the last K-step may cover only half of the lanes
+                xa = *(const float4*)(ta + k);
+                xb = *(const float4*)(tb + k);
+                q0 = qrow[k];
+                q1 = qrow[k + 1];
+                q2 = qrow[k + 2];
+                q3 = qrow[k + 3];
+            }
+            acc_a = __builtin_amdgcn_mfma_f64_16x16x4f64(q0, (double)xa.x, acc_a, 0, 0, 0);
+            acc_b = __builtin_amdgcn_mfma_f64_16x16x4f64(q0, (double)xb.x, acc_b, 0, 0, 0);
+            acc_a = __builtin_amdgcn_mfma_f64_16x16x4f64(q1, (double)xa.y, acc_a, 0, 0, 0);
+            acc_b = __builtin_amdgcn_mfma_f64_16x16x4f64(q1, (double)xb.y, acc_b, 0, 0, 0);
+            acc_a = __builtin_amdgcn_mfma_f64_16x16x4f64(q2, (double)xa.z, acc_a, 0, 0, 0);
+            acc_b = __builtin_amdgcn_mfma_f64_16x16x4f64(q2, (double)xb.z, acc_b, 0, 0, 0);
+            acc_a = __builtin_amdgcn_mfma_f64_16x16x4f64(q3, (double)xa.w, acc_a, 0, 0, 0);
+            acc_b = __builtin_amdgcn_mfma_f64_16x16x4f64(q3, (double)xb.w, acc_b, 0, 0, 0);
+        }
+    }
+}
+
+// Scores: S = Q D^T per candidate doc on the f64 matrix pipe, 16 query vectors x 16 tokens per accumulator tile.
+// Operand maps of v_mfma_f64_16x16x4_f64 (MI355X guide): A[l&15][k = l>>4], B[k = l>>4][l&15], one f64 per lane;
+// D: col = l&15, row = (l>>4) + 4*reg.  Lane l therefore loads 4 consecutive dims (k = K + 4*(l>>4) .. +3) of query
+// vector i0 + (l&15) from LDS and of token t0 + (l&15) from HBM/L2 (a float4, widened to double) and feeds them to 4
+// MFMAs; which k a lane holds does not matter as long as A and B agree.
 __global__ __launch_bounds__(kGqrThreads) void k_gqr_multi(GqrMultiArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int dp = a.dpad, ld = gqr_multi_ld(dp);
     double* Q = (double*)smem;
-    double* sc = Q + (size_t)a.nq_pad * a.dpad;
+    double* sc = Q + (size_t)a.nq_pad * ld;
     double* comp = sc + a.P;
     double* g = comp + a.P;
     double* red = g + a.P;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nq = a.q_off[b + 1] - a.q_off[b];
-    const int dp = a.dpad;
     const int32_t* cand = a.cand + (int64_t)b * a.P;
     int32_t* arg = a.arg_ws + (int64_t)b * a.P * a.nq_pad;
     int n = 0;
     for (int j = tid; j < a.P; j += kGqrThreads) n += cand[j] >= 0;
     n = (int)(gqr_block_sum((double)n, red) + 0.5);
-    for (int e = tid; e < a.nq_pad * dp; e += kGqrThreads)
-        Q[e] = e < nq * dp ? a.q0[(int64_t)a.q_off[b] * dp + e] : 0.0;
+    for (int e = tid; e < a.nq_pad * dp; e += kGqrThreads) {
+        const int i = e / dp, k = e - i * dp;
+        Q[(size_t)i * ld + k] = i < nq ? a.q0[((int64_t)a.q_off[b] + i) * dp + k] : 0.0;
+    }
     for (int j = tid; j < n; j += kGqrThreads) comp[j] = a.comp[(int64_t)b * a.P + j];
     __syncthreads();
     const double den = (double)max(nq, 1);
+    const int col = lane & 15, kk = lane >> 4;
     for (int step = 0; step <= a.prm.n_steps; ++step) {
-        // ---- scores: one wave per candidate, lanes over its tokens, kGqrQChunk query vectors per sweep
+        // ---- scores: one wave per candidate doc
         for (int j = wave; j < n; j += kGqrThreads / 64) {
             const int64_t r0 = a.blk_off[cand[j]] * 32, r1 = a.blk_off[cand[j] + 1] * 32;
             double total = 0.0;
             for (int i0 = 0; i0 < nq; i0 += kGqrQChunk) {
-                double best[kGqrQChunk];
-                int barg[kGqrQChunk];
+                const double* qrow = Q + (size_t)(i0 + col) * ld;
+                double best[4];
+                int barg[4];
 #pragma unroll
-                for (int ii = 0; ii < kGqrQChunk; ++ii) {
-                    best[ii] = -__builtin_inf();
-                    barg[ii] = 0x7FFFFFFF;
+                for (int r = 0; r < 4; ++r) {
+                    best[r] = -__builtin_inf();
+                    barg[r] = 0x7FFFFFFF;
                 }
-                for (int64_t r = r0 + lane; r < r1; r += 64) {
-                    const float* row = a.tok + r * dp;
-                    double acc[kGqrQChunk];
+                for (int64_t t0 = r0; t0 < r1; t0 += 32) {  // docs own whole 32-row blocks: two 16-token tiles at a time
+                    const float* ta = a.tok + (t0 + col) * dp;
+                    const float* tb = ta + 16 * (int64_t)dp;
+                    f64x4 acc_a = {0.0, 0.0, 0.0, 0.0}, acc_b = {0.0, 0.0, 0.0, 0.0};
+                    if (dp == 128) gqr_tile_pair<8>(ta, tb, qrow, kk, dp, acc_a, acc_b);  // ColBERT / ColPali: unrolled
+                    else gqr_tile_pair<0>(ta, tb, qrow, kk, dp, acc_a, acc_b);
+                    // acc[r] = <q_{i0 + kk + 4r}, token t0 (+16) + col>; rows ascend per lane: strict > keeps the first maximum
 #pragma unroll
-                    for (int ii = 0; ii < kGqrQChunk; ++ii) acc[ii] = 0.0;
-                    for (int k = 0; k < dp; k += 4) {
-                        const float4 x = *(const float4*)(row + k);
-#pragma unroll
-                        for (int ii = 0; ii < kGqrQChunk; ++ii) {
-                            const double* qv = Q + (size_t)(i0 + ii) * dp + k;
-                            acc[ii] = fma((double)x.x, qv[0], acc[ii]);
-                            acc[ii] = fma((double)x.y, qv[1], acc[ii]);
-                            acc[ii] = fma((double)x.z, qv[2], acc[ii]);
-                            acc[ii] = fma((double)x.w, qv[3], acc[ii]);
+                    for (int r = 0; r < 4; ++r) {
+                        if (acc_a[r] > best[r]) {
+                            best[r] = acc_a[r];
+                            barg[r] = (int)(t0 + col);
+                        }
+                        if (acc_b[r] > best[r]) {
+                            best[r] = acc_b[r];
+                            barg[r] = (int)(t0 + 16 + col);
                         }
                     }
-#pragma unroll
-                    for (int ii = 0; ii < kGqrQChunk; ++ii)
-                        if (acc[ii] > best[ii]) {  // rows ascend per lane: strict > keeps the first maximum
-                            best[ii] = acc[ii];
-                            barg[ii] = (int)r;
-                        }
                 }
 #pragma unroll
-                for (int ii = 0; ii < kGqrQChunk; ++ii) {
-                    double v = best[ii];
-                    int w = barg[ii];
+                for (int r = 0; r < 4; ++r) {
+                    double v = best[r];
+                    int w = barg[r];
 #pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
+                    for (int o = 8; o > 0; o >>= 1) {  // over the 16 token columns of this lane's row group
                         const double ov = __shfl_xor(v, o);
                         const int ow = __shfl_xor(w, o);
                         if (ov > v || (ov == v && ow < w)) {
@@ -273,25 +333,27 @@ __global__ __launch_bounds__(kGqrThreads) void k_gqr_multi(GqrMultiArgs a) {
                             w = ow;
                         }
                     }
-                    if (i0 + ii < nq) {
-                        total += v;  // (every lane holds the same value)
-                        if (lane == 0) arg[(int64_t)j * a.nq_pad + i0 + ii] = w;
+                    const int i = i0 + kk + 4 * r;
+                    if (col == 0 && i < nq) {
+                        total += v;
+                        arg[(int64_t)j * a.nq_pad + i] = w;
                     }
                 }
             }
+            total += __shfl_xor(total, 16);  // the four lanes with col == 0 hold the partial sums; the others hold 0
+            total += __shfl_xor(total, 32);
             if (lane == 0) sc[j] = total / den;
         }
         __syncthreads();
         if (step == a.prm.n_steps) break;
         gqr_logit_grad(sc, comp, g, n, a.prm, red);
         // ---- Q[i] -= lr * sum_j g_j * tok[argmax_ji] / n_q     (:113-127, :357-360)
-        __threadfence_block();
         for (int e = tid; e < nq * dp; e += kGqrThreads) {
             const int i = e / dp, k = e - i * dp;
             double acc = 0.0;
             for (int j = 0; j < n; ++j)
                 acc += g[j] * ((double)a.tok[(int64_t)arg[(int64_t)j * a.nq_pad + i] * dp + k] / den);
-            Q[e] -= a.prm.lr * acc;
+            Q[(size_t)i * ld + k] -= a.prm.lr * acc;
         }
         __syncthreads();
     }

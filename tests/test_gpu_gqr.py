@@ -123,6 +123,14 @@ def test_late_interaction_pools_at_colbert_shape_match_oracle(pkg, oracle):
         t0 = time.perf_counter()
         got = idx.gqr_refine_maxsim(qtok, qoff, pools, comp, 25, 0.1, 1.0, 0.5)
         print(f"gqr_refine_maxsim: {B} queries x {P} docs, 25 steps: {(time.perf_counter() - t0) * 1e3:.2f} ms")
+        # a page-sized block (the 16 queries repeated): what a batched run() launches at once
+        rep = 32
+        big_q = np.concatenate([qtok] * rep, axis=0)
+        big_off = np.concatenate([[0], np.cumsum(np.tile(q_lens, rep))]).astype(np.int32)
+        t0 = time.perf_counter()
+        big = idx.gqr_refine_maxsim(big_q, big_off, np.tile(pools, (rep, 1)), np.tile(comp, (rep, 1)), 25, 0.1, 1.0, 0.5)
+        print(f"gqr_refine_maxsim: {B * rep} queries x {P} docs, 25 steps: {(time.perf_counter() - t0) * 1e3:.2f} ms")
+        assert np.array_equal(big[:B], got) and np.array_equal(big[-B:], got)
     tokd = tok.astype(np.float64)
     for b in (0, 5, 15):
         docs = [tokd[off[i]:off[i + 1]] for i in pools[b]]
