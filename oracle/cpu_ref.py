@@ -55,6 +55,10 @@ def lib() -> ctypes.CDLL:
         L.orc_maxsim_topk.argtypes = [f32p, i64p, ctypes.c_int64, ctypes.c_int, f32p, i32p, ctypes.c_int,
                                       ctypes.c_int, f32p, i64p, ctypes.c_int]
         L.orc_num_threads.restype = ctypes.c_int
+        L.orc_verify_topk.restype = ctypes.c_int64
+        L.orc_verify_topk.argtypes = [f32p, ctypes.c_int64, ctypes.c_int, f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                      f64p, i64p]
+        L.orc_fpenv_fix_count.restype = ctypes.c_int
         _lib = L
     return _lib
 
@@ -69,6 +73,19 @@ def _p(a: np.ndarray, ct):
 
 def num_threads() -> int:
     return int(lib().orc_num_threads())
+
+
+def debug_team() -> tuple[int, int, int]:
+    """(threads that entered a parallel region, team size they saw, distinct thread numbers) -- all three must agree."""
+    a, b = ctypes.c_int(0), ctypes.c_int(0)
+    lib().orc_debug_team.restype = ctypes.c_int
+    entered = lib().orc_debug_team(ctypes.byref(a), ctypes.byref(b))
+    return int(entered), int(a.value), int(b.value)
+
+
+def fpenv_fix_count() -> int:
+    """How many times an oracle thread was found with a non-default floating-point environment (and reset)."""
+    return int(lib().orc_fpenv_fix_count())
 
 
 def dot(a, b) -> float:
@@ -89,11 +106,20 @@ def cosine_distance(q, c, seq: bool = False) -> float:
     return float(fn(_p(q, ctypes.c_float), _p(c, ctypes.c_float), q.shape[0]))
 
 
-def topk_search(C, Q, k: int, metric: str = "cosine", threads: int = 0) -> tuple[np.ndarray, np.ndarray]:
+rejected_results = 0  # multi-threaded results that failed the single-threaded re-check (see topk_search)
+
+
+def topk_search(C, Q, k: int, metric: str = "cosine", threads: int = 0, verify: bool = True
+                ) -> tuple[np.ndarray, np.ndarray]:
     """Exact brute-force top-k.  Returns (distance float64 [B,k], rows int64 [B,k]); pads with NaN / -1.
 
     distance = pgvector cosine distance (metric="cosine") or negative inner product ("ip");
     order = (distance asc, NaN last, row asc).
+
+    verify: every returned pair is re-derived single-threaded (orc_verify_topk).  A result that fails is recomputed with
+    one thread and counted in `rejected_results` -- seen (rarely, never reproduced in isolation) on a 256-CPU host
+    throttled to a 16-CPU quota, where a 256-thread run once returned a row with another row's distance.  The timed
+    CPU baseline passes verify=False.
     """
     C, Q = _f32(C), _f32(Q)
     if Q.ndim == 1:
@@ -107,6 +133,13 @@ def topk_search(C, Q, k: int, metric: str = "cosine", threads: int = 0) -> tuple
                                threads)
     if rc != 0:
         raise ValueError(f"orc_topk_search failed rc={rc}")
+    if verify and n > 0 and threads != 1:
+        m = 0 if metric == "cosine" else 1
+        if lib().orc_verify_topk(_p(C, ctypes.c_float), n, d, _p(Q, ctypes.c_float), B, k, m, _p(dist, ctypes.c_double),
+                                 _p(rows, ctypes.c_int64)) != 0:
+            global rejected_results
+            rejected_results += 1
+            return topk_search(C, Q, k, metric, threads=1, verify=False)
     return dist, rows
 
 

@@ -47,13 +47,56 @@
 #include <math.h>
 #include <sched.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <xmmintrin.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
 
 #define ORC_QB 64 /* queries scored together per corpus row (vector lanes) */
+
+/*
+ * Default worker count: what OpenMP offers, capped by the container's CPU bandwidth quota (cgroup v2 cpu.max,
+ * "quota period"): a box that shows 256 CPUs but grants 16 CPUs' worth of time runs 256 spinning threads far slower
+ * than 16, and the throttling makes every barrier a scheduling lottery.
+ */
+static int orc_default_threads(void) {
+    int nt = 1;
+#ifdef _OPENMP
+    nt = omp_get_max_threads();
+#endif
+    FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (f) {
+        char quota[32];
+        long period = 0;
+        if (fscanf(f, "%31s %ld", quota, &period) == 2 && period > 0 && strcmp(quota, "max") != 0) {
+            long q = atol(quota);
+            int cap = (int)((q + period - 1) / period);
+            if (cap >= 1 && cap < nt) nt = cap;
+        }
+        fclose(f);
+    }
+    return nt;
+}
+
+/*
+ * The oracle's arithmetic is IEEE round-to-nearest with denormals: make that a property of this file, not of
+ * whatever floating-point environment a worker thread inherited (pthreads copy the creator's MXCSR; a thread created
+ * while some other library had flush-to-zero or a directed rounding mode set keeps it for life, and e.g. float
+ * overflow then yields FLT_MAX instead of +inf).  Called at the top of every parallel region and entry point;
+ * orc_fpenv_fix_count() reports how often a non-default environment was found.
+ */
+static int orc_fpenv_fixes = 0;
+static inline void orc_default_fpenv(void) {
+    const unsigned csr = _mm_getcsr();
+    if ((csr & 0xFFC0u) != 0x1F80u) { /* bits 6..15: DAZ, exception masks, rounding control, FTZ */
+        __atomic_fetch_add(&orc_fpenv_fixes, 1, __ATOMIC_RELAXED);
+        _mm_setcsr(0x1F80u | (csr & 0x3Fu));
+    }
+}
+int orc_fpenv_fix_count(void) { return __atomic_load_n(&orc_fpenv_fixes, __ATOMIC_RELAXED); }
 
 /*
  * Pin the calling OpenMP worker to one allowed CPU.  Some sandboxes/VMs keep all
@@ -62,6 +105,7 @@
  * library (torch) may have initialised libgomp before this one is loaded.
  */
 static void orc_pin_thread(void) {
+    orc_default_fpenv();
 #ifdef _OPENMP
     static __thread int pinned = 0;
     if (pinned || omp_get_num_threads() <= 1) return;
@@ -119,7 +163,7 @@ static void orc_nrm2_rows(const float* rows, int64_t lo, int64_t hi, int d, floa
 }
 
 void orc_row_nrm2(const float* rows, int64_t n, int d, float* out) {
-#pragma omp parallel
+#pragma omp parallel num_threads(orc_default_threads())
     {
         orc_pin_thread();
         int tid = 0, nt = 1;
@@ -198,7 +242,7 @@ int orc_topk_search(const float* C, int64_t n, int d, const float* Q, int B, int
     if (n == 0 || B == 0) return 0;
     int nthreads = 1;
 #ifdef _OPENMP
-    nthreads = threads > 0 ? threads : omp_get_max_threads();
+    nthreads = threads > 0 ? threads : orc_default_threads();
 #endif
     (void)threads;
     float* cn = (float*)malloc(sizeof(float) * (size_t)n);
@@ -320,7 +364,7 @@ int orc_maxsim_topk(const float* tok, const int64_t* offsets, int64_t n_docs, in
     if (d <= 0 || B < 0 || k <= 0 || n_docs < 0) return -1;
     int nthreads = 1;
 #ifdef _OPENMP
-    nthreads = threads > 0 ? threads : omp_get_max_threads();
+    nthreads = threads > 0 ? threads : orc_default_threads();
 #endif
     (void)threads;
     /* per-thread partial lists over a slice of the documents, merged per query (same total order) */
@@ -366,10 +410,65 @@ int orc_maxsim_topk(const float* tok, const int64_t* offsets, int64_t n_docs, in
     return 0;
 }
 
-int orc_num_threads(void) {
+/*
+ * Self-check of the OpenMP runtime binding: inside a parallel region every thread must see a distinct
+ * omp_get_thread_num() below omp_get_num_threads().  (If a process holds two OpenMP runtimes and this library's
+ * GOMP_parallel and omp_get_* resolve to different ones, every thread reports tid 0 of 1 -- all of them would then
+ * work on the same slice and the same partial lists.)  Returns threads that entered the region; *out_nt = the team
+ * size they saw, *out_distinct = number of distinct thread numbers.
+ */
+int orc_debug_team(int* out_nt, int* out_distinct) {
+    int entered = 0, nt_seen = 0;
+    unsigned char seen[4096];
+    memset(seen, 0, sizeof(seen));
+#pragma omp parallel num_threads(orc_default_threads())
+    {
+        int tid = 0, nt = 1;
 #ifdef _OPENMP
-    return omp_get_max_threads();
-#else
-    return 1;
+        tid = omp_get_thread_num();
+        nt = omp_get_num_threads();
 #endif
+        __atomic_fetch_add(&entered, 1, __ATOMIC_RELAXED);
+        __atomic_store_n(&nt_seen, nt, __ATOMIC_RELAXED);
+        if (tid >= 0 && tid < 4096) __atomic_store_n(&seen[tid], 1, __ATOMIC_RELAXED);
+    }
+    int distinct = 0;
+    for (int i = 0; i < 4096; ++i) distinct += seen[i];
+    *out_nt = nt_seen;
+    *out_distinct = distinct;
+    return entered;
+}
+
+int orc_num_threads(void) { return orc_default_threads(); }
+
+/*
+ * Independent single-threaded check of a top-k result (any producer): every returned (query,row) pair must carry the
+ * exact distance of that pair, rows must be distinct and the list must follow the total order.  Does not prove
+ * completeness.  Returns the number of offending entries.
+ */
+int64_t orc_verify_topk(const float* C, int64_t n, int d, const float* Q, int B, int k, int metric, const double* dist,
+                        const int64_t* rows) {
+    orc_default_fpenv();
+    int64_t bad = 0;
+    for (int b = 0; b < B; ++b) {
+        const float* q = Q + (int64_t)b * d;
+        const float nq = orc_dot(q, q, d);
+        for (int s = 0; s < k; ++s) {
+            const int64_t r = rows[(int64_t)b * k + s];
+            const double dv = dist[(int64_t)b * k + s];
+            if (r < 0) continue; /* padding */
+            if (r >= n) {
+                ++bad;
+                continue;
+            }
+            const float* c = C + r * (int64_t)d;
+            const float dot = orc_dot(c, q, d);
+            const double want = metric == 0 ? orc_cosine_distance_from(dot, nq, orc_dot(c, c, d)) : (double)dot * -1.0;
+            if (!((isnan(want) && isnan(dv)) || want == dv)) ++bad;
+            if (s > 0 && rows[(int64_t)b * k + s - 1] >= 0 &&
+                !orc_before(dist[(int64_t)b * k + s - 1], rows[(int64_t)b * k + s - 1], dv, r))
+                ++bad;
+        }
+    }
+    return bad;
 }

@@ -1,5 +1,5 @@
 """GPU: a fixed slice of the randomized differential campaign (tools/fuzz_parity.py) -- random shapes, data modes and
-option settings vs the CPU oracle, bit for bit.  The open-ended form is `python tools/fuzz_parity.py --seconds N`."""
+option settings vs the CPU oracle, bit for bit (search paths) / to float64 rounding (GQR refinement).  The open-ended form is `python tools/fuzz_parity.py --seconds N`."""
 
 import sys
 from pathlib import Path
@@ -19,8 +19,8 @@ def test_fuzz_slice(native_built, oracle, base):
         seed = base * 1_000_003 + case
         rng = np.random.default_rng(seed)
         u = rng.random()
-        kind = "maxsim" if u < 0.3 else "session" if u < 0.45 else "single"
+        kind = fz.pick_kind(u)
         try:
-            {"maxsim": fz.check_maxsim, "single": fz.check_single, "session": fz.check_session}[kind](rng, case)
+            fz.CHECKS[kind](rng, case)
         except AssertionError as e:  # pragma: no cover - a failure names the seed to replay
             raise AssertionError(f"seed {seed} ({kind}): {e}") from e

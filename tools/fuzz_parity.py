@@ -2,7 +2,7 @@
 
 Runs random shapes / data modes / option settings for a wall-clock budget and stops at the first mismatch, printing the
 seed of the failing case.  Test infrastructure (it uses oracle/), meant for a GPU box:
-    python tools/fuzz_parity.py --seconds 300 [--seed 1] [--only single|maxsim]
+    python tools/fuzz_parity.py --seconds 300 [--seed 1] [--only single|maxsim|session|gqr]
 """
 import argparse
 import sys
@@ -66,6 +66,8 @@ def check_single(rng, case):
         opts["chunk0_rows"] = int(rng.choice([256, 512, 2048]))
     row_offset = int(rng.choice([0, 0, 12345, 2**33]))
     desc = f"single n={n} d={d} B={B} k={k} mode={mode} metric={metric} opts={opts} row_offset={row_offset}"
+    import hashlib
+    h_in = hashlib.sha1(C.tobytes() + Q.tobytes()).hexdigest()
     with pkg.Mi355Index(d, metric) as idx:
         for key, val in opts.items():
             idx.set_option(key, val)
@@ -88,8 +90,24 @@ def check_single(rng, case):
     m = ~np.isnan(dist)
     ok = ok and np.array_equal(dist[m].view(np.uint64), rd[m].view(np.uint64))
     if not ok:
-        bad = np.argwhere(rows != rr)
-        raise AssertionError(f"MISMATCH {desc} stats={stats} first bad (query,slot)={bad[:3].tolist()}")
+        bad = np.argwhere((rows != rr) | ((dist != rd) & ~(np.isnan(dist) & np.isnan(rd))))
+        q0 = int(bad[0][0]) if len(bad) else 0
+        # who moved?  the inputs (host memory), the oracle (threads), or the GPU result
+        h_now = hashlib.sha1(C.tobytes() + Q.tobytes()).hexdigest()
+        rd1, rr1 = cpu_ref.topk_search(C, Q, k, metric=metric, threads=1)
+        rd2, rr2 = cpu_ref.topk_search(C, Q, k, metric=metric)
+        rr1 = np.where(rr1 >= 0, rr1 + row_offset, rr1)
+        rr2 = np.where(rr2 >= 0, rr2 + row_offset, rr2)
+        with pkg.Mi355Index(d, metric) as idx2:
+            idx2.set_option("row_offset", row_offset)
+            idx2.add(C)
+            _, rows2 = idx2.search(Q, k)
+        desc += (f" [inputs changed: {h_in != h_now}; oracle(1 thread) == oracle: {np.array_equal(rr1, rr)}; oracle again == oracle: "
+                 f"{np.array_equal(rr2, rr)}; gpu == oracle(1 thread): {np.array_equal(rows, rr1)}; gpu again == gpu: {np.array_equal(rows2, rows)}; oracle fp-env resets: {cpu_ref.fpenv_fix_count()}; omp team {cpu_ref.debug_team()}; omp libs "
+                 f"{sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'omp' in l.split()[-1]))}]")
+        raise AssertionError(f"MISMATCH {desc} stats={stats} first bad (query,slot)={bad[:3].tolist()} "
+                             f"gpu rows {rows[q0][:8].tolist()} dist {dist[q0][:8].tolist()} | "
+                             f"ref rows {rr[q0][:8].tolist()} dist {rd[q0][:8].tolist()}")
     return desc + f" stats={stats}"
 
 
@@ -200,21 +218,128 @@ def check_maxsim(rng, case):
     return desc + f" stats={stats}"
 
 
+def check_gqr(rng, case):
+    """Guided Query Refinement kernels vs oracle/gqr_ref.py (float64: agreement to rounding, not bit for bit)."""
+    from oracle import gqr_ref
+
+    n_steps = int(rng.integers(1, 41))
+    lr = float(np.exp(rng.uniform(np.log(0.01), np.log(1.0))))
+    temp = float(np.exp(rng.uniform(np.log(0.05), np.log(4.0))))
+    alpha = float(rng.choice([0.0, 1.0, rng.random()]))
+    prm = (n_steps, lr, temp, alpha)
+    B = int(rng.choice([1, 3, 17, 64]))
+    P = int(rng.choice([1, 2, 9, 40, 130, 400]))
+    sizes = rng.integers(1, P + 1, size=B)
+    sizes[0] = P
+    comp = np.zeros((B, P))
+    for b, m in enumerate(sizes):
+        comp[b, :m] = rng.dirichlet(np.ones(m) * float(rng.choice([0.1, 1.0, 10.0])))
+    form = str(rng.choice(["single", "multi", "scores"]))
+    desc = f"gqr {form} B={B} P={P} steps={n_steps} lr={lr:.3g} T={temp:.3g} alpha={alpha:.3g}"
+    tol = 1e-8
+    if form == "scores":
+        prim = rng.standard_normal((B, P)) * float(rng.choice([0.1, 1.0, 30.0]))
+        with pkg.Mi355Index(8) as idx:
+            got = idx.gqr_refine_scores(prim, sizes.astype(np.int32), comp, *prm)
+        for b, m in enumerate(sizes):
+            exp = gqr_ref.refine_scores(prim[b, :m], comp[b, :m], *prm)
+            if not (np.abs(got[b, :m] - exp).max() <= tol * max(1.0, np.abs(exp).max()) and np.isnan(got[b, m:]).all()):
+                raise AssertionError(f"MISMATCH {desc} query {b}: {np.abs(got[b, :m] - exp).max()}")
+        return desc
+    if form == "single":
+        d = int(rng.choice([2, 7, 48, 384, 768, 1000]))
+        n = int(rng.choice([P, 3 * P + 5, 5000]))
+        C = corpus(rng, n, d, str(rng.choice(["plain", "scaled", "clustered", "dups"])))
+        C[rng.integers(0, n)] = 0.0
+        Q = rng.standard_normal((B, d)).astype(np.float32).astype(np.float64)
+        if rng.random() < 0.2:
+            Q[rng.integers(0, B)] = 0.0
+        pools = np.full((B, P), -1, dtype=np.int64)
+        for b, m in enumerate(sizes):
+            pools[b, :m] = rng.integers(0, n, size=m)  # repeats allowed: a row may enter a pool twice
+        off = int(rng.choice([0, 12345]))
+        with pkg.Mi355Index(d) as idx:
+            idx.add(C)
+            idx.set_option("row_offset", off)
+            got = idx.gqr_refine(Q, np.where(pools >= 0, pools + off, pools), comp, *prm)
+        Cd = C.astype(np.float64)
+        for b, m in enumerate(sizes):
+            exp = gqr_ref.refine_single(Q[b], Cd[pools[b, :m]], comp[b, :m], *prm)
+            if not (np.abs(got[b, :m] - exp).max() <= tol and np.isnan(got[b, m:]).all()):
+                raise AssertionError(f"MISMATCH {desc} d={d} n={n} query {b}: {np.abs(got[b, :m] - exp).max()}")
+        return desc + f" d={d} n={n}"
+    d = int(rng.choice([8, 20, 96, 128, 200]))
+    n_docs = int(rng.choice([P, 2 * P + 3, 900]))
+    lens = rng.integers(1, int(rng.choice([3, 40, 180])) + 1, size=n_docs)
+    tok = rng.standard_normal((int(lens.sum()), d)).astype(np.float32)
+    if rng.random() < 0.7:
+        tok /= np.linalg.norm(tok, axis=1, keepdims=True)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    q_lens = rng.choice([1, 5, 16, 17, 32, 60], size=B)
+    if (int(q_lens.max()) + 15) // 16 * 16 * (d + 9) * 8 + 3 * P * 8 > 150_000:  # LDS budget of one workgroup
+        q_lens = np.minimum(q_lens, 32)
+    qtok = rng.standard_normal((int(q_lens.sum()), d)).astype(np.float32).astype(np.float64)
+    qoff = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
+    pools = np.full((B, P), -1, dtype=np.int64)
+    for b, m in enumerate(sizes):
+        pools[b, :m] = rng.integers(0, n_docs, size=m)
+    with pkg.Mi355Index(d) as idx:
+        idx.add_multivec(tok, off)
+        got = idx.gqr_refine_maxsim(qtok, qoff, pools, comp, *prm)
+    tokd = tok.astype(np.float64)
+    for b in sorted(set([0, B - 1, int(rng.integers(0, B))])):  # the numpy loop is slow: three queries per case
+        m = int(sizes[b])
+        docs = [tokd[off[i]:off[i + 1]] for i in pools[b, :m]]
+        exp = gqr_ref.refine_multi(qtok[qoff[b]:qoff[b + 1]], docs, comp[b, :m], *prm)
+        err = np.abs(got[b, :m] - exp).max()
+        if not (err <= tol * max(1.0, np.abs(exp).max()) and np.isnan(got[b, m:]).all()):
+            raise AssertionError(f"MISMATCH {desc} d={d} docs={n_docs} query {b}: {err}")
+    return desc + f" d={d} docs={n_docs}"
+
+
+CHECKS = {"maxsim": check_maxsim, "single": check_single, "session": check_session, "gqr": check_gqr}
+
+
+def pick_kind(u: float) -> str:
+    return "maxsim" if u < 0.3 else "session" if u < 0.45 else "gqr" if u > 0.9 else "single"
+
+
+def poison_device_memory(pattern: str, gib: int = 24) -> None:
+    """Fill then free a large part of the device memory with a byte pattern, so that later allocations of this process
+    come back dirty: buffers the library reads before writing show up as mismatches instead of passing on zero pages."""
+    rng = np.random.default_rng(12345)
+    chunk = 256 << 20
+    if pattern == "random":
+        img = rng.integers(0, 256, size=chunk, dtype=np.uint8)
+    else:
+        img = np.full(chunk, int(pattern, 16), dtype=np.uint8)
+    with pkg.Mi355Index(8) as idx:
+        ptrs = [idx.dev_alloc(chunk) for _ in range(gib * 4)]
+        for p in ptrs:
+            idx.dev_upload(p, img)
+        for p in ptrs:
+            idx.dev_free(p)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--only", choices=["single", "maxsim", "session"], default=None)
+    ap.add_argument("--only", choices=["single", "maxsim", "session", "gqr"], default=None)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--start", type=int, default=0, help="first case number (cases are seeded by number)")
+    ap.add_argument("--poison", default=None, help="hex byte (e.g. ff, 7f) or 'random': dirty the device memory first")
     a = ap.parse_args()
-    t0, case, counts = time.time(), 0, {"single": 0, "maxsim": 0, "session": 0}
+    if a.poison:
+        poison_device_memory(a.poison)
+    t0, case, counts = time.time(), a.start, {"single": 0, "maxsim": 0, "session": 0, "gqr": 0}
     while time.time() - t0 < a.seconds:
         seed = a.seed * 1_000_003 + case
         rng = np.random.default_rng(seed)
         u = rng.random()
-        kind = a.only or ("maxsim" if u < 0.3 else "session" if u < 0.45 else "single")
+        kind = a.only or pick_kind(u)
         try:
-            msg = {"maxsim": check_maxsim, "single": check_single, "session": check_session}[kind](rng, case)
+            msg = CHECKS[kind](rng, case)
         except Exception as e:  # noqa: BLE001
             print(f"FAILED case {case} seed {seed} kind {kind}: {e}")
             sys.exit(1)
@@ -222,7 +347,10 @@ def main():
         if a.verbose:
             print(f"ok {case} seed {seed}: {msg}", flush=True)
         case += 1
-    print(f"fuzz ok: {case} cases in {time.time() - t0:.0f} s ({counts}), seed base {a.seed}")
+    print(f"fuzz ok: {case} cases in {time.time() - t0:.0f} s ({counts}), seed base {a.seed}; "
+          f"oracle results rejected by the single-thread re-check: {cpu_ref.rejected_results}; "
+          f"oracle threads found with a non-default fp environment: {cpu_ref.fpenv_fix_count()}; omp team "
+          f"{cpu_ref.debug_team()}; omp libs {sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'omp' in l.split()[-1]))}")
 
 
 if __name__ == "__main__":
