@@ -53,7 +53,7 @@ def parse_args():
                     help="run the all-gather + merge path even at world size 1 (exercises the multi-GPU code on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=2_500_000)
-    ap.add_argument("--cpu-sample-queries", type=int, default=1024)
+    ap.add_argument("--cpu-sample-queries", type=int, default=3072, help="CPU baseline: queries timed (whole blocks of the pool)")
     return ap.parse_args()
 
 
@@ -345,9 +345,9 @@ def main() -> None:
         from oracle import cpu_ref
 
         S = keep_sample.shape[0]
-        nq = min(args.cpu_sample_queries, B)
+        nq = max(1, min(args.cpu_sample_queries, n_pool * B))
         Cs = keep_sample
-        Qs = qpool[0, :nq].cpu().numpy()
+        Qs = qpool.reshape(n_pool * B, d)[:nq].cpu().numpy()  # the first blocks of the query pool
         cpu_ref.topk_search(Cs[:2048], Qs[:8], k)  # warm the library / thread pool
         tc = time.perf_counter()
         rd, rr = cpu_ref.topk_search(Cs, Qs, k, metric=args.metric, verify=False)  # timed: no re-check inside
