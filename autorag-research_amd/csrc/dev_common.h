@@ -38,6 +38,7 @@ struct QueryState {
     int* status;        // [Bpad]
     // screen bound and int8-screen state
     float* E;           // [Bpad] rigorous bound on |screen value - exact cosine| for this query (both screen dtypes)
+    float* E16;         // [Bpad] the bf16 bound of this query whatever the active screen (second screen inside k_prune)
     float* sc;          // [Bpad] int8 screen: value of one accumulator unit, S_q * S_c  (1 for the bf16 screen)
     int* thr_i;         // [Bpad] int8 screen: emit iff acc >= thr_i  (conservative integer image of thr)
     int8_t* qhat8;      // [Bpad, dpad8] int8 quantised normalised queries
@@ -364,6 +365,46 @@ __device__ __forceinline__ float staged_dot(float* tile, const float* my_row, co
         for (int k0 = 0; k0 < d; k0 += kStageCols) {
             stage_rows(tile, my_row, k0, d, lane);
             acc = chain_piece(tile, lane, qv + k0, min(kStageCols, d - k0), acc);
+        }
+    }
+    return acc;
+}
+
+// Same staging for bf16 rows: a row of 2*words bf16 values is moved as `words` 32-bit words; word w holds elements
+// 2w (low half) and 2w+1 (high half).  qv: the bf16 query expanded to fp32 in LDS, element order.  fp32 accumulation of
+// exact products in k order (what the bf16 MFMA screen computes up to the order of its fp32 sums).
+__device__ __forceinline__ float chain_piece16(const float* tile, int lane, const float* qv, int kn_words, float acc) {
+    const float* t = tile + lane * kStageLd;
+    for (int w = 0; w + 4 <= kn_words; w += 4) {
+        const uint4 tv = *(const uint4*)(t + w);
+        const float4 qa = *(const float4*)(qv + 2 * w), qb = *(const float4*)(qv + 2 * w + 4);
+        acc = __builtin_fmaf(__uint_as_float(tv.x << 16), qa.x, acc);
+        acc = __builtin_fmaf(__uint_as_float(tv.x & 0xFFFF0000u), qa.y, acc);
+        acc = __builtin_fmaf(__uint_as_float(tv.y << 16), qa.z, acc);
+        acc = __builtin_fmaf(__uint_as_float(tv.y & 0xFFFF0000u), qa.w, acc);
+        acc = __builtin_fmaf(__uint_as_float(tv.z << 16), qb.x, acc);
+        acc = __builtin_fmaf(__uint_as_float(tv.z & 0xFFFF0000u), qb.y, acc);
+        acc = __builtin_fmaf(__uint_as_float(tv.w << 16), qb.z, acc);
+        acc = __builtin_fmaf(__uint_as_float(tv.w & 0xFFFF0000u), qb.w, acc);
+    }
+    return acc;
+}
+// words must be a multiple of 4 (shadow rows are padded to 64 elements)
+__device__ __forceinline__ float staged_dot16(float* tile, const float* my_row_words, const float* qv, int words, int lane) {
+    float acc = 0.0f;
+    StageRows sr;
+    StagePiece p0, p1;
+    stage_rows_init(sr, my_row_words, lane);
+    stage_issue(p0, sr, 0, words, lane);
+    if (kStageCols < words) stage_issue(p1, sr, kStageCols, words, lane);
+    for (int k0 = 0; k0 < words; k0 += 2 * kStageCols) {
+        stage_commit(tile, p0, lane);
+        if (k0 + 2 * kStageCols < words) stage_issue(p0, sr, k0 + 2 * kStageCols, words, lane);
+        acc = chain_piece16(tile, lane, qv + 2 * k0, min(kStageCols, words - k0), acc);
+        if (k0 + kStageCols < words) {
+            stage_commit(tile, p1, lane);
+            if (k0 + 3 * kStageCols < words) stage_issue(p1, sr, k0 + 3 * kStageCols, words, lane);
+            acc = chain_piece16(tile, lane, qv + 2 * (k0 + kStageCols), min(kStageCols, words - k0 - kStageCols), acc);
         }
     }
     return acc;

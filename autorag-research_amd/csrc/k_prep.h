@@ -158,6 +158,7 @@ __global__ __launch_bounds__(64) void k_prep_queries(const float* __restrict__ q
             st.thr_row[b] = -1;
             st.status[b] = 0;
             st.E[b] = bf16_screen_bound(0.00390625f, bf16_ec, d);
+            st.E16[b] = st.E[b];
             st.sc[b] = 1.0f;
             st.thr_i[b] = 0x7FFFFFFF;
         }
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(64) void k_prep_queries(const float* __restrict__ q
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) eq2 += __shfl_xor(eq2, o);
     float E = bf16_screen_bound(sqrtf(eq2) * 1.001f, bf16_ec, d), sc = 1.0f;
+    const float E16 = E;
     if (i8_step > 0.0f) {
         // per-query step S_q = max|q_hat| / 127, residual norm measured like the corpus side
         float mx = 0.0f;
@@ -215,6 +217,7 @@ __global__ __launch_bounds__(64) void k_prep_queries(const float* __restrict__ q
     if (lane == 0) {
         st.qn[b] = acc;
         st.E[b] = E;
+        st.E16[b] = E16;
         st.sc[b] = sc;
         // cosine screen cannot rank an irregular query: park it (never emits) and flag it for the scan path
         // (metric 2 = test hook: every query screens with thresholds at -inf)

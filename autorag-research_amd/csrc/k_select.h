@@ -26,6 +26,8 @@ struct PruneArgs {
     int exact;           // 0: screen candidates (re-score), 1: cand_val already holds the exact dot
     const uint8_t* flag8;  // int8 screen only (else nullptr): rows outside the int8 shadow
     float cmax;            // inner-product metric: largest stored row norm (inflated); thresholds are cos >= dot_k / (|q| cmax)
+    const uint16_t* shadow16;  // optional [n, dpad] bf16 shadow: second screen of round-B candidates (int8 screen, cosine)
+    int dpad;
 };                         // (the screen bound is per query: st.E[q])
 
 // Two instantiations share the code: a small one (1 wave, <= 1024 entries, ~36 KiB LDS, 4 workgroups
@@ -36,11 +38,13 @@ constexpr int kPruneSmallThreads = 64, kPruneSmallSort = 1024;
 constexpr int kPruneBigThreads = 256, kPruneBigSort = kSortMax;
 
 // dynamic LDS: SK[SORT] u64 | SR[SORT] i32 | X = max(Lf[SORT] f32, stage tiles) | R[SORT] i32 | qs[d] f32 | 2 scalars
-__host__ __device__ inline size_t prune_lds_bytes(int d, int threads, int sortmax) {
+//              | q16[dpad16] f32 (one-wave form only: the bf16 query of the second screen, expanded)
+__host__ __device__ inline size_t prune_qs_floats(int d) { return ((size_t)d + 3) / 4 * 4 + 16; }  // qs + scalars, 16-B multiple
+__host__ __device__ inline size_t prune_lds_bytes(int d, int threads, int sortmax, int dpad16) {
     size_t x = (size_t)(threads / kWave) * kStageFloats * sizeof(float);
     size_t lf = (size_t)sortmax * sizeof(float);
     if (lf > x) x = lf;
-    return (size_t)sortmax * 8 + (size_t)sortmax * 4 + x + (size_t)sortmax * 4 + (size_t)d * 4 + 64;
+    return (size_t)sortmax * 8 + (size_t)sortmax * 4 + x + (size_t)sortmax * 4 + prune_qs_floats(d) * 4 + (size_t)dpad16 * 4;
 }
 
 template <int THREADS, int SORT>
@@ -56,8 +60,9 @@ __global__ __launch_bounds__(THREADS) void k_prune(PruneArgs a) {
     float* tiles = (float*)X;
     int32_t* R = (int32_t*)(X + xbytes);
     float* qs = (float*)(X + xbytes + (size_t)SORT * 4);
-    // two scalars at the very end of the dynamic region (no static LDS: keeps the carve 16-B aligned)
-    int& s_cnt = *(int*)(X + xbytes + (size_t)SORT * 4 + (size_t)a.d * 4);
+    // two scalars behind the query (no static LDS: keeps the carve 16-B aligned), then the expanded bf16 query
+    int& s_cnt = *(int*)(X + xbytes + (size_t)SORT * 4 + (prune_qs_floats(a.d) - 16) * 4);
+    float* q16 = qs + prune_qs_floats(a.d);
 
     const int q = a.qlist ? a.qlist[blockIdx.x] : blockIdx.x;
     const int tid = threadIdx.x;
@@ -118,6 +123,8 @@ __global__ __launch_bounds__(THREADS) void k_prune(PruneArgs a) {
                 key[j] = kk;
             }
             for (int k = lane; k < a.d; k += kWave) qs[k] = a.q[(int64_t)q * a.d + k];
+            if (a.shadow16 != nullptr)
+                for (int k = lane; k < a.dpad; k += kWave) q16[k] = bf16_bits_to_f32(a.st.qhat[(int64_t)q * a.dpad + k]);
             const int n_cand = wave_count_ge(key, 1u);
             // wave-local exact re-score of the candidates listed in R[0..n) -> SK/SR[dst..]
             auto rescore_list = [&](int n, int dst) {
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(THREADS) void k_prune(PruneArgs a) {
             int nB = 0;
             if (n_cand > nA) {
                 // ---- cut = (k-th largest exact similarity over kept U round A) - E: as float, rounded down
-                float cut = -__builtin_inff();
+                float cut = -__builtin_inff(), cut16 = -__builtin_inff();
                 if (n1 >= a.k) {
                     uint32_t sk[kSelPerLane];
 #pragma unroll
@@ -185,12 +192,36 @@ __global__ __launch_bounds__(THREADS) void k_prune(PruneArgs a) {
                         const float kth = __uint_as_float((xs & 0x80000000u) ? (xs & 0x7FFFFFFFu) : ~xs);  // invert the key
                         // cosine: candidates carry v, exact <= v + E.  inner product: they carry the upper bound itself.
                         cut = a.metric == 0 ? kth - E * 1.001f - 2e-6f : kth - fabsf(kth) * 4e-6f - 1e-30f;
+                        if (a.shadow16 != nullptr && a.metric == 0) cut16 = kth - a.st.E16[q] * 1.001f - 2e-6f;
                     }
                 }
                 // ---- round B: everything that can still reach the top-k (v + E >= exact k-th best)
                 const uint32_t xB = cut == -__builtin_inff() ? 1u : f32_order_key(cut);
                 nB = compact(xB, SORT, false);
                 wave_sync();
+                if (a.shadow16 != nullptr && cut16 != -__builtin_inff() && nB > 0) {
+                    // ---- second screen: the bf16 image of every survivor (half the bytes of its fp32 row) under the
+                    // bf16 bound (~5x tighter than the int8 one): t16 + E16 < exact k-th best -> cannot reach the top-k.
+                    // NaN (irregular row: no bf16 image) compares false and stays.  Survivors are compacted in place.
+                    const int words = a.dpad / 2;
+                    int nS = 0;
+                    for (int base = 0; base < nB; base += kWave) {
+                        const int e = base + lane;
+                        const bool live = e < nB;
+                        const int ci = live ? R[e] : 0;
+                        const float* rp = live ? (const float*)(a.shadow16 + (int64_t)crow[ci] * a.dpad) : nullptr;
+                        const float t16 = staged_dot16(tile, rp, q16, words, lane);
+                        const bool keep = live && !(t16 < cut16);
+                        const unsigned long long bal = __builtin_amdgcn_ballot_w64(keep);
+                        const int pos = nS + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32),
+                                                                           __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+                        wave_sync();  // every lane holds its entry of this batch: slots below base + 64 may be rewritten
+                        if (keep) R[pos] = ci;
+                        nS += __builtin_popcountll(bal);
+                    }
+                    nB = nS;
+                    wave_sync();
+                }
                 rescore_list(nB, n1);
             }
             if (lane == 0) a.stat[2 * q + 1] += (unsigned long long)(nA + nB);

@@ -86,6 +86,7 @@ int ensure_qstate(mi355dr_index* idx) {
     HIPCHECK(idx, hipMalloc(&idx->st.thr_row, B * sizeof(int32_t)));
     HIPCHECK(idx, hipMalloc(&idx->st.status, B * sizeof(int)));
     HIPCHECK(idx, hipMalloc(&idx->st.E, B * sizeof(float)));
+    HIPCHECK(idx, hipMalloc(&idx->st.E16, B * sizeof(float)));
     HIPCHECK(idx, hipMalloc(&idx->st.sc, B * sizeof(float)));
     HIPCHECK(idx, hipMalloc(&idx->st.thr_i, B * sizeof(int)));
     HIPCHECK(idx, hipMalloc(&idx->st.qhat8, B * idx->dpad8));
@@ -100,14 +101,14 @@ int ensure_qstate(mi355dr_index* idx) {
     HIPCHECK(idx, hipMalloc(&idx->stat_dev, 2 * B * sizeof(unsigned long long)));
     HIPCHECK(idx, hipMemsetAsync(idx->stat_dev, 0, 2 * B * sizeof(unsigned long long), idx->stream));
     // the prune / scan kernels use more than the default 64 KiB of dynamic LDS
-    if (prune_lds_bytes(idx->dim, kPruneBigThreads, kPruneBigSort) > 160 * 1024 || scan_lds_bytes(idx->dim, 1) > 160 * 1024)
+    if (prune_lds_bytes(idx->dim, kPruneBigThreads, kPruneBigSort, 0) > 160 * 1024 || scan_lds_bytes(idx->dim, 1) > 160 * 1024)
         return fail(idx, MI355DR_E_UNSUPPORTED, "dim too large for the select kernels' LDS budget");
     HIPCHECK(idx, hipFuncSetAttribute((const void*)k_prune<kPruneBigThreads, kPruneBigSort>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)prune_lds_bytes(idx->dim, kPruneBigThreads, kPruneBigSort)));
+                                      (int)prune_lds_bytes(idx->dim, kPruneBigThreads, kPruneBigSort, 0)));
     HIPCHECK(idx, hipFuncSetAttribute((const void*)k_prune<kPruneSmallThreads, kPruneSmallSort>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)prune_lds_bytes(idx->dim, kPruneSmallThreads, kPruneSmallSort)));
+                                      (int)prune_lds_bytes(idx->dim, kPruneSmallThreads, kPruneSmallSort, idx->dpad)));
     {
         int per = kScanQ;
         while (per > 1 && scan_lds_bytes(idx->dim, per) > 150 * 1024) per >>= 1;
@@ -193,12 +194,16 @@ int launch_prune(mi355dr_index* idx, hipStream_t s, int nblocks, const int* qlis
     pa.exact = exact;
     pa.flag8 = use_i8(idx) ? idx->flag8 : nullptr;
     pa.cmax = idx->cmax;
+    // int8 screen, cosine: candidates that survive the exact cut are screened once more on their bf16 shadow rows
+    // (half the bytes of an fp32 row, a bound ~5x tighter) before the exact re-score
+    pa.shadow16 = (use_i8(idx) && idx->metric == 0 && !exact && idx->prefilter16) ? idx->shadow : nullptr;
+    pa.dpad = idx->dpad;
     // small instantiation first (common case, whole block resident), then the large one for what it skipped
     hipLaunchKernelGGL((k_prune<kPruneSmallThreads, kPruneSmallSort>), dim3(nblocks), dim3(kPruneSmallThreads),
-                       prune_lds_bytes(idx->dim, kPruneSmallThreads, kPruneSmallSort), s, pa);
+                       prune_lds_bytes(idx->dim, kPruneSmallThreads, kPruneSmallSort, pa.shadow16 ? idx->dpad : 0), s, pa);
     HIPCHECK(idx, hipGetLastError());
     hipLaunchKernelGGL((k_prune<kPruneBigThreads, kPruneBigSort>), dim3(nblocks), dim3(kPruneBigThreads),
-                       prune_lds_bytes(idx->dim, kPruneBigThreads, kPruneBigSort), s, pa);
+                       prune_lds_bytes(idx->dim, kPruneBigThreads, kPruneBigSort, 0), s, pa);
     HIPCHECK(idx, hipGetLastError());
     return MI355DR_OK;
 }
@@ -559,7 +564,7 @@ void mi355dr_destroy(mi355dr_index* idx) {
     (void)hipSetDevice(idx->device);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
     void* ptrs[] = {idx->n2max_dev, idx->bf16_res2_dev, idx->retry_q[0], idx->retry_dist[0], idx->retry_rows[0], idx->retry_map[0], idx->retry_q[1],
-                    idx->retry_dist[1], idx->retry_rows[1], idx->retry_map[1], idx->shadow8, idx->flag8, idx->irr8_rows, idx->irr8_count, idx->st.E, idx->st.sc, idx->st.thr_i,
+                    idx->retry_dist[1], idx->retry_rows[1], idx->retry_map[1], idx->shadow8, idx->flag8, idx->irr8_rows, idx->irr8_count, idx->st.E, idx->st.E16, idx->st.sc, idx->st.thr_i,
                     idx->st.qhat8,
                     idx->rows, idx->shadow, idx->nrm2, idx->irr_rows, idx->irr_count, idx->st.qn, idx->st.qhat,
                     idx->st.thr, idx->st.cnt, idx->st.best_n, idx->st.best_key, idx->st.best_row, idx->st.thr_key,
@@ -755,6 +760,8 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
     } else if (k == "chunk_growth") {
         if (value < 1) return fail(idx, MI355DR_E_INVALID, "chunk_growth must be >= 1");
         idx->chunk_growth = value;
+    } else if (k == "prefilter16") {
+        idx->prefilter16 = value != 0;
     } else if (k == "cand_cap") {
         if (value < 16 || value > kCandCap) return fail(idx, MI355DR_E_INVALID, "cand_cap must be in [16,2048]");
         idx->cap = (int)value;

@@ -398,3 +398,32 @@ def test_encode_and_index_without_leaving_the_gpu(pkg, oracle):
         rd, rr = oracle.topk_search(stored, q, 5)
         assert np.array_equal(rows, rr) and np.array_equal(dist.view(np.uint64), rd.view(np.uint64))
         assert (rows[:, 0] == np.arange(7)).all() or (dist[:, 0] < 1e-6).all()  # every text finds itself (or a duplicate)
+
+
+@pytest.mark.parametrize("mode", ["gauss", "clustered"])
+def test_bf16_second_screen_inside_the_prune_keeps_results_exact(pkg, oracle, mode):
+    """option "prefilter16" (off by default: no measurable gain): round-B candidates of the int8 screen are screened once
+    more on their bf16 shadow rows before the exact re-score.  Same ids, same float8 distances, fewer exact re-scores."""
+    rng = np.random.default_rng(31)
+    n, d, B, k = 60_000, 256, 200, 10
+    C = rng.standard_normal((n, d)).astype(np.float32)
+    if mode == "clustered":
+        cen = rng.standard_normal((300, d)).astype(np.float32)
+        C = cen[rng.integers(0, 300, size=n)] + (0.05 * rng.standard_normal((n, d))).astype(np.float32)
+    C[17] = 0.0
+    C[18] = np.nan
+    C[19] *= 1e20
+    Q = C[rng.integers(0, n, size=B)] + (0.05 * rng.standard_normal((B, d))).astype(np.float32)
+    rd, rr = oracle.topk_search(C, Q, k)
+    rescored = {}
+    for pf in (0, 1):
+        with pkg.Mi355Index(d) as idx:
+            idx.set_option("screen_dtype", "i8")
+            idx.set_option("prefilter16", pf)
+            idx.add(C)
+            dist, rows = idx.search(Q, k)
+            rescored[pf] = idx.stat("rescored")
+        assert np.array_equal(rows, rr)
+        m = ~np.isnan(rd)
+        assert np.array_equal(np.isnan(dist), ~m) and np.array_equal(dist[m].view(np.uint64), rd[m].view(np.uint64))
+    assert rescored[1] <= rescored[0]

@@ -64,6 +64,8 @@ def check_single(rng, case):
         opts["chunk_growth"] = int(rng.choice([1, 2, 5, 7]))
     if rng.random() < 0.2:
         opts["chunk0_rows"] = int(rng.choice([256, 512, 2048]))
+    if rng.random() < 0.25:
+        opts["prefilter16"] = 1
     row_offset = int(rng.choice([0, 0, 12345, 2**33]))
     desc = f"single n={n} d={d} B={B} k={k} mode={mode} metric={metric} opts={opts} row_offset={row_offset}"
     import hashlib

@@ -35,6 +35,8 @@ if rng.random() < 0.2:
     opts["chunk_growth"] = int(rng.choice([1, 2, 5, 7]))
 if rng.random() < 0.2:
     opts["chunk0_rows"] = int(rng.choice([256, 512, 2048]))
+if rng.random() < 0.25:
+    opts["prefilter16"] = 1
 row_offset = int(rng.choice([0, 0, 12345, 2**33]))
 print(f"n={n} d={d} B={B} k={k} mode={mode} metric={metric} opts={opts} off={row_offset}")
 special = [i for i in range(n) if not np.isfinite(C[i]).all() or (C[i] == 0).all() or np.abs(C[i]).max() > 1e20 or np.abs(C[i]).max() < 1e-20]
