@@ -28,6 +28,7 @@ struct PruneArgs {
     float cmax;            // inner-product metric: largest stored row norm (inflated); thresholds are cos >= dot_k / (|q| cmax)
     const uint16_t* shadow16;  // optional [n, dpad] bf16 shadow: second screen of round-B candidates (int8 screen, cosine)
     int dpad;
+    int round_a;           // rows re-scored before the cut is known (0: max(32, 2k)); always at least k, at most 64
 };                         // (the screen bound is per query: st.E[q])
 
 // Two instantiations share the code: a small one (1 wave, <= 1024 entries, ~36 KiB LDS, 4 workgroups
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(THREADS) void k_prune(PruneArgs a) {
             };
             wave_sync();  // qs visible
             // ---- round A: the best-looking candidates (see the general form below for the reasoning)
-            const int wantA = min(n_cand, min(kWave, max(32, 2 * a.k)));
+            const int wantA = min(n_cand, min(kWave, max(a.k, a.round_a > 0 ? a.round_a : max(32, 2 * a.k))));
             int nA = 0;
             if (wantA > 0) {
                 const uint32_t xA = wave_nth_largest(key, wantA);

@@ -198,6 +198,7 @@ int launch_prune(mi355dr_index* idx, hipStream_t s, int nblocks, const int* qlis
     // (half the bytes of an fp32 row, a bound ~5x tighter) before the exact re-score
     pa.shadow16 = (use_i8(idx) && idx->metric == 0 && !exact && idx->prefilter16) ? idx->shadow : nullptr;
     pa.dpad = idx->dpad;
+    pa.round_a = idx->round_a;
     // small instantiation first (common case, whole block resident), then the large one for what it skipped
     hipLaunchKernelGGL((k_prune<kPruneSmallThreads, kPruneSmallSort>), dim3(nblocks), dim3(kPruneSmallThreads),
                        prune_lds_bytes(idx->dim, kPruneSmallThreads, kPruneSmallSort, pa.shadow16 ? idx->dpad : 0), s, pa);
@@ -760,6 +761,9 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
     } else if (k == "chunk_growth") {
         if (value < 1) return fail(idx, MI355DR_E_INVALID, "chunk_growth must be >= 1");
         idx->chunk_growth = value;
+    } else if (k == "round_a") {
+        if (value < 0 || value > 64) return fail(idx, MI355DR_E_INVALID, "round_a must be in [0,64]");
+        idx->round_a = (int)value;
     } else if (k == "prefilter16") {
         idx->prefilter16 = value != 0;
     } else if (k == "cand_cap") {

@@ -48,6 +48,7 @@ def parse_args():
     ap.add_argument("--chunk0", type=int, default=0, help="override the first (emit-all) chunk size")
     ap.add_argument("--growth", type=int, default=0, help="override the chunk growth factor")
     ap.add_argument("--screen", choices=["auto", "bf16", "i8"], default="auto", help="screen element type")
+    ap.add_argument("--round-a", type=int, default=None, help="k_prune: rows re-scored before the cut is known (tuning)")
     ap.add_argument("--prefilter16", type=int, default=None, help="0/1: bf16 second screen inside the prune (default: library default)")
     ap.add_argument("--metric", choices=["cosine", "ip"], default="cosine", help="cosine (headline) or inner product")
     ap.add_argument("--force-dist", action="store_true",
@@ -183,6 +184,8 @@ def main() -> None:
     idx.set_option("screen_dtype", args.screen)
     if args.prefilter16 is not None:
         idx.set_option("prefilter16", args.prefilter16)
+    if args.round_a is not None:
+        idx.set_option("round_a", args.round_a)
     t_build = time.time()
     keep_parts = []
     keep_rows = 0
