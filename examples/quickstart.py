@@ -5,7 +5,8 @@
 
 1. single-vector index: add fp32 rows, exact cosine top-k for a block of queries (ids + float8 distances)
 2. multi-vector store: ragged docs, exact MaxSim top-k, candidate re-scoring
-3. the reference-shaped pipelines over an in-memory store: vector search, image (MaxSim) search, HEAVEN two-stage
+3. the reference-shaped pipelines over an in-memory store: vector search, image (MaxSim) search, HEAVEN two-stage,
+   Guided Query Refinement over two child retrievers
 4. group-nDCG of the persisted results
 """
 import asyncio
@@ -18,6 +19,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 
 import autorag_research_amd as amd  # noqa: E402
 from autorag_research_amd.evaluation import evaluate  # noqa: E402
+from autorag_research_amd.gqr import Mi355GQRHybridRetrievalPipeline  # noqa: E402
 from autorag_research_amd.heaven import Mi355HEAVENRetrievalPipeline  # noqa: E402
 from autorag_research_amd.metrics import retrieval_ndcg  # noqa: E402
 from autorag_research_amd.pipelines import Mi355ImageVectorSearchRetrievalPipeline, Mi355VectorSearchRetrievalPipeline  # noqa: E402
@@ -75,3 +77,23 @@ img.close()
 heaven = Mi355HEAVENRetrievalPipeline(lambda: store, "mi355_heaven", stage1_candidate_count=100, pos_tagger=None)
 print("HEAVEN (cosine top-100 -> candidate MaxSim):", [r["doc_id"] for r in asyncio.run(heaven._retrieve_by_id("q2", 3))])
 heaven.close()
+
+
+class ToyLexicalRetriever:
+    """Stands in for a BM25 child pipeline: any object with `name` and an async `_retrieve_by_id(query_id, k)`."""
+
+    name, search_mode, retrieval_unit, _embedding_model = "toy_lexical", "single", "chunk", None
+
+    async def _retrieve_by_id(self, query_id, top_k):
+        i = int(str(query_id)[1:])
+        picks = [ids[i]] + [ids[(37 * i + 11 * j) % 2000] for j in range(1, top_k)]
+        return [{"doc_id": pk, "score": 9.0 - 0.5 * j, "content": None} for j, pk in enumerate(picks)]
+
+
+dense = Mi355VectorSearchRetrievalPipeline(lambda: store, "mi355_vector_search_child", search_mode="single")
+gqr = Mi355GQRHybridRetrievalPipeline(lambda: store, "mi355_gqr_hybrid", dense, ToyLexicalRetriever(), n_steps=25)
+print("GQR (dense + lexical pool, 25 refinement steps on the GPU):",
+      [(r["doc_id"], round(r["score"], 3)) for r in asyncio.run(gqr._retrieve_by_id("q5", 3))])
+print("GQR run (whole page refined in one launch):", gqr.run(top_k=5))
+gqr.close()
+dense.close()
