@@ -245,10 +245,13 @@ def check_gqr(rng, case):
             got = idx.gqr_refine_scores(prim, sizes.astype(np.int32), comp, *prm)
         for b, m in enumerate(sizes):
             exp = gqr_ref.refine_scores(prim[b, :m], comp[b, :m], *prm)
-            perm = rng.permutation(m)  # conditioning: the same oracle with the candidates in another order
-            alt = np.empty(m)
-            alt[perm] = gqr_ref.refine_scores(prim[b, :m][perm], comp[b, :m][perm], *prm)
-            lim = tol * max(1.0, np.abs(exp).max()) + 20.0 * np.abs(exp - alt).max()  # (lr/T^2 >> 1 is chaotic)
+            spread = 0.0  # conditioning: the same oracle with the candidates in another order (3 draws)
+            for _ in range(3):
+                perm = rng.permutation(m)
+                alt = np.empty(m)
+                alt[perm] = gqr_ref.refine_scores(prim[b, :m][perm], comp[b, :m][perm], *prm)
+                spread = max(spread, float(np.abs(exp - alt).max()))
+            lim = tol * max(1.0, np.abs(exp).max()) + 100.0 * spread  # (lr/T^2 >> 1 is chaotic: last bits grow per step)
             if not (np.abs(got[b, :m] - exp).max() <= lim and np.isnan(got[b, m:]).all()):
                 raise AssertionError(f"MISMATCH {desc} query {b}: {np.abs(got[b, :m] - exp).max()} > {lim}")
         return desc
@@ -275,7 +278,7 @@ def check_gqr(rng, case):
             # conditioning of the case itself: the same oracle on column-permuted data (identical mathematics, other
             # rounding).  A sharp softmax over 40 steps amplifies last-bit differences; the kernel is held to that noise.
             alt = gqr_ref.refine_single(Q[b][perm], Cd[pools[b, :m]][:, perm], comp[b, :m], *prm)
-            lim = tol + 20.0 * np.abs(exp - alt).max()
+            lim = tol + 100.0 * np.abs(exp - alt).max()
             if not (np.abs(got[b, :m] - exp).max() <= lim and np.isnan(got[b, m:]).all()):
                 raise AssertionError(f"MISMATCH {desc} d={d} n={n} query {b}: {np.abs(got[b, :m] - exp).max()} > {lim}")
         return desc + f" d={d} n={n}"
@@ -305,7 +308,7 @@ def check_gqr(rng, case):
         perm = rng.permutation(d)
         alt = gqr_ref.refine_multi(qtok[qoff[b]:qoff[b + 1]][:, perm], [D[:, perm] for D in docs], comp[b, :m], *prm)
         err = np.abs(got[b, :m] - exp).max()
-        lim = tol * max(1.0, np.abs(exp).max()) + 20.0 * np.abs(exp - alt).max()  # (an argmax flip mid-trajectory shows here too)
+        lim = tol * max(1.0, np.abs(exp).max()) + 100.0 * np.abs(exp - alt).max()  # (an argmax flip mid-trajectory shows here too)
         if not (err <= lim and np.isnan(got[b, m:]).all()):
             raise AssertionError(f"MISMATCH {desc} d={d} docs={n_docs} query {b}: {err} > {lim}")
     return desc + f" d={d} docs={n_docs}"
