@@ -245,13 +245,16 @@ def check_gqr(rng, case):
             got = idx.gqr_refine_scores(prim, sizes.astype(np.int32), comp, *prm)
         for b, m in enumerate(sizes):
             exp = gqr_ref.refine_scores(prim[b, :m], comp[b, :m], *prm)
-            spread = 0.0  # conditioning: the same oracle with the candidates in another order (3 draws)
-            for _ in range(3):
-                perm = rng.permutation(m)
-                alt = np.empty(m)
-                alt[perm] = gqr_ref.refine_scores(prim[b, :m][perm], comp[b, :m][perm], *prm)
-                spread = max(spread, float(np.abs(exp - alt).max()))
-            lim = tol * max(1.0, np.abs(exp).max()) + 100.0 * spread  # (lr/T^2 >> 1 is chaotic: last bits grow per step)
+            # conditioning of the case: the same oracle on inputs moved by one part in 1e15 and on reordered candidates.
+            # With lr/T^2 >> 1 the iteration is chaotic (amplifications of 1e8..1e11 measured): any two float64
+            # implementations then differ, and the kernel is held to that spread instead of a fixed tolerance.
+            wiggle = 1.0 + 1e-15 * np.sign(rng.standard_normal(m))
+            spread = float(np.abs(exp - gqr_ref.refine_scores(prim[b, :m] * wiggle, comp[b, :m], *prm)).max())
+            perm = rng.permutation(m)
+            alt = np.empty(m)
+            alt[perm] = gqr_ref.refine_scores(prim[b, :m][perm], comp[b, :m][perm], *prm)
+            spread = max(spread, float(np.abs(exp - alt).max()))
+            lim = tol * max(1.0, np.abs(exp).max()) + 100.0 * spread
             if not (np.abs(got[b, :m] - exp).max() <= lim and np.isnan(got[b, m:]).all()):
                 raise AssertionError(f"MISMATCH {desc} query {b}: {np.abs(got[b, :m] - exp).max()} > {lim}")
         return desc
@@ -278,7 +281,9 @@ def check_gqr(rng, case):
             # conditioning of the case itself: the same oracle on column-permuted data (identical mathematics, other
             # rounding).  A sharp softmax over 40 steps amplifies last-bit differences; the kernel is held to that noise.
             alt = gqr_ref.refine_single(Q[b][perm], Cd[pools[b, :m]][:, perm], comp[b, :m], *prm)
-            lim = tol + 100.0 * np.abs(exp - alt).max()
+            alt2 = gqr_ref.refine_single(Q[b] * (1.0 + 1e-15 * np.sign(rng.standard_normal(d))), Cd[pools[b, :m]],
+                                         comp[b, :m], *prm)
+            lim = tol + 100.0 * max(np.abs(exp - alt).max(), np.abs(exp - alt2).max())
             if not (np.abs(got[b, :m] - exp).max() <= lim and np.isnan(got[b, m:]).all()):
                 raise AssertionError(f"MISMATCH {desc} d={d} n={n} query {b}: {np.abs(got[b, :m] - exp).max()} > {lim}")
         return desc + f" d={d} n={n}"
@@ -307,8 +312,11 @@ def check_gqr(rng, case):
         exp = gqr_ref.refine_multi(qtok[qoff[b]:qoff[b + 1]], docs, comp[b, :m], *prm)
         perm = rng.permutation(d)
         alt = gqr_ref.refine_multi(qtok[qoff[b]:qoff[b + 1]][:, perm], [D[:, perm] for D in docs], comp[b, :m], *prm)
+        qb = qtok[qoff[b]:qoff[b + 1]]
+        alt2 = gqr_ref.refine_multi(qb * (1.0 + 1e-15 * np.sign(rng.standard_normal(qb.shape))), docs, comp[b, :m], *prm)
         err = np.abs(got[b, :m] - exp).max()
-        lim = tol * max(1.0, np.abs(exp).max()) + 100.0 * np.abs(exp - alt).max()  # (an argmax flip mid-trajectory shows here too)
+        lim = tol * max(1.0, np.abs(exp).max()) + 100.0 * max(np.abs(exp - alt).max(), np.abs(exp - alt2).max())
+        # (an argmax flip mid-trajectory shows in the spread too)
         if not (err <= lim and np.isnan(got[b, m:]).all()):
             raise AssertionError(f"MISMATCH {desc} d={d} docs={n_docs} query {b}: {err} > {lim}")
     return desc + f" d={d} docs={n_docs}"
