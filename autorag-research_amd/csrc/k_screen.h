@@ -159,54 +159,69 @@ __device__ __forceinline__ void wave_queue_flush(const ScreenArgs& a, const int3
 template <bool I8>
 __device__ __forceinline__ void screen_queue_block(const ScreenArgs& a, f32x16 acc, int q, int rbase, int row_end,
                                                    float th, int thi, float sc, int32_t* que, int& que_n) {
-    bool any;
+    // maxima of the four groups of four registers first (same 15 max operations as one flat reduction): the append
+    // path below skips a whole group with one compare
+    bool any, gany[4];
     if constexpr (I8) {
         const i32x16 v = __builtin_bit_cast(i32x16, acc);
-        int m = v[0];
+        int g[4];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) m = max(m, v[r]);
-        any = m >= thi;
+        for (int i = 0; i < 4; ++i) g[i] = max(max(v[4 * i], v[4 * i + 1]), max(v[4 * i + 2], v[4 * i + 3]));
+        any = max(max(g[0], g[1]), max(g[2], g[3])) >= thi;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gany[i] = g[i] >= thi;
     } else {
-        float m = acc[0];
+        float g[4];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
-        any = m >= th;
+        for (int i = 0; i < 4; ++i) g[i] = fmaxf(fmaxf(acc[4 * i], acc[4 * i + 1]), fmaxf(acc[4 * i + 2], acc[4 * i + 3]));
+        any = fmaxf(fmaxf(g[0], g[1]), fmaxf(g[2], g[3])) >= th;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gany[i] = g[i] >= th;
     }
     if (__builtin_amdgcn_ballot_w64(any) == 0) return;  // wave-uniform: almost always taken
+    // A hit costs the whole workgroup this traversal (the other waves wait at the next K-step barrier), so it is kept
+    // short: one compare + one scalar branch per group of four accumulator registers, then per register of a group with
+    // a hit; the row bound is only tested in the hit branch (rows past row_end exist in the last tile of a chunk only,
+    // and their values are finite garbage at worst).
     // The queue is written with inline-asm LDS stores on purpose: for compiler-visible LDS accesses the waitcnt
     // insertion assumes they may alias the in-flight LDS-DMA and puts s_waitcnt vmcnt(0) in front
-    // (tests/test_build_pipeline.py checks the generated code).
+    // (tests/test_build_pipeline.py checks the generated code).  No wait after the stores: LDS operations of one wave
+    // execute in order, the flush's reads come later in the same wave.
     const unsigned a_q = lds_addr(que), a_r = a_q + 4u * kWaveQueueCap, a_v = a_q + 8u * kWaveQueueCap;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = rbase + (r & 3) + 8 * (r >> 2);
-        bool hit;
-        if constexpr (I8) hit = __builtin_bit_cast(i32x16, acc)[r] >= thi;
-        else hit = acc[r] >= th;
-        hit = hit && row < row_end;
-        const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
-        if (bal == 0) continue;  // wave-uniform
-        if (hit) {
-            const unsigned e =
-                (unsigned)que_n + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
-            float val;
-            if constexpr (I8) val = (float)__builtin_bit_cast(i32x16, acc)[r] * sc;
-            else val = acc[r];
-            if (e < (unsigned)kWaveQueueCap) {
-                asm volatile("ds_write_b32 %0, %1" ::"v"(a_q + 4u * e), "v"(q) : "memory");
-                asm volatile("ds_write_b32 %0, %1" ::"v"(a_r + 4u * e), "v"(row) : "memory");
-                asm volatile("ds_write_b32 %0, %1" ::"v"(a_v + 4u * e), "v"(val) : "memory");
-            } else {  // queue full (a burst of hits inside one tile): direct global append, slow but correct
-                const int slot = atomicAdd(&a.cnt[q], 1);
-                if (slot < a.cap) {
-                    a.cand_row[(int64_t)q * a.cap + slot] = row;
-                    a.cand_val[(int64_t)q * a.cap + slot] = val;
+    for (int gi = 0; gi < 4; ++gi) {
+        if (__builtin_amdgcn_ballot_w64(gany[gi]) == 0) continue;  // wave-uniform: no hit in this group of four
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+            const int r = 4 * gi + ri;
+            bool hit;
+            if constexpr (I8) hit = __builtin_bit_cast(i32x16, acc)[r] >= thi;
+            else hit = acc[r] >= th;
+            if (__builtin_amdgcn_ballot_w64(hit) == 0) continue;  // wave-uniform
+            const int row = rbase + (r & 3) + 8 * (r >> 2);
+            hit = hit && row < row_end;
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
+            if (hit) {
+                const unsigned e = (unsigned)que_n +
+                                   __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+                float val;
+                if constexpr (I8) val = (float)__builtin_bit_cast(i32x16, acc)[r] * sc;
+                else val = acc[r];
+                if (e < (unsigned)kWaveQueueCap) {
+                    asm volatile("ds_write_b32 %0, %1" ::"v"(a_q + 4u * e), "v"(q) : "memory");
+                    asm volatile("ds_write_b32 %0, %1" ::"v"(a_r + 4u * e), "v"(row) : "memory");
+                    asm volatile("ds_write_b32 %0, %1" ::"v"(a_v + 4u * e), "v"(val) : "memory");
+                } else {  // queue full (a burst of hits inside one tile): direct global append, slow but correct
+                    const int slot = atomicAdd(&a.cnt[q], 1);
+                    if (slot < a.cap) {
+                        a.cand_row[(int64_t)q * a.cap + slot] = row;
+                        a.cand_val[(int64_t)q * a.cap + slot] = val;
+                    }
                 }
             }
+            que_n += __builtin_popcountll(bal);  // may run past the capacity: the flush clamps
         }
-        que_n += __builtin_popcountll(bal);  // may run past the capacity: the flush clamps
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
 // first chunk: every (query,row) becomes a candidate at slot row-row0 (counts are set by the host)
