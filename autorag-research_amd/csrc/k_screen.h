@@ -168,6 +168,7 @@ __device__ __forceinline__ void screen_queue_block(const ScreenArgs& a, f32x16 a
 #pragma unroll
         for (int i = 0; i < 4; ++i) g[i] = max(max(v[4 * i], v[4 * i + 1]), max(v[4 * i + 2], v[4 * i + 3]));
         any = max(max(g[0], g[1]), max(g[2], g[3])) >= thi;
+        if (__builtin_amdgcn_ballot_w64(any) == 0) return;  // wave-uniform: almost always taken
 #pragma unroll
         for (int i = 0; i < 4; ++i) gany[i] = g[i] >= thi;
     } else {
@@ -175,10 +176,10 @@ __device__ __forceinline__ void screen_queue_block(const ScreenArgs& a, f32x16 a
 #pragma unroll
         for (int i = 0; i < 4; ++i) g[i] = fmaxf(fmaxf(acc[4 * i], acc[4 * i + 1]), fmaxf(acc[4 * i + 2], acc[4 * i + 3]));
         any = fmaxf(fmaxf(g[0], g[1]), fmaxf(g[2], g[3])) >= th;
+        if (__builtin_amdgcn_ballot_w64(any) == 0) return;  // wave-uniform: almost always taken
 #pragma unroll
         for (int i = 0; i < 4; ++i) gany[i] = g[i] >= th;
     }
-    if (__builtin_amdgcn_ballot_w64(any) == 0) return;  // wave-uniform: almost always taken
     // A hit costs the whole workgroup this traversal (the other waves wait at the next K-step barrier), so it is kept
     // short: one compare + one scalar branch per group of four accumulator registers, then per register of a group with
     // a hit; the row bound is only tested in the hit branch (rows past row_end exist in the last tile of a chunk only,
