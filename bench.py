@@ -380,10 +380,19 @@ def main() -> None:
         rd_, rr_ = res[0].cpu().numpy(), res[1].cpu().numpy()
         assert (np.diff(rd_, axis=1) >= 0).all(), "distances not ascending"
         assert rr_.min() >= 0 and rr_.max() < n_total
-        print(json.dumps(result))
     idx.close()
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner through C stdio; on a pipe that buffer would be flushed at exit, AFTER the
+        # result.  Flush it now so that the JSON line is the last line of rank 0's output.
+        import ctypes
+
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001 - purely cosmetic
+            pass
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":
