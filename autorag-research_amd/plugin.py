@@ -6,6 +6,12 @@ copies the YAML files it finds in that module's package (flat or under `retrieva
 """
 
 from .gqr import Mi355GQRHybridPipelineConfig, Mi355GQRHybridRetrievalPipeline  # noqa: F401
+from .hybrid import (  # noqa: F401
+    Mi355HybridCCPipelineConfig,
+    Mi355HybridCCRetrievalPipeline,
+    Mi355HybridRRFPipelineConfig,
+    Mi355HybridRRFRetrievalPipeline,
+)
 from .heaven import Mi355HEAVENPipelineConfig, Mi355HEAVENRetrievalPipeline  # noqa: F401
 from .pipelines import (  # noqa: F401
     Mi355ImageVectorSearchPipelineConfig,

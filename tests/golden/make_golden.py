@@ -22,6 +22,9 @@ Fixtures written next to this file:
                            and ImageVectorSearchRetrievalPipeline._retrieve_by_id
                            (pipelines/retrieval/image_vector_search.py:65-94) driven over a fake
                            Unit-of-Work whose SQL operators are answered by the CPU oracle.
+  hybrid_golden.json       _rrf_fuse / _cc_fuse (pipelines/retrieval/hybrid.py:46-178, all four normalisers of util.py:371-530)
+                           on seeded and edge-case result lists, and HybridRRF/CC _retrieve_by_id (:403-419) over the fake
+                           Unit-of-Work with the recorded lexical child.
   gqr_golden.npz / .json   Guided Query Refinement: outputs of GQRHybridRetrievalPipeline._optimize_query_embedding /
                            _optimize_query_multi_embedding / _optimize_in_score_space (pipelines/retrieval/
                            gqr_hybrid.py:306-362) on seeded pools, and of _retrieve_by_id (:472-489) over the fake
@@ -518,12 +521,74 @@ def make_gqr_flow(svc: "_FakeService", chunk_ids: list) -> dict:
     return out
 
 
+# --------------------------------------------------------------------------------------
+# 5. hybrid fusion
+# --------------------------------------------------------------------------------------
+
+
+def make_hybrid(svc: "_FakeService", chunk_ids: list) -> dict:
+    import autorag_research.pipelines.retrieval.hybrid as ref_hybrid
+
+    rng = np.random.default_rng(2718)
+
+    def ranked(ids, scores):
+        order = np.argsort(-np.asarray(scores), kind="stable")
+        return [{"doc_id": ids[i], "score": float(scores[i])} for i in order]
+
+    lists = []
+    for case in range(6):
+        n1, n2 = int(rng.integers(1, 21)), int(rng.integers(1, 21))
+        pool = [int(x) for x in rng.choice(500, size=40, replace=False)]
+        a = ranked(pool[:n1], rng.standard_normal(n1))
+        b = ranked([pool[i] for i in rng.choice(40, size=n2, replace=False)], rng.gamma(2.0, 3.0, size=n2))
+        lists.append((a, b))
+    # edge cases: one empty list, identical scores, fully disjoint, string ids
+    lists.append(([], ranked([1, 2, 3], [3.0, 2.0, 1.0])))
+    lists.append((ranked([1, 2, 3], [0.5, 0.5, 0.5]), ranked([2, 3, 4], [7.0, 7.0, 7.0])))
+    lists.append((ranked([1, 2], [0.9, 0.1]), ranked([3, 4], [5.0, 4.0])))
+    lists.append((ranked(["a", "b", "c"], [0.9, 0.8, 0.1]), ranked(["c", "d"], [12.0, 3.0])))
+    out = {"lists": [{"results_1": a, "results_2": b} for a, b in lists], "rrf": [], "cc": []}
+    for a, b in lists:
+        out["rrf"].append({"k": 60, "top_k": 10, "fetch_k": 20, "expected": ref_hybrid._rrf_fuse(a, b, 60, 10, 20)})
+        per = {}
+        for method in ("mm", "tmm", "z", "dbsf"):
+            for w in (0.5, 0.2):
+                per[f"{method}:{w}"] = ref_hybrid._cc_fuse(a, b, w, 10, method, -1.0 if method == "tmm" else None,
+                                                           0.0 if method == "tmm" else None)
+        out["cc"].append(per)
+    # pipeline flows over the fake UoW: dense child = the reference's VectorSearchRetrievalPipeline, second child = recorded
+    gq = json.loads((HERE / "gqr_golden.json").read_text())
+    lexical = gq["lexical"]
+    loop = asyncio.new_event_loop()
+    dense = VectorSearchRetrievalPipeline.__new__(VectorSearchRetrievalPipeline)
+    dense.search_mode, dense._service, dense._embedding_model, dense.name = "single", svc, None, "vs_single"
+    flows = {}
+    for name, cls, attrs in (
+        ("rrf", ref_hybrid.HybridRRFRetrievalPipeline, {"rrf_k": 60}),
+        ("cc_mm", ref_hybrid.HybridCCRetrievalPipeline, {"weight": 0.6, "normalize_method": "mm", "pipeline_1_min": None,
+                                                         "pipeline_2_min": None}),
+        ("cc_tmm", ref_hybrid.HybridCCRetrievalPipeline, {"weight": 0.5, "normalize_method": "tmm", "pipeline_1_min": -1.0,
+                                                          "pipeline_2_min": 0.0}),
+        ("cc_z", ref_hybrid.HybridCCRetrievalPipeline, {"weight": 0.3, "normalize_method": "z", "pipeline_1_min": None,
+                                                        "pipeline_2_min": None}),
+    ):
+        p = cls.__new__(cls)
+        p._retrieval_pipeline_1, p._retrieval_pipeline_2, p.fetch_k_multiplier = dense, _RecordedChild("lexical", lexical), 2
+        for k_, v_ in attrs.items():
+            setattr(p, k_, v_)
+        flows[name] = {"attrs": attrs, "results": {q: loop.run_until_complete(p._retrieve_by_id(q, 5)) for q in ("q0", "q3")}}
+    loop.close()
+    out["flows"] = flows
+    return out
+
+
 def main() -> None:
     (HERE / "metrics_golden.json").write_text(json.dumps(make_metrics(), indent=1))
     np.savez_compressed(HERE / "scores_golden.npz", **make_scores())
     (HERE / "service_golden.json").write_text(json.dumps(make_service(), indent=1))
     np.savez_compressed(HERE / "gqr_golden.npz", **make_gqr_arrays())
     (HERE / "gqr_golden.json").write_text(json.dumps(make_gqr_flow(_LAST["svc"], _LAST["ids"]), indent=1))
+    (HERE / "hybrid_golden.json").write_text(json.dumps(make_hybrid(_LAST["svc"], _LAST["ids"]), indent=1))
     print("wrote", sorted(p.name for p in HERE.iterdir()))
 
 

@@ -170,6 +170,21 @@ def check_gqr_flow(store, make_primary, atol=1e-9):
         p.close()
 
 
+def same_ranking(got: list, exp: list, atol: float = 1e-12) -> None:
+    """Same scores position by position; same ids wherever the score is unique (the reference breaks exact ties by the
+    iteration order of a Python set)."""
+    assert len(got) == len(exp)
+    gs, es = [r["score"] for r in got], [r["score"] for r in exp]
+    assert np.allclose(gs, es, rtol=0, atol=atol)
+    for i, (g, e) in enumerate(zip(got, exp)):
+        tied = sum(abs(x - e["score"]) <= atol for x in es) > 1
+        if not tied:
+            assert g["doc_id"] == e["doc_id"], (i, g, e)
+    tie_ids = lambda rs: sorted(str(r["doc_id"]) for r in rs if sum(abs(x - r["score"]) <= atol for x in es) > 1)  # noqa: E731
+    if len(got) < 10:  # a tie group cut by top_k may legitimately keep different members
+        assert tie_ids(got) == tie_ids(exp)
+
+
 def load_service_golden():
     return json.loads((GOLDEN / "service_golden.json").read_text())
 
