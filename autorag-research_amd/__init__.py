@@ -7,7 +7,7 @@ Layout: csrc/ (HIP kernels + C ABI -> libmi355dr.so), _native.py (ctypes), index
 store.py / service.py / pipelines.py (host-side mirror of the reference's repository / service /
 pipeline interfaces for this path), heaven.py (HEAVEN two-stage caller: cosine top-N then candidate MaxSim),
 gqr.py (Guided Query Refinement caller: candidate-pool refinement loops on the GPU), hybrid.py (RRF / convex-combination
-fusion of two child pipelines),
+fusion of two child pipelines), hyde.py (hypothetical-document retrieval),
 metrics.py (retrieval metrics), embeddings.py (embedding interfaces), shards.py (fp32 shard files: memory-mapped,
 chunked load), sharded.py (row-sharded multi-GPU search).
 """

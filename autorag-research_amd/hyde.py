@@ -1,0 +1,136 @@
+"""HyDE retrieval (hypothetical-document embeddings) on the MI355X path.
+
+Mirrors the reference's HyDEPipelineConfig / HyDERetrievalPipeline (pipelines/retrieval/hyde.py:31-241): an LLM writes a
+passage that would answer the query, the passage -- not the query -- is embedded, and the embedding is searched
+(`vector_search_by_embedding`, :232-238).  The LLM and the embedding model are the caller's (anything with `ainvoke` /
+`aembed_query`, i.e. LangChain objects, or plain callables); the search is `mi355dr_search`.  What this module adds over
+the reference's per-query flow is the page form used by `run()`: all passages of a page are generated, embedded with one
+`embed_documents` call when the model has it, and searched as ONE block on the GPU.
+"""
+
+from __future__ import annotations
+
+import asyncio
+import inspect
+from dataclasses import dataclass, field
+from typing import Any
+
+import numpy as np
+
+from .compat import BaseRetrievalPipelineConfig
+from .pipelines import Mi355BaseRetrievalPipeline
+
+DEFAULT_HYDE_PROMPT_TEMPLATE = """Please write a passage to answer the question.
+Question: {query}
+Passage:"""  # the paper's general template (Gao et al. 2022), as the reference uses (hyde.py:25-27)
+
+
+@dataclass(kw_only=True)
+class Mi355HyDEPipelineConfig(BaseRetrievalPipelineConfig):
+    """Fields as HyDEPipelineConfig (hyde.py:31-91) + `device`.  String values name configs of the host framework: the
+    embedding is resolved like everywhere in this package, an LLM name needs the reference's `load_llm`."""
+
+    llm: Any
+    embedding: Any
+    prompt_template: str = field(default=DEFAULT_HYDE_PROMPT_TEMPLATE)
+    device: int = 0
+
+    def __setattr__(self, name: str, value: Any) -> None:
+        if name == "embedding" and isinstance(value, str):
+            from .embeddings import load_embedding_model
+
+            value = load_embedding_model(value)
+        elif name == "llm" and isinstance(value, str):
+            try:
+                from autorag_research.injection import load_llm  # type: ignore
+            except Exception as e:  # noqa: BLE001
+                raise ValueError(f"llm {value!r} was given by name, which needs autorag_research.injection.load_llm; "  # noqa: TRY003
+                                 "pass a model instance instead") from e
+            value = load_llm(value)
+        super().__setattr__(name, value)
+
+    def get_pipeline_class(self) -> type["Mi355HyDERetrievalPipeline"]:
+        return Mi355HyDERetrievalPipeline
+
+    def get_pipeline_kwargs(self) -> dict[str, Any]:
+        return {"llm": self.llm, "embedding": self.embedding, "prompt_template": self.prompt_template, "device": self.device}
+
+
+class Mi355HyDERetrievalPipeline(Mi355BaseRetrievalPipeline):
+    """LLM passage -> embedding -> exact cosine top-k over `chunk` rows on the GPU."""
+
+    retrieval_unit = "chunk"
+
+    def __init__(self, session_factory: Any, name: str, llm: Any, embedding: Any,
+                 prompt_template: str = DEFAULT_HYDE_PROMPT_TEMPLATE, schema: Any | None = None, device: int = 0):
+        self.llm = llm
+        self.embedding = embedding
+        if "{query}" not in prompt_template:
+            raise ValueError("prompt_template must contain '{query}' placeholder")
+        self.prompt_template = prompt_template
+        super().__init__(session_factory, name, schema, device=device)
+
+    def _get_pipeline_config(self) -> dict[str, Any]:
+        return {"type": "mi355_hyde", "retrieval_unit": self.retrieval_unit, "prompt_template": self.prompt_template}
+
+    @staticmethod
+    def _extract_response_content(response: Any) -> str:
+        """Chat models answer with a message object, completion models with a string (hyde.py:190-203)."""
+        return str(response.content) if hasattr(response, "content") else str(response)
+
+    async def _generate_hypothetical_document(self, query_text: str) -> str:
+        prompt = self.prompt_template.format(query=query_text)
+        if hasattr(self.llm, "ainvoke"):
+            response = await self.llm.ainvoke(prompt)
+        else:
+            response = self.llm(prompt)
+            if inspect.isawaitable(response):
+                response = await response
+        return self._extract_response_content(response)
+
+    def _query_text(self, query_id) -> str:
+        q = self._service._store().get_query(query_id)
+        if q is None:
+            raise ValueError(f"Query {query_id} not found")  # noqa: TRY003  (fetch_query_texts, retrieval_pipeline.py:552-571)
+        return q.contents
+
+    async def _retrieve_by_id(self, query_id, top_k: int) -> list[dict[str, Any]]:
+        return await self._retrieve_by_text(self._query_text(query_id), top_k)
+
+    async def _retrieve_by_text(self, query_text: str, top_k: int) -> list[dict[str, Any]]:
+        passage = await self._generate_hypothetical_document(query_text)
+        embedding = await self.embedding.aembed_query(passage)
+        return self._service.vector_search_by_embedding(embedding=embedding, top_k=top_k)
+
+    def _retrieve_block(self, query_ids: list, top_k: int) -> list[list[dict] | None]:
+        """A page: passages generated concurrently, embedded in one batch, searched as one GPU block."""
+
+        async def passages():
+            async def one(qid):
+                try:
+                    return await self._generate_hypothetical_document(self._query_text(qid))
+                except Exception:  # noqa: BLE001 - that query is reported as failed
+                    return None
+
+            return await asyncio.gather(*[one(q) for q in query_ids])
+
+        docs = asyncio.run(passages())
+        live = [i for i, p in enumerate(docs) if p is not None]
+        out: list[list[dict] | None] = [None] * len(query_ids)
+        if not live:
+            return out
+        texts = [docs[i] for i in live]
+        if hasattr(self.embedding, "embed_documents"):
+            vecs = self.embedding.embed_documents(texts)
+        else:
+            async def embed_all():
+                return [await self.embedding.aembed_query(t) for t in texts]
+
+            vecs = asyncio.run(embed_all())
+        block = self._service._single_block(np.asarray(vecs, dtype=np.float32), top_k, "chunk")
+        for i, res in zip(live, block):
+            out[i] = res
+        return out
+
+
+__all__ = ["DEFAULT_HYDE_PROMPT_TEMPLATE", "Mi355HyDEPipelineConfig", "Mi355HyDERetrievalPipeline"]

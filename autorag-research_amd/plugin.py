@@ -6,6 +6,7 @@ copies the YAML files it finds in that module's package (flat or under `retrieva
 """
 
 from .gqr import Mi355GQRHybridPipelineConfig, Mi355GQRHybridRetrievalPipeline  # noqa: F401
+from .hyde import Mi355HyDEPipelineConfig, Mi355HyDERetrievalPipeline  # noqa: F401
 from .hybrid import (  # noqa: F401
     Mi355HybridCCPipelineConfig,
     Mi355HybridCCRetrievalPipeline,

@@ -1,6 +1,7 @@
 """Generate the committed golden fixtures by IMPORTING the reference (build container only).
 
-Run:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+Run:  PYTHONHASHSEED=0 PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+(the hash seed only fixes how the reference's _cc_fuse orders exact score ties between string ids: it iterates a set)
 
 /root/reference never travels to the GPU box, so its outputs are frozen here as data:
 inputs (or the seeds that regenerate them) + expected outputs.  No reference source is
@@ -25,6 +26,8 @@ Fixtures written next to this file:
   hybrid_golden.json       _rrf_fuse / _cc_fuse (pipelines/retrieval/hybrid.py:46-178, all four normalisers of util.py:371-530)
                            on seeded and edge-case result lists, and HybridRRF/CC _retrieve_by_id (:403-419) over the fake
                            Unit-of-Work with the recorded lexical child.
+  hyde_golden.json         HyDERetrievalPipeline._retrieve_by_id / _retrieve_by_text (pipelines/retrieval/hyde.py:205-238) with
+                           deterministic stand-in LLM / embedding objects (hyde_fake_models, shared with the test).
   gqr_golden.npz / .json   Guided Query Refinement: outputs of GQRHybridRetrievalPipeline._optimize_query_embedding /
                            _optimize_query_multi_embedding / _optimize_in_score_space (pipelines/retrieval/
                            gqr_hybrid.py:306-362) on seeded pools, and of _retrieve_by_id (:472-489) over the fake
@@ -582,6 +585,48 @@ def make_hybrid(svc: "_FakeService", chunk_ids: list) -> dict:
     return out
 
 
+# --------------------------------------------------------------------------------------
+# 6. HyDE
+# --------------------------------------------------------------------------------------
+
+
+def hyde_fake_models(dim: int):
+    """Deterministic stand-ins shared with the test: the "LLM" echoes the question inside a passage (as a chat message
+    object), the "embedding" derives a vector from the text's bytes."""
+
+    class FakeLLM:
+        async def ainvoke(self, prompt):
+            return _Obj(content="A passage about: " + prompt.split("Question: ")[1].split("\n")[0])
+
+    class FakeEmbedding:
+        @staticmethod
+        def vec(text):
+            seed = sum((i + 1) * b for i, b in enumerate(text.encode())) % (2**32)
+            return [float(x) for x in np.random.default_rng(seed).standard_normal(dim).astype(np.float32)]
+
+        async def aembed_query(self, text):
+            return self.vec(text)
+
+        def embed_documents(self, texts):
+            return [self.vec(t) for t in texts]
+
+    return FakeLLM(), FakeEmbedding()
+
+
+def make_hyde(svc: "_FakeService") -> dict:
+    from autorag_research.pipelines.retrieval.hyde import DEFAULT_HYDE_PROMPT_TEMPLATE, HyDERetrievalPipeline
+
+    llm, emb = hyde_fake_models(32)
+    p = HyDERetrievalPipeline.__new__(HyDERetrievalPipeline)
+    p.llm, p.embedding, p.prompt_template, p._service = llm, emb, DEFAULT_HYDE_PROMPT_TEMPLATE, svc
+    loop = asyncio.new_event_loop()
+    out = {"prompt_template": DEFAULT_HYDE_PROMPT_TEMPLATE, "top_k": 6,
+           "results": {q: loop.run_until_complete(p._retrieve_by_id(q, 6)) for q in ("q0", "q4")},
+           "by_text": loop.run_until_complete(p._retrieve_by_text("what is late interaction?", 6))}
+    loop.close()
+    return out
+
+
 def main() -> None:
     (HERE / "metrics_golden.json").write_text(json.dumps(make_metrics(), indent=1))
     np.savez_compressed(HERE / "scores_golden.npz", **make_scores())
@@ -589,6 +634,7 @@ def main() -> None:
     np.savez_compressed(HERE / "gqr_golden.npz", **make_gqr_arrays())
     (HERE / "gqr_golden.json").write_text(json.dumps(make_gqr_flow(_LAST["svc"], _LAST["ids"]), indent=1))
     (HERE / "hybrid_golden.json").write_text(json.dumps(make_hybrid(_LAST["svc"], _LAST["ids"]), indent=1))
+    (HERE / "hyde_golden.json").write_text(json.dumps(make_hyde(_LAST["svc"]), indent=1))
     print("wrote", sorted(p.name for p in HERE.iterdir()))
 
 
