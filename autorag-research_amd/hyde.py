@@ -4,8 +4,8 @@ Mirrors the reference's HyDEPipelineConfig / HyDERetrievalPipeline (pipelines/re
 passage that would answer the query, the passage -- not the query -- is embedded, and the embedding is searched
 (`vector_search_by_embedding`, :232-238).  The LLM and the embedding model are the caller's (anything with `ainvoke` /
 `aembed_query`, i.e. LangChain objects, or plain callables); the search is `mi355dr_search`.  What this module adds over
-the reference's per-query flow is the page form used by `run()`: all passages of a page are generated, embedded with one
-`embed_documents` call when the model has it, and searched as ONE block on the GPU.
+the reference's per-query flow is the page form used by `run()`: all passages of a page are generated concurrently, embedded (through the
+model's query side, batched when it offers `embed_queries`), and searched as ONE block on the GPU.
 """
 
 from __future__ import annotations
@@ -103,7 +103,7 @@ class Mi355HyDERetrievalPipeline(Mi355BaseRetrievalPipeline):
         return self._service.vector_search_by_embedding(embedding=embedding, top_k=top_k)
 
     def _retrieve_block(self, query_ids: list, top_k: int) -> list[list[dict] | None]:
-        """A page: passages generated concurrently, embedded in one batch, searched as one GPU block."""
+        """A page: passages generated concurrently, embedded, searched as one GPU block."""
 
         async def passages():
             async def one(qid):
@@ -120,11 +120,15 @@ class Mi355HyDERetrievalPipeline(Mi355BaseRetrievalPipeline):
         if not live:
             return out
         texts = [docs[i] for i in live]
-        if hasattr(self.embedding, "embed_documents"):
-            vecs = self.embedding.embed_documents(texts)
+
+        # the passages go through `aembed_query` like in the reference (hyde.py:229-230) -- NOT `embed_documents`:
+        # asymmetric models encode queries and documents differently, and the block form must return what the
+        # per-query form returns.  A model may offer `embed_queries` (a batch of query-side embeddings) to batch this.
+        if hasattr(self.embedding, "embed_queries"):
+            vecs = self.embedding.embed_queries(texts)
         else:
             async def embed_all():
-                return [await self.embedding.aembed_query(t) for t in texts]
+                return await asyncio.gather(*[self.embedding.aembed_query(t) for t in texts])
 
             vecs = asyncio.run(embed_all())
         block = self._service._single_block(np.asarray(vecs, dtype=np.float32), top_k, "chunk")
