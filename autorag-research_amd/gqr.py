@@ -33,7 +33,7 @@ from typing import Any, Literal
 import numpy as np
 
 from .compat import BaseRetrievalPipelineConfig, EmbeddingError
-from .pipelines import Mi355BaseRetrievalPipeline
+from .pipelines import Mi355BaseRetrievalPipeline, child_page
 
 CandidatePoolMode = Literal["primary", "union"]
 ScorerMode = Literal["auto", "single", "multi"]
@@ -267,21 +267,13 @@ class Mi355GQRHybridRetrievalPipeline(Mi355BaseRetrievalPipeline):
         return self._run_gqr_block([self._item_by_id(query_id, top_k, primary, complementary)])[0]
 
     def _retrieve_block(self, query_ids: list, top_k: int) -> list[list[dict] | None]:
-        """A page of queries: the children answer per query (their own contract), the refinement is ONE launch per
+        """A page of queries: each child answers the page (one GPU block when it can), the refinement is ONE launch per
         branch for the whole page."""
         fetch_k = top_k * self.fetch_k_multiplier
 
-        async def gather():
-            pairs = []
-            for qid in query_ids:
-                try:
-                    pairs.append(await self._children_by_id(qid, fetch_k))
-                except Exception:  # noqa: BLE001 - a failed child fails that query only (reported in failed_queries)
-                    logger.exception(f"GQR child retrieval failed for query {qid}")
-                    pairs.append(None)
-            return pairs
-
-        pairs = asyncio.run(gather())
+        page_p = child_page(self._primary_retrieval_pipeline, query_ids, fetch_k)
+        page_c = child_page(self._complementary_retrieval_pipeline, query_ids, fetch_k)
+        pairs = [None if a is None or b is None else (a, b) for a, b in zip(page_p, page_c)]
         live = [(i, qid, pc) for i, (qid, pc) in enumerate(zip(query_ids, pairs)) if pc is not None]
         ranked = self._run_gqr_block([self._item_by_id(qid, top_k, pc[0], pc[1]) for _, qid, pc in live])
         out: list[list[dict] | None] = [None] * len(query_ids)

@@ -15,7 +15,6 @@ list's new ids) where `_cc_fuse` iterates a Python set, so exact score ties reso
 
 from __future__ import annotations
 
-import asyncio
 import logging
 from dataclasses import dataclass
 from pathlib import Path
@@ -23,7 +22,7 @@ from typing import Any, Literal
 
 from .compat import BaseRetrievalPipelineConfig
 from .gqr import _load_child
-from .pipelines import Mi355BaseRetrievalPipeline, get_retrieval_pipeline_unit
+from .pipelines import Mi355BaseRetrievalPipeline, child_page, get_retrieval_pipeline_unit
 
 NormalizationMethod = Literal["mm", "tmm", "z", "dbsf"]
 logger = logging.getLogger("AutoRAG-Research")
@@ -211,31 +210,10 @@ class _Mi355HybridBase(Mi355BaseRetrievalPipeline):
         results_2 = await self._retrieval_pipeline_2._retrieve_by_text(query_text, fetch_k)
         return self._fuse_results(results_1, results_2, top_k, fetch_k)
 
-    def _child_page(self, child: Any, query_ids: list, fetch_k: int) -> list[list[dict] | None]:
-        """A child's answers for a page: one GPU block when it can (`_retrieve_block`), else query by query."""
-        block = getattr(child, "_retrieve_block", None)
-        if callable(block):
-            try:
-                return block(query_ids, fetch_k)
-            except NotImplementedError:
-                pass
-
-        async def one_by_one():
-            out: list[list[dict] | None] = []
-            for qid in query_ids:
-                try:
-                    out.append(await child._retrieve_by_id(qid, fetch_k))
-                except Exception:  # noqa: BLE001 - a failed child fails that query only
-                    logger.exception(f"hybrid child {getattr(child, 'name', child)!r} failed for query {qid}")
-                    out.append(None)
-            return out
-
-        return asyncio.run(one_by_one())
-
     def _retrieve_block(self, query_ids: list, top_k: int) -> list[list[dict] | None]:
         fetch_k = top_k * self.fetch_k_multiplier
-        page_1 = self._child_page(self._retrieval_pipeline_1, query_ids, fetch_k)
-        page_2 = self._child_page(self._retrieval_pipeline_2, query_ids, fetch_k)
+        page_1 = child_page(self._retrieval_pipeline_1, query_ids, fetch_k)
+        page_2 = child_page(self._retrieval_pipeline_2, query_ids, fetch_k)
         return [None if a is None or b is None else self._fuse_results(a, b, top_k, fetch_k) for a, b in zip(page_1, page_2)]
 
 

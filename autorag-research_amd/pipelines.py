@@ -83,6 +83,32 @@ class Mi355BaseRetrievalPipeline(BasePipeline, ABC):
         self._service.close()
 
 
+def child_page(child: Any, query_ids: list, top_k: int) -> list[list[dict] | None]:
+    """What a child retrieval pipeline answers for a page of query ids (wrapper pipelines: hybrid fusion, GQR).  One GPU
+    block when the child can (`_retrieve_block`), else query by query through its `_retrieve_by_id` contract; a query
+    the child fails on is None (reported in `failed_queries` by the caller's run)."""
+    import asyncio  # noqa: PLC0415
+
+    block = getattr(child, "_retrieve_block", None)
+    if callable(block):
+        try:
+            return block(query_ids, top_k)
+        except NotImplementedError:
+            pass
+
+    async def one_by_one():
+        out: list[list[dict] | None] = []
+        for qid in query_ids:
+            try:
+                out.append(await child._retrieve_by_id(qid, top_k))
+            except Exception:  # noqa: BLE001 - a failed child fails that query only
+                logger.exception(f"child pipeline {getattr(child, 'name', child)!r} failed for query {qid}")
+                out.append(None)
+        return out
+
+    return asyncio.run(one_by_one())
+
+
 class _VectorSearchMixin:
     search_mode: str
     retrieval_unit: str | None
