@@ -6,7 +6,7 @@
 1. single-vector index: add fp32 rows, exact cosine top-k for a block of queries (ids + float8 distances)
 2. multi-vector store: ragged docs, exact MaxSim top-k, candidate re-scoring
 3. the reference-shaped pipelines over an in-memory store: vector search, image (MaxSim) search, HEAVEN two-stage,
-   Guided Query Refinement over two child retrievers
+   Guided Query Refinement, RRF / convex-combination fusion and HyDE over child retrievers
 4. group-nDCG of the persisted results
 """
 import asyncio
@@ -21,6 +21,8 @@ import autorag_research_amd as amd  # noqa: E402
 from autorag_research_amd.evaluation import evaluate  # noqa: E402
 from autorag_research_amd.gqr import Mi355GQRHybridRetrievalPipeline  # noqa: E402
 from autorag_research_amd.heaven import Mi355HEAVENRetrievalPipeline  # noqa: E402
+from autorag_research_amd.hybrid import Mi355HybridCCRetrievalPipeline, Mi355HybridRRFRetrievalPipeline  # noqa: E402
+from autorag_research_amd.hyde import Mi355HyDERetrievalPipeline  # noqa: E402
 from autorag_research_amd.metrics import retrieval_ndcg  # noqa: E402
 from autorag_research_amd.pipelines import Mi355ImageVectorSearchRetrievalPipeline, Mi355VectorSearchRetrievalPipeline  # noqa: E402
 from autorag_research_amd.store import InMemoryStore, RetrievalRelation  # noqa: E402
@@ -96,4 +98,32 @@ print("GQR (dense + lexical pool, 25 refinement steps on the GPU):",
       [(r["doc_id"], round(r["score"], 3)) for r in asyncio.run(gqr._retrieve_by_id("q5", 3))])
 print("GQR run (whole page refined in one launch):", gqr.run(top_k=5))
 gqr.close()
+
+rrf = Mi355HybridRRFRetrievalPipeline(lambda: store, "mi355_hybrid_rrf", dense, ToyLexicalRetriever())
+cc = Mi355HybridCCRetrievalPipeline(lambda: store, "mi355_hybrid_cc", dense, ToyLexicalRetriever(), weight=0.7, normalize_method="z")
+print("hybrid RRF:", [r["doc_id"] for r in asyncio.run(rrf._retrieve_by_id("q5", 3))],
+      "| hybrid CC (z-score, w=0.7):", [r["doc_id"] for r in asyncio.run(cc._retrieve_by_id("q5", 3))])
+print("hybrid RRF run:", rrf.run(top_k=5))
+rrf.close()
+cc.close()
 dense.close()
+
+
+class EchoLLM:
+    """Stands in for the LLM of HyDE: anything with an async `ainvoke(prompt)` (a LangChain chat model, ...)."""
+
+    async def ainvoke(self, prompt):
+        return "a passage that restates: " + prompt
+
+
+class NearestRowEmbedding:
+    """Stands in for the passage encoder: here it simply returns the stored vector of the chunk the text mentions."""
+
+    async def aembed_query(self, text):
+        digits = "".join(ch for ch in text.split("chunk")[-1] if ch.isdigit())
+        return emb[int(digits or 0) % 2000].tolist()
+
+
+hyde = Mi355HyDERetrievalPipeline(lambda: store, "mi355_hyde", EchoLLM(), NearestRowEmbedding())
+print("HyDE (LLM passage -> embedding -> exact top-k):", [r["doc_id"] for r in asyncio.run(hyde._retrieve_by_id("q6", 3))])
+hyde.close()
