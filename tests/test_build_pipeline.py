@@ -69,6 +69,12 @@ def test_screen256_keeps_dma_in_flight(screen_asm, i8):
         if o.startswith("ds_write_b32"):
             assert not any("vmcnt" in p for p in ops[max(0, i - 6):i] if p.startswith("s_waitcnt")), ops[i - 6:i + 1]
     assert not any(o.startswith("scratch_") for o in ops), "register spill in the screen kernel"
+    # ... and must not be followed by a wait for themselves: a hit stalls the whole workgroup for as long as this path
+    # takes (DESIGN 4.1 "what a hit costs"); LDS operations of one wave execute in order, the flush reads them later
+    writes = [i for i, o in enumerate(ops) if o.startswith("ds_write_b32")]
+    assert writes and len(writes) % 3 == 0
+    for i in writes[2::3]:  # the last store of every (query, row, value) entry
+        assert not any(p.startswith("s_waitcnt") and "lgkmcnt(0)" in p for p in ops[i + 1:i + 5]), ops[i:i + 6]
 
 
 @pytest.mark.parametrize("i8", [False, True])
