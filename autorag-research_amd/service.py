@@ -127,20 +127,30 @@ class Mi355RetrievalService:
         Q = np.stack([q.embedding for q in queries]).astype(np.float32, copy=False)
         return self._single_block(Q, top_k, unit)
 
+    @staticmethod
+    def _results_from_block(table: ChunkTable, pos_of_row: np.ndarray, rows: np.ndarray, scores: np.ndarray,
+                            with_content: bool) -> list[list[dict]]:
+        """[B,k] index rows (-1 padded at the tail) + float64 scores -> the reference's list of result dicts per query.
+        Built from whole-array conversions: a page is B*k results, and one Python-level numpy access per result costs
+        more than the GPU pass that produced them."""
+        k = rows.shape[1]
+        neg = rows < 0
+        n_valid = np.where(neg.any(axis=1), neg.argmax(axis=1), k).tolist()
+        pos = pos_of_row[np.where(neg, 0, rows)].tolist()
+        sc = scores.tolist()
+        ids, contents = table.ids, table.contents
+        if with_content:
+            return [[{"doc_id": ids[p], "score": s, "content": contents[p]} for p, s in zip(pr[:n], sr[:n])]
+                    for pr, sr, n in zip(pos, sc, n_valid)]
+        return [[{"doc_id": ids[p], "score": s, "content": None} for p, s in zip(pr[:n], sr[:n])]
+                for pr, sr, n in zip(pos, sc, n_valid)]
+
     def _single_block(self, Q: np.ndarray, top_k: int, unit: str) -> list[list[dict]]:
         u = self._unit(unit)
         ix = u.ensure_single()
         dist, rows = ix.search(Q, top_k)
-        out = []
-        for b in range(Q.shape[0]):
-            res = []
-            for dv, r in zip(dist[b], rows[b]):
-                if r < 0:
-                    break
-                # reference: score = 1 - distance (retrieval_pipeline.py:522-524), Python float arithmetic
-                res.append(self._make_retrieval_result(u.table, int(u.single_rows[r]), 1 - float(dv), unit == "chunk"))
-            out.append(res)
-        return out
+        # reference: score = 1 - distance (retrieval_pipeline.py:522-524) in Python float arithmetic = IEEE double
+        return self._results_from_block(u.table, u.single_rows, rows, 1.0 - dist, unit == "chunk")
 
     def vector_search_by_embedding(self, embedding: list[float], top_k: int = 10, unit: str = "chunk") -> list[dict]:
         if len(embedding) == 0:  # reference: `if not query_vector: return []` (base.py:403-404)
@@ -159,14 +169,10 @@ class Mi355RetrievalService:
         qtok = np.concatenate([mats[i] for i in live], axis=0)
         qoff = np.concatenate([[0], np.cumsum([lens[i] for i in live])]).astype(np.int32)
         dist, rows = ix.search_maxsim(qtok, qoff, top_k)
-        for j, i in enumerate(live):
-            n_q = max(1, lens[i])
-            res = []
-            for dv, r in zip(dist[j], rows[j]):
-                if r < 0:
-                    break
-                # reference: score = -distance / n_query_vectors (retrieval_pipeline.py:511-514)
-                res.append(self._make_retrieval_result(u.table, int(u.multi_rows[r]), -float(dv) / n_q, unit == "chunk"))
+        # reference: score = -distance / n_query_vectors (retrieval_pipeline.py:511-514): float(f32) negated, divided
+        n_q = np.maximum(1, np.asarray([lens[i] for i in live], dtype=np.int64))[:, None]
+        scores = -dist.astype(np.float64) / n_q
+        for i, res in zip(live, self._results_from_block(u.table, u.multi_rows, rows, scores, unit == "chunk")):
             out[i] = res
         return out
 
