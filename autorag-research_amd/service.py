@@ -325,10 +325,17 @@ class Mi355RetrievalService:
                 offset += batch_size
                 continue
             results = block_func(qids, top_k) if block_func is not None else asyncio.run(page(qids))
-            rows = self._collect_retrieval_results(qids, results, pipeline_id, failed, result_id_key)
-            if rows:
-                store.bulk_insert(unit, rows)
-                total_results += len(rows)
+            insert_page = getattr(store, "insert_page", None)
+            if callable(insert_page):
+                # a store that takes a page as it is (ranked lists per query): skips flattening it into one dict per
+                # result row only to regroup them by query again
+                failed.extend(q for q, r in zip(qids, results, strict=True) if r is None)
+                total_results += insert_page(unit, pipeline_id, qids, results)
+            else:
+                rows = self._collect_retrieval_results(qids, results, pipeline_id, failed, result_id_key)
+                if rows:
+                    store.bulk_insert(unit, rows)
+                    total_results += len(rows)
             total_queries += len([r for r in results if r is not None])
             offset += len(queries)
             logger.info(f"Processed {total_queries} queries, stored {total_results} results")

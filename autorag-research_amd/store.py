@@ -134,6 +134,17 @@ class InMemoryStore:
         tab = self.results_table(unit)
         return {q for q in query_ids if tab.get((pipeline_id, q))}
 
+    def insert_page(self, unit: str, pipeline_id: int, query_ids: list, results: list) -> int:
+        """A page of ranked lists (None = failed query) at once; same table contents as bulk_insert of the reference's
+        row dicts {query_id, pipeline_id, chunk_id|image_chunk_id, rel_score}.  Returns the number of rows stored."""
+        tab = self.results_table(unit)
+        n = 0
+        for qid, res in zip(query_ids, results, strict=True):
+            if res:
+                tab.setdefault((pipeline_id, qid), []).extend([(r["doc_id"], float(r["score"])) for r in res])
+                n += len(res)
+        return n
+
     def bulk_insert(self, unit: str, rows: list[dict[str, Any]]) -> None:
         tab = self.results_table(unit)
         key = "image_chunk_id" if unit == "image_chunk" else "chunk_id"
