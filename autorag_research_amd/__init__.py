@@ -1,11 +1,18 @@
-"""Importable alias of the hyphen-named package directory ``autorag-research_amd/``.
+"""autorag_research_amd -- MI355X-native dense-retrieval core for AutoRAG-Research's Vector Search hot path.
 
-Python cannot import a directory whose name contains '-', so this one-file package re-points its
-``__path__`` at the real directory and runs that directory's ``__init__``.  All code lives there.
+Distribution name ``autorag-research-amd``; import name and directory ``autorag_research_amd`` (a plain package:
+the pipeline YAMLs under ``retrieval/`` and ``configs/`` and the built ``libmi355dr.so`` are package data).
+
+Layout: csrc/ (HIP kernels + C ABI -> libmi355dr.so), _native.py (ctypes), index.py (one GPU shard),
+store.py / service.py / pipelines.py (host-side mirror of the reference's repository / service /
+pipeline interfaces for this path), heaven.py (HEAVEN two-stage caller: cosine top-N then candidate MaxSim),
+gqr.py (Guided Query Refinement caller: candidate-pool refinement loops on the GPU), hybrid.py (RRF / convex-combination
+fusion of two child pipelines), hyde.py (hypothetical-document retrieval),
+metrics.py (retrieval metrics), embeddings.py (embedding interfaces), shards.py (fp32 shard files: memory-mapped,
+chunked load), sharded.py (row-sharded multi-GPU search).
 """
 
-from pathlib import Path as _Path
+__version__ = "0.1.0"
 
-_real = _Path(__file__).resolve().parent.parent / "autorag-research_amd"
-__path__ = [str(_real)]
-exec(compile((_real / "__init__.py").read_text(), str(_real / "__init__.py"), "exec"))
+from .index import Mi355Index  # noqa: F401
+from ._native import NativeError  # noqa: F401

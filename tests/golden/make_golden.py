@@ -52,36 +52,10 @@ sys.path.insert(0, "/root/reference")
 sys.dont_write_bytecode = True
 
 
-def _stub(name: str) -> None:
-    m = types.ModuleType(name)
-    m.__path__ = []  # type: ignore[attr-defined]
-    m.__getattr__ = lambda n: type(n, (object,), {  # type: ignore[assignment]
-        "__init__": lambda s, *a, **k: None,
-        "__class_getitem__": classmethod(lambda c, i: c),
-    })
-    sys.modules[name] = m
+sys.path.insert(0, str(HERE))
+from ref_import import import_reference  # noqa: E402
 
-
-for _n in ["tiktoken", "evaluate", "hydra", "hydra.utils", "langchain_core", "langchain_core.embeddings",
-           "langchain_core.language_models", "nltk", "omegaconf", "pgvector", "pgvector.sqlalchemy", "rouge_score",
-           "rouge_score.rouge_scorer", "sacrebleu", "sacrebleu.metrics", "sacrebleu.metrics.bleu", "tenacity",
-           "psycopg", "dotenv"]:
-    _stub(_n)
-
-from sqlalchemy.types import UserDefinedType  # noqa: E402
-
-
-class _Vector(UserDefinedType):
-    cache_ok = True
-
-    def __init__(self, dim=None):
-        self.dim = dim
-
-    def get_col_spec(self, **kw):
-        return f"VECTOR({self.dim})"
-
-
-sys.modules["pgvector.sqlalchemy"].Vector = _Vector  # type: ignore[attr-defined]
+import_reference()
 
 from autorag_research.evaluation.metrics import retrieval as ref_metrics  # noqa: E402
 from autorag_research.evaluation.metrics.util import calculate_cosine_similarity  # noqa: E402

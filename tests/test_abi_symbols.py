@@ -43,7 +43,7 @@ def test_no_cpu_fallback_without_gpu(native_built):
 
 
 def test_product_never_imports_the_oracle():
-    pkg = ROOT / "autorag-research_amd"
+    pkg = ROOT / "autorag_research_amd"
     for p in list(pkg.rglob("*.py")) + list(pkg.rglob("*.h")) + list(pkg.rglob("*.hip")):
         src = p.read_text()
         assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), p

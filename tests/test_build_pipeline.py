@@ -12,7 +12,7 @@ from pathlib import Path
 import pytest
 
 ROOT = Path(__file__).resolve().parents[1]
-CSRC = ROOT / "autorag-research_amd" / "csrc"
+CSRC = ROOT / "autorag_research_amd" / "csrc"
 
 
 def _kernel_bodies(asm: str) -> dict[str, list[str]]:
