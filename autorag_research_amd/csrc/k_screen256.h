@@ -45,6 +45,31 @@ __host__ __device__ inline unsigned screen256_grid(int n_ctiles, int n_qtiles) {
     return 8u * (unsigned)(need < lmax ? need : lmax);
 }
 
+// ---- developer timeline trace (tools/screen_bench, ABL bit 4): waves 0 and 4 of workgroup 0 stamp s_memtime at four
+// points of every phase of K-steps [kTraceG0, kTraceG0 + kTraceSteps) into the 2 KiB of LDS behind the queues.
+constexpr int kTraceG0 = 24, kTraceSteps = 6, kTraceStamps = kTraceSteps * 16;
+constexpr int kTraceOff = kRingBytes + 8 * kWaveQueueCap * 12;  // == kScreen256Lds
+__device__ unsigned long long* g_trace_out;  // [2][kTraceStamps], set with hipMemcpyToSymbol
+// stamp with the scalar-memory wait (only where no LDS read is outstanding or a full lgkmcnt(0) is due anyway)
+#define MI355_TR_STAMP(ON, ADDR)                                                                       \
+    do {                                                                                               \
+        if (ON) {                                                                                      \
+            unsigned long long t__;                                                                    \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                \
+            asm volatile("ds_write_b64 %0, %1" ::"v"(ADDR), "v"(t__) : "memory");                      \
+            ADDR += 8;                                                                                 \
+        }                                                                                              \
+    } while (0)
+// stamp whose value is picked up later (in front of a barrier, with ds_reads in flight): issue only
+#define MI355_TR_ISSUE(ON, T) do { if (ON) asm volatile("s_memtime %0" : "=s"(T)::"memory"); } while (0)
+#define MI355_TR_STORE(ON, ADDR, T)                                                                    \
+    do {                                                                                               \
+        if (ON) {                                                                                      \
+            asm volatile("ds_write_b64 %0, %1" ::"v"(ADDR), "v"(T) : "memory");                        \
+            ADDR += 8;                                                                                 \
+        }                                                                                              \
+    } while (0)
+
 #define MI355_BARRIER()                      \
     do {                                     \
         __builtin_amdgcn_sched_barrier(0);   \
@@ -156,33 +181,26 @@ __global__ __launch_bounds__(512, 2) void k_screen256(ScreenArgs a) {
     } while (0)
 #define MI355_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 // one K-step that also stages the next K-step (of this tile or of the next one): PAR = ring parity being read
+#define MI355_PHASE(SS, LOADS, I, J, PAR, SA, KO)                                                      \
+    do {                                                                                              \
+        MI355_TR_STAMP(tr_on, tr_addr);                                                               \
+        MI355_STAGE(SS, (PAR) ^ 1, SA, KO);                                                            \
+        LOADS;                                                                                        \
+        MI355_WAIT_VM(4);                                                                             \
+        MI355_TR_ISSUE(tr_on, tr_l);                                                                  \
+        MI355_BARRIER();                                                                              \
+        MI355_TR_STAMP(tr_on, tr_addr);                                                               \
+        MI355_TR_STORE(tr_on, tr_addr, tr_l);                                                         \
+        MI355_MFMA(I, J);                                                                             \
+        MI355_TR_STAMP(tr_on, tr_addr);                                                               \
+        MI355_BARRIER();                                                                              \
+    } while (0)
 #define MI355_KSTEP_STAGING(PAR, SA, KO)                                                                \
     do {                                                                                              \
-        MI355_STAGE(0, (PAR) ^ 1, SA, KO);                                                             \
-        MI355_LOAD_A(0, PAR);                                                                         \
-        MI355_LOAD_B(0, PAR);                                                                         \
-        MI355_WAIT_VM(4);                                                                             \
-        MI355_BARRIER();                                                                              \
-        MI355_MFMA(0, 0);                                                                             \
-        MI355_BARRIER();                                                                              \
-        MI355_STAGE(1, (PAR) ^ 1, SA, KO);                                                             \
-        MI355_LOAD_B(1, PAR);                                                                         \
-        MI355_WAIT_VM(4);                                                                             \
-        MI355_BARRIER();                                                                              \
-        MI355_MFMA(0, 1);                                                                             \
-        MI355_BARRIER();                                                                              \
-        MI355_STAGE(2, (PAR) ^ 1, SA, KO);                                                             \
-        MI355_LOAD_A(1, PAR);                                                                         \
-        MI355_WAIT_VM(4);                                                                             \
-        MI355_BARRIER();                                                                              \
-        MI355_MFMA(1, 1);                                                                             \
-        MI355_BARRIER();                                                                              \
-        MI355_STAGE(3, (PAR) ^ 1, SA, KO);                                                             \
-        MI355_LOAD_B(0, PAR);                                                                         \
-        MI355_WAIT_VM(4);                                                                             \
-        MI355_BARRIER();                                                                              \
-        MI355_MFMA(1, 0);                                                                             \
-        MI355_BARRIER();                                                                              \
+        MI355_PHASE(0, MI355_LOAD_A(0, PAR); MI355_LOAD_B(0, PAR), 0, 0, PAR, SA, KO);                 \
+        MI355_PHASE(1, MI355_LOAD_B(1, PAR), 0, 1, PAR, SA, KO);                                       \
+        MI355_PHASE(2, MI355_LOAD_A(1, PAR), 1, 1, PAR, SA, KO);                                       \
+        MI355_PHASE(3, MI355_LOAD_B(0, PAR), 1, 0, PAR, SA, KO);                                       \
     } while (0)
 
     // ---- prologue: stage K-step 0 of the first tile completely
@@ -196,6 +214,11 @@ __global__ __launch_bounds__(512, 2) void k_screen256(ScreenArgs a) {
 
     int par = 0;  // ring parity of the K-step being consumed
     bool first_k = true;
+    // developer trace (ABL bit 4): see MI355_TR_* above
+    int gk = 0;
+    bool tr_on = false;
+    unsigned tr_addr = lds_addr(smem + kTraceOff + group * (kTraceStamps * 8));
+    unsigned long long tr_l = 0;
     for (;;) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -214,9 +237,11 @@ __global__ __launch_bounds__(512, 2) void k_screen256(ScreenArgs a) {
             const bool last = t + 1 == T;
             const char* const sA = last ? baseA_next : baseA;
             const int64_t ko = last ? 0 : (int64_t)(t + 1) * kRowB;
+            if (ABL & 16) tr_on = blockIdx.x == 0 && (wave & 3) == 0 && gk >= kTraceG0 && gk < kTraceG0 + kTraceSteps;
             MI355_KSTEP_STAGING(par, sA, ko);
             par ^= 1;
             first_k = false;
+            ++gk;
         }
         baseA = baseA_next;
 
@@ -256,6 +281,12 @@ __global__ __launch_bounds__(512, 2) void k_screen256(ScreenArgs a) {
 #undef MI355_MFMA
 #undef MI355_WAIT_VM
 #undef MI355_KSTEP_STAGING
+#undef MI355_PHASE
+    if ((ABL & 16) && blockIdx.x == 0 && (wave & 3) == 0) {  // dump the trace
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long* src = (const unsigned long long*)(smem + kTraceOff + group * (kTraceStamps * 8));
+        for (int i = lane; i < kTraceStamps; i += 64) g_trace_out[group * kTraceStamps + i] = src[i];
+    }
 
     // ---- flush this wave's candidate queue: one global atomic per entry
     wave_queue_flush(a, que, min(que_n, kWaveQueueCap));

@@ -1,0 +1,404 @@
+// k_screen256b.h -- second form of the large-block screen (256 corpus rows x 256 queries per tile, 8 waves, persistent).
+//
+// Same contract, tile, wave layout, LDS image and ping-pong as k_screen256 (k_screen256.h); what changes is WHEN things
+// happen inside a K-step, after reading the first form's ISA and timeline (DESIGN.md 4.1 "second form"):
+//
+//  * Both query halves stay in registers (fb0, fb1: +16 VGPRs), so B0 is read ONCE per K-step instead of twice
+//    (-4 of 28 ds_read_b128 per wave and K-step) -- and, more important, every ring slot now has its LAST reader in the
+//    first three phases of a K-step.
+//  * Ring slots are re-staged as soon as they are free, with the data of the K-step TWO ahead (first form: one ahead,
+//    staged in the same order every K-step, which left the vmcnt(4) wait only 2 phases of DMA flight).  Schedule for
+//    K-step g, ring parity P = g&1:
+//        phase 0: read A0(P) B0(P) | stage B1(g+1) -> (P^1)   [slot last read in phase 1 of K-step g-1]
+//        phase 1: read B1(P)       | stage A1(g+1) -> (P^1)   [last read in phase 2 of g-1]
+//        phase 2: read A1(P)       | stage A0(g+2) -> (P)     [last read in phase 0 of THIS K-step: 2 barriers ago]
+//        phase 3: (no reads)       | stage B0(g+2) -> (P)     [last read in phase 0 of this K-step]
+//    Every half-tile is needed 5-6 phases after its issue; the wait in front of each barrier is vmcnt(8) = FOUR
+//    half-tiles (64 KiB per workgroup) still in flight, twice the first form's lead.  Hazard rules unchanged: a
+//    half-tile is read in the phase after the wait that covers it (2 barriers for the waiting wave, 1 for the other
+//    group), a slot is re-staged >= 2 barriers after its last reader's lgkmcnt(0).
+//  * The LOAD half issues its ds_reads BEFORE the two LDS-DMA instructions (their issue alone costs 60-180 cycles each
+//    under load; the reads are what the next MFMA half waits for).
+//  * No per-tile epilogue block.  A quadrant (i,j) of the accumulators is final after phase p(i,j) of the tile's last
+//    K-step and is overwritten in phase p(i,j) of the next tile's first K-step, so its threshold test runs in a LOAD half
+//    in between (quadrants 00, 01, 11 in phases 1, 2, 3 of the last K-step, quadrant 10 in phase 1 of the next tile's first
+//    K-step) and its 32 accumulator registers are zeroed in the LOAD half right before their first MFMA: ~25 + 32 VALU
+//    instructions next to the OTHER group's MFMA half, instead of ~300 in one block during which the matrix pipe of
+//    both groups idles (at d = 768 int8 a tile is only 6 K-steps long).
+//  * A burst that overflows a wave's LDS candidate queue inside one tile no longer falls back to returning global atomics
+//    inside the K loop: the query is flagged kStOverflow and re-screened by the host's retry path (exactness kept, the
+//    hot loop has no vector-memory instruction besides the DMA).
+#pragma once
+#include "k_screen256.h"
+
+namespace mi355 {
+
+struct ScreenArgs2 : ScreenArgs {
+    int* status;  // [Bpad] per-query status bits (kStOverflow is set when a wave's queue overflows)
+};
+
+template <bool I8>
+__device__ __forceinline__ void screen_queue_block2(const ScreenArgs2& a, f32x16 acc, int q, int rbase, int row_end,
+                                                    float th, int thi, float sc, int32_t* que, int& que_n) {
+    bool any, gany[4];
+    if constexpr (I8) {
+        const i32x16 v = __builtin_bit_cast(i32x16, acc);
+        int g[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[i] = max(max(v[4 * i], v[4 * i + 1]), max(v[4 * i + 2], v[4 * i + 3]));
+        any = max(max(g[0], g[1]), max(g[2], g[3])) >= thi;
+        if (__builtin_amdgcn_ballot_w64(any) == 0) return;  // wave-uniform: almost always taken
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gany[i] = g[i] >= thi;
+    } else {
+        float g[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[i] = fmaxf(fmaxf(acc[4 * i], acc[4 * i + 1]), fmaxf(acc[4 * i + 2], acc[4 * i + 3]));
+        any = fmaxf(fmaxf(g[0], g[1]), fmaxf(g[2], g[3])) >= th;
+        if (__builtin_amdgcn_ballot_w64(any) == 0) return;  // wave-uniform: almost always taken
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gany[i] = g[i] >= th;
+    }
+    const unsigned a_q = lds_addr(que), a_r = a_q + 4u * kWaveQueueCap, a_v = a_q + 8u * kWaveQueueCap;
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+        if (__builtin_amdgcn_ballot_w64(gany[gi]) == 0) continue;  // wave-uniform: no hit in this group of four
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+            const int r = 4 * gi + ri;
+            bool hit;
+            if constexpr (I8) hit = __builtin_bit_cast(i32x16, acc)[r] >= thi;
+            else hit = acc[r] >= th;
+            if (__builtin_amdgcn_ballot_w64(hit) == 0) continue;  // wave-uniform
+            const int row = rbase + (r & 3) + 8 * (r >> 2);
+            hit = hit && row < row_end;
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
+            if (hit) {
+                const unsigned e = (unsigned)que_n +
+                                   __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+                float val;
+                if constexpr (I8) val = (float)__builtin_bit_cast(i32x16, acc)[r] * sc;
+                else val = acc[r];
+                if (e < (unsigned)kWaveQueueCap) {
+                    asm volatile("ds_write_b32 %0, %1" ::"v"(a_q + 4u * e), "v"(q) : "memory");
+                    asm volatile("ds_write_b32 %0, %1" ::"v"(a_r + 4u * e), "v"(row) : "memory");
+                    asm volatile("ds_write_b32 %0, %1" ::"v"(a_v + 4u * e), "v"(val) : "memory");
+                } else {  // queue full: the query is re-screened by the host (no returning atomic in the K loop)
+                    __hip_atomic_fetch_or(&a.status[q], kStOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            que_n += __builtin_popcountll(bal);  // may run past the capacity: the flush clamps
+        }
+    }
+}
+
+// ---- one 1-KiB piece (U = 0,1) of half-tile type S into ring parity `par`; src = the half-tile's first row + K offset
+// LDS-DMA with the source address split as the hardware takes it: a wave-uniform 64-bit base in SGPRs + a 32-bit
+// per-lane offset (the "saddr" form of global_load).  The builtin form adds the two into a 64-bit VGPR pair per lane
+// (one v_lshl_add_u64 per piece, and twice the address payload from the register file to the texture addresser).  M0 =
+// LDS destination of the wave's 1-KiB piece; it is written in the same statement (the compiler does not preserve it).
+__device__ __forceinline__ void glds16_saddr(const char* sbase, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+template <int S, bool SADDR>
+__device__ __forceinline__ void kb_stage(char* smem, int wave, int par, const char* src, const unsigned (&voff)[2], int u) {
+    char* const dst = smem + (4 * par + S) * kHalfBytes + (2 * wave + u) * 1024;
+    if constexpr (SADDR) glds16_saddr(src, voff[u], lds_addr(dst));
+    else glds16(src + voff[u], dst);
+}
+
+// ABL (developer switches for tools/screen_bench / screen_trace, 0 in the library):
+//   bit2 (4)   no s_setprio            bit3 (8)   wait for the ds_reads before the barrier instead of after it
+//   bit4 (16)  timeline trace          bit5 (32)  NM = 1: the second 1-KiB piece of every half-tile is issued inside the
+//   MFMA half (after the 4th MFMA)     bit6 (64)  NM = 2: both pieces inside the MFMA half (after the 2nd and 6th MFMA)
+//   bit8 (256) TAIL = 1 / bit9 (512) TAIL = 2: the phase's second barrier is passed before the last 2 / 4 MFMAs are issued,
+//              so the other group's first MFMAs queue behind them and the matrix pipe does not drain during the hand-over
+//   bit7 (128) every workgroup starts its K walk at a different K-step (sharers of a tile do not ask the L2 for the same
+//              lines at the same moment)
+constexpr int kScreen256bAbl = 64 | 1024 | 2048;  // what the library runs: NM = 2, SADDR, FAN (A/B in tools/screen_bench)
+template <int ABL, bool I8>
+__global__ __launch_bounds__(512, 2) void k_screen256b(ScreenArgs2 a) {
+    constexpr int NM = (ABL & 64) ? 2 : ((ABL & 32) ? 1 : 0);
+    constexpr bool SADDR = (ABL & 1024) != 0;  // LDS-DMA through the SGPR-base + 32-bit-offset form (inline asm)
+    constexpr bool FAN = (ABL & 2048) != 0;    // balance the LOAD halves: 8/4/8/4 ds_reads instead of 12/4/8/0
+    constexpr int TAIL = (ABL & 512) ? 2 : ((ABL & 256) ? 1 : 0);  // K sub-steps (2 MFMAs each) issued AFTER the second barrier
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int group = wave >> 2;  // 0 leads, 1 runs one barrier behind
+    const int wr = group, wc = wave & 3;
+    int32_t* const que = (int32_t*)(smem + kRingBytes + wave * (kWaveQueueCap * 12));  // [q | row | value bits]
+    int que_n = 0;                                                                       // wave-uniform
+
+    const int b = blockIdx.x;
+    const int xcd = b & 7;
+    const int l = b >> 3;
+    const int cslot = l / a.n_qtiles;
+    const int qt = l - cslot * a.n_qtiles;
+    const int cstep = ((int)(gridDim.x >> 3) / a.n_qtiles) * 8;  // corpus tiles between two visits
+    int ctl = cslot * 8 + xcd;
+    if (ctl >= a.n_ctiles) return;
+    const int q0 = qt * kT2;
+    const int64_t row_bytes = a.row_bytes;
+
+    // ---- DMA sources (as in k_screen256): this wave stages local rows [16*wave + 8u, +8) of every half-tile
+    unsigned voffA[2], voffB[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int r = (2 * wave + u) * 8 + (lane >> 3);      // local row 0..127
+        const int c = (lane & 7) ^ ((r >> 1) & 7);           // source chunk for this LDS slot (swizzle)
+        const int arow0 = 128 * (r >> 6) + (r & 63);         // + 64*i
+        const int bcol0 = 64 * (r >> 5) + (r & 31);          // + 32*j
+        voffA[u] = (unsigned)(arow0 * (int)row_bytes + c * 16);
+        voffB[u] = (unsigned)(bcol0 * (int)row_bytes + c * 16);
+    }
+    const char* const baseB = (const char*)a.qhat + (int64_t)q0 * row_bytes;
+    const int64_t tile_stride_bytes = (int64_t)cstep * kT2 * row_bytes;
+    const int64_t half_A = 64 * row_bytes, half_B = 32 * row_bytes;
+    int offA[2], offB;
+    {
+        const int g = lane >> 5;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const int r = wr * 64 + rb * 32 + (lane & 31);
+            offA[rb] = r * kRowB + ((g ^ ((r >> 1) & 7)) << 4);
+        }
+        const int r = wc * 32 + (lane & 31);
+        offB = r * kRowB + ((g ^ ((r >> 1) & 7)) << 4);
+    }
+    float th[2], scq[2];
+    int thi[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = q0 + 64 * wc + 32 * j + (lane & 31);
+        th[j] = a.thr[q];
+        thi[j] = I8 ? a.thr_i[q] : 0;
+        scq[j] = I8 ? a.sc[q] : 1.0f;
+    }
+    // These loads must be complete IN THE COMPILER'S BOOKS before the first LDS-DMA is issued: its waitcnt insertion does
+    // not see the counted asm waits below, and would otherwise put s_waitcnt vmcnt(0) in front of the first use of a
+    // threshold -- inside the K loop, draining the whole prefetch (tests/test_build_pipeline.py checks the ISA).
+    asm volatile("" ::"v"(th[0]), "v"(th[1]), "v"(thi[0]), "v"(thi[1]), "v"(scq[0]), "v"(scq[1]));
+
+    // accumulators start at "never a hit": the first tile's phase 1 tests quadrant (1,0) of a tile that does not exist
+    f32x16 acc[2][2][2];  // [row half i][row block rb][query half j]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][rb][j][r] = I8 ? __int_as_float((int)0x80000000) : -__builtin_inff();
+    bf16x8 fa[2][4], fb0[4], fb1[4];  // typed bf16x8 also for int8 data: see the NOTE in k_screen.h (waitcnt insertion)
+    bf16x8 fan[2][2];                 // FAN: K sub-steps 0,1 of the NEXT K-step's A0, read one phase early (phase 3)
+    const int T = a.ksteps;
+    const int kend = T * kRowB;
+
+#define KB_READ_A(I, PAR)                                                                             \
+    do {                                                                                              \
+        const char* s__ = smem + (4 * (PAR) + ((I) ? 3 : 0)) * kHalfBytes;                            \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                              \
+            _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                          \
+                fa[rb][kk] = __builtin_bit_cast(bf16x8, *(const uint4*)(s__ + (offA[rb] ^ (kk * 32)))); \
+    } while (0)
+// A0 split for FAN: K sub-steps [K0, K0+2) of A0 in parity PAR into DST[rb][kk - KD]
+#define KB_READ_A0_PART(PAR, K0, KD, DST)                                                             \
+    do {                                                                                              \
+        const char* s__ = smem + (4 * (PAR)) * kHalfBytes;                                            \
+        _Pragma("unroll") for (int kk = (K0); kk < (K0) + 2; ++kk)                                    \
+            _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                          \
+                DST[rb][kk - (KD)] = __builtin_bit_cast(bf16x8, *(const uint4*)(s__ + (offA[rb] ^ (kk * 32)))); \
+    } while (0)
+#define KB_READ_B(J, PAR, FB)                                                                         \
+    do {                                                                                              \
+        const char* s__ = smem + (4 * (PAR) + 1 + (J)) * kHalfBytes;                                  \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                              \
+            FB[kk] = __builtin_bit_cast(bf16x8, *(const uint4*)(s__ + (offB ^ (kk * 32))));           \
+    } while (0)
+// the phase's half-tile: type SS into parity SPAR from SRC (first row of the half-tile + K offset), rows by VOFF
+#define KB_STG(U) kb_stage<SS__, SADDR>(smem, wave, spar__, ssrc__, *svoff__, U)
+#define KB_PIN() __builtin_amdgcn_sched_barrier(0)
+#define KB_ZERO(I, J)                                                                                 \
+    do {                                                                                              \
+        asm volatile("; zero quadrant");  /* keeps this a branch: if-converted it is 32 v_cndmask in EVERY K-step */ \
+        _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                              \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[I][rb][J][r] = 0.0f;                   \
+    } while (0)
+// threshold test of quadrant (I,J) of the tile whose first row is ROW0
+#define KB_TEST(I, J, ROW0)                                                                           \
+    do {                                                                                              \
+        int lane_e = lane;                                                                            \
+        asm volatile("" : "+v"(lane_e));                                                              \
+        const int q__ = q0 + 64 * wc + 32 * (J) + (lane_e & 31);                                      \
+        _Pragma("unroll") for (int rb = 0; rb < 2; ++rb) {                                            \
+            const int rbase__ = (ROW0) + 128 * wr + 64 * (I) + 32 * rb + 4 * (lane_e >> 5);           \
+            screen_queue_block2<I8>(a, acc[I][rb][J], q__, rbase__, row_end, th[J], thi[J], scq[J], que, que_n); \
+        }                                                                                             \
+    } while (0)
+#define KB_WAIT_VM_N()                                                                                \
+    do {                                                                                              \
+        if constexpr (NM == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                       \
+        else if constexpr (NM == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");                  \
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                         \
+    } while (0)
+// One phase.  LOAD half: READS (ds_reads first), then the pieces of this phase's half-tile that are not issued inside the
+// MFMA half, EXTRA (accumulator zeroing / threshold tests at tile boundaries), the counted DMA wait (WAIT = 1) | barrier |
+// MFMA half: 8 MFMAs on quadrant (I,J), the remaining DMA pieces between them | barrier.
+#define KB_PHASE(READS, SS, SPAR, SSRC, SVOFF, EXTRA, WAIT, I, J, FB)                                  \
+    do {                                                                                              \
+        constexpr int SS__ = (SS);                                                                    \
+        const int spar__ = (SPAR);                                                                    \
+        const char* const ssrc__ = (SSRC);                                                            \
+        const unsigned(*svoff__)[2] = &(SVOFF);                                                       \
+        MI355_TR_STAMP(tr_on, tr_addr);                                                               \
+        READS;                                                                                        \
+        if constexpr (NM < 2) KB_STG(0);                                                              \
+        if constexpr (NM < 1) KB_STG(1);                                                              \
+        EXTRA;                                                                                        \
+        if (ABL & 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               \
+        if (WAIT) KB_WAIT_VM_N();                                                                     \
+        MI355_TR_ISSUE(tr_on, tr_l);                                                                  \
+        MI355_BARRIER();                                                                              \
+        MI355_TR_STAMP(tr_on, tr_addr);                                                               \
+        MI355_TR_STORE(tr_on, tr_addr, tr_l);                                                         \
+        if (!(ABL & 4)) __builtin_amdgcn_s_setprio(1);                                                \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                            \
+            if (kk == 4 - TAIL) { /* hand the matrix pipe over while the last MFMAs are still to be issued */ \
+                MI355_TR_STAMP(tr_on, tr_addr);                                                       \
+                MI355_BARRIER();                                                                      \
+            }                                                                                         \
+            _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                          \
+                acc[I][rb][J] = screen_mfma<I8>((FAN && (I) == 0 && kk < 2) ? fan[rb][kk] : fa[rb][kk], FB[kk],  \
+                                                acc[I][rb][J]);                                       \
+            if constexpr (NM == 2) {                                                                  \
+                if (kk == 0) { KB_PIN(); KB_STG(0); KB_PIN(); }                                       \
+                if (kk == (TAIL >= 2 ? 1 : 2)) { KB_PIN(); KB_STG(1); KB_PIN(); }                     \
+            }                                                                                         \
+            if constexpr (NM == 1) {                                                                  \
+                if (kk == 1) { KB_PIN(); KB_STG(1); KB_PIN(); }                                       \
+            }                                                                                         \
+        }                                                                                             \
+        if (!(ABL & 4)) __builtin_amdgcn_s_setprio(0);                                                \
+        if (TAIL == 0) {                                                                              \
+            MI355_TR_STAMP(tr_on, tr_addr);                                                           \
+            MI355_BARRIER();                                                                          \
+        }                                                                                             \
+    } while (0)
+
+    // staging cursors: position g+1 (c1) and g+2 (c2) of the workgroup's K-step sequence = (tile base, K offset, K-steps
+    // done in that tile); past the last tile they stay on it (dummy re-stage of valid memory, drained before the exit)
+    const int rot = (ABL & 128) ? (l % T) * kRowB : 0;  // K offset the walk starts at (the sum over K-steps is order-free)
+    const char* c1_base = (const char*)a.shadow + (int64_t)(a.ct0 + ctl) * kT2 * row_bytes;
+    int c1_k = rot, c1_n = 0, c1_ctl = ctl;
+    const char* c2_base;
+    int c2_k, c2_n, c2_ctl;
+#define KB_ADVANCE(BASE, K, N, CTL)                                                                   \
+    do {                                                                                              \
+        K += kRowB;                                                                                   \
+        if (K == kend) K = 0;                                                                         \
+        if (++N == T) {                                                                               \
+            N = 0;                                                                                    \
+            if (CTL + cstep < a.n_ctiles) {                                                           \
+                CTL += cstep;                                                                         \
+                BASE += tile_stride_bytes;                                                            \
+            }                                                                                         \
+        }                                                                                             \
+    } while (0)
+
+    // ---- prologue: K-step 0 completely (parity 0), A0 and B0 of K-step 1 (parity 1)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) kb_stage<0, SADDR>(smem, wave, 0, c1_base + c1_k, voffA, u);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) kb_stage<1, SADDR>(smem, wave, 0, baseB + c1_k, voffB, u);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) kb_stage<2, SADDR>(smem, wave, 0, baseB + half_B + c1_k, voffB, u);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) kb_stage<3, SADDR>(smem, wave, 0, c1_base + half_A + c1_k, voffA, u);
+    KB_ADVANCE(c1_base, c1_k, c1_n, c1_ctl);  // c1 = position 1
+#pragma unroll
+    for (int u = 0; u < 2; ++u) kb_stage<0, SADDR>(smem, wave, 1, c1_base + c1_k, voffA, u);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) kb_stage<1, SADDR>(smem, wave, 1, baseB + c1_k, voffB, u);
+    c2_base = c1_base;
+    c2_k = c1_k;
+    c2_n = c1_n;
+    c2_ctl = c1_ctl;
+    KB_ADVANCE(c2_base, c2_k, c2_n, c2_ctl);  // c2 = position 2
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // K-step 0 has landed
+    MI355_BARRIER();
+    if constexpr (FAN) KB_READ_A0_PART(0, 0, 0, fan);  // (every later K-step gets these in phase 3 of its predecessor)
+    if (group == 1) MI355_BARRIER();  // stagger: group 1's LOAD halves line up with group 0's MFMA halves
+
+    const int row_end = (int)a.row_end;
+    int par = 0, t = 0;
+    int gk = 0;  // developer trace (ABL bit 4): see MI355_TR_* in k_screen256.h
+    bool tr_on = false;
+    unsigned tr_addr = lds_addr(smem + kTraceOff + group * (kTraceStamps * 8));
+    unsigned long long tr_l = 0;
+    int row0_cur = (a.ct0 + ctl) * kT2, row0_prev = row0_cur;  // rows < 2^31 (checked by the host)
+    for (;;) {
+        const bool first = t == 0, last = t + 1 == T;
+        if (first && que_n > kWaveQueueCap / 2) {  // wave-uniform, rare: this wave stalls on vector memory once
+            wave_queue_flush(a, que, min(que_n, kWaveQueueCap));
+            que_n = 0;
+        }
+        if (ABL & 16) tr_on = blockIdx.x == 0 && (wave & 3) == 0 && gk >= kTraceG0 && gk < kTraceG0 + kTraceSteps;
+        // phase 0: quadrant (0,0); stage B1 of K-step g+1
+        KB_PHASE(KB_READ_B(0, par, fb0); if constexpr (FAN) KB_READ_A0_PART(par, 2, 0, fa); else KB_READ_A(0, par), 2, par ^ 1,
+                 baseB + half_B + c1_k, voffB,
+                 if (first) KB_ZERO(0, 0), 1, 0, 0, fb0);
+        // phase 1: quadrant (0,1); stage A1 of K-step g+1; the previous tile's last quadrant is tested here
+        KB_PHASE(KB_READ_B(1, par, fb1), 3, par ^ 1, c1_base + half_A + c1_k, voffA,
+                 if (first) { KB_TEST(1, 0, row0_prev); KB_ZERO(0, 1); } if (last) KB_TEST(0, 0, row0_cur), 1, 0, 1, fb1);
+        // phase 2: quadrant (1,1); stage A0 of K-step g+2 (its slot was read in phase 0 of this K-step)
+        KB_PHASE(KB_READ_A(1, par), 0, par, c2_base + c2_k, voffA,
+                 if (first) KB_ZERO(1, 1); if (last) KB_TEST(0, 1, row0_cur), FAN ? 1 : 0, 1, 1, fb1);
+        // phase 3: quadrant (1,0); stage B0 of K-step g+2
+        KB_PHASE(if constexpr (FAN) KB_READ_A0_PART(par ^ 1, 0, 0, fan), 1, par, baseB + c2_k, voffB,
+                 if (first) KB_ZERO(1, 0); if (last) KB_TEST(1, 1, row0_cur), 1, 1, 0, fb0);
+
+        par ^= 1;
+        ++gk;
+        c1_base = c2_base;
+        c1_k = c2_k;
+        c1_n = c2_n;
+        c1_ctl = c2_ctl;
+        KB_ADVANCE(c2_base, c2_k, c2_n, c2_ctl);
+        if (last) {
+            row0_prev = row0_cur;
+            if (ctl + cstep >= a.n_ctiles) break;
+            ctl += cstep;
+            row0_cur = (a.ct0 + ctl) * kT2;
+            t = 0;
+        } else {
+            ++t;
+        }
+    }
+    KB_TEST(1, 0, row0_prev);  // the last tile's last quadrant
+    if (group == 0) MI355_BARRIER();  // balance the stagger barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the dummy prefetches must land before the LDS is freed
+    if ((ABL & 16) && blockIdx.x == 0 && (wave & 3) == 0) {  // dump the trace
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long* src = (const unsigned long long*)(smem + kTraceOff + group * (kTraceStamps * 8));
+        for (int i = lane; i < kTraceStamps; i += 64) g_trace_out[group * kTraceStamps + i] = src[i];
+    }
+
+#undef KB_READ_A
+#undef KB_READ_B
+#undef KB_READ_A0_PART
+#undef KB_STG
+#undef KB_PIN
+#undef KB_ZERO
+#undef KB_TEST
+#undef KB_WAIT_VM_N
+#undef KB_PHASE
+#undef KB_ADVANCE
+
+    // ---- flush this wave's candidate queue: one global atomic per entry
+    wave_queue_flush(a, que, min(que_n, kWaveQueueCap));
+}
+
+}  // namespace mi355

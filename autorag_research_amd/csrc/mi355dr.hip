@@ -6,6 +6,7 @@
 #include "k_scan.h"
 #include "k_screen.h"
 #include "k_screen256.h"
+#include "k_screen256b.h"
 #include "k_select.h"
 
 using namespace mi355;
@@ -121,6 +122,10 @@ int ensure_qstate(mi355dr_index* idx) {
                                       kScreen256Lds));
     HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen256<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kScreen256Lds));
+    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen256b<kScreen256bAbl, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kScreen256Lds));
+    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen256b<kScreen256bAbl, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kScreen256Lds));
     HIPCHECK(idx, hipFuncSetAttribute((const void*)k_merge_topk, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kSortMax * 12));
     idx->qstate_ready = true;
@@ -234,7 +239,8 @@ int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t 
     // hit, which the per-lane global append of k_screen handles better than k_screen256's small per-wave queues
     const int tile = (emit_all || r_end - r0 <= kSmallChunkRows) ? kTileM : screen_tile(B);
     const bool i8 = use_i8(idx);
-    ScreenArgs sa{};
+    ScreenArgs2 sa{};
+    sa.status = idx->st.status;
     sa.shadow = i8 ? (const void*)idx->shadow8 : (const void*)idx->shadow;
     sa.qhat = i8 ? (const void*)idx->st.qhat8 : (const void*)idx->st.qhat;
     sa.thr = idx->st.thr;
@@ -256,11 +262,16 @@ int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t 
     const int64_t grid = round_up(sa.n_ctiles, 8) * sa.n_qtiles;
     if (tile == kT2) {
         const unsigned g2 = screen256_grid(sa.n_ctiles, sa.n_qtiles);  // persistent: <= one workgroup per CU
-        if (i8) hipLaunchKernelGGL((k_screen256<0, true>), dim3(g2), dim3(512), kScreen256Lds, s, sa);
-        else hipLaunchKernelGGL((k_screen256<0, false>), dim3(g2), dim3(512), kScreen256Lds, s, sa);
+        if (idx->screen_form == 1) {
+            if (i8) hipLaunchKernelGGL((k_screen256b<kScreen256bAbl, true>), dim3(g2), dim3(512), kScreen256Lds, s, sa);
+            else hipLaunchKernelGGL((k_screen256b<kScreen256bAbl, false>), dim3(g2), dim3(512), kScreen256Lds, s, sa);
+        } else {
+            if (i8) hipLaunchKernelGGL((k_screen256<0, true>), dim3(g2), dim3(512), kScreen256Lds, s, (ScreenArgs)sa);
+            else hipLaunchKernelGGL((k_screen256<0, false>), dim3(g2), dim3(512), kScreen256Lds, s, (ScreenArgs)sa);
+        }
     } else {
-        if (i8) hipLaunchKernelGGL(k_screen<true>, dim3((unsigned)grid), dim3(256), kScreenLds, s, sa);
-        else hipLaunchKernelGGL(k_screen<false>, dim3((unsigned)grid), dim3(256), kScreenLds, s, sa);
+        if (i8) hipLaunchKernelGGL(k_screen<true>, dim3((unsigned)grid), dim3(256), kScreenLds, s, (ScreenArgs)sa);
+        else hipLaunchKernelGGL(k_screen<false>, dim3((unsigned)grid), dim3(256), kScreenLds, s, (ScreenArgs)sa);
     }
     HIPCHECK(idx, hipGetLastError());
     if (emit_all) {  // every row of the chunk was stored at slot row-r0 for every query
@@ -766,6 +777,9 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
         idx->round_a = (int)value;
     } else if (k == "prefilter16") {
         idx->prefilter16 = value != 0;
+    } else if (k == "screen_form") {
+        if (value < 0 || value > 1) return fail(idx, MI355DR_E_INVALID, "screen_form must be 0 or 1");
+        idx->screen_form = (int)value;
     } else if (k == "cand_cap") {
         if (value < 16 || value > kCandCap) return fail(idx, MI355DR_E_INVALID, "cand_cap must be in [16,2048]");
         idx->cap = (int)value;

@@ -53,6 +53,7 @@ def parse_args():
     ap.add_argument("--round-a", type=int, default=None, help="k_prune: rows re-scored before the cut is known (tuning)")
     ap.add_argument("--prefilter16", type=int, default=None, help="0/1: bf16 second screen inside the prune (default: library default)")
     ap.add_argument("--metric", choices=["cosine", "ip"], default="cosine", help="cosine (headline) or inner product")
+    ap.add_argument("--screen-form", type=int, default=None, help="developer A/B: 0 = first form of k_screen256, 1 = second form")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the all-gather + merge path even at world size 1 (exercises the multi-GPU code on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -188,6 +189,8 @@ def main() -> None:
         idx.set_option("prefilter16", args.prefilter16)
     if args.round_a is not None:
         idx.set_option("round_a", args.round_a)
+    if args.screen_form is not None:
+        idx.set_option("screen_form", args.screen_form)
     t_build = time.time()
     keep_parts = []
     keep_rows = 0

@@ -18,7 +18,7 @@ CSRC = ROOT / "autorag_research_amd" / "csrc"
 def _kernel_bodies(asm: str) -> dict[str, list[str]]:
     out, name = {}, None
     for line in asm.split("\n"):
-        if line.startswith("_ZN5mi355") and line.split(":")[0].endswith("ScreenArgsE") and ":" in line:
+        if line.startswith("_ZN5mi355") and line.split(":")[0].endswith(("ScreenArgsE", "ScreenArgs2E")) and ":" in line:
             name = line.split(":")[0]
             out[name] = []
         elif name is not None:
@@ -75,6 +75,48 @@ def test_screen256_keeps_dma_in_flight(screen_asm, i8):
     assert writes and len(writes) % 3 == 0
     for i in writes[2::3]:  # the last store of every (query, row, value) entry
         assert not any(p.startswith("s_waitcnt") and "lgkmcnt(0)" in p for p in ops[i + 1:i + 5]), ops[i:i + 6]
+
+
+def _loop_blocks(ops: list[str]) -> list[str]:
+    """The instructions between the first and the last MFMA (the persistent K loop incl. its cold branches)."""
+    mf = [i for i, o in enumerate(ops) if o.startswith("v_mfma")]
+    return ops[mf[0]:mf[-1] + 1]
+
+
+@pytest.mark.parametrize("i8", [False, True])
+def test_screen256b_pipeline(screen_asm, i8):
+    """Second form (the one the library launches): one K-step body; LDS-DMA issued BETWEEN the MFMAs through the
+    SGPR-base + 32-bit-offset form; counted waits vmcnt(6) in front of all four barriers; the only full vector-memory
+    wait inside the loop is the queue flush's (returning atomics, rare)."""
+    names = [n for n in screen_asm if "k_screen256bILi" in n and n.endswith(f"ELb{int(i8)}EEEvNS_11ScreenArgs2E")]
+    assert len(names) == 1, sorted(screen_asm)
+    ops = screen_asm[names[0]]
+    want = "v_mfma_i32_32x32x32_i8" if i8 else "v_mfma_f32_32x32x16_bf16"
+    mf = [o for o in ops if o.startswith("v_mfma")]
+    assert len(mf) == 32 and all(o.startswith(want) for o in mf)
+    assert not any(o.startswith("scratch_") for o in ops), "register spill in the screen kernel"
+    loop = _loop_blocks(ops)
+    glds = [o for o in loop if o.startswith("global_load_lds_dwordx4")]
+    assert len(glds) == 8 and all(", s[" in o for o in glds), glds  # saddr form: `v_off, s[base:base+1]`
+    assert sum(o.startswith("s_waitcnt") and "vmcnt(6)" in o for o in ops) == 4  # one per phase, the first above the first MFMA
+    # a vmcnt(0) inside the loop is allowed only next to the flush's global atomic
+    for i, o in enumerate(loop):
+        if _is_vm0(o):
+            assert any(p.startswith("global_atomic") for p in loop[max(0, i - 4):i]), loop[max(0, i - 6):i + 1]
+    # every MFMA quadrant: the two DMA pieces sit between MFMAs, not in the LOAD half
+    idx = [i for i, o in enumerate(loop) if o.startswith("v_mfma")]
+    for q in range(4):
+        seg = loop[idx[8 * q]:idx[8 * q + 7] + 1]
+        assert sum(o.startswith("global_load_lds") for o in seg) == 2, seg
+    # the hit path's queue stores are inline asm: no vector-memory wait in front of them, no LDS wait behind them
+    writes = [i for i, o in enumerate(ops) if o.startswith("ds_write_b32")]
+    assert writes and len(writes) % 3 == 0
+    for i in writes:
+        assert not any("vmcnt" in p for p in ops[max(0, i - 6):i] if p.startswith("s_waitcnt")), ops[i - 6:i + 1]
+    for i in writes[2::3]:
+        assert not any(p.startswith("s_waitcnt") and "lgkmcnt(0)" in p for p in ops[i + 1:i + 5]), ops[i:i + 6]
+    # a wave's queue overflow flags the query (no returning atomic): a non-returning global OR
+    assert any(o.startswith("global_atomic_or ") and "sc0" not in o for o in ops)
 
 
 @pytest.mark.parametrize("i8", [False, True])

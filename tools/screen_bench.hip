@@ -14,6 +14,7 @@
 #include "dev_common.h"
 #include "k_screen.h"
 #include "k_screen256.h"
+#include "k_screen256b.h"
 
 using namespace mi355;
 
@@ -89,6 +90,14 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)k_screen256<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
     CK(hipFuncSetAttribute((const void*)k_screen256<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
     CK(hipFuncSetAttribute((const void*)k_screen256<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
+    CK(hipFuncSetAttribute((const void*)k_screen256b<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
+    CK(hipFuncSetAttribute((const void*)k_screen256b<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
+#define SB_FORMS(X) X(1088) X(1024) X(1092) X(3136) X(3072) X(3140)
+#define SB_ATTR(A) CK(hipFuncSetAttribute((const void*)k_screen256b<A, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
+    SB_FORMS(SB_ATTR)
+    int* status;
+    CK(hipMalloc(&status, Bpad * 4));
+    CK(hipMemset(status, 0, Bpad * 4));
     // int8 variants (1128 / 1256) reuse the same buffers as raw bytes: rows of dpad8 = round_up(d,128) int8;
     // timing only (the integer thresholds are parked at INT_MAX)
     const int dpad8 = (d + 127) / 128 * 128;
@@ -108,7 +117,8 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e1));
 
     auto launch = [&](int variant) {
-        ScreenArgs sa{};
+        ScreenArgs2 sa{};
+        sa.status = status;
         sa.shadow = shadow;
         sa.qhat = qhat;
         sa.thr = thr;
@@ -125,33 +135,75 @@ int main(int argc, char** argv) {
         sa.cap = cap;
         sa.ct0 = 0;
         sa.row_end = N;
-        if (variant == 128) {
+        if (variant == 128) {  // (ScreenArgs2 slices to ScreenArgs for the first-form kernels)
             sa.n_ctiles = (int)((N + 127) / 128);
             sa.n_qtiles = (B + 127) / 128;
             const int64_t grid = (int64_t)((sa.n_ctiles + 7) / 8 * 8) * sa.n_qtiles;
-            if (i8) hipLaunchKernelGGL(k_screen<true>, dim3((unsigned)grid), dim3(256), kScreenLds, 0, sa);
-            else hipLaunchKernelGGL(k_screen<false>, dim3((unsigned)grid), dim3(256), kScreenLds, 0, sa);
+            if (i8) hipLaunchKernelGGL(k_screen<true>, dim3((unsigned)grid), dim3(256), kScreenLds, 0, (ScreenArgs)sa);
+            else hipLaunchKernelGGL(k_screen<false>, dim3((unsigned)grid), dim3(256), kScreenLds, 0, (ScreenArgs)sa);
         } else {
             sa.n_ctiles = (int)((N + 255) / 256);
             sa.n_qtiles = (B + 255) / 256;
             int64_t grid = screen256_grid(sa.n_ctiles, sa.n_qtiles);
             if (getenv("GRIDDIV")) grid = grid / atoi(getenv("GRIDDIV")) / 8 / sa.n_qtiles * 8 * sa.n_qtiles;  // fewer CUs busy
-            if (i8) {
-                hipLaunchKernelGGL((k_screen256<0, true>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa);
+            if (variant >= 300) {  // second form (k_screen256b): 300 + ABL
+                const int abl = variant - 300;
+                if (!i8) hipLaunchKernelGGL((k_screen256b<0, false>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa);
+#define SB_LAUNCH(A) else if (abl == A) hipLaunchKernelGGL((k_screen256b<A, true>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa);
+                SB_FORMS(SB_LAUNCH)
+                else hipLaunchKernelGGL((k_screen256b<0, true>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa);
+            } else if (i8) {
+                hipLaunchKernelGGL((k_screen256<0, true>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, (ScreenArgs)sa);
             } else switch (variant - 256) {
-                case 0: hipLaunchKernelGGL((k_screen256<0, false>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa); break;
-                case 1: hipLaunchKernelGGL((k_screen256<1, false>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa); break;
-                case 2: hipLaunchKernelGGL((k_screen256<2, false>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa); break;
-                case 3: hipLaunchKernelGGL((k_screen256<3, false>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa); break;
-                default: hipLaunchKernelGGL((k_screen256<4, false>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa); break;
+                case 0: hipLaunchKernelGGL((k_screen256<0, false>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, (ScreenArgs)sa); break;
+                case 1: hipLaunchKernelGGL((k_screen256<1, false>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, (ScreenArgs)sa); break;
+                case 2: hipLaunchKernelGGL((k_screen256<2, false>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, (ScreenArgs)sa); break;
+                case 3: hipLaunchKernelGGL((k_screen256<3, false>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, (ScreenArgs)sa); break;
+                default: hipLaunchKernelGGL((k_screen256<4, false>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, (ScreenArgs)sa); break;
             }
         }
         CK(hipGetLastError());
     };
 
+    std::vector<int> variants = {1256, 2324, 2388, 2392, 4372, 4436, 4440};
+    if (getenv("VARIANTS")) {
+        variants.clear();
+        for (char* tok = strtok(getenv("VARIANTS"), ","); tok; tok = strtok(nullptr, ",")) variants.push_back(atoi(tok));
+    }
     const double flops = 2.0 * B * (double)N * d;
+    if (getenv("ROUNDS")) {
+        // interleaved A/B (the chip is power-limited: the first launches after idle run ~10 % faster than sustained ones, and
+        // boxes differ): ROUNDS rounds, every variant once per round back to back, thresholds parked; median / mean per variant
+        const int rounds = atoi(getenv("ROUNDS"));
+        hipLaunchKernelGGL(k_fillf, dim3((Bpad + 255) / 256), dim3(256), 0, 0, thr, Bpad, INFINITY);
+        std::vector<std::vector<float>> ms(variants.size());
+        for (int w = 0; w < 3; ++w)
+            for (int variant : variants) launch(variant);  // warm-up
+        CK(hipDeviceSynchronize());
+        for (int r = 0; r < rounds; ++r)
+            for (size_t v = 0; v < variants.size(); ++v) {
+                CK(hipEventRecord(e0));
+                launch(variants[v]);
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                float t;
+                CK(hipEventElapsedTime(&t, e0, e1));
+                ms[v].push_back(t);
+            }
+        for (size_t v = 0; v < variants.size(); ++v) {
+            std::vector<float> x = ms[v];
+            std::sort(x.begin(), x.end());
+            double mean = 0;
+            for (float t : x) mean += t;
+            mean /= x.size();
+            printf("variant %4d: median %.3f ms (%.0f TOP/s)  mean %.3f ms (%.0f)  min %.3f  max %.3f   [%d interleaved rounds]\n", variants[v],
+                   x[x.size() / 2], flops / x[x.size() / 2] / 1e9, mean, flops / mean / 1e9, x.front(), x.back(), rounds);
+        }
+        return 0;
+    }
     std::vector<std::vector<Cand>> sets;
-    for (int variant : {128, 256, 257, 258, 259, 1128, 1256}) {
+    std::vector<int> set_kind;  // 0 = bf16 data, 1 = int8 data (candidate sets are compared within a kind)
+    for (int variant : variants) {
         if (only && variant != only) continue;
         // (1) pure compute
         hipLaunchKernelGGL(k_fillf, dim3((Bpad + 255) / 256), dim3(256), 0, 0, thr, Bpad, INFINITY);
@@ -202,6 +254,13 @@ int main(int argc, char** argv) {
         // (2) finite threshold: collect candidates
         const float T0 = 4.6f / sqrtf((float)d);  // ~4.6 sigma
         hipLaunchKernelGGL(k_fillf, dim3((Bpad + 255) / 256), dim3(256), 0, 0, thr, B, T0);
+        {   // int8 variants: bytes uniform in [-128,127] -> acc ~ N(0, d * 5461^2); same 4.6 sigma
+            std::vector<int> hi(Bpad, 0x7FFFFFFF);
+            for (int q = 0; q < B; ++q) hi[q] = (int)(4.6f * sqrtf((float)d) * 5461.0f);
+            CK(hipMemcpy(thr_i, hi.data(), Bpad * 4, hipMemcpyHostToDevice));
+            std::vector<float> one(Bpad, 1.0f);
+            CK(hipMemcpy(scv, one.data(), Bpad * 4, hipMemcpyHostToDevice));
+        }
         CK(hipMemset(cnt, 0, Bpad * 4));
         launch(variant);
         CK(hipDeviceSynchronize());
@@ -220,21 +279,36 @@ int main(int argc, char** argv) {
         std::sort(s.begin(), s.end());
         printf("   threshold %.4f: %zu candidates, %lld overflowed queries\n", T0, s.size(), over);
         sets.push_back(s);
+        set_kind.push_back(variant >= 1000 ? 1 : 0);
+        {
+            std::vector<int> hi(Bpad, 0x7FFFFFFF);
+            CK(hipMemcpy(thr_i, hi.data(), Bpad * 4, hipMemcpyHostToDevice));
+            std::vector<int> hs(Bpad);
+            CK(hipMemcpy(hs.data(), status, Bpad * 4, hipMemcpyDeviceToHost));
+            long long fl = 0;
+            for (int q = 0; q < B; ++q) fl += hs[q] != 0;
+            if (fl) printf("   %lld queries flagged overflow by the kernel\n", fl);
+            CK(hipMemset(status, 0, Bpad * 4));
+        }
     }
     bool all_same = true;
     if (only) return 0;
     for (size_t v = 1; v < sets.size(); ++v) {
-        bool same = sets[0].size() == sets[v].size();
+        size_t ref = 0;
+        while (set_kind[ref] != set_kind[v]) ++ref;
+        if (ref == v) continue;
+        const std::vector<Cand>& s0 = sets[ref];
+        bool same = s0.size() == sets[v].size();
         double maxdiff = 0;
         if (same)
-            for (size_t i = 0; i < sets[0].size(); ++i) {
-                if (sets[0][i].q != sets[v][i].q || sets[0][i].row != sets[v][i].row) {
+            for (size_t i = 0; i < s0.size(); ++i) {
+                if (s0[i].q != sets[v][i].q || s0[i].row != sets[v][i].row) {
                     same = false;
                     break;
                 }
-                maxdiff = std::max(maxdiff, (double)fabsf(sets[0][i].v - sets[v][i].v));
+                maxdiff = std::max(maxdiff, (double)fabsf(s0[i].v - sets[v][i].v));
             }
-        printf("candidate set %zu vs 0: %s (max |dv| %.3g)\n", v, same ? "IDENTICAL" : "DIFFER", maxdiff);
+        printf("candidate set %zu (variant %d) vs %zu: %s (max |dv| %.3g)\n", v, variants[v], ref, same ? "IDENTICAL" : "DIFFER", maxdiff);
         all_same = all_same && same;
     }
     return all_same ? 0 : 2;
