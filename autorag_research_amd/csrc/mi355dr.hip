@@ -370,11 +370,7 @@ int run_scan(mi355dr_index* idx, hipStream_t s, const std::vector<int>& qs, int 
     const int nq_all = (int)qs.size();
     hipLaunchKernelGGL(k_reset_queries, dim3((nq_all + 255) / 256), dim3(256), 0, s, idx->st, idx->qlist_dev, nq_all);
     HIPCHECK(idx, hipGetLastError());
-    // queries per launch limited by the LDS the query block needs
-    int per = kScanQ;
-    while (per > 1 && scan_lds_bytes(idx->dim, per) > 150 * 1024) per >>= 1;
-    if (scan_lds_bytes(idx->dim, per) > 160 * 1024)
-        return fail(idx, MI355DR_E_UNSUPPORTED, "dim too large for the scan kernel's LDS budget");
+    const int per = kScanQ;  // queries per launch: one 32-column MFMA block (LDS use does not depend on the dimension)
     for (int off = 0; off < nq_all; off += per) {
         const int nq = std::min(per, nq_all - off);
         int64_t done = 0;

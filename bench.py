@@ -29,10 +29,16 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 
-CHUNK_ROWS = 250_000  # generation granule; shard boundaries are multiples of it for world in {1,2,4,8}
+from autorag_research_amd import synth  # noqa: E402
+from autorag_research_amd.synth import CHUNK_ROWS  # noqa: E402
+
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
-MFMA_I8_PEAK_TOPS = 5000.0  # int8 MFMA = 2x the bf16 rate on gfx950 (2xK; the guide's ubench ceiling is 4404)
+MFMA_I8_PEAK_TOPS = 5000.0  # int8 MFMA = 2x the bf16 rate on gfx950 (2xK): the dense peak the fraction is quoted against
+# cdna_hip_programming.md "MFMA ubench throughput": i8 32x32x32 (the instruction this kernel issues) 4404 TOPS,
+# i8 16x16x64 3944 TOPS (the figure MI355X_MICROARCH.md's MFMA table carries); bf16 32x32x16 2382 TF
+MFMA_I8_UBENCH_TOPS = {"32x32x32": 4404.0, "16x16x64": 3944.0}
+MFMA_BF16_UBENCH_TF = 2382.0
 
 
 def parse_args():
@@ -57,18 +63,83 @@ def parse_args():
     ap.add_argument("--force-dist", action="store_true",
                     help="run the all-gather + merge path even at world size 1 (exercises the multi-GPU code on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (planted-answer nDCG, PCIe-inclusive "
+                                                           "rate, BLAS / torch / B=1 CPU baselines)")
+    ap.add_argument("--data", choices=["gaussian", "anisotropic"], default="gaussian",
+                    help="gaussian = BASELINE headline; anisotropic = power-law spectrum + near-duplicate clusters (the offline "
+                         "stand-in for bge-base on BEIR nq, config C2: use with --metric ip --k 100)")
     ap.add_argument("--cpu-sample-rows", type=int, default=2_500_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=3072, help="CPU baseline: queries timed (whole blocks of the pool)")
     return ap.parse_args()
 
 
-def gen_chunk(torch, chunk_index: int, rows: int, dim: int, device):
-    """Deterministic chunk: N(0,1) rows, L2-normalised (seed 1234 + chunk, independent of the world size)."""
-    g = torch.Generator(device=device)
-    g.manual_seed(1234 + chunk_index)
-    x = torch.randn((rows, dim), generator=g, device=device, dtype=torch.float32)
-    x /= x.norm(dim=1, keepdim=True)
-    return x
+def cpu_shape_baselines(Cs: np.ndarray, Qs: np.ndarray, k: int, metric: str, n_total: int, exact_rows_fn) -> list:
+    """SURVEY.md 8(d) / BASELINE.md 2: the reference's engine (PostgreSQL) cannot run here, so beside the exact-chain
+    oracle the same math is timed the way a numpy / torch CPU VectorSearch would issue it -- BLAS `Q_block @ C^T` in row
+    chunks + argpartition, torch.mm + topk -- and in the reference's CALL SHAPE, one query at a time (B = 1).  Bounded
+    samples (seconds each), scaled linearly to N; ids compared with the exact chain's on the same sample (BLAS sums in another
+    order than the exact chain, so near-ties may legitimately swap: the agreement is reported, not asserted)."""
+    import torch
+
+    out = []
+    S = min(Cs.shape[0], 500_000)
+    C = np.ascontiguousarray(Cs[:S])
+    Q = np.ascontiguousarray(Qs[:1024])
+    inv = 1.0 / np.linalg.norm(C, axis=1) if metric == "cosine" else None
+    try:
+        from threadpoolctl import threadpool_info
+
+        blas_threads = max([t.get("num_threads", 1) for t in threadpool_info() if t.get("user_api") == "blas"] or [1])
+    except Exception:  # noqa: BLE001
+        blas_threads = None
+
+    def np_block(Qb):
+        best = None
+        for r0 in range(0, S, 100_000):
+            sc = Qb @ C[r0:r0 + 100_000].T
+            if inv is not None:
+                sc *= inv[None, r0:r0 + 100_000]
+            part = np.argpartition(-sc, min(k, sc.shape[1] - 1), axis=1)[:, :k]
+            v = np.take_along_axis(sc, part, axis=1)
+            cand = (v, part + r0)
+            best = cand if best is None else (np.concatenate([best[0], cand[0]], 1), np.concatenate([best[1], cand[1]], 1))
+        o = np.argsort(-best[0], axis=1, kind="stable")[:, :k]
+        return np.take_along_axis(best[1], o, axis=1)
+
+    np_block(Q[:8])
+    t = time.perf_counter()
+    rows_np = np_block(Q)
+    t = time.perf_counter() - t
+    agree = float(np.mean(rows_np == exact_rows_fn(C, Q)))
+    out.append({"kind": "numpy-blas", "value": round(len(Q) / t * S / n_total, 3), "unit": "queries/s", "cores": blas_threads,
+                "sample": f"fp32 Q_block[{len(Q)}] @ C[{S}]^T in 100k-row chunks + argpartition/argsort, {t:.2f} s, scaled to "
+                          f"N={n_total}", "ids_equal_to_exact_chain": round(agree, 6)})
+    Ct, Qt = torch.from_numpy(C), torch.from_numpy(Q)
+    it = torch.from_numpy(inv) if inv is not None else None
+
+    def torch_block(Qb):
+        sc = Qb @ Ct.T
+        if it is not None:
+            sc *= it[None, :]
+        return torch.topk(sc, k, dim=1).indices
+
+    torch_block(Qt[:8])
+    nqt = min(256, len(Q))
+    t = time.perf_counter()
+    torch_block(Qt[:nqt])
+    t = time.perf_counter() - t
+    out.append({"kind": "torch-cpu", "value": round(nqt / t * S / n_total, 3), "unit": "queries/s",
+                "cores": torch.get_num_threads(),
+                "sample": f"torch.mm(Q[{nqt}], C[{S}]^T) + torch.topk, {t:.2f} s, scaled to N={n_total}"})
+    t = time.perf_counter()
+    for i in range(16):
+        torch_block(Qt[i:i + 1])
+    t = time.perf_counter() - t
+    out.append({"kind": "torch-cpu, B=1 call shape", "value": round(16 / t * S / n_total, 3), "unit": "queries/s",
+                "cores": torch.get_num_threads(),
+                "sample": f"the same, ONE query per call (how the reference's pipeline calls its engine: "
+                          f"pipelines/retrieval/vector_search.py:157-169), 16 calls over C[{S}], {t:.2f} s, scaled to N={n_total}"})
+    return out
 
 
 def main_maxsim(args) -> None:
@@ -191,13 +262,40 @@ def main() -> None:
         idx.set_option("round_a", args.round_a)
     if args.screen_form is not None:
         idx.set_option("screen_form", args.screen_form)
+    aniso = synth.Anisotropic(torch, d, device) if args.data == "anisotropic" else None
+
+    def gen_chunk(c: int, rows: int):
+        return aniso.chunk(c, rows) if aniso is not None else synth.gaussian_chunk(torch, c, rows, d, device)
+
+    # query pool in HBM: 10 blocks, cycled by the timed steps -- plus ONE extra block that is never timed: the
+    # planted-answer block of SURVEY.md 8(d) (1-3 relevant rows per query written into the corpus at recorded positions;
+    # ~2k rows of 10 M, invisible to the timed queries), from which nDCG@10 is computed after the timed region
+    n_pool = 10
+    if aniso is not None:
+        qpool = aniso.queries(n_pool * B).reshape(n_pool, B, d)
+        q_plant = aniso.queries(B, seed=555)
+    else:
+        gq = torch.Generator(device=device)
+        gq.manual_seed(4321)
+        qpool = torch.randn((n_pool, B, d), generator=gq, device=device, dtype=torch.float32)
+        qpool /= qpool.norm(dim=2, keepdim=True)
+        gq.manual_seed(555)
+        q_plant = torch.randn((B, d), generator=gq, device=device, dtype=torch.float32)
+        q_plant /= q_plant.norm(dim=1, keepdim=True)
+    plant_window = min(n_total, args.cpu_sample_rows)
+    p_pos, p_vec, p_owner, p_sigma = synth.planted_answers(torch, q_plant, plant_window)
+    p_pos_t = torch.as_tensor(p_pos, device=device)
+
     t_build = time.time()
     keep_parts = []
     keep_rows = 0
     want_sample = rank == 0 and world == 1 and not args.no_cpu_baseline
     for c in range(c_lo, c_hi):
         rows = min(CHUNK_ROWS, n_total - c * CHUNK_ROWS)
-        x = gen_chunk(torch, c, rows, d, device)
+        x = gen_chunk(c, rows)
+        sel = (p_pos_t >= c * CHUNK_ROWS) & (p_pos_t < c * CHUNK_ROWS + rows)
+        if bool(sel.any()):
+            x[p_pos_t[sel] - c * CHUNK_ROWS] = p_vec[sel]
         torch.cuda.synchronize()
         idx.add_device(x.data_ptr(), rows)
         if want_sample and keep_rows < args.cpu_sample_rows:
@@ -209,12 +307,6 @@ def main() -> None:
     torch.cuda.synchronize()
     t_build = time.time() - t_build
 
-    # query pool in HBM: 10 blocks, cycled
-    gq = torch.Generator(device=device)
-    gq.manual_seed(4321)
-    n_pool = 10
-    qpool = torch.randn((n_pool, B, d), generator=gq, device=device, dtype=torch.float32)
-    qpool /= qpool.norm(dim=2, keepdim=True)
     # the shard result is written straight into the packed [2,B,k] block one all-gather sends:
     # plane 0 = float8 distance bits, plane 1 = global rows
     packed = torch.empty((2, B, k), device=device, dtype=torch.int64)
@@ -284,21 +376,33 @@ def main() -> None:
     # HBM traffic of the dominant kernel from the committed PMC pass of this same command (rocprofv3 cannot run
     # inside the timed region): bytes per screened row x rows per launch.  See tools/collect_traffic.sh.
     traffic = None
-    tfile = ROOT / "profiles" / ("r01_traffic_i8.json" if i8 else "r01_traffic.json")
-    if tfile.exists() and B > 128 and d == 768 and launches:
-        per_row = json.loads(tfile.read_text())["hbm_read_bytes_per_screened_row"]
-        traffic = round(per_row * screen_rows / launches)
+    traffic_src = None
+    for tname in (("r02_traffic_i8.json", "r01_traffic_i8.json") if i8 else ("r02_traffic.json", "r01_traffic.json")):
+        tfile = ROOT / "profiles" / tname
+        if tfile.exists() and B > 128 and d == 768 and launches:
+            per_row = json.loads(tfile.read_text())["hbm_read_bytes_per_screened_row"]
+            traffic = round(per_row * screen_rows / launches)
+            traffic_src = f"REPLAYED, not measured in this run: {per_row:.0f} B per screened row from profiles/{tname} " \
+                          "(rocprofv3 --pmc FETCH_SIZE pass of this same command, x1024 x2 gfx950 correction; " \
+                          "tools/collect_traffic.sh) x the rows one launch screened here"
+            break
+    ubench = (MFMA_I8_UBENCH_TOPS["32x32x32"] if i8 else MFMA_BF16_UBENCH_TF)
     roof = {
         "bound": "mfma",
-        "kernel": ("k_screen256" if B > 128 else "k_screen") + ("<int8>" if i8 else "<bf16>"),
+        "kernel": ("k_screen256b" if B > 128 else "k_screen") + ("<int8>" if i8 else "<bf16>"),
         "op": "int8 multiply-add ops (v_mfma_i32_32x32x32_i8)" if i8 else "bf16 flops (v_mfma_f32_32x32x16_bf16)",
         "achieved": round(alg_flops / screen_s / 1e12, 2) if screen_s > 0 else None,
         "peak": peak,
         "unit": "TFLOP/s",
         "frac": round(alg_flops / screen_s / 1e12 / peak, 4) if screen_s > 0 else None,
+        "frac_of_ubench_ceiling": round(alg_flops / screen_s / 1e12 / ubench, 4) if screen_s > 0 else None,
+        "ubench_ceiling": {"this_instruction": ubench,
+                           "note": "cdna_hip_programming.md MFMA ubench table: i8 32x32x32 4404 TOPS, i8 16x16x64 3944 TOPS "
+                                   "(the row MI355X_MICROARCH.md quotes), bf16 32x32x16 2382 TF"},
         "traffic": traffic,
         "traffic_unit": "HBM read bytes per launch (PMC FETCH_SIZE, gfx950-corrected), vs algorithmic "
                         f"{round(alg_bytes / max(launches, 1))}",
+        "traffic_source": traffic_src,
         "launches": launches,
         "avg_launch_ms": round(screen_s * 1e3 / max(launches, 1), 4),
         "kernel_ms_per_step": round(screen_s * 1e3 / max(args.steps, 1), 3),
@@ -351,6 +455,64 @@ def main() -> None:
         },
     }
 
+    # ---- untimed extras -------------------------------------------------------------------------------------------
+    from autorag_research_amd.metrics import MetricInput, retrieval_ndcg
+
+    gt_or, gt_and = synth.ground_truth(p_owner, p_pos, B)
+
+    def ndcg_at_10(rows_2d) -> dict:
+        """nDCG@10 (reference semantics: evaluation/metrics/retrieval.py:71-144) of ranked row ids under both ground-truth
+        shapes the reference ingests (data/beir.py:191-194)."""
+        top = [[str(int(r)) for r in row[:10]] for row in rows_2d]
+        v_or = retrieval_ndcg([MetricInput(retrieval_gt=g, retrieved_ids=t) for g, t in zip(gt_or, top)])
+        v_and = retrieval_ndcg([MetricInput(retrieval_gt=g, retrieved_ids=t) for g, t in zip(gt_and, top)])
+        return {"or_group": round(float(np.mean(v_or)), 6), "and_chain": round(float(np.mean(v_and)), 6)}
+
+    if not args.no_extras:
+        # (1) the nDCG half of the metric: the planted block against the WHOLE (sharded) corpus, same code path as a step
+        kk = max(k, 10)
+        if kk != k:
+            pk = torch.empty((2, B, kk), device=device, dtype=torch.int64)
+            pd_, pr_ = pk[0].view(torch.float64), pk[1]
+            idx.search_device(q_plant.data_ptr(), B, kk, pd_.data_ptr(), pr_.data_ptr(), stream)
+            if use_dist:
+                pall = torch.empty((world, 2, B, kk), device=device, dtype=torch.int64)
+                dist.all_gather_into_tensor(pall.view(-1), pk.view(-1))
+                fd = torch.empty((B, kk), device=device, dtype=torch.float64)
+                fr = torch.empty((B, kk), device=device, dtype=torch.int64)
+                idx.merge_topk_packed_device(pall.data_ptr(), world, B, kk, fd.data_ptr(), fr.data_ptr(), stream)
+                pr_ = fr
+        else:
+            idx.search_device(q_plant.data_ptr(), B, k, out_dist.data_ptr(), out_rows.data_ptr(), stream)
+            pr_ = out_rows
+            if use_dist:
+                dist.all_gather_into_tensor(packed_all.view(-1), packed.view(-1))
+                idx.merge_topk_packed_device(packed_all.data_ptr(), world, B, k, fin_dist.data_ptr(), fin_rows.data_ptr(),
+                                             stream)
+                pr_ = fin_rows
+        torch.cuda.synchronize()
+        plant_rows_full = pr_.cpu().numpy()
+        if rank == 0:
+            nd = ndcg_at_10(plant_rows_full)
+            hard = float(np.mean(p_sigma >= 5.0))
+            result["ndcg_at_10"] = {**nd, "queries": B, "planted_rows": int(p_pos.size),
+                                    "corpus_rows": n_total,
+                                    "note": f"planted-answer block (SURVEY 8d): 1-3 relevant rows per query, sigma in "
+                                            f"{{0.3,0.6,1,5,7}} ({hard:.0%} of them hard: cos ~0.2/0.14); group-nDCG as the "
+                                            "reference computes it (BEIR = one OR-group, hotpotqa = AND-chain)"}
+    if rank == 0 and world == 1 and not args.no_extras:
+        # (2) PCIe-inclusive rate: the host entry point (H2D of the query block, D2H of [B,k]) instead of device buffers
+        qh = [qpool[i % n_pool].cpu().numpy() for i in range(3)]
+        idx.search(qh[0], k)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(5):
+            idx.search(qh[i % 3], k)
+        t1 = (time.perf_counter() - t1) / 5
+        result["extra"]["pcie_inclusive"] = {"ms_per_step": round(t1 * 1e3, 3), "queries_per_s": round(B / t1, 1),
+                                             "note": "mi355dr_search: pageable host queries in (H2D), float8 distances + "
+                                                     "int64 rows out (D2H), one blocking call per step; NOT `value`"}
+
     # ---- CPU baseline (rank 0, N=1 run only): the oracle on a bounded sample of the same workload
     if rank == 0 and world == 1 and not args.no_cpu_baseline and keep_sample is not None:
         from oracle import cpu_ref
@@ -378,8 +540,23 @@ def main() -> None:
                       f"{qps_sample:.1f} queries/s at N={S}, scaled linearly to N={n_total}; {tc:.1f} s of CPU work",
             "parity_on_sample": parity,
         }
+        if not args.no_extras:
+            # the planted block on the SAME sample through both paths: nDCG from the GPU ids == nDCG from the oracle's ids
+            Qp = q_plant.cpu().numpy()
+            od_, or_ = cpu_ref.topk_search(Cs, Qp, max(k, 10), metric=args.metric)
+            with pkg.Mi355Index(d, args.metric, device=local_rank) as sidx:
+                sidx.add(Cs)
+                gd_, gr_ = sidx.search(Qp, max(k, 10))
+            n_gpu, n_cpu = ndcg_at_10(gr_), ndcg_at_10(or_)
+            result["ndcg_at_10"]["sample_check"] = {
+                "rows": S, "gpu": n_gpu, "oracle": n_cpu,
+                "identical": bool(n_gpu == n_cpu and np.array_equal(gr_, or_) and np.array_equal(gd_, od_))}
+            assert n_gpu == n_cpu, "nDCG@10 from the GPU ids differs from nDCG@10 from the oracle ids"
+            result["cpu_baselines"] = cpu_shape_baselines(
+                Cs, Qs, k, args.metric, n_total,
+                lambda C_, Q_: cpu_ref.topk_search(C_, Q_, k, metric=args.metric, verify=False)[1])
     if rank == 0:
-        # sanity: results are sorted, in range, and every query found its own planted neighbours (none planted here)
+        # sanity: results are sorted and in range
         rd_, rr_ = res[0].cpu().numpy(), res[1].cpu().numpy()
         assert (np.diff(rd_, axis=1) >= 0).all(), "distances not ascending"
         assert rr_.min() >= 0 and rr_.max() < n_total
