@@ -24,7 +24,8 @@ ABI_SYMBOLS = [
     "mi355dr_search", "mi355dr_search_device", "mi355dr_add_multivec", "mi355dr_size_multivec",
     "mi355dr_search_maxsim", "mi355dr_maxsim_subset", "mi355dr_gqr_refine", "mi355dr_gqr_refine_maxsim",
     "mi355dr_gqr_refine_scores", "mi355dr_merge_topk_device", "mi355dr_pack_topk_device",
-    "mi355dr_merge_topk_packed_device", "mi355dr_set_option", "mi355dr_get_stat",
+    "mi355dr_merge_topk_packed_device", "mi355dr_comm_unique_id", "mi355dr_comm_init", "mi355dr_comm_world",
+    "mi355dr_search_sharded_device", "mi355dr_set_option", "mi355dr_get_stat",
     "mi355dr_reset_stats", "mi355dr_timer_start", "mi355dr_timer_stop", "mi355dr_synchronize",
     "mi355dr_dev_alloc", "mi355dr_dev_free", "mi355dr_dev_upload", "mi355dr_dev_download",
     "mi355dr_debug_screen_dense", "mi355dr_debug_screen_bound", "mi355dr_debug_rescore",
@@ -125,6 +126,14 @@ def load() -> ctypes.CDLL:
     L.mi355dr_pack_topk_device.argtypes = [vp, vp, vp, c_int, c_int, vp, vp]
     L.mi355dr_merge_topk_packed_device.restype = c_int
     L.mi355dr_merge_topk_packed_device.argtypes = [vp, vp, c_int, c_int, c_int, vp, vp, vp]
+    L.mi355dr_comm_unique_id.restype = c_int
+    L.mi355dr_comm_unique_id.argtypes = [vp, ctypes.c_size_t]
+    L.mi355dr_comm_init.restype = c_int
+    L.mi355dr_comm_init.argtypes = [vp, c_int, c_int, vp, ctypes.c_size_t]
+    L.mi355dr_comm_world.restype = c_int
+    L.mi355dr_comm_world.argtypes = [vp]
+    L.mi355dr_search_sharded_device.restype = c_int
+    L.mi355dr_search_sharded_device.argtypes = [vp, vp, c_int, c_int, vp, vp, vp]
     L.mi355dr_set_option.restype = c_int
     L.mi355dr_set_option.argtypes = [vp, ctypes.c_char_p, i64]
     L.mi355dr_get_stat.restype = c_int

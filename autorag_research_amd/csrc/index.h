@@ -91,6 +91,13 @@ struct mi355dr_index {
     std::vector<mi355::EventPair> ev_pool, ev_pending;
     hipEvent_t t0 = nullptr, t1 = nullptr;
 
+    // RCCL communicator of a row-sharded index (mi355dr_comm.hip)
+    void* comm = nullptr;
+    int comm_rank = 0, comm_world = 0;
+    int64_t* comm_packed = nullptr;      // [2, kQBlockMax, k] this rank's packed block
+    int64_t* comm_packed_all = nullptr;  // [world, 2, kQBlockMax, k]
+    size_t comm_cap = 0;
+
     // multi-vector store (MaxSim), owned by mi355dr_maxsim.hip
     mi355::MultiVecStore* mv = nullptr;
 };
@@ -100,6 +107,7 @@ namespace mi355 {
 
 int fail(mi355dr_index* idx, int code, const std::string& msg);  // mi355dr.hip
 void multivec_destroy(mi355dr_index* idx);                       // mi355dr_maxsim.hip
+void comm_destroy(mi355dr_index* idx);                           // mi355dr_comm.hip
 // read-only view of the multi-vector store for kernels outside mi355dr_maxsim.hip (GQR refinement)
 struct MultiVecView {
     const float* tok;             // [blocks*32, dpad] device

@@ -581,6 +581,7 @@ void mi355dr_destroy(mi355dr_index* idx) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     multivec_destroy(idx);
+    comm_destroy(idx);
     if (idx->status_host) (void)hipHostFree(idx->status_host);
     for (auto& p : idx->ev_pool) {
         (void)hipEventDestroy(p.a);

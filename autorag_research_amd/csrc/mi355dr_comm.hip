@@ -1,0 +1,156 @@
+// mi355dr_comm.hip -- row-sharded search inside the C ABI: RCCL communicator per index, one packed all-gather of the
+// per-shard [B,k] lists over xGMI and the world*k -> k merge, all on the caller's stream.
+//
+// RCCL is bound at run time (dlopen + dlsym), not at link time:
+//   * a host that never shards does not need librccl at all (the library keeps loading without it);
+//   * a host that already carries an RCCL (PyTorch-ROCm bundles its own librccl.so with the same soname) must not get a
+//     second copy: RTLD_NOLOAD finds the one already mapped, only then the default search path is tried.
+// The ncclUniqueId travels through the HOST's own channel (MPI, a torch store, a file): rank 0 calls
+// mi355dr_comm_unique_id, every rank calls mi355dr_comm_init with the same 128 bytes.
+#include <dlfcn.h>
+
+#include "index.h"
+
+namespace {
+
+// the few RCCL entry points used, with the types of rccl.h (ncclResult_t = int, ncclDataType_t ncclInt64 = 4)
+struct NcclUniqueId {
+    char internal[128];
+};
+typedef int (*fn_get_unique_id)(NcclUniqueId*);
+typedef int (*fn_comm_init_rank)(void** comm, int nranks, NcclUniqueId id, int rank);
+typedef int (*fn_comm_destroy)(void* comm);
+typedef int (*fn_all_gather)(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t s);
+typedef const char* (*fn_get_error_string)(int);
+constexpr int kNcclInt64 = 4;
+
+struct RcclApi {
+    void* handle = nullptr;
+    fn_get_unique_id get_unique_id = nullptr;
+    fn_comm_init_rank comm_init_rank = nullptr;
+    fn_comm_destroy comm_destroy = nullptr;
+    fn_all_gather all_gather = nullptr;
+    fn_get_error_string error_string = nullptr;
+    std::string why;
+};
+
+RcclApi& rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so.1", "librccl.so"};
+        for (const char* n : names)
+            if (!api.handle) api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);  // a copy the process already has
+        for (const char* n : names)
+            if (!api.handle) api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!api.handle) api.handle = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!api.handle) {
+            const char* e = dlerror();
+            api.why = std::string("librccl not found: ") + (e ? e : "?");
+            return;
+        }
+        api.get_unique_id = (fn_get_unique_id)dlsym(api.handle, "ncclGetUniqueId");
+        api.comm_init_rank = (fn_comm_init_rank)dlsym(api.handle, "ncclCommInitRank");
+        api.comm_destroy = (fn_comm_destroy)dlsym(api.handle, "ncclCommDestroy");
+        api.all_gather = (fn_all_gather)dlsym(api.handle, "ncclAllGather");
+        api.error_string = (fn_get_error_string)dlsym(api.handle, "ncclGetErrorString");
+        if (!api.get_unique_id || !api.comm_init_rank || !api.comm_destroy || !api.all_gather) api.why = "librccl lacks an entry point";
+    });
+    return api;
+}
+
+int nccl_fail(mi355dr_index* idx, const char* what, int rc) {
+    RcclApi& r = rccl();
+    return mi355::fail(idx, MI355DR_E_HIP, std::string(what) + " failed: " + (r.error_string ? r.error_string(rc) : "rccl error"));
+}
+
+}  // namespace
+
+namespace mi355 {
+void comm_destroy(mi355dr_index* idx) {
+    if (idx->comm) {
+        RcclApi& r = rccl();
+        if (r.comm_destroy) (void)r.comm_destroy(idx->comm);
+        idx->comm = nullptr;
+    }
+    if (idx->comm_packed) (void)hipFree(idx->comm_packed);
+    if (idx->comm_packed_all) (void)hipFree(idx->comm_packed_all);
+    idx->comm_packed = idx->comm_packed_all = nullptr;
+    idx->comm_cap = 0;
+}
+}  // namespace mi355
+
+extern "C" {
+
+int mi355dr_comm_unique_id(void* out, size_t len) {
+    if (!out || len < sizeof(NcclUniqueId)) return mi355::fail(nullptr, MI355DR_E_INVALID, "unique id buffer must hold 128 bytes");
+    RcclApi& r = rccl();
+    if (!r.why.empty()) return mi355::fail(nullptr, MI355DR_E_UNSUPPORTED, r.why);
+    NcclUniqueId id;
+    const int rc = r.get_unique_id(&id);
+    if (rc != 0) return nccl_fail(nullptr, "ncclGetUniqueId", rc);
+    memcpy(out, &id, sizeof(id));
+    return MI355DR_OK;
+}
+
+int mi355dr_comm_init(mi355dr_index* idx, int rank, int world, const void* nccl_unique_id, size_t id_len) {
+    if (!idx) return mi355::fail(nullptr, MI355DR_E_INVALID, "null index");
+    if (world < 1 || rank < 0 || rank >= world) return mi355::fail(idx, MI355DR_E_INVALID, "need 0 <= rank < world");
+    if (!nccl_unique_id || id_len < sizeof(NcclUniqueId)) return mi355::fail(idx, MI355DR_E_INVALID, "unique id must be 128 bytes");
+    RcclApi& r = rccl();
+    if (!r.why.empty()) return mi355::fail(idx, MI355DR_E_UNSUPPORTED, r.why);
+    std::lock_guard<std::mutex> g(idx->mu);
+    HIPCHECK(idx, hipSetDevice(idx->device));
+    mi355::comm_destroy(idx);
+    NcclUniqueId id;
+    memcpy(&id, nccl_unique_id, sizeof(id));
+    void* comm = nullptr;
+    const int rc = r.comm_init_rank(&comm, world, id, rank);
+    if (rc != 0) return nccl_fail(idx, "ncclCommInitRank", rc);
+    idx->comm = comm;
+    idx->comm_rank = rank;
+    idx->comm_world = world;
+    return MI355DR_OK;
+}
+
+int mi355dr_comm_world(const mi355dr_index* idx) { return idx && idx->comm ? idx->comm_world : 0; }
+
+int mi355dr_search_sharded_device(mi355dr_index* idx, const float* queries_dev, int B, int k, double* out_dist_dev,
+                                  int64_t* out_rows_dev, void* stream) {
+    if (!idx) return mi355::fail(nullptr, MI355DR_E_INVALID, "null index");
+    if (!idx->comm) return mi355::fail(idx, MI355DR_E_INVALID, "mi355dr_comm_init has not been called on this index");
+    if (B < 0 || k <= 0 || k > mi355::kKMax) return mi355::fail(idx, MI355DR_E_INVALID, "bad B / k");
+    if ((int64_t)idx->comm_world * k > mi355::kSortMax) return mi355::fail(idx, MI355DR_E_UNSUPPORTED, "world*k exceeds 4096");
+    if (B == 0) return MI355DR_OK;
+    RcclApi& r = rccl();
+    HIPCHECK(idx, hipSetDevice(idx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : idx->stream;
+    const int world = idx->comm_world;
+    {   // staging: one packed [2, nb, k] int64 block per rank (plane 0 = float8 distance bits, plane 1 = global rows)
+        std::lock_guard<std::mutex> g(idx->mu);
+        const size_t need = (size_t)2 * mi355::kQBlockMax * k;
+        if (idx->comm_cap < need) {
+            if (idx->comm_packed) (void)hipFree(idx->comm_packed);
+            if (idx->comm_packed_all) (void)hipFree(idx->comm_packed_all);
+            idx->comm_packed = idx->comm_packed_all = nullptr;
+            idx->comm_cap = 0;
+            HIPCHECK(idx, hipMalloc(&idx->comm_packed, need * sizeof(int64_t)));
+            HIPCHECK(idx, hipMalloc(&idx->comm_packed_all, need * sizeof(int64_t) * world));
+            idx->comm_cap = need;
+        }
+    }
+    for (int b0 = 0; b0 < B; b0 += mi355::kQBlockMax) {
+        const int nb = std::min(mi355::kQBlockMax, B - b0);
+        const size_t plane = (size_t)nb * k;
+        // the shard's list goes straight into the packed block (the float8 plane is written as doubles)
+        CHECK(mi355dr_search_device(idx, queries_dev + (int64_t)b0 * idx->dim, nb, k, (double*)idx->comm_packed,
+                                    idx->comm_packed + plane, s));
+        const int rc = r.all_gather(idx->comm_packed, idx->comm_packed_all, 2 * plane, kNcclInt64, idx->comm, s);
+        if (rc != 0) return nccl_fail(idx, "ncclAllGather", rc);
+        CHECK(mi355dr_merge_topk_packed_device(idx, idx->comm_packed_all, world, nb, k, out_dist_dev + (int64_t)b0 * k,
+                                               out_rows_dev + (int64_t)b0 * k, s));
+    }
+    return MI355DR_OK;  // asynchronous on `s` after the last block's search
+}
+
+}  // extern "C"

@@ -118,6 +118,30 @@ class Mi355Index:
             self._h, ctypes.c_void_p(int(packed_all_ptr)), int(world), int(B), int(k), ctypes.c_void_p(int(out_dist_ptr)),
             ctypes.c_void_p(int(out_rows_ptr)), ctypes.c_void_p(int(stream) if stream else None)))
 
+    # ---- row-sharded search inside the library (RCCL, no torch): include/mi355dr.h "row-sharded search" ----
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """128-byte ncclUniqueId (call on ONE rank, hand it to every rank through the host's own channel)."""
+        from ._native import load
+
+        buf = ctypes.create_string_buffer(128)
+        check(None, load().mi355dr_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p), 128))
+        return buf.raw
+
+    def comm_init(self, rank: int, world: int, unique_id: bytes) -> None:
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        check(self._h, self._lib.mi355dr_comm_init(self._h, int(rank), int(world), ctypes.cast(buf, ctypes.c_void_p), 128))
+
+    def comm_world(self) -> int:
+        return int(self._lib.mi355dr_comm_world(self._h))
+
+    def search_sharded_device(self, q_ptr: int, B: int, k: int, out_dist_ptr: int, out_rows_ptr: int,
+                              stream: int | None = None) -> None:
+        """Local search + ONE ncclAllGather + merge, on device buffers (every rank: same queries in, same result out)."""
+        check(self._h, self._lib.mi355dr_search_sharded_device(
+            self._h, ctypes.c_void_p(int(q_ptr)), int(B), int(k), ctypes.c_void_p(int(out_dist_ptr)),
+            ctypes.c_void_p(int(out_rows_ptr)), ctypes.c_void_p(int(stream) if stream else None)))
+
     # ---- multi-vector ----
     def add_multivec(self, vecs, offsets) -> None:
         vecs = f32c(vecs)

@@ -71,6 +71,8 @@ class ShardedSearcher:
         self.index = index_factory(dim, metric, device)
         self.device = device
         self.row_offset = 0
+        self.force_pipeline = False  # tests: run the gather + merge pipeline at world size 1 too
+        self.overlapped_blocks = 0   # blocks whose gather ran under the next block's search (host pipeline; tests)
 
     def add_local(self, rows, global_row0: int) -> None:
         """Add this rank's rows; `global_row0` is the global index of its first row (set once)."""
@@ -79,29 +81,87 @@ class ShardedSearcher:
             self.index.set_option("row_offset", self.row_offset)
         self.index.add(rows)
 
-    def search(self, queries, k: int) -> tuple[np.ndarray, np.ndarray]:
-        """Every rank passes the same queries; every rank gets the same global [B,k] result."""
-        dist_l, rows_l = self.index.search(queries, k)
-        if self.world == 1:
-            return dist_l, rows_l
+    def search(self, queries, k: int, block: int = 1024) -> tuple[np.ndarray, np.ndarray]:
+        """Every rank passes the same queries; every rank gets the same global [B,k] result.
+
+        Queries are served in blocks of `block`; the all-gather + merge of block i runs while block i+1 is searched
+        (second stream + double-buffered packed blocks on the GPU, an asynchronous collective on CPU/gloo), so the
+        collective's latency and the merge are off the critical path for every block but the last.  On the nccl
+        backend the shard's list never leaves the device before the gather: the library writes it straight into the
+        packed [2,B,k] block (plane 0 = float8 distance bits, plane 1 = global rows) that ONE all-gather sends."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        if self.world == 1 and not self.force_pipeline:
+            return self.index.search(q, k)
+        if self.backend == "nccl" and hasattr(self.index, "search_device"):
+            return self._search_device_pipelined(q, k, block)
+        return self._search_host_pipelined(q, k, block)
+
+    def _search_device_pipelined(self, q: np.ndarray, k: int, block: int):
         import torch
 
-        on_gpu = self.backend == "nccl"
-        dev = torch.device("cuda", self.device) if on_gpu else torch.device("cpu")
-        B = dist_l.shape[0]
-        # one all-gather of the packed [2,B,k] int64 block: plane 0 = float8 distance bits, plane 1 = rows
-        packed = torch.from_numpy(np.stack([np.ascontiguousarray(dist_l).view(np.int64), rows_l])).to(dev)
-        gathered = torch.empty((self.world, 2, B, k), dtype=torch.int64, device=dev)
-        self._dist.all_gather_into_tensor(gathered.view(-1), packed.view(-1), group=self.group)
-        if on_gpu and hasattr(self.index, "merge_topk_packed_device"):
-            out_d = torch.empty((B, k), dtype=torch.float64, device=dev)
-            out_r = torch.empty((B, k), dtype=torch.int64, device=dev)
-            torch.cuda.current_stream().synchronize()
-            self.index.merge_topk_packed_device(gathered.data_ptr(), self.world, B, k, out_d.data_ptr(),
-                                                out_r.data_ptr(), torch.cuda.current_stream().cuda_stream)
-            return out_d.cpu().numpy(), out_r.cpu().numpy()  # .cpu() synchronises the stream the merge ran on
-        g = gathered.cpu().numpy()
-        return merge_topk_host(np.ascontiguousarray(g[:, 0]).view(np.float64), np.ascontiguousarray(g[:, 1]), k)
+        dist, dev = self._dist, torch.device("cuda", self.device)
+        B = q.shape[0]
+        qd = torch.from_numpy(q).to(dev)
+        out_d = torch.empty((B, k), dtype=torch.float64, device=dev)
+        out_r = torch.empty((B, k), dtype=torch.int64, device=dev)
+        nbmax = min(block, B)
+        packed = [torch.empty((2 * nbmax * k,), dtype=torch.int64, device=dev) for _ in range(2)]
+        gathered = [torch.empty((self.world * 2 * nbmax * k,), dtype=torch.int64, device=dev) for _ in range(2)]
+        compute = torch.cuda.current_stream(dev)
+        comm = torch.cuda.Stream(dev)
+        done = [None, None]
+        for i, b0 in enumerate(range(0, B, block)):
+            nb, buf = min(block, B - b0), i & 1
+            if done[buf] is not None:
+                compute.wait_event(done[buf])  # the gather that read this packed block two blocks ago
+            pk = packed[buf][: 2 * nb * k]
+            self.index.search_device(qd[b0:b0 + nb].data_ptr(), nb, k, pk.data_ptr(), pk[nb * k:].data_ptr(),
+                                     compute.cuda_stream)
+            ready = torch.cuda.Event()
+            ready.record(compute)
+            with torch.cuda.stream(comm):
+                comm.wait_event(ready)
+                ga = gathered[buf][: self.world * 2 * nb * k]
+                dist.all_gather_into_tensor(ga, pk, group=self.group)
+                self.index.merge_topk_packed_device(ga.data_ptr(), self.world, nb, k, out_d[b0:b0 + nb].data_ptr(),
+                                                    out_r[b0:b0 + nb].data_ptr(), comm.cuda_stream)
+                done[buf] = torch.cuda.Event()
+                done[buf].record(comm)
+        comm.synchronize()
+        return out_d.cpu().numpy(), out_r.cpu().numpy()
+
+    def _search_host_pipelined(self, q: np.ndarray, k: int, block: int):
+        """CPU / gloo form of the same pipeline (tests): asynchronous all-gather of block i, local search of block i+1,
+        then wait + host merge of block i."""
+        import torch
+
+        dist = self._dist
+        B = q.shape[0]
+        out_d = np.full((B, k), np.nan)
+        out_r = np.full((B, k), -1, dtype=np.int64)
+        pending = None
+
+        def finish(p):
+            work, ga, b0, nb = p
+            work.wait()
+            g = ga.numpy().reshape(self.world, 2, nb, k)
+            d, r = merge_topk_host(np.ascontiguousarray(g[:, 0]).view(np.float64), np.ascontiguousarray(g[:, 1]), k)
+            out_d[b0:b0 + nb], out_r[b0:b0 + nb] = d, r
+
+        for b0 in range(0, B, block):
+            nb = min(block, B - b0)
+            dist_l, rows_l = self.index.search(q[b0:b0 + nb], k)
+            if pending is not None:
+                finish(pending)
+            pk = torch.from_numpy(np.stack([np.ascontiguousarray(dist_l).view(np.int64), rows_l]).reshape(-1))
+            ga = torch.empty((self.world * pk.numel(),), dtype=torch.int64)
+            work = dist.all_gather_into_tensor(ga, pk, group=self.group, async_op=True)
+            pending = (work, ga, b0, nb)
+            self.overlapped_blocks += 1 if b0 + block < B else 0
+        finish(pending)
+        return out_d, out_r
 
     # ---- multi-vector (MaxSim): docs sharded by cumulative token count, same gather + merge ----
     def add_local_multivec(self, vecs, offsets, global_doc0: int) -> None:
@@ -125,6 +185,14 @@ class ShardedSearcher:
         packed = torch.from_numpy(np.stack([d64.view(np.int64), rows_l])).to(dev)
         gathered = torch.empty((self.world, 2, B, k), dtype=torch.int64, device=dev)
         self._dist.all_gather_into_tensor(gathered.view(-1), packed.view(-1), group=self.group)
+        if on_gpu and hasattr(self.index, "merge_topk_packed_device"):
+            # the world*k -> k merge stays on the device (k_merge_topk, same total order); the MaxSim entry point of
+            # the library returns host arrays, so only the [B,k] lists make the round trip
+            out_d = torch.empty((B, k), dtype=torch.float64, device=dev)
+            out_r = torch.empty((B, k), dtype=torch.int64, device=dev)
+            self.index.merge_topk_packed_device(gathered.data_ptr(), self.world, B, k, out_d.data_ptr(), out_r.data_ptr(),
+                                                torch.cuda.current_stream(dev).cuda_stream)
+            return out_d.cpu().numpy().astype(np.float32), out_r.cpu().numpy()
         g = gathered.cpu().numpy()
         out_d, out_r = merge_topk_host(np.ascontiguousarray(g[:, 0]).view(np.float64), np.ascontiguousarray(g[:, 1]), k)
         return out_d.astype(np.float32), out_r

@@ -62,6 +62,9 @@ def parse_args():
     ap.add_argument("--screen-form", type=int, default=None, help="developer A/B: 0 = first form of k_screen256, 1 = second form")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the all-gather + merge path even at world size 1 (exercises the multi-GPU code on one GPU)")
+    ap.add_argument("--comm", choices=["torch", "lib"], default="torch",
+                    help="N > 1: all-gather through torch.distributed (RCCL, overlapped with the next step's search on a second "
+                         "stream) or through the library's own RCCL communicator (mi355dr_search_sharded_device)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (planted-answer nDCG, PCIe-inclusive "
                                                            "rate, BLAS / torch / B=1 CPU baselines)")
@@ -308,26 +311,50 @@ def main() -> None:
     t_build = time.time() - t_build
 
     # the shard result is written straight into the packed [2,B,k] block one all-gather sends:
-    # plane 0 = float8 distance bits, plane 1 = global rows
-    packed = torch.empty((2, B, k), device=device, dtype=torch.int64)
+    # plane 0 = float8 distance bits, plane 1 = global rows.  Two sets: the all-gather + merge of step i run on a second
+    # stream under the search of step i+1.
+    packed2 = [torch.empty((2, B, k), device=device, dtype=torch.int64) for _ in range(2)]
+    packed = packed2[0]
     out_dist = packed[0].view(torch.float64)
     out_rows = packed[1]
     if use_dist:
-        packed_all = torch.empty((world, 2, B, k), device=device, dtype=torch.int64)
-        fin_dist = torch.empty((B, k), device=device, dtype=torch.float64)
-        fin_rows = torch.empty((B, k), device=device, dtype=torch.int64)
+        packed_all2 = [torch.empty((world, 2, B, k), device=device, dtype=torch.int64) for _ in range(2)]
+        packed_all = packed_all2[0]
+        fin_dist2 = [torch.empty((B, k), device=device, dtype=torch.float64) for _ in range(2)]
+        fin_rows2 = [torch.empty((B, k), device=device, dtype=torch.int64) for _ in range(2)]
+        fin_dist, fin_rows = fin_dist2[0], fin_rows2[0]
+        comm_stream = torch.cuda.Stream(device)
+        gather_done = [None, None]
+        if args.comm == "lib":  # the library's own communicator: the unique id travels through torch's store
+            uid = [pkg.Mi355Index.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            idx.comm_init(rank, world, uid[0])
     stream = torch.cuda.current_stream().cuda_stream
 
     def step(i: int):
         q = qpool[i % n_pool]
-        idx.search_device(q.data_ptr(), B, k, out_dist.data_ptr(), out_rows.data_ptr(), stream)
-        if use_dist:
+        if not use_dist:
+            idx.search_device(q.data_ptr(), B, k, out_dist.data_ptr(), out_rows.data_ptr(), stream)
+            return out_dist, out_rows
+        buf = i & 1
+        if args.comm == "lib":
+            idx.search_sharded_device(q.data_ptr(), B, k, fin_dist2[buf].data_ptr(), fin_rows2[buf].data_ptr(), stream)
+            return fin_dist2[buf], fin_rows2[buf]
+        if gather_done[buf] is not None:
+            torch.cuda.current_stream().wait_event(gather_done[buf])  # the gather that read this block two steps ago
+        pk = packed2[buf]
+        idx.search_device(q.data_ptr(), B, k, pk[0].data_ptr(), pk[1].data_ptr(), stream)
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(ready)
             # one all-gather of the packed [2,B,k] (distance bits, rows) block per rank, then the merge kernel
-            dist.all_gather_into_tensor(packed_all.view(-1), packed.view(-1))
-            idx.merge_topk_packed_device(packed_all.data_ptr(), world, B, k, fin_dist.data_ptr(), fin_rows.data_ptr(),
-                                         stream)
-            return fin_dist, fin_rows
-        return out_dist, out_rows
+            dist.all_gather_into_tensor(packed_all2[buf].view(-1), pk.view(-1))
+            idx.merge_topk_packed_device(packed_all2[buf].data_ptr(), world, B, k, fin_dist2[buf].data_ptr(),
+                                         fin_rows2[buf].data_ptr(), comm_stream.cuda_stream)
+            gather_done[buf] = torch.cuda.Event()
+            gather_done[buf].record(comm_stream)
+        return fin_dist2[buf], fin_rows2[buf]
 
     for i in range(args.warmup):
         step(i)
@@ -439,7 +466,8 @@ def main() -> None:
             "dim": d,
             "k": k,
             "queries_per_step": B,
-            "parallelism": f"row-shard x{world}" + (" + all-gather top-k merge" if world > 1 else ""),
+            "parallelism": f"row-shard x{world}" + ((" + all-gather top-k merge (" + ("library RCCL communicator" if args.comm == "lib"
+                            else "torch.distributed, overlapped with the next step on a second stream") + ")") if use_dist else ""),
             "arithmetic": ("int8" if i8 else "bf16") + " MFMA screen over a normalised shadow corpus (rigorous "
                           "per-query error bound), exact fp32 chain re-score, float8 distance (results bit-exact vs "
                           "CPU oracle)",

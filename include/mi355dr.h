@@ -147,6 +147,21 @@ int mi355dr_pack_topk_device(mi355dr_index* idx, const double* dist_dev, const i
 int mi355dr_merge_topk_packed_device(mi355dr_index* idx, const int64_t* packed_all_dev, int world, int B, int k,
                                      double* out_dist_dev, int64_t* out_rows_dev, void* stream);
 
+/* ---- row-sharded search inside the library: one index = one shard on one GPU, one process per GPU.
+ * Replaces nothing in the reference (its engine is one PostgreSQL server); it is the data-parallel form of
+ * `ORDER BY distance LIMIT k` (orm/repository/base.py:409-415): every rank searches its rows with "row_offset" set, ONE
+ * ncclAllGather (RCCL over xGMI) of the packed [2,B,k] (float8 distance bits, int64 global row) block per rank, then the
+ * world*k -> k merge under the same total order: bit-identical to the single-GPU result on every rank.
+ * RCCL is bound at run time (dlopen): a host that never calls these needs no librccl.  The 128-byte ncclUniqueId is
+ * created on one rank (mi355dr_comm_unique_id) and handed to every rank through the host's own channel. */
+int mi355dr_comm_unique_id(void* out_128_bytes, size_t len);
+int mi355dr_comm_init(mi355dr_index* idx, int rank, int world, const void* nccl_unique_id, size_t id_len);
+int mi355dr_comm_world(const mi355dr_index* idx);  /* 0 before mi355dr_comm_init */
+/* device buffers in / out like mi355dr_search_device; every rank passes the same queries and receives the same result;
+ * asynchronous on `stream` (NULL = the index's own stream) after the last block's local search */
+int mi355dr_search_sharded_device(mi355dr_index* idx, const float* queries_dev, int B, int k, double* out_dist_dev,
+                                  int64_t* out_rows_dev, void* stream);
+
 /* ---- options / stats / timing ----
  * options: "path" (MI355DR_PATH_*), "screen_dtype" (MI355DR_SCREEN_*), "row_offset", "profile" (0/1: HIP-event
  *          timing of the dominant kernel), "chunk0_rows", "chunk_growth", "cand_cap", "prefilter16" (1: int8 screen only, a bf16 second

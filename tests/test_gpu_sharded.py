@@ -1,0 +1,75 @@
+"""GPU, one rank (the build's GPU box has one GPU): the device-resident multi-GPU path end to end at world size 1 --
+(1) the library's own RCCL communicator (mi355dr_comm_init + mi355dr_search_sharded_device: local search, ncclAllGather,
+merge), (2) ShardedSearcher's pipelined torch.distributed path (gather + merge of block i on a second stream under the
+search of block i+1).  Both must reproduce the plain search bit for bit.  The N > 1 logic itself (shard bounds, global
+row ids, cross-shard ties, overlapped blocks) runs under gloo in tests/test_sharded_gloo.py."""
+
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+_CHILD = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=%(port)r, RANK="0", WORLD_SIZE="1")
+import torch
+import torch.distributed as dist
+import autorag_research_amd as pkg
+from autorag_research_amd.sharded import ShardedSearcher
+
+rng = np.random.default_rng(11)
+n, d, B, k = 40000, 256, 700, 10
+C = rng.standard_normal((n, d)).astype(np.float32)
+Q = rng.standard_normal((B, d)).astype(np.float32)
+with pkg.Mi355Index(d) as ref:
+    ref.set_option("row_offset", 1000)
+    ref.add(C)
+    rd, rr = ref.search(Q, k)
+
+# (1) the library's communicator
+idx = pkg.Mi355Index(d)
+idx.set_option("row_offset", 1000)
+idx.add(C)
+assert idx.comm_world() == 0
+idx.comm_init(0, 1, pkg.Mi355Index.comm_unique_id())
+assert idx.comm_world() == 1
+qd = torch.from_numpy(Q).cuda()
+od = torch.empty((B, k), dtype=torch.float64, device="cuda")
+orow = torch.empty((B, k), dtype=torch.int64, device="cuda")
+idx.search_sharded_device(qd.data_ptr(), B, k, od.data_ptr(), orow.data_ptr(), torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()
+assert np.array_equal(orow.cpu().numpy(), rr) and np.array_equal(od.cpu().numpy().view(np.uint64), rd.view(np.uint64))
+idx.close()
+
+# (2) ShardedSearcher over torch.distributed (nccl = RCCL), pipelined blocks
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+s = ShardedSearcher(d, "cosine", device=0)
+s.force_pipeline = True
+s.add_local(C, 1000)
+d2, r2 = s.search(Q, k, block=256)   # 3 blocks: gathers of blocks 0 and 1 overlap the searches of blocks 1 and 2
+assert np.array_equal(r2, rr) and np.array_equal(d2.view(np.uint64), rd.view(np.uint64))
+s.close()
+dist.destroy_process_group()
+print("SHARDED_OK")
+"""
+
+
+def test_device_resident_sharded_paths_at_world_one(native_built):
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _CHILD % {"root": str(ROOT), "port": port}], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0 and "SHARDED_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

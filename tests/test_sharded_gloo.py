@@ -47,6 +47,10 @@ def _worker(rank: int, world: int, port: int, out_dir: str):
     s = ShardedSearcher(d, "cosine", index_factory=OracleIndex)
     s.add_local(C[lo:hi], lo)
     dist_g, rows_g = s.search(Q, k)
+    # the same through the overlapped pipeline: 3 blocks of <= 4 queries, the gather of block i under the search of i+1
+    dist_p, rows_p = s.search(Q, k, block=4)
+    assert s.overlapped_blocks == 2
+    assert np.array_equal(rows_p, rows_g) and np.array_equal(dist_p.view(np.uint64), dist_g.view(np.uint64))
     # k larger than one shard's rows still merges correctly
     dist_big, rows_big = s.search(Q[:2], 40)
     # multi-vector store sharded by cumulative token count
