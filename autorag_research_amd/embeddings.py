@@ -185,6 +185,11 @@ class TorchEncoderEmbeddings(Embeddings):
     def embed_documents(self, texts: list[str]) -> list[list[float]]:
         return self.encode_to_device(texts).cpu().tolist()
 
+    def embed_queries(self, texts: list[str]) -> list[list[float]]:
+        """Batched QUERY-side embeddings (ingest.py, the HyDE block).  This encoder has one tower, so it equals
+        embed_documents; an asymmetric model puts its query prefix / instruction here."""
+        return self.embed_documents(texts)
+
     def embed_query(self, text: str) -> list[float]:
         return self._forward([text])[0].cpu().tolist()
 

@@ -11,6 +11,7 @@ model's query side, batched when it offers `embed_queries`), and searched as ONE
 from __future__ import annotations
 
 import asyncio
+import logging
 import inspect
 from dataclasses import dataclass, field
 from typing import Any
@@ -19,6 +20,8 @@ import numpy as np
 
 from .compat import BaseRetrievalPipelineConfig
 from .pipelines import Mi355BaseRetrievalPipeline
+
+logger = logging.getLogger("AutoRAG-Research")
 
 DEFAULT_HYDE_PROMPT_TEMPLATE = """Please write a passage to answer the question.
 Question: {query}
@@ -106,11 +109,22 @@ class Mi355HyDERetrievalPipeline(Mi355BaseRetrievalPipeline):
         """A page: passages generated concurrently, embedded, searched as one GPU block."""
 
         async def passages():
+            attempts, delay0 = getattr(self, "_run_retry", (1, 0.0))
+
             async def one(qid):
-                try:
-                    return await self._generate_hypothetical_document(self._query_text(qid))
-                except Exception:  # noqa: BLE001 - that query is reported as failed
-                    return None
+                # the reference retries a failing query with exponential backoff before it gives it up
+                # (retrieval_pipeline.py:222-236); so does the block form, per passage
+                delay = delay0
+                for attempt in range(attempts):
+                    try:
+                        return await self._generate_hypothetical_document(self._query_text(qid))
+                    except Exception:  # noqa: BLE001
+                        if attempt + 1 >= attempts:
+                            logger.exception(f"HyDE passage generation failed for query {qid} after {attempts} attempts")
+                            return None  # that query is reported as failed
+                        await asyncio.sleep(min(max(delay, delay0), 60))
+                        delay *= 2
+                return None
 
             return await asyncio.gather(*[one(q) for q in query_ids])
 

@@ -3,9 +3,12 @@
 Mirrors BaseIngestionService._embed_entities / embed_all_queries / embed_all_chunks
 (autorag_research/orm/service/base_ingestion.py:326-495, 542-624) and TextEmbeddingDataIngestor.embed_all /
 embed_all_late_interaction (autorag_research/data/base.py:57-72, 110-125): find rows whose embedding is NULL,
-embed them, store the vectors.  The reference embeds ONE text per model forward (`aembed_query` under a
-semaphore); here rows go through `embed_documents` in batches of `batch_size`, and multi-vector models fill
-the ragged store.  Returns the number of rows embedded, like the reference.
+embed them, store the vectors.  The reference embeds ONE text per model forward (`aembed_query` under a semaphore) -- and it
+feeds the model's QUERY side to queries AND chunks (data/base.py:63-71): for asymmetric encoders (query / passage
+prefixes, instructions) the stored vectors, hence rankings and nDCG, depend on that.  The default `side="query"` here
+does the same, batched through `embed_queries` when the model offers it; `side="document"` (the model's
+`embed_documents`) is an explicit deviation for callers that want passage-side chunk vectors.  Multi-vector models
+fill the ragged store.  Returns the number of rows embedded, like the reference.
 """
 
 from __future__ import annotations
@@ -18,14 +21,23 @@ from .embeddings import MultiVectorBaseEmbedding
 from .store import ChunkTable, InMemoryStore
 
 
-def _embed_texts(model: Any, texts: list[str], batch_size: int) -> list:
+def _embed_texts(model: Any, texts: list[str], batch_size: int, side: str = "query") -> list:
+    if side not in ("query", "document"):
+        raise ValueError("side must be 'query' (the reference's behaviour) or 'document'")
     out: list = []
     for i in range(0, len(texts), batch_size):
-        out.extend(model.embed_documents(texts[i: i + batch_size]))
+        part = texts[i: i + batch_size]
+        if side == "document":
+            out.extend(model.embed_documents(part))
+        elif hasattr(model, "embed_queries"):
+            out.extend(model.embed_queries(part))
+        else:
+            out.extend(model.embed_query(t) for t in part)
     return out
 
 
-def embed_all_chunks(store: InMemoryStore, model: Any, batch_size: int = 128, unit: str = "chunk") -> int:
+def embed_all_chunks(store: InMemoryStore, model: Any, batch_size: int = 128, unit: str = "chunk",
+                     side: str = "query") -> int:
     """Fill `embedding` (single-vector model) or `embeddings` (multi-vector model) of every row that lacks it."""
     table: ChunkTable = store.image_chunks if unit == "image_chunk" else store.chunks
     n = len(table)
@@ -37,7 +49,7 @@ def embed_all_chunks(store: InMemoryStore, model: Any, batch_size: int = 128, un
         todo = [i for i in range(n) if not have or table.mv_offsets[i + 1] == table.mv_offsets[i]]
         if not todo:
             return 0
-        new = _embed_texts(model, [texts[i] for i in todo], batch_size)
+        new = _embed_texts(model, [texts[i] for i in todo], batch_size, side)
         docs = [None] * n
         if have:
             for i in range(n):
@@ -57,7 +69,7 @@ def embed_all_chunks(store: InMemoryStore, model: Any, batch_size: int = 128, un
         todo = [i for i in range(n) if np.isnan(table.embedding[i]).all()]
     if not todo:
         return 0
-    vecs = np.asarray(_embed_texts(model, [texts[i] for i in todo], batch_size), dtype=np.float32)
+    vecs = np.asarray(_embed_texts(model, [texts[i] for i in todo], batch_size, side), dtype=np.float32)
     if table.embedding is None:
         table.embedding = np.full((n, vecs.shape[1]), np.nan, dtype=np.float32)
     table.embedding[todo] = vecs
@@ -97,10 +109,7 @@ def embed_all_queries(store: InMemoryStore, model: Any, batch_size: int = 128) -
     if not todo:
         return 0
     texts = [store.queries[q].contents or "" for q in todo]
-    out: list = []
-    for i in range(0, len(texts), batch_size):
-        part = texts[i: i + batch_size]
-        out.extend([model.embed_query(t) for t in part] if multi else model.embed_documents(part))
+    out = _embed_texts(model, texts, batch_size, "query")
     for q, v in zip(todo, out):
         if multi:
             store.queries[q].embeddings = np.asarray(v, dtype=np.float32)

@@ -73,6 +73,7 @@ class Mi355BaseRetrievalPipeline(BasePipeline, ABC):
         unit = get_retrieval_pipeline_unit(self) or "chunk"
         if unit == "mixed":
             raise ValueError("Mixed retrieval_unit persistence is not supported; override run() with an explicit persistence path.")
+        self._run_retry = (max(1, max_retries), retry_delay)  # block forms that call fallible services (HyDE's LLM) honour it
         return self._service._run_pipeline(
             retrieval_func=self._retrieve_by_id, pipeline_id=self.pipeline_id, unit=unit, top_k=top_k,
             batch_size=batch_size, max_concurrency=max_concurrency, max_retries=max_retries, retry_delay=retry_delay,

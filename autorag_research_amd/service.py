@@ -23,7 +23,7 @@ from typing import Any, Literal
 import numpy as np
 
 from .index import Mi355Index
-from .store import ChunkTable, InMemoryStore
+from .store import ChunkTable, InMemoryStore, UowStore
 
 logger = logging.getLogger("AutoRAG-Research")
 
@@ -69,16 +69,46 @@ class _UnitIndex:
         self.single = self.multi = None
 
 
+def _is_store(obj: Any) -> bool:
+    return all(hasattr(obj, a) for a in ("get_or_create_pipeline", "get_all_queries", "completed_query_ids", "chunks"))
+
+
 class Mi355RetrievalService:
-    def __init__(self, session_factory: Callable[[], InMemoryStore], schema: Any | None = None, device: int = 0):
+    """`session_factory` is what the caller of the pipeline passes:
+
+    * a callable returning a store (InMemoryStore, or any object with that interface) -- standalone use, bench, tests;
+    * a SQLAlchemy `sessionmaker`, which is what the reference's Executor and its wrapper pipelines pass
+      (executor.py:326-333, hybrid.py `_load_pipeline`).  The service then builds the reference's own
+      `RetrievalPipelineService(session_factory, schema)` and reads / writes the database through it (store.UowStore);
+      that needs the `autorag_research` package importable, which it is wherever the Executor runs.
+    """
+
+    def __init__(self, session_factory: Callable[[], Any], schema: Any | None = None, device: int = 0):
         self.session_factory = session_factory
         self._schema = schema
         self._device = device
         self._units: dict[str, _UnitIndex] = {}
+        self._uow_store: UowStore | None = None
+        probe = session_factory()
+        if not _is_store(probe):
+            close = getattr(probe, "close", None)
+            if callable(close):
+                close()
+            try:
+                from autorag_research.orm.service.retrieval_pipeline import RetrievalPipelineService  # noqa: PLC0415
+            except ImportError as e:  # pragma: no cover - only outside a reference installation
+                raise TypeError(
+                    f"session_factory() returned a {type(probe).__name__}, not a store; a SQLAlchemy sessionmaker is served "
+                    "through the reference's RetrievalPipelineService, which needs `autorag_research` importable") from e
+            self._uow_store = UowStore(RetrievalPipelineService(session_factory, schema))
 
     # ---- plumbing ----
-    def _store(self) -> InMemoryStore:
-        return self.session_factory()
+    def _store(self) -> Any:
+        return self._uow_store if self._uow_store is not None else self.session_factory()
+
+    def delete_pipeline_results(self, pipeline_id) -> int:
+        """Reference RetrievalPipelineService.delete_pipeline_results (:359-372): the Executor's health-check cleanup."""
+        return self._store().delete_pipeline_results(pipeline_id)
 
     def _unit(self, unit: str) -> _UnitIndex:
         if unit not in self._units:
@@ -279,7 +309,7 @@ class Mi355RetrievalService:
         """
         store = self._store()
         result_id_key = "image_chunk_id" if unit == "image_chunk" else "chunk_id"
-        configured = store.pipelines.get(pipeline_id, {}).get("config", {}).get("retrieval_unit", "chunk")
+        configured = store.pipeline_config(pipeline_id).get("retrieval_unit", "chunk")
         if configured == "mixed":
             raise ValueError(f"Pipeline {pipeline_id!r} is configured for mixed results, which cannot be persisted directly.")
         if configured != unit:
@@ -324,7 +354,19 @@ class Mi355RetrievalService:
             if not qids:
                 offset += batch_size
                 continue
-            results = block_func(qids, top_k) if block_func is not None else asyncio.run(page(qids))
+            if block_func is not None:
+                try:
+                    results = block_func(qids, top_k)
+                except Exception:  # noqa: BLE001
+                    # one bad query (missing / malformed embedding, too many query vectors for a block, an embedding-batch
+                    # error) must not abort the run: the page falls back to the reference's per-query path, where retries,
+                    # backoff and `failed_queries` apply to that query alone (retrieval_pipeline.py:222-236)
+                    logger.exception(f"block retrieval failed for a page of {len(qids)} queries; retrying it query by query")
+                    if retrieval_func is None:
+                        raise
+                    results = asyncio.run(page(qids))
+            else:
+                results = asyncio.run(page(qids))
             insert_page = getattr(store, "insert_page", None)
             if callable(insert_page):
                 # a store that takes a page as it is (ranked lists per query): skips flattening it into one dict per

@@ -150,3 +150,127 @@ class InMemoryStore:
         key = "image_chunk_id" if unit == "image_chunk" else "chunk_id"
         for r in rows:
             tab.setdefault((r["pipeline_id"], r["query_id"]), []).append((r[key], float(r["rel_score"])))
+
+    def pipeline_config(self, pipeline_id) -> dict[str, Any]:
+        return dict(self.pipelines.get(pipeline_id, {}).get("config", {}))
+
+    def delete_pipeline_results(self, pipeline_id) -> int:
+        """Rows of both result tables for one pipeline (reference delete_pipeline_results, retrieval_pipeline.py:359-372)."""
+        n = 0
+        for tab in (self.chunk_results, self.image_chunk_results):
+            for key in [k for k in tab if k[0] == pipeline_id]:
+                n += len(tab.pop(key))
+        return n
+
+    def delete_pipeline(self, pipeline_id) -> None:
+        """What the reference Executor's health-check cleanup does after the results are gone (executor.py:372-383)."""
+        name = self.pipelines.pop(pipeline_id, {}).get("name")
+        self._pipeline_by_name.pop(name, None)
+
+
+def _as_vec(x) -> np.ndarray | None:
+    return None if x is None else np.ascontiguousarray(x, dtype=np.float32)
+
+
+class UowStore:
+    """The same store interface over the REFERENCE's own service / Unit-of-Work objects -- what makes the plugin run inside
+    the reference's Executor, which hands every pipeline a SQLAlchemy sessionmaker (executor.py:326-333, 408-416).
+
+    `ref_service` is an `autorag_research.orm.service.retrieval_pipeline.RetrievalPipelineService` (or anything with the
+    same `_create_uow()` / `get_or_create_pipeline()`): queries are paged through `uow.queries`, the corpus is exported once
+    per table through `uow.chunks` / `uow.image_chunks` (`embedding VECTOR(d)`, `embeddings VECTOR(d)[]`, NULLs kept as
+    NULLs), result rows go back through the result repositories' `bulk_insert` in the reference's own row-dict format
+    (retrieval_pipeline.py:151-182, 283-288), so evaluation and reporting read them like any other pipeline's.
+    Mi355RetrievalService builds one of these by itself when `session_factory()` does not return a store."""
+
+    EXPORT_PAGE = 50_000
+
+    def __init__(self, ref_service: Any):
+        self._svc = ref_service
+        self._tables: dict[str, ChunkTable] = {}
+
+    # ---- pipelines ----
+    def get_or_create_pipeline(self, name: str, config: dict[str, Any]):
+        return self._svc.get_or_create_pipeline(name, config)
+
+    def pipeline_config(self, pipeline_id) -> dict[str, Any]:
+        with self._svc._create_uow() as uow:
+            p = uow.pipelines.get_by_id(pipeline_id)
+            return dict(getattr(p, "config", None) or {}) if p is not None else {}
+
+    def delete_pipeline_results(self, pipeline_id) -> int:
+        return self._svc.delete_pipeline_results(pipeline_id)
+
+    # ---- queries ----
+    @staticmethod
+    def _query_row(q) -> QueryRow:
+        return QueryRow(id=q.id, contents=getattr(q, "contents", None), embedding=_as_vec(getattr(q, "embedding", None)),
+                        embeddings=_as_vec(getattr(q, "embeddings", None)))
+
+    def get_query(self, qid):
+        with self._svc._create_uow() as uow:
+            q = uow.queries.get_by_id(qid)
+            return None if q is None else self._query_row(q)
+
+    def get_all_queries(self, limit: int, offset: int) -> list[QueryRow]:
+        with self._svc._create_uow() as uow:
+            return [self._query_row(q) for q in uow.queries.get_all(limit=limit, offset=offset)]
+
+    def find_query_by_text(self, text: str):
+        with self._svc._create_uow() as uow:
+            q = uow.queries.find_by_contents(text)
+            return None if q is None else self._query_row(q)
+
+    # ---- corpus export (once per table) ----
+    def _export(self, repo_name: str) -> ChunkTable:
+        if repo_name in self._tables:
+            return self._tables[repo_name]
+        ids, contents, single, multi = [], [], [], []
+        offset = 0
+        while True:
+            with self._svc._create_uow() as uow:
+                page = getattr(uow, repo_name).get_all(limit=self.EXPORT_PAGE, offset=offset)
+                for c in page:
+                    ids.append(c.id)
+                    contents.append(getattr(c, "contents", None))
+                    single.append(_as_vec(getattr(c, "embedding", None)))
+                    multi.append(_as_vec(getattr(c, "embeddings", None)))
+            if len(page) < self.EXPORT_PAGE:
+                break
+            offset += len(page)
+        t = ChunkTable(ids=ids, contents=contents)
+        d1 = next((v.shape[0] for v in single if v is not None), 0)
+        if d1:
+            t.embedding = np.full((len(ids), d1), np.nan, dtype=np.float32)  # NaN row = NULL (skipped like `IS NOT NULL`)
+            for i, v in enumerate(single):
+                if v is not None:
+                    t.embedding[i] = v
+        if any(m is not None and len(m) for m in multi):
+            dm = next(m.shape[1] for m in multi if m is not None and len(m))
+            lens = [0 if m is None else m.shape[0] for m in multi]
+            t.mv_offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            t.mv_tokens = np.concatenate([m.reshape(-1, dm) for m in multi if m is not None and len(m)], axis=0)
+        self._tables[repo_name] = t
+        return t
+
+    @property
+    def chunks(self) -> ChunkTable:
+        return self._export("chunks")
+
+    @property
+    def image_chunks(self) -> ChunkTable:
+        return self._export("image_chunks")
+
+    # ---- results ----
+    @staticmethod
+    def _result_repo(uow, unit: str):
+        return uow.image_chunk_results if unit == "image_chunk" else uow.chunk_results
+
+    def completed_query_ids(self, unit: str, pipeline_id, query_ids) -> set:
+        with self._svc._create_uow() as uow:
+            return {r.query_id for r in self._result_repo(uow, unit).get_by_query_and_pipeline(list(query_ids), pipeline_id)}
+
+    def bulk_insert(self, unit: str, rows: list[dict[str, Any]]) -> None:
+        with self._svc._create_uow() as uow:
+            self._result_repo(uow, unit).bulk_insert(rows)
+            uow.commit()

@@ -28,6 +28,8 @@ Fixtures written next to this file:
                            Unit-of-Work with the recorded lexical child.
   hyde_golden.json         HyDERetrievalPipeline._retrieve_by_id / _retrieve_by_text (pipelines/retrieval/hyde.py:205-238) with
                            deterministic stand-in LLM / embedding objects (hyde_fake_models, shared with the test).
+  executor_golden.json     the reference's plugin_registry scan of this package and its Executor's health-check -> run -> verify
+                           flow (executor.py:308-463) over Mi355VectorSearchPipelineConfig: PipelineResult + persisted rows.
   gqr_golden.npz / .json   Guided Query Refinement: outputs of GQRHybridRetrievalPipeline._optimize_query_embedding /
                            _optimize_query_multi_embedding / _optimize_in_score_space (pipelines/retrieval/
                            gqr_hybrid.py:306-362) on seeded pools, and of _retrieve_by_id (:472-489) over the fake
@@ -609,6 +611,106 @@ def make_hyde(svc: "_FakeService") -> dict:
     return out
 
 
+# --------------------------------------------------------------------------------------
+# 8. the reference's own plugin registry + Executor driving THIS plugin
+# --------------------------------------------------------------------------------------
+
+
+def make_executor() -> dict:
+    """`plugin_registry._scan_module_yamls` (plugin_registry.py:90-120) over the installed package, then the reference
+    Executor's health-check -> run -> verify flow (`_health_check_pipeline` executor.py:308-354, `_run_pipeline_with_retry`
+    :383-463) with `Mi355VectorSearchPipelineConfig`, twice: the pipeline handed (a) a store factory and (b) a sessionmaker-like
+    factory as the Executor gets from DBConnection, in which case the plugin goes through a RetrievalPipelineService (here the
+    duck-typed one of tests/helpers.py -- no PostgreSQL in the build container).  No GPU here either: the index is the
+    oracle-backed stand-in, so what is frozen is the HOST flow (stats dicts, PipelineResult, persisted rows)."""
+    import dataclasses
+
+    import autorag_research.executor as ref_executor
+    import autorag_research.plugin_registry as ref_registry
+    from autorag_research.config import ExecutorConfig
+
+    sys.path.insert(0, str(HERE.parent))
+    import helpers
+
+    import autorag_research_amd as pkg
+    import autorag_research_amd.compat as compat
+    import autorag_research_amd.service as amd_service
+    from autorag_research_amd.pipelines import Mi355VectorSearchPipelineConfig
+
+    assert compat.HAVE_REFERENCE, "the plugin must subclass the reference's own config / pipeline bases here"
+    amd_service.Mi355Index = helpers.OracleIndex
+    out: dict = {}
+    infos = ref_registry._scan_module_yamls(pkg, "mi355_vector_search", "pipelines")
+    out["registry_scan"] = sorted([i.config_name, i.subcategory, i.category, i.plugin_name] for i in infos)
+
+    class EvalService:  # what the Executor needs of RetrievalEvaluationService when no metric is configured
+        def __init__(self, verify, delete_pipeline):
+            self.verify_pipeline_completion, self._delete_pipeline = verify, delete_pipeline
+
+        def _create_uow(self):
+            outer = self
+
+            class U:
+                evaluation_results = type("R", (), {"delete_by_pipeline": staticmethod(lambda pid: 0)})()
+                pipelines = type("P", (), {"delete_by_id": staticmethod(lambda pid: outer._delete_pipeline(pid))})()
+
+                def __enter__(self):
+                    return self
+
+                def __exit__(self, *a):
+                    return False
+
+                def commit(self):
+                    pass
+
+            return U()
+
+    def drive(session_factory, eval_service, rows_of):
+        cfg = Mi355VectorSearchPipelineConfig(name="mi355_vector_search", search_mode="single", top_k=4, batch_size=4,
+                                              retry_delay=0.0)
+        e = ref_executor.Executor.__new__(ref_executor.Executor)
+        e.session_factory, e._schema, e._config_dir = session_factory, None, None
+        e.config = ExecutorConfig(pipelines=[cfg], metrics=[], max_retries=1, health_check_queries=2)
+        e._retrieval_eval_service = eval_service
+        e._health_check_pipeline(cfg)            # raises HealthCheckError unless 2 queries ran clean and were cleaned up
+        after_health = len(rows_of())
+        res = e._run_pipeline_with_retry(cfg)
+        rows = sorted(rows_of(), key=lambda r: (str(r[0]), -r[2], str(r[1])))
+        return {"rows_left_by_health_check": after_health, "pipeline_result": dataclasses.asdict(res) | {
+            "pipeline_type": res.pipeline_type.value}, "persisted": [[q, c, s] for q, c, s in rows]}
+
+    # (a) store factory
+    store, _ = helpers.build_golden_stores()
+    del store.queries["q_noemb"]                 # (the health check demands failed_queries == [])
+    store.query_order.remove("q_noemb")
+
+    def store_rows():
+        return [(q, c, s) for (pid, q), lst in store.chunk_results.items() for c, s in lst]
+
+    def store_verify(pid):
+        return all(store.chunk_results.get((pid, q)) for q in store.query_order)
+
+    out["store_factory"] = drive(lambda: store, EvalService(store_verify, store.delete_pipeline), store_rows)
+    # (b) sessionmaker-like factory -> RetrievalPipelineService -> UowStore
+    store2, _ = helpers.build_golden_stores()
+    del store2.queries["q_noemb"]
+    store2.query_order.remove("q_noemb")
+    tables = helpers.ref_tables_from_store(store2)
+    import autorag_research.orm.service.retrieval_pipeline as ref_rps
+
+    real_service = ref_rps.RetrievalPipelineService
+    ref_rps.RetrievalPipelineService = lambda sf, schema=None: helpers.FakeRefService(sf, schema)
+    try:
+        fake = helpers.FakeRefService(tables=tables)
+        out["sessionmaker"] = drive(helpers.FakeSessionmaker(tables),
+                                    EvalService(fake.verify_pipeline_completion, lambda pid: tables["pipelines"].pop(pid, None)),
+                                    lambda: [(r["query_id"], r["chunk_id"], r["rel_score"]) for r in tables["chunk_results"]])
+    finally:
+        ref_rps.RetrievalPipelineService = real_service
+    assert out["sessionmaker"]["persisted"] == out["store_factory"]["persisted"]
+    return out
+
+
 def main() -> None:
     (HERE / "metrics_golden.json").write_text(json.dumps(make_metrics(), indent=1))
     np.savez_compressed(HERE / "scores_golden.npz", **make_scores())
@@ -617,6 +719,7 @@ def main() -> None:
     (HERE / "gqr_golden.json").write_text(json.dumps(make_gqr_flow(_LAST["svc"], _LAST["ids"]), indent=1))
     (HERE / "hybrid_golden.json").write_text(json.dumps(make_hybrid(_LAST["svc"], _LAST["ids"]), indent=1))
     (HERE / "hyde_golden.json").write_text(json.dumps(make_hyde(_LAST["svc"]), indent=1))
+    (HERE / "executor_golden.json").write_text(json.dumps(make_executor(), indent=1))
     print("wrote", sorted(p.name for p in HERE.iterdir()))
 
 

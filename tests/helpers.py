@@ -201,3 +201,137 @@ def build_golden_stores():
     s.add_queries(qids, contents=[f"query text {i}" for i in range(6)], embedding=list(g["Q"]), embeddings=g["Qm"])
     s.add_queries(["q_noemb"], contents=["no embedding"], embedding=[None], embeddings=[None])
     return s, g
+
+
+# ---- a stand-in for the REFERENCE's RetrievalPipelineService / Unit of Work (only its public shape) --------------------
+class _Obj:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class FakeRefService:
+    """Duck-typed `autorag_research.orm.service.retrieval_pipeline.RetrievalPipelineService` over plain Python tables:
+    `_create_uow()` -> context manager with the repositories the Vector Search path touches (names and call shapes as in
+    retrieval_pipeline.py:255-288, 359-372 and orm/repository/*.py).  Vectors come back as Python lists / None (NULL),
+    like SQLAlchemy hands them out.  Test infrastructure for store.UowStore."""
+
+    def __init__(self, session_factory=None, schema=None, *, tables=None):
+        self.session_factory, self.schema = session_factory, schema
+        self.t = tables if tables is not None else getattr(session_factory, "tables")
+        self.uow_opened = 0
+
+    class _Uow:
+        def __init__(self, svc):
+            t = svc.t
+
+            class Queries:
+                def get_by_id(self, qid):
+                    return next((q for q in t["queries"] if q.id == qid), None)
+
+                def get_all(self, limit=None, offset=None):
+                    return t["queries"][offset or 0:(offset or 0) + (limit if limit is not None else len(t["queries"]))]
+
+                def find_by_contents(self, text):
+                    return next((q for q in t["queries"] if q.contents == text), None)
+
+            class Chunks:
+                def __init__(self, rows):
+                    self.rows = rows
+
+                def get_all(self, limit=None, offset=None):
+                    return self.rows[offset or 0:(offset or 0) + (limit if limit is not None else len(self.rows))]
+
+            class Results:
+                def __init__(self, rows, key):
+                    self.rows, self.key = rows, key
+
+                def get_by_query_and_pipeline(self, query_ids, pipeline_id):
+                    qs = set(query_ids)
+                    return [_Obj(**r) for r in self.rows if r["pipeline_id"] == pipeline_id and r["query_id"] in qs]
+
+                def bulk_insert(self, rows):
+                    for r in rows:
+                        assert set(r) == {"query_id", "pipeline_id", self.key, "rel_score"}, r
+                    self.rows.extend(dict(r) for r in rows)
+
+                def delete_by_pipeline(self, pipeline_id):
+                    n = len(self.rows)
+                    self.rows[:] = [r for r in self.rows if r["pipeline_id"] != pipeline_id]
+                    return n - len(self.rows)
+
+            class Pipelines:
+                def get_by_id(self, pid):
+                    p = t["pipelines"].get(pid)
+                    return None if p is None else _Obj(id=pid, name=p["name"], config=p["config"])
+
+                def delete_by_id(self, pid):
+                    t["pipelines"].pop(pid, None)
+
+            self.queries, self.pipelines = Queries(), Pipelines()
+            self.chunks, self.image_chunks = Chunks(t["chunks"]), Chunks(t["image_chunks"])
+            self.chunk_results = Results(t["chunk_results"], "chunk_id")
+            self.image_chunk_results = Results(t["image_chunk_results"], "image_chunk_id")
+            self.evaluation_results = _Obj(delete_by_pipeline=lambda pid: 0)
+            self.committed = 0
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def commit(self):
+            self.committed += 1
+
+    def _create_uow(self):
+        self.uow_opened += 1
+        return FakeRefService._Uow(self)
+
+    def get_or_create_pipeline(self, name, config, *, strict=False):
+        for pid, p in self.t["pipelines"].items():
+            if p["name"] == name:
+                return pid, False
+        pid = max(self.t["pipelines"], default=0) + 1
+        self.t["pipelines"][pid] = {"name": name, "config": dict(config)}
+        return pid, True
+
+    def delete_pipeline_results(self, pipeline_id):
+        with self._create_uow() as uow:
+            return uow.chunk_results.delete_by_pipeline(pipeline_id) + uow.image_chunk_results.delete_by_pipeline(pipeline_id)
+
+    def verify_pipeline_completion(self, pipeline_id):
+        done = {r["query_id"] for r in self.t["chunk_results"] + self.t["image_chunk_results"] if r["pipeline_id"] == pipeline_id}
+        return all(q.id in done for q in self.t["queries"])
+
+
+def ref_tables_from_store(store) -> dict:
+    """The tables of an InMemoryStore the way the reference's ORM would hand them out (lists / None)."""
+    def rows(tab):
+        out = []
+        for i, pk in enumerate(tab.ids):
+            emb = None
+            if tab.embedding is not None and not np.isnan(tab.embedding[i]).all():
+                emb = [float(x) for x in tab.embedding[i]]
+            mv = None
+            if tab.mv_offsets is not None and tab.mv_offsets[i + 1] > tab.mv_offsets[i]:
+                mv = [[float(x) for x in r] for r in tab.mv_tokens[tab.mv_offsets[i]:tab.mv_offsets[i + 1]]]
+            out.append(_Obj(id=pk, contents=tab.contents[i], embedding=emb, embeddings=mv))
+        return out
+
+    qs = [_Obj(id=q.id, contents=q.contents, embedding=None if q.embedding is None else [float(x) for x in q.embedding],
+               embeddings=None if q.embeddings is None else [[float(x) for x in r] for r in q.embeddings])
+          for q in (store.queries[k] for k in store.query_order)]
+    return {"queries": qs, "chunks": rows(store.chunks), "image_chunks": rows(store.image_chunks), "pipelines": {},
+            "chunk_results": [], "image_chunk_results": []}
+
+
+class FakeSessionmaker:
+    """What the reference Executor passes as `session_factory`: calling it yields a session object, NOT a store."""
+
+    def __init__(self, tables):
+        self.tables = tables
+        self.sessions = 0
+
+    def __call__(self):
+        self.sessions += 1
+        return _Obj(close=lambda: None, execute=lambda *a, **k: None)
