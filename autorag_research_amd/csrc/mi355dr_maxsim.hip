@@ -118,6 +118,7 @@ struct MsArgs {
     int nq_launch;          // queries in this launch (<= 4)
     int q_col0[4];          // first column of each query (multiple of 32)
     int q_len[4];           // real token count of each query
+    int clamp0;             // 1: every query token contributes max(0, max_j <q_i, d_j>)  (ColBERT reranker, rerankers/colbert.py:79)
 };
 
 // Column order inside every group of 8 dims, for BOTH stored token rows and the staged query rows:
@@ -253,6 +254,7 @@ __global__ __launch_bounds__(kMsThreads, 2) void k_maxsim(MsArgs a) {
             for (int cbi = 0; cbi < 4; ++cbi)
                 if (cbi == (c >> 5)) v = run[cbi];
             v = __shfl(v, c & 31, kWave);
+            if (a.clamp0) v = fmaxf(v, 0.0f);
             accd = accd + (-v);
         }
         if (lane == 0) a.dist[(int64_t)qi * a.n_items + item] = b1 > b0 ? accd : __uint_as_float(0x7FC00000u);
@@ -750,6 +752,138 @@ int mi355dr_add_multivec(mi355dr_index* idx, const float* vecs, const int64_t* o
     return MI355DR_OK;
 }
 
+namespace {
+
+__device__ __forceinline__ uint16_t dev_bf16_rn(float f) {  // same rounding as host_bf16_rn
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7F800000u) == 0x7F800000u) return (uint16_t)((u >> 16) | ((u & 0xFFFFu) ? 0x40u : 0u));
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// one workgroup (64 lanes) per NEW 32-row block: the padded fp32 image (columns permuted like the host path), the bf16
+// fragment image, and the store-wide maxima of the screen bound (non-negative doubles order like their bit patterns)
+__global__ __launch_bounds__(64) void k_ms_build(const float* __restrict__ vecs, const int64_t* __restrict__ doc_tok0,
+                                                  const int64_t* __restrict__ doc_T, const int32_t* __restrict__ blk_doc,
+                                                  const int64_t* __restrict__ doc_blk0, int d, int dp, int nkk, int64_t blk_base,
+                                                  float* tok, uint16_t* tok16, unsigned long long* stats, int* not_finite) {
+    const int64_t b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int i = blk_doc[b];
+    const int64_t T = doc_T[i], bi = b - doc_blk0[i];
+    for (int r = 0; r < kMsBlkRows; ++r) {
+        const float* sv = vecs + (doc_tok0[i] + min(bi * kMsBlkRows + r, T - 1)) * (int64_t)d;
+        float* dst = tok + ((blk_base + b) * kMsBlkRows + r) * (int64_t)dp;
+        for (int j = lane; j < dp; j += 64) {
+            const int c = ms_perm(j);
+            dst[j] = c < d ? sv[c] : 0.0f;
+        }
+    }
+    {
+        const int r = lane & 31, hf = lane >> 5;
+        const float* sv = vecs + (doc_tok0[i] + min(bi * kMsBlkRows + r, T - 1)) * (int64_t)d;
+        for (int kk = 0; kk < nkk; ++kk) {
+            uint16_t* dst = tok16 + ((((blk_base + b) * nkk + kk) * 64 + lane) * (int64_t)8);
+            for (int j = 0; j < 8; ++j) {
+                const int c = kk * 16 + hf * 8 + j;
+                dst[j] = c < d ? dev_bf16_rn(sv[c]) : (uint16_t)0;
+            }
+        }
+    }
+    if (lane < kMsBlkRows && bi * kMsBlkRows + lane < T) {  // the real tokens of this block: norms, residual, finiteness
+        const float* sv = vecs + (doc_tok0[i] + bi * kMsBlkRows + lane) * (int64_t)d;
+        double n2 = 0.0, n16 = 0.0, r2 = 0.0;
+        bool fin = true;
+        for (int c = 0; c < d; ++c) {
+            const float f = sv[c];
+            fin = fin && (fabsf(f) <= 3.402823466e38f);
+            const double x = f, x16 = __uint_as_float((uint32_t)dev_bf16_rn(f) << 16);
+            n2 += x * x;
+            n16 += x16 * x16;
+            r2 += (x - x16) * (x - x16);
+        }
+        if (!fin) atomicExch(not_finite, 1);
+        if (n2 == n2 && n2 <= 1.7976931348623157e308) {
+            atomicMax(&stats[0], (unsigned long long)__double_as_longlong(sqrt(n2)));
+            atomicMax(&stats[1], (unsigned long long)__double_as_longlong(sqrt(n16)));
+            atomicMax(&stats[2], (unsigned long long)__double_as_longlong(sqrt(r2)));
+        }
+    }
+}
+
+}  // namespace
+
+int mi355dr_add_multivec_device(mi355dr_index* idx, const float* vecs_dev, const int64_t* offsets, int64_t n_docs) {
+    if (!idx) return fail(nullptr, MI355DR_E_INVALID, "null index");
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (n_docs < 0 || !offsets || (n_docs > 0 && offsets[n_docs] > 0 && !vecs_dev))
+        return fail(idx, MI355DR_E_INVALID, "bad multi-vector arguments");
+    if (n_docs == 0) return MI355DR_OK;
+    for (int64_t i = 0; i < n_docs; ++i)
+        if (offsets[i + 1] < offsets[i]) return fail(idx, MI355DR_E_INVALID, "offsets must be non-decreasing");
+    HIPCHECK(idx, hipSetDevice(idx->device));
+    if (!idx->mv) {
+        idx->mv = new MultiVecStore();
+        idx->mv->dpad = (int)round_up(idx->dim, 8);
+        idx->mv->nkk = (int)round_up(idx->dim, 16) / 16;
+        idx->mv->blk_off_host.push_back(0);
+    }
+    MultiVecStore* m = idx->mv;
+    if (m->n_docs + n_docs >= ((int64_t)1 << 31)) return fail(idx, MI355DR_E_UNSUPPORTED, "too many docs");
+    std::vector<int64_t> tok0(n_docs), T(n_docs), blk0(n_docs);
+    std::vector<int32_t> blk_doc;
+    int64_t new_blocks = 0;
+    for (int64_t i = 0; i < n_docs; ++i) {
+        tok0[i] = offsets[i];
+        T[i] = offsets[i + 1] - offsets[i];
+        blk0[i] = new_blocks;
+        const int64_t nb = (T[i] + kMsBlkRows - 1) / kMsBlkRows;
+        for (int64_t b = 0; b < nb; ++b) blk_doc.push_back((int32_t)i);
+        new_blocks += nb;
+        m->blk_off_host.push_back(m->n_blocks + new_blocks);
+    }
+    CHECK(ms_reserve(idx, m, m->n_blocks + new_blocks, m->n_docs + n_docs));
+    if (new_blocks > 0) {
+        int64_t *tok0_d = nullptr, *T_d = nullptr, *blk0_d = nullptr;
+        int32_t* blk_doc_d = nullptr;
+        unsigned long long* stats_d = nullptr;
+        int* nf_d = nullptr;
+        HIPCHECK(idx, hipMalloc(&tok0_d, n_docs * sizeof(int64_t)));
+        HIPCHECK(idx, hipMalloc(&T_d, n_docs * sizeof(int64_t)));
+        HIPCHECK(idx, hipMalloc(&blk0_d, n_docs * sizeof(int64_t)));
+        HIPCHECK(idx, hipMalloc(&blk_doc_d, blk_doc.size() * sizeof(int32_t)));
+        HIPCHECK(idx, hipMalloc(&stats_d, 3 * sizeof(unsigned long long)));
+        HIPCHECK(idx, hipMalloc(&nf_d, sizeof(int)));
+        hipStream_t s = idx->stream;
+        HIPCHECK(idx, hipMemcpyAsync(tok0_d, tok0.data(), n_docs * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        HIPCHECK(idx, hipMemcpyAsync(T_d, T.data(), n_docs * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        HIPCHECK(idx, hipMemcpyAsync(blk0_d, blk0.data(), n_docs * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        HIPCHECK(idx, hipMemcpyAsync(blk_doc_d, blk_doc.data(), blk_doc.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        HIPCHECK(idx, hipMemsetAsync(stats_d, 0, 3 * sizeof(unsigned long long), s));
+        HIPCHECK(idx, hipMemsetAsync(nf_d, 0, sizeof(int), s));
+        hipLaunchKernelGGL(k_ms_build, dim3((unsigned)new_blocks), dim3(64), 0, s, vecs_dev, tok0_d, T_d, blk_doc_d, blk0_d, idx->dim,
+                           m->dpad, m->nkk, m->n_blocks, m->tok, (uint16_t*)m->tok16, stats_d, nf_d);
+        HIPCHECK(idx, hipGetLastError());
+        unsigned long long st[3] = {0, 0, 0};
+        int nf = 0;
+        HIPCHECK(idx, hipMemcpyAsync(st, stats_d, sizeof(st), hipMemcpyDeviceToHost, s));
+        HIPCHECK(idx, hipMemcpyAsync(&nf, nf_d, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHECK(idx, hipStreamSynchronize(s));
+        double v[3];
+        memcpy(v, st, sizeof(v));
+        m->tok_norm_max = std::max(m->tok_norm_max, v[0]);
+        m->tok16_norm_max = std::max(m->tok16_norm_max, v[1]);
+        m->tok_res_max = std::max(m->tok_res_max, v[2]);
+        if (nf) m->finite = false;
+        for (void* p : {(void*)tok0_d, (void*)T_d, (void*)blk0_d, (void*)blk_doc_d, (void*)stats_d, (void*)nf_d}) (void)hipFree(p);
+    }
+    HIPCHECK(idx, hipMemcpy(m->blk_off, m->blk_off_host.data(), m->blk_off_host.size() * sizeof(int64_t),
+                            hipMemcpyHostToDevice));
+    m->n_blocks += new_blocks;
+    m->n_docs += n_docs;
+    return MI355DR_OK;
+}
+
 int64_t mi355dr_size_multivec(const mi355dr_index* idx) { return idx && idx->mv ? idx->mv->n_docs : 0; }
 
 namespace {
@@ -1103,8 +1237,8 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
     return MI355DR_OK;
 }
 
-int mi355dr_maxsim_subset(mi355dr_index* idx, const float* qtok, const int32_t* q_offsets, int B, const int64_t* doc_ids,
-                          int m_ids, float* out_dist) {
+static int maxsim_subset_impl(mi355dr_index* idx, const float* qtok, const int32_t* q_offsets, int B, const int64_t* doc_ids,
+                              int m_ids, int clamp0, float* out_dist) {
     if (!idx) return fail(nullptr, MI355DR_E_INVALID, "null index");
     std::lock_guard<std::mutex> g(idx->mu);
     if (B < 0 || m_ids < 0 || !q_offsets || (B > 0 && m_ids > 0 && (!doc_ids || !out_dist)))
@@ -1164,6 +1298,7 @@ int mi355dr_maxsim_subset(mi355dr_index* idx, const float* qtok, const int32_t* 
         a.nq_launch = 1;
         a.q_col0[0] = 0;
         a.q_len[0] = nq;
+        a.clamp0 = clamp0;
         hipLaunchKernelGGL(k_maxsim, dim3((unsigned)std::min<int64_t>((m_ids + 3) / 4, kMsListGrid)), dim3(kMsThreads), lds,
                            s, a);
         HIPCHECK(idx, hipGetLastError());
@@ -1175,6 +1310,17 @@ int mi355dr_maxsim_subset(mi355dr_index* idx, const float* qtok, const int32_t* 
     (void)hipFree(dist_dev);
     (void)hipFree(q_dev);
     return MI355DR_OK;
+}
+
+int mi355dr_maxsim_subset(mi355dr_index* idx, const float* qtok, const int32_t* q_offsets, int B, const int64_t* doc_ids,
+                          int m_ids, float* out_dist) {
+    return maxsim_subset_impl(idx, qtok, q_offsets, B, doc_ids, m_ids, 0, out_dist);
+}
+
+int mi355dr_maxsim_subset_ex(mi355dr_index* idx, const float* qtok, const int32_t* q_offsets, int B, const int64_t* doc_ids,
+                             int m_ids, int flags, float* out_dist) {
+    if (flags & ~MI355DR_MAXSIM_CLAMP0) return fail(idx, MI355DR_E_INVALID, "unknown maxsim flag");
+    return maxsim_subset_impl(idx, qtok, q_offsets, B, doc_ids, m_ids, (flags & MI355DR_MAXSIM_CLAMP0) ? 1 : 0, out_dist);
 }
 
 }  // extern "C"

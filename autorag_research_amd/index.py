@@ -153,6 +153,16 @@ class Mi355Index:
         check(self._h, self._lib.mi355dr_add_multivec(self._h, ptr(vecs, ctypes.c_float),
                                                       ptr(offsets, ctypes.c_int64), offsets.shape[0] - 1))
 
+    def add_multivec_device(self, vecs_ptr: int, offsets) -> None:
+        """Docs whose token / patch vectors already sit in device memory ([sum_T, dim] fp32 at `vecs_ptr`, e.g. an
+        encoder's output tensor): the padded store, its bf16 fragment copy and the screen's bound quantities are built
+        by a kernel, nothing is copied to the host.  `offsets` is a host array [n_docs + 1]."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        if offsets.ndim != 1 or offsets.shape[0] < 1 or offsets[0] != 0:
+            raise ValueError("offsets must start at 0")
+        check(self._h, self._lib.mi355dr_add_multivec_device(self._h, ctypes.c_void_p(int(vecs_ptr)),
+                                                             ptr(offsets, ctypes.c_int64), offsets.shape[0] - 1))
+
     def n_docs(self) -> int:
         return int(self._lib.mi355dr_size_multivec(self._h))
 
@@ -168,8 +178,9 @@ class Mi355Index:
                                                        ptr(dist, ctypes.c_float), ptr(rows, ctypes.c_int64)))
         return dist, rows
 
-    def maxsim_subset(self, qtok, q_offsets, doc_ids) -> np.ndarray:
-        """Exact MaxSim distance of each query to its own list of docs: doc_ids [B, m] -> distances [B, m] (NaN = skipped)."""
+    def maxsim_subset(self, qtok, q_offsets, doc_ids, clamp0: bool = False) -> np.ndarray:
+        """Exact MaxSim distance of each query to its own list of docs: doc_ids [B, m] -> distances [B, m] (NaN = skipped).
+        `clamp0`: every query vector contributes max(0, max_j <q_i, d_j>) (the ColBERT reranker's MaxSim)."""
         qtok = f32c(qtok).reshape(-1, self.dim)
         q_offsets = np.ascontiguousarray(q_offsets, dtype=np.int32)
         ids = np.ascontiguousarray(doc_ids, dtype=np.int64)
@@ -177,9 +188,9 @@ class Mi355Index:
         if ids.ndim != 2 or ids.shape[0] != B:
             raise ValueError("doc_ids must be [B, m]")
         out = np.empty(ids.shape, dtype=np.float32)
-        check(self._h, self._lib.mi355dr_maxsim_subset(self._h, ptr(qtok, ctypes.c_float), ptr(q_offsets, ctypes.c_int32),
-                                                       B, ptr(ids, ctypes.c_int64), ids.shape[1],
-                                                       ptr(out, ctypes.c_float)))
+        check(self._h, self._lib.mi355dr_maxsim_subset_ex(self._h, ptr(qtok, ctypes.c_float), ptr(q_offsets, ctypes.c_int32),
+                                                          B, ptr(ids, ctypes.c_int64), ids.shape[1], 1 if clamp0 else 0,
+                                                          ptr(out, ctypes.c_float)))
         return out
 
     # ---- Guided Query Refinement of candidate pools (reference gqr_hybrid.py:306-362) ----

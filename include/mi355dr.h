@@ -101,6 +101,9 @@ int mi355dr_search_device(mi355dr_index* idx, const float* queries_dev, int B, i
 /* ---- corpus + search (multi-vector, MaxSim) ----
  * vecs: host [sum_T, dim] fp32, offsets: [n_docs+1] (doc i owns rows offsets[i]..offsets[i+1]). */
 int mi355dr_add_multivec(mi355dr_index* idx, const float* vecs, const int64_t* offsets, int64_t n_docs);
+/* the same from DEVICE memory (an encoder's output never leaves HBM: embeddings/colpali.py:168-245 `embed_image(s)` /
+ * `embed_documents` -> [T,128] patch / token tensors): vecs_dev = device [sum_T, dim], offsets = HOST [n_docs+1] */
+int mi355dr_add_multivec_device(mi355dr_index* idx, const float* vecs_dev, const int64_t* offsets, int64_t n_docs);
 int64_t mi355dr_size_multivec(const mi355dr_index* idx);
 /* qtok: host [sum_nq, dim], q_offsets: [B+1].  out_dist: [B,k] fp32 (= -sum_i max_j <q_i,d_j>). */
 int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* q_offsets, int B, int k,
@@ -112,6 +115,12 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
  * out_dist: host [B, m] fp32, NaN for skipped ids, docs without vectors and queries without vectors. */
 int mi355dr_maxsim_subset(mi355dr_index* idx, const float* qtok, const int32_t* q_offsets, int B, const int64_t* doc_ids,
                           int m, float* out_dist);
+/* The same with flags.  MI355DR_MAXSIM_CLAMP0: every query vector contributes max(0, max_j <q_i, d_j>) -- the ColBERT
+ * reranker's MaxSim (autorag_research/rerankers/colbert.py:63-84: padding masked, `clamp(min=0)`, mean over the VALID query
+ * tokens): pass only the valid tokens of query and documents; score = -distance / n_valid_query_tokens. */
+#define MI355DR_MAXSIM_CLAMP0 1
+int mi355dr_maxsim_subset_ex(mi355dr_index* idx, const float* qtok, const int32_t* q_offsets, int B, const int64_t* doc_ids,
+                             int m, int flags, float* out_dist);
 
 /* ---- Guided Query Refinement of candidate pools (GQR hybrid pipeline) ----
  * Replaces the per-query numpy loops of autorag_research/pipelines/retrieval/gqr_hybrid.py: `_optimize_query_embedding`

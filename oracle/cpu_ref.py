@@ -195,3 +195,21 @@ def np_maxsim_scores(doc_list, q) -> np.ndarray:
     q64 = np.asarray(q, dtype=np.float64)
     return np.array([np.max(q64 @ np.asarray(dm, dtype=np.float64).T, axis=1).sum() / max(q64.shape[0], 1)
                      for dm in doc_list])
+
+
+def colbert_rerank_scores(query_emb, query_mask, doc_embs, doc_masks) -> np.ndarray:
+    """Restatement of the reference ColBERT reranker's `_maxsim_score` (autorag_research/rerankers/colbert.py:63-84) for one
+    query against n documents on padded inputs: fp32 `Q @ D^T`, document padding -> -inf, row max, clamp(min=0), query padding
+    multiplied out, sum / number of valid query tokens.  Pinned by tests/golden/rerank_golden.npz (outputs of the reference's
+    own method); the fp32 summation order of torch.matmul is not part of its contract, so parity is to 1e-6."""
+    q = np.asarray(query_emb, dtype=np.float32).reshape(-1, np.asarray(query_emb).shape[-1])
+    qm = np.asarray(query_mask).reshape(-1).astype(np.float32)
+    out = np.zeros((len(doc_embs),), dtype=np.float64)
+    for i, (d, m) in enumerate(zip(doc_embs, doc_masks)):
+        sim = q @ np.asarray(d, dtype=np.float32).T
+        sim = np.where(np.asarray(m).reshape(1, -1) == 0, -np.inf, sim).astype(np.float32)
+        mx = sim.max(axis=-1) if sim.shape[1] else np.full((q.shape[0],), -np.inf, np.float32)
+        mx = np.maximum(mx, np.float32(0.0)) * qm
+        with np.errstate(invalid="ignore", divide="ignore"):
+            out[i] = float(np.float32(mx.sum(dtype=np.float32)) / np.float32(qm.sum(dtype=np.float32)))
+    return out

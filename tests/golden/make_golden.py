@@ -30,6 +30,7 @@ Fixtures written next to this file:
                            deterministic stand-in LLM / embedding objects (hyde_fake_models, shared with the test).
   executor_golden.json     the reference's plugin_registry scan of this package and its Executor's health-check -> run -> verify
                            flow (executor.py:308-463) over Mi355VectorSearchPipelineConfig: PipelineResult + persisted rows.
+  rerank_golden.npz        ColBERTReranker._maxsim_score (rerankers/colbert.py:63-84) on seeded padded token tensors.
   gqr_golden.npz / .json   Guided Query Refinement: outputs of GQRHybridRetrievalPipeline._optimize_query_embedding /
                            _optimize_query_multi_embedding / _optimize_in_score_space (pipelines/retrieval/
                            gqr_hybrid.py:306-362) on seeded pools, and of _retrieve_by_id (:472-489) over the fake
@@ -711,6 +712,39 @@ def make_executor() -> dict:
     return out
 
 
+# --------------------------------------------------------------------------------------
+# 9. ColBERT reranker MaxSim (rerankers/colbert.py:63-84)
+# --------------------------------------------------------------------------------------
+
+
+def make_rerank() -> dict:
+    """`ColBERTReranker._maxsim_score` (the method, unbound -- no checkpoint needed) on seeded L2-normalised token tensors:
+    ragged documents behind padding masks, padded query tokens, a document with no valid token, negative maxima (clamp)."""
+    import torch
+
+    from autorag_research.rerankers.colbert import ColBERTReranker
+
+    g = torch.Generator().manual_seed(20260928)
+    out = {}
+    for case, (d, lq, n_valid_q, doc_lens, ld) in enumerate([(16, 9, 7, [5, 12, 1, 0, 9, 12], 12), (128, 32, 32, [40, 3, 64, 17], 64),
+                                                             (24, 4, 2, [6, 6], 6)]):
+        q = torch.nn.functional.normalize(torch.randn((1, lq, d), generator=g), dim=-1)
+        qm = torch.zeros((1, lq), dtype=torch.long)
+        qm[0, :n_valid_q] = 1
+        docs = torch.nn.functional.normalize(torch.randn((len(doc_lens), ld, d), generator=g), dim=-1)
+        if case == 0:
+            docs[4] = -q[0, :1].expand(ld, d) * 0.5 + 0.01 * docs[4]   # every similarity negative -> clamp(min=0) matters
+            docs[4] = torch.nn.functional.normalize(docs[4], dim=-1)
+        dm = torch.zeros((len(doc_lens), ld), dtype=torch.long)
+        for i, n in enumerate(doc_lens):
+            dm[i, :n] = 1
+        sc = [ColBERTReranker._maxsim_score(None, q, qm, docs[i:i + 1], dm[i:i + 1]) for i in range(len(doc_lens))]
+        out[f"q{case}"], out[f"qm{case}"] = q.numpy(), qm.numpy()
+        out[f"d{case}"], out[f"dm{case}"] = docs.numpy(), dm.numpy()
+        out[f"score{case}"] = np.asarray(sc, dtype=np.float64)
+    return out
+
+
 def main() -> None:
     (HERE / "metrics_golden.json").write_text(json.dumps(make_metrics(), indent=1))
     np.savez_compressed(HERE / "scores_golden.npz", **make_scores())
@@ -720,6 +754,7 @@ def main() -> None:
     (HERE / "hybrid_golden.json").write_text(json.dumps(make_hybrid(_LAST["svc"], _LAST["ids"]), indent=1))
     (HERE / "hyde_golden.json").write_text(json.dumps(make_hyde(_LAST["svc"]), indent=1))
     (HERE / "executor_golden.json").write_text(json.dumps(make_executor(), indent=1))
+    np.savez_compressed(HERE / "rerank_golden.npz", **make_rerank())
     print("wrote", sorted(p.name for p in HERE.iterdir()))
 
 

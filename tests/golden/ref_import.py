@@ -33,6 +33,10 @@ def import_reference() -> None:
     if getattr(import_reference, "_done", False):
         return
     sys.dont_write_bytecode = True
+    try:  # before the stand-ins exist: torch's import walks sys.modules with `inspect`, which trips over their __getattr__
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
     for n in STUBBED:

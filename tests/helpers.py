@@ -48,7 +48,16 @@ class OracleIndex:
         d, r = self._o.maxsim_topk(self._tok, self._off, qtok, q_offsets, k)
         return d, np.where(r >= 0, r + self.row_offset, r)
 
-    def maxsim_subset(self, qtok, q_offsets, doc_ids):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    def close(self):
+        pass
+
+    def maxsim_subset(self, qtok, q_offsets, doc_ids, clamp0=False):
         q = np.ascontiguousarray(qtok, dtype=np.float32).reshape(-1, self.dim)
         ids = np.asarray(doc_ids, dtype=np.int64)
         out = np.full(ids.shape, np.nan, dtype=np.float32)
@@ -57,7 +66,11 @@ class OracleIndex:
             qb = q[q_offsets[b]:q_offsets[b + 1]]
             for j, i in enumerate(ids[b]):
                 if 0 <= i < n_docs and self._off[i + 1] > self._off[i] and qb.shape[0]:
-                    out[b, j] = self._o.maxsim_distance(self._tok[self._off[i]:self._off[i + 1]], qb)
+                    doc = self._tok[self._off[i]:self._off[i + 1]]
+                    if clamp0:  # ColBERT reranker form: every query token contributes max(0, max_j <q_i, d_j>)
+                        out[b, j] = -np.maximum((qb @ doc.T).max(axis=1), np.float32(0)).sum(dtype=np.float32)
+                    else:
+                        out[b, j] = self._o.maxsim_distance(doc, qb)
         return out
 
     # ---- GQR refinement: same surface as Mi355Index.gqr_refine*, answered by oracle/gqr_ref.py ----
