@@ -39,11 +39,18 @@ int ensure_capacity(mi355dr_index* idx, int64_t want_rows) {
     float* nrm2 = nullptr;
     int8_t* shadow8 = nullptr;
     uint8_t* flag8 = nullptr;
-    HIPCHECK(idx, hipMalloc(&rows, (size_t)new_cap * idx->dim * sizeof(float)));
-    HIPCHECK(idx, hipMalloc(&shadow, (size_t)new_cap * idx->dpad * sizeof(uint16_t)));
-    HIPCHECK(idx, hipMalloc(&nrm2, (size_t)new_cap * sizeof(float)));
-    HIPCHECK(idx, hipMalloc(&shadow8, (size_t)new_cap * idx->dpad8));
-    HIPCHECK(idx, hipMalloc(&flag8, (size_t)new_cap));
+    {   // all five or none: a failed allocation must not leak the ones before it
+        hipError_t e = hipMalloc(&rows, (size_t)new_cap * idx->dim * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(&shadow, (size_t)new_cap * idx->dpad * sizeof(uint16_t));
+        if (e == hipSuccess) e = hipMalloc(&nrm2, (size_t)new_cap * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(&shadow8, (size_t)new_cap * idx->dpad8);
+        if (e == hipSuccess) e = hipMalloc(&flag8, (size_t)new_cap);
+        if (e != hipSuccess) {
+            for (void* p : {(void*)rows, (void*)shadow, (void*)nrm2, (void*)shadow8, (void*)flag8})
+                if (p) (void)hipFree(p);
+            HIPCHECK(idx, e);
+        }
+    }
     HIPCHECK(idx, hipMemsetAsync(shadow, 0, (size_t)new_cap * idx->dpad * sizeof(uint16_t), idx->stream));
     HIPCHECK(idx, hipMemsetAsync(shadow8, 0, (size_t)new_cap * idx->dpad8, idx->stream));
     HIPCHECK(idx, hipMemsetAsync(flag8, 0, (size_t)new_cap, idx->stream));
@@ -617,15 +624,20 @@ static int add_rows_impl(mi355dr_index* idx, const float* rows, int64_t n, hipMe
     CHECK(ensure_capacity(idx, idx->n + n));
     hipStream_t s = idx->stream;
     HIPCHECK(idx, hipMemcpyAsync(idx->rows + idx->n * idx->dim, rows, (size_t)n * idx->dim * sizeof(float), kind, s));
-    hipLaunchKernelGGL(k_row_nrm2, dim3((unsigned)((n + kWave - 1) / kWave)), dim3(kWave), 0, s, idx->rows, idx->n, n,
-                       idx->dim, idx->nrm2, idx->n2max_dev);
-    HIPCHECK(idx, hipGetLastError());
-    hipLaunchKernelGGL(k_build_shadow, dim3((unsigned)n), dim3(256), 0, s, idx->rows, idx->nrm2, idx->n, n, idx->dim,
-                       idx->dpad, idx->shadow, idx->irr_rows, idx->irr_count, idx->bf16_res2_dev);
-    HIPCHECK(idx, hipGetLastError());
-    hipLaunchKernelGGL(k_build_shadow8, dim3((unsigned)n), dim3(256), 0, s, idx->rows, idx->nrm2, idx->n, n, idx->dim,
-                       idx->dpad8, i8_corpus_step(idx->dim), idx->shadow8, idx->flag8, idx->irr8_rows, idx->irr8_count);
-    HIPCHECK(idx, hipGetLastError());
+    // the per-row build kernels run one workgroup per row: a grid is kept below 2^22 rows (gridDim.x * blockDim.x < 2^32)
+    constexpr int64_t kBuildSlice = (int64_t)1 << 22;
+    for (int64_t r0 = 0; r0 < n; r0 += kBuildSlice) {
+        const int64_t m = std::min(kBuildSlice, n - r0), first = idx->n + r0;
+        hipLaunchKernelGGL(k_row_nrm2, dim3((unsigned)((m + kWave - 1) / kWave)), dim3(kWave), 0, s, idx->rows, first, m,
+                           idx->dim, idx->nrm2, idx->n2max_dev);
+        HIPCHECK(idx, hipGetLastError());
+        hipLaunchKernelGGL(k_build_shadow, dim3((unsigned)m), dim3(256), 0, s, idx->rows, idx->nrm2, first, m, idx->dim,
+                           idx->dpad, idx->shadow, idx->irr_rows, idx->irr_count, idx->bf16_res2_dev);
+        HIPCHECK(idx, hipGetLastError());
+        hipLaunchKernelGGL(k_build_shadow8, dim3((unsigned)m), dim3(256), 0, s, idx->rows, idx->nrm2, first, m, idx->dim,
+                           idx->dpad8, i8_corpus_step(idx->dim), idx->shadow8, idx->flag8, idx->irr8_rows, idx->irr8_count);
+        HIPCHECK(idx, hipGetLastError());
+    }
     int irr = 0, irr8 = 0;
     HIPCHECK(idx, hipMemcpyAsync(&irr, idx->irr_count, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHECK(idx, hipMemcpyAsync(&irr8, idx->irr8_count, sizeof(int), hipMemcpyDeviceToHost, s));

@@ -30,6 +30,8 @@ Fixtures written next to this file:
                            deterministic stand-in LLM / embedding objects (hyde_fake_models, shared with the test).
   executor_golden.json     the reference's plugin_registry scan of this package and its Executor's health-check -> run -> verify
                            flow (executor.py:308-463) over Mi355VectorSearchPipelineConfig: PipelineResult + persisted rows.
+  pgtext_golden.json       VectorArray.process_bind_param / process_result_value (orm/types.py:210-277), _vec_to_pg_literal /
+                           _vecs_to_pg_array (orm/repository/base.py:54-76): the text forms of VECTOR(d) / VECTOR(d)[].
   rerank_golden.npz        ColBERTReranker._maxsim_score (rerankers/colbert.py:63-84) on seeded padded token tensors.
   gqr_golden.npz / .json   Guided Query Refinement: outputs of GQRHybridRetrievalPipeline._optimize_query_embedding /
                            _optimize_query_multi_embedding / _optimize_in_score_space (pipelines/retrieval/
@@ -745,6 +747,32 @@ def make_rerank() -> dict:
     return out
 
 
+# --------------------------------------------------------------------------------------
+# 10. PostgreSQL text formats of the vector columns (orm/types.py, orm/repository/base.py)
+# --------------------------------------------------------------------------------------
+
+
+def make_pgtext() -> dict:
+    from autorag_research.orm.repository.base import _vec_to_pg_literal, _vecs_to_pg_array
+    from autorag_research.orm.types import VectorArray
+
+    rng = np.random.default_rng(1618)
+    va = VectorArray(4)
+    cases = []
+    mats = [rng.standard_normal((3, 4)).astype(np.float32), (rng.standard_normal((1, 4)) * 1e-6).astype(np.float32),
+            np.array([[1.0, -2.5, 0.0, 1e20], [3.0, 4.0, -0.0, 5e-324]], dtype=np.float64), np.zeros((0, 4), np.float32)]
+    for m in mats:
+        as_list = [[float(x) for x in row] for row in m]
+        bind = va.process_bind_param(as_list, None)
+        cases.append({"values": as_list, "bind": bind, "parsed": va.process_result_value(bind, None),
+                      "sql_array": _vecs_to_pg_array(as_list) if as_list else None,
+                      "literals": [_vec_to_pg_literal(r) for r in as_list]})
+    hand = ['{"[1,2,3,4]","[5, 6 ,7,8]"}', '{"[0.5,-1e-05,3.25E+2,7]"}', "{}"]
+    return {"cases": cases, "null_bind": va.process_bind_param(None, None), "null_result": va.process_result_value(None, None),
+            "hand_strings": [{"text": h, "parsed": va.process_result_value(h, None)} for h in hand],
+            "preparsed": va.process_result_value([[1, 2], np.array([3.5, 4.5])], None)}
+
+
 def main() -> None:
     (HERE / "metrics_golden.json").write_text(json.dumps(make_metrics(), indent=1))
     np.savez_compressed(HERE / "scores_golden.npz", **make_scores())
@@ -755,6 +783,7 @@ def main() -> None:
     (HERE / "hyde_golden.json").write_text(json.dumps(make_hyde(_LAST["svc"]), indent=1))
     (HERE / "executor_golden.json").write_text(json.dumps(make_executor(), indent=1))
     np.savez_compressed(HERE / "rerank_golden.npz", **make_rerank())
+    (HERE / "pgtext_golden.json").write_text(json.dumps(make_pgtext(), indent=1))
     print("wrote", sorted(p.name for p in HERE.iterdir()))
 
 
