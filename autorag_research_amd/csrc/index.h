@@ -59,6 +59,8 @@ struct mi355dr_index {
     double* out_dist_dev = nullptr;  // [kQBlockMax, kKMax]
     int64_t* out_rows_dev = nullptr;
     unsigned long long* stat_dev = nullptr;  // [2*kQBlockMax]: per query (candidates, re-scored)
+    int* prune_skip = nullptr;   // [2 + 2*kQBlockMax] hand-over lists of k_prune (PruneArgs::skip_list)
+    int prune_parity = 0;
 
     // options
     int path = 0;  // MI355DR_PATH_AUTO

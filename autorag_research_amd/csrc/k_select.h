@@ -29,6 +29,12 @@ struct PruneArgs {
     const uint16_t* shadow16;  // optional [n, dpad] bf16 shadow: second screen of round-B candidates (int8 screen, cosine)
     int dpad;
     int round_a;           // rows re-scored before the cut is known (0: max(32, 2k)); always at least k, at most 64
+    // hand-over from the one-wave instantiation to the general one: [0], [1] = number of queries the one-wave form left
+    // (two counters, used alternately by successive prunes), [2 + p * kQBlockMax ...] = their indices.  With it the general
+    // form runs on a small grid that walks the list (usually empty: ~3 us instead of a 1024-workgroup launch); nullptr or a
+    // `qlist` (exact path) = one workgroup per query as before.
+    int* skip_list;
+    int skip_parity;
 };                         // (the screen bound is per query: st.E[q])
 
 // Two instantiations share the code: a small one (1 wave, <= 1024 entries, ~36 KiB LDS, 4 workgroups
@@ -49,8 +55,36 @@ __host__ __device__ inline size_t prune_lds_bytes(int d, int threads, int sortma
 }
 
 template <int THREADS, int SORT>
+__device__ void prune_body(const PruneArgs& a, char* smem);
+
+template <int THREADS, int SORT>
 __global__ __launch_bounds__(THREADS) void k_prune(PruneArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // (LDS carve: prune_body; two scalars sit behind the query -- no static LDS keeps the carve 16-B aligned)
+    const bool list_mode = a.skip_list != nullptr && a.qlist == nullptr;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    int q = a.qlist ? a.qlist[blockIdx.x] : blockIdx.x;
+    if (SORT == kPruneBigSort && list_mode) {
+        // general form on a small grid: each workgroup takes the entries blockIdx.x, +gridDim.x, ... of the hand-over list.
+        // Workgroup 0 re-arms the OTHER counter for the next prune (nothing touches it during this launch).
+        if (blockIdx.x == 0 && tid == 0) a.skip_list[a.skip_parity ^ 1] = 0;
+        const int n_left = a.skip_list[a.skip_parity];
+        for (int i = blockIdx.x; i < n_left; i += gridDim.x) {
+            PruneArgs b = a;
+            b.skip_list = nullptr;
+            b.qlist = a.skip_list + 2 + a.skip_parity * kQBlockMax + i - 0;  // read as qlist[blockIdx.x]: shift below
+            b.qlist -= blockIdx.x;
+            prune_body<THREADS, SORT>(b, smem);
+            __syncthreads();
+        }
+        return;
+    }
+    prune_body<THREADS, SORT>(a, smem);
+}
+
+template <int THREADS, int SORT>
+__device__ void prune_body(const PruneArgs& a, char* smem) {
     constexpr int kWaves = THREADS / kWave;
     uint64_t* SK = (uint64_t*)smem;
     int32_t* SR = (int32_t*)(smem + (size_t)SORT * 8);
@@ -61,25 +95,36 @@ __global__ __launch_bounds__(THREADS) void k_prune(PruneArgs a) {
     float* tiles = (float*)X;
     int32_t* R = (int32_t*)(X + xbytes);
     float* qs = (float*)(X + xbytes + (size_t)SORT * 4);
-    // two scalars behind the query (no static LDS: keeps the carve 16-B aligned), then the expanded bf16 query
     int& s_cnt = *(int*)(X + xbytes + (size_t)SORT * 4 + (prune_qs_floats(a.d) - 16) * 4);
     float* q16 = qs + prune_qs_floats(a.d);
-
+    const bool list_mode = a.skip_list != nullptr && a.qlist == nullptr;
     const int q = a.qlist ? a.qlist[blockIdx.x] : blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int raw_cnt = a.st.cnt[q];
     const int n_best = a.st.best_n[q];
     if (raw_cnt == 0) return;  // nothing new; kept list and thresholds stay as they are
+    auto leave_for_general = [&]() {  // one-wave form: hand the query over
+        if (list_mode && tid == 0) {
+            const int i = atomicAdd(&a.skip_list[a.skip_parity], 1);
+            a.skip_list[2 + a.skip_parity * kQBlockMax + i] = q;
+        }
+    };
     if (raw_cnt > a.cap) {     // overflow: do not commit; the query is recomputed by the guaranteed path
-        if (SORT < kPruneBigSort) return;  // let the large instantiation record it
+        if (SORT < kPruneBigSort) {  // let the large instantiation record it
+            leave_for_general();
+            return;
+        }
         if (tid == 0) {
             a.st.status[q] |= kStOverflow;
             a.st.cnt[q] = 0;
         }
         return;
     }
-    if (n_best + raw_cnt > SORT) return;  // too many for this instantiation: left for the large one
+    if (n_best + raw_cnt > SORT) {  // too many for this instantiation: left for the large one
+        if (SORT < kPruneBigSort) leave_for_general();
+        return;
+    }
     const int n_new = raw_cnt;
     const int32_t* crow = a.cand_row + (int64_t)q * a.cap;
     const float* cval = a.cand_val + (int64_t)q * a.cap;

@@ -3,7 +3,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/traffic; mkdir -p $OUT
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline $@"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-extras $@"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $OUT -o fetch -- python bench.py $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $OUT -o write -- python bench.py $ARGS > $OUT/write.log 2>&1
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -f csv -d $OUT -o tcc -- python bench.py $ARGS > $OUT/tcc.log 2>&1

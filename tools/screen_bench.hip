@@ -92,7 +92,7 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)k_screen256<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
     CK(hipFuncSetAttribute((const void*)k_screen256b<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
     CK(hipFuncSetAttribute((const void*)k_screen256b<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
-#define SB_FORMS(X) X(1088) X(1024) X(1092) X(3136) X(3072) X(3140)
+#define SB_FORMS(X) X(3136) X(3072) X(3104) X(3140)
 #define SB_ATTR(A) CK(hipFuncSetAttribute((const void*)k_screen256b<A, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
     SB_FORMS(SB_ATTR)
     int* status;
@@ -165,7 +165,7 @@ int main(int argc, char** argv) {
         CK(hipGetLastError());
     };
 
-    std::vector<int> variants = {1256, 2324, 2388, 2392, 4372, 4436, 4440};
+    std::vector<int> variants = {1256, 4372, 4404, 4436, 4440};
     if (getenv("VARIANTS")) {
         variants.clear();
         for (char* tok = strtok(getenv("VARIANTS"), ","); tok; tok = strtok(nullptr, ",")) variants.push_back(atoi(tok));
