@@ -52,7 +52,10 @@ def parse_args():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--workload", choices=["single", "maxsim"], default="single",
                     help="single = headline cosine top-k (default); maxsim = multi-vector late interaction (SURVEY 8a row a2)")
-    ap.add_argument("--docs", type=int, default=50_000, help="maxsim: documents (tokens/doc ~ U{32..180}, d=128)")
+    ap.add_argument("--docs", type=int, default=100_000, help="maxsim: documents (d=128)")
+    ap.add_argument("--tokens", choices=["text", "page"], default="text",
+                    help="maxsim: 'text' = U{32..180} vectors per doc, 32-vector queries (ColBERT-like); 'page' = 1030 patch "
+                         "vectors per doc, 24-vector queries (ColPali-like)")
     ap.add_argument("--chunk0", type=int, default=0, help="override the first (emit-all) chunk size")
     ap.add_argument("--growth", type=int, default=0, help="override the chunk growth factor")
     ap.add_argument("--screen", choices=["auto", "bf16", "i8"], default="auto", help="screen element type")
@@ -145,74 +148,102 @@ def cpu_shape_baselines(Cs: np.ndarray, Qs: np.ndarray, k: int, metric: str, n_t
     return out
 
 
-def main_maxsim(args) -> None:
-    """Secondary workload: MaxSim top-k (VectorChord `@#`), ColBERT-like synthetic data, 1 GPU.
+def run_maxsim(args, n_docs: int, tokens: str, nq: int, steps: int, warmup: int, cpu_sample_docs: int = 0) -> dict:
+    """MaxSim top-k (VectorChord `@#`) on a synthetic multi-vector store built ON THE DEVICE (token vectors generated in
+    HBM, handed to the index by pointer: mi355dr_add_multivec_device).  `tokens` = "text" (ColBERT-like: U{32..180} vectors
+    per doc) or "page" (ColPali-like: 1030 patch vectors per doc); d = 128, unit-norm vectors, seed 777.
+    A step = one block of 4 queries x `nq` query vectors against every document: bf16 MFMA screen over the bf16 fragment
+    copy (HBM-bound), exact fp32 MFMA kernel on the candidates; wall clock includes H2D of the queries and D2H of [4,k]."""
+    import torch
 
-    step = one block of 4 queries x 32 query vectors against every document: bf16 MFMA screen over a bf16 copy of the
-    tokens (HBM-bound), exact fp32 (MFMA f32) kernel on the candidates; results bit-identical to the exact full scan.
-    """
     import autorag_research_amd as pkg
-    from oracle import cpu_ref
 
-    d, nq, qblock, k = 128, 32, 4, args.k
+    d, qblock, k = 128, 4, args.k
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     rng = np.random.default_rng(777)
-    lens = rng.integers(32, 181, size=args.docs)
-    tok = rng.standard_normal((int(lens.sum()), d), dtype=np.float32)
-    tok /= np.linalg.norm(tok, axis=1, keepdims=True)
-    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-    n_q = qblock * (args.steps + args.warmup)
+    lens = rng.integers(32, 181, size=n_docs) if tokens == "text" else np.full((n_docs,), 1030, dtype=np.int64)
+    idx = pkg.Mi355Index(d, "cosine", device=dev.index)
+    g = torch.Generator(device=dev)
+    g.manual_seed(777)
+    t_build = time.perf_counter()
+    docs_per_chunk = max(1, (1 << 22) // int(lens.max()))
+    keep = None
+    for d0 in range(0, n_docs, docs_per_chunk):
+        ln = lens[d0:d0 + docs_per_chunk]
+        x = torch.randn((int(ln.sum()), d), generator=g, device=dev, dtype=torch.float32)
+        x /= x.norm(dim=1, keepdim=True)
+        torch.cuda.synchronize()
+        idx.add_multivec_device(x.data_ptr(), np.concatenate([[0], np.cumsum(ln)]).astype(np.int64))
+        if keep is None and cpu_sample_docs:
+            S = min(cpu_sample_docs, len(ln))
+            keep = (x[: int(ln[:S].sum())].cpu().numpy(), np.concatenate([[0], np.cumsum(ln[:S])]).astype(np.int64))
+        del x
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
+    n_q = qblock * (steps + warmup)
     qtok = rng.standard_normal((n_q * nq, d), dtype=np.float32)
     qtok /= np.linalg.norm(qtok, axis=1, keepdims=True)
-    idx = pkg.Mi355Index(d, "cosine", device=0)
-    idx.add_multivec(tok, off)
     qoff = (np.arange(qblock + 1) * nq).astype(np.int32)
 
     def step(i):
         return idx.search_maxsim(qtok[i * qblock * nq:(i + 1) * qblock * nq], qoff, k)
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        res = step(args.warmup + i)
+    for i in range(steps):
+        res = step(warmup + i)
     el = time.perf_counter() - t0
+    assert (np.diff(res[0], axis=1) >= 0).all()
     blocks = int(((lens + 31) // 32).sum())
-    flops = 2.0 * (qblock * nq) * blocks * 32 * d * args.steps   # what the screen issues (32-row padded docs)
-    alg_bytes = float(lens.sum()) * d * 4 * args.steps           # fp32 token rows read once per 4-query pass (SURVEY 8d)
-    streamed = float(blocks) * 32 * ((d + 15) // 16 * 16) * 2 * args.steps  # bf16 fragment store the screen streams
+    alg_bytes = float(lens.sum()) * d * 4 * steps                # fp32 token rows read once per 4-query pass (SURVEY 8d)
+    streamed = float(blocks) * 32 * d * 2 * steps                # bf16 fragment store the screen streams
+    flops = 2.0 * (qblock * nq) * blocks * 32 * d * steps        # what the screen issues (32-row padded docs)
     screened, cands, fb = idx.stat("maxsim_screened"), idx.stat("maxsim_candidates"), idx.stat("maxsim_fallbacks")
     out = {
-        "metric": "queries/sec", "value": round(args.steps * qblock / el, 2), "unit": "queries/s", "n_gpus": 1,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el * 1e3 / args.steps, 3),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"MaxSim top-{k}: {args.docs} docs, {int(lens.sum())} doc vectors (U{{32..180}}/doc), d=128, "
-                               f"{qblock} queries x {nq} vectors per step", "includes": "H2D of the query block, D2H of results"},
-        "roofline": {"bound": "hbm", "kernel": "k_maxsim16", "achieved": round(alg_bytes / el / 1e9, 1),
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_bytes / el / 1e9 / HBM_PEAK_GBS, 4),
-                     "traffic": None,
-                     "note": "algorithmic fp32 token bytes over WALL-CLOCK per step (screen + select + exact re-score of "
-                             "the candidates + copies); the screen streams the bf16 copy",
-                     "streamed_GBps": round(streamed / el / 1e9, 1),
-                     "screen_tflops": round(flops / el / 1e12, 2)},
-        "extra": {"queries_screened": screened, "candidates_per_query": round(cands / max(screened, 1), 1),
-                  "exact_full_scan_fallbacks": fb},
+        "workload": f"MaxSim top-{k}: {n_docs} docs, {int(lens.sum())} doc vectors ({'U{32..180}' if tokens == 'text' else '1030'}"
+                    f"/doc), d=128, {qblock} queries x {nq} vectors per step; store built on the device in {t_build:.2f} s",
+        "queries_per_s": round(steps * qblock / el, 2), "ms_per_step": round(el * 1e3 / steps, 3), "steps": steps,
+        "includes": "H2D of the query block, D2H of results",
+        "roofline": {"bound": "hbm", "kernel": "k_maxsim16", "achieved": round(alg_bytes / el / 1e9, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(alg_bytes / el / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                     "note": "algorithmic fp32 token bytes over WALL-CLOCK per step (screen + select + exact re-score of the "
+                             "candidates + copies); the screen streams the bf16 copy",
+                     "streamed_GBps": round(streamed / el / 1e9, 1), "screen_tflops": round(flops / el / 1e12, 2)},
+        "queries_screened": screened, "candidates_per_query": round(cands / max(screened, 1), 1),
+        "exact_full_scan_fallbacks": fb,
     }
-    if not args.no_cpu_baseline:
-        S = min(args.docs, 20000)
+    if keep is not None:
+        from oracle import cpu_ref
+
+        tok_s, off_s = keep
+        S = off_s.shape[0] - 1
         tc = time.perf_counter()
-        rd, rr = cpu_ref.maxsim_topk(tok[: off[S]], off[: S + 1], qtok[: qblock * nq], qoff, k)
+        rd, rr = cpu_ref.maxsim_topk(tok_s, off_s, qtok[: qblock * nq], qoff, k)
         tc = time.perf_counter() - tc
-        with pkg.Mi355Index(d, "cosine", device=0) as s2:
-            s2.add_multivec(tok[: off[S]], off[: S + 1])
+        with pkg.Mi355Index(d, "cosine", device=dev.index) as s2:
+            s2.add_multivec(tok_s, off_s)
             gd, gr = s2.search_maxsim(qtok[: qblock * nq], qoff, k)
-        out["cpu_baseline"] = {"value": round(qblock / tc * S / args.docs, 4), "unit": "queries/s",
-                               "cores": cpu_ref.num_threads(), "kind": "port",
-                               "sample": f"oracle MaxSim on the first {S} docs x {qblock} queries, scaled linearly to "
-                                         f"{args.docs} docs; {tc:.1f} s of CPU work",
+        out["cpu_baseline"] = {"value": round(qblock / tc * S / n_docs, 4), "unit": "queries/s", "cores": cpu_ref.num_threads(),
+                               "kind": "port", "sample": f"oracle MaxSim on the first {S} docs x {qblock} queries, scaled "
+                                                         f"linearly to {n_docs} docs; {tc:.1f} s of CPU work",
                                "parity_on_sample": bool(np.array_equal(gr, rr) and np.array_equal(gd, rd))}
-    assert (np.diff(res[0], axis=1) >= 0).all()
-    print(json.dumps(out))
     idx.close()
+    return out
+
+
+def main_maxsim(args) -> None:
+    """Secondary workload as the whole bench line: `python bench.py --workload maxsim [--docs N] [--tokens text|page]`."""
+    r = run_maxsim(args, args.docs, args.tokens, 32 if args.tokens == "text" else 24, args.steps, args.warmup,
+                   0 if args.no_cpu_baseline else 2000)
+    out = {"metric": "queries/sec", "value": r["queries_per_s"], "unit": "queries/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": r["workload"], "includes": r["includes"]}, "roofline": r["roofline"],
+           "extra": {kk: r[kk] for kk in ("queries_screened", "candidates_per_query", "exact_full_scan_fallbacks")}}
+    if "cpu_baseline" in r:
+        out["cpu_baseline"] = r["cpu_baseline"]
+    print(json.dumps(out))
 
 
 def main() -> None:
@@ -540,6 +571,13 @@ def main() -> None:
         result["extra"]["pcie_inclusive"] = {"ms_per_step": round(t1 * 1e3, 3), "queries_per_s": round(B / t1, 1),
                                              "note": "mi355dr_search: pageable host queries in (H2D), float8 distances + "
                                                      "int64 rows out (D2H), one blocking call per step; NOT `value`"}
+
+    if rank == 0 and world == 1 and not args.no_extras and args.data == "gaussian":
+        # (3) the multi-vector half of the path (configs C4 / C5) at SURVEY 8(d) sizes, as secondary figures of the same run
+        result["maxsim"] = {
+            "colbert_like": run_maxsim(args, 100_000, "text", 32, 25, 3, 0 if args.no_cpu_baseline else 1500),
+            "colpali_like": run_maxsim(args, 20_000, "page", 24, 15, 3, 0),
+        }
 
     # ---- CPU baseline (rank 0, N=1 run only): the oracle on a bounded sample of the same workload
     if rank == 0 and world == 1 and not args.no_cpu_baseline and keep_sample is not None:
