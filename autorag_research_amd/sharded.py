@@ -1,4 +1,6 @@
-"""Row-sharded multi-GPU search: one process per GPU, local exact top-k, one all-gather, one merge.
+"""Multi-GPU search: one process per GPU, a (row shards x query groups) grid of ranks.
+
+Row sharding (ShardedSearcher): local exact top-k, one all-gather, one merge.
 
 The reference has no counterpart (its engine is a single PostgreSQL server, SURVEY.md section 2 rows
 32-34); this is the data-parallel form of `ORDER BY distance LIMIT k`: rank r owns a contiguous row range
@@ -7,6 +9,13 @@ int64 row) lists -- B*k*16 bytes per rank, e.g. 160 KiB at B=1024,k=10 -- and me
 the same total order (distance asc, NaN last, row asc), so the result is bit-identical to the
 single-GPU result.  `torch.distributed` is the transport: backend "nccl" is RCCL over xGMI on the GPU
 box (tensors stay on the device and the merge runs in libmi355dr), "gloo" on CPU tests (host merge).
+
+Query groups (GridLayout / GridSearcher): a rank holds as much of the corpus as its HBM takes -- 288 GB per MI355X is ~50 M
+fp32 rows of d = 768 with both screen copies -- so the corpus is cut into only as many row shards R as it NEEDS, and the
+world / R groups of R ranks each serve their own query blocks: independent units, no collective between groups (the
+row-shard exchange stays inside a group).  With R = 1 there is no data-path collective at all.  Why it matters: the
+per-pass costs that do not shrink with the shard (candidate appends, the exact re-score launches)
+make 8 shards of 1.25 M rows cost 1.9 ms per 1024-query pass where 1/8 of the 10 M-row pass would be 1.05 ms.
 """
 
 from __future__ import annotations
@@ -50,6 +59,66 @@ def merge_topk_host(dist_all: np.ndarray, rows_all: np.ndarray, k: int) -> tuple
         out_d[b, : order.size] = db[order]
         out_r[b, : order.size] = rb[order]
     return out_d, out_r
+
+
+def resident_bytes_per_row(dim: int) -> int:
+    """HBM bytes one stored row costs in libmi355dr: fp32 row + bf16 shadow (64-element pad) + int8 shadow (128-element
+    pad) + squared norm + int8 flag."""
+    return 4 * dim + 2 * ((dim + 63) // 64 * 64) + ((dim + 127) // 128 * 128) + 5
+
+
+def auto_row_shards(n_rows: int, dim: int, world: int, hbm_bytes: int, fraction: float = 0.6) -> int:
+    """Fewest row shards R (a divisor of `world`) whose shard fits in `fraction` of one GPU's HBM."""
+    need = n_rows * resident_bytes_per_row(dim)
+    for r in range(1, world + 1):
+        if world % r == 0 and need / r <= fraction * hbm_bytes:
+            return r
+    return world
+
+
+class GridLayout:
+    """rank -> (shard, group) for a world of `row_shards` x `query_groups` ranks; ranks of one group are consecutive
+    (rank = group * row_shards + shard), so a group's row-shard exchange stays between neighbouring GPUs."""
+
+    def __init__(self, world: int, rank: int, row_shards: int):
+        if row_shards < 1 or world % row_shards:
+            raise ValueError(f"row_shards={row_shards} does not divide the world size {world}")
+        self.world, self.rank, self.row_shards = world, rank, row_shards
+        self.query_groups = world // row_shards
+        self.shard, self.group = rank % row_shards, rank // row_shards
+
+    @classmethod
+    def parse(cls, spec: str, world: int, rank: int, n_rows: int = 0, dim: int = 0, hbm_bytes: int = 0) -> "GridLayout":
+        """'auto' (fewest row shards that fit), 'rows' (world x 1), 'queries' (1 x world) or 'RxQ'."""
+        if spec == "auto":
+            return cls(world, rank, auto_row_shards(n_rows, dim, world, hbm_bytes) if hbm_bytes else 1)
+        if spec == "rows":
+            return cls(world, rank, world)
+        if spec == "queries":
+            return cls(world, rank, 1)
+        r, q = (int(x) for x in spec.lower().split("x"))
+        if r * q != world:
+            raise ValueError(f"layout {spec} does not match the world size {world}")
+        return cls(world, rank, r)
+
+    def group_ranks(self, group: int | None = None) -> list[int]:
+        g = self.group if group is None else group
+        return list(range(g * self.row_shards, (g + 1) * self.row_shards))
+
+    def make_row_group(self, dist) -> Any:
+        """The process group of this rank's row shards (every rank creates every group: torch.distributed's rule).
+        None when the group is the whole world or a single rank."""
+        if self.row_shards == self.world:
+            return None
+        mine = None
+        for g in range(self.query_groups):
+            pg = dist.new_group(self.group_ranks(g)) if self.row_shards > 1 else None
+            if g == self.group:
+                mine = pg
+        return mine
+
+    def describe(self) -> str:
+        return f"{self.row_shards} row shard(s) x {self.query_groups} query group(s)"
 
 
 class ShardedSearcher:
@@ -196,6 +265,95 @@ class ShardedSearcher:
         g = gathered.cpu().numpy()
         out_d, out_r = merge_topk_host(np.ascontiguousarray(g[:, 0]).view(np.float64), np.ascontiguousarray(g[:, 1]), k)
         return out_d.astype(np.float32), out_r
+
+    def close(self) -> None:
+        self.index.close()
+
+
+class GridSearcher:
+    """One rank of a (row shards x query groups) grid.  Every rank passes the same queries and gets the same [B,k] result:
+    query blocks are dealt round-robin to the groups, each group answers its blocks with its row-sharded searcher (a plain
+    index when it has one shard), and one all-gather of the finished [B,k] lists (16 B per entry) hands every rank the whole
+    result -- the only traffic between groups, after the search."""
+
+    def __init__(self, dim: int, layout: GridLayout, metric: str = "cosine", device: int = 0,
+                 index_factory: Callable[..., Any] | None = None):
+        import torch.distributed as dist
+
+        self._dist, self.layout, self.device = dist, layout, device
+        self.backend = dist.get_backend() if dist.is_initialized() else None
+        if layout.row_shards > 1:
+            group = layout.make_row_group(dist)
+            self.rows = ShardedSearcher(dim, metric, device, index_factory, group=group)
+            if self.rows.world != layout.row_shards:
+                raise RuntimeError("row group size does not match the layout")
+        else:
+            layout.make_row_group(dist)  # (no groups to create; kept for symmetry)
+            self.rows = _SingleShard(dim, metric, device, index_factory)
+        self.index = self.rows.index
+
+    def local_rows(self, n_rows: int, granule: int = 1) -> tuple[int, int]:
+        """Global row range [lo, hi) this rank stores."""
+        return shard_bounds(n_rows, self.layout.row_shards, self.layout.shard, granule)
+
+    def add_local(self, rows, global_row0: int) -> None:
+        self.rows.add_local(rows, global_row0)
+
+    def search(self, queries, k: int, block: int = 1024) -> tuple[np.ndarray, np.ndarray]:
+        import torch
+
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        B, Q = q.shape[0], self.layout.query_groups
+        if Q == 1:
+            return self.rows.search(q, k, block)
+        n_blocks = (B + block - 1) // block
+        mine = [b for b in range(n_blocks) if b % Q == self.layout.group]
+        per_group = (n_blocks + Q - 1) // Q * block  # padded number of queries one group can own
+        d_l = np.full((per_group, k), np.nan)
+        r_l = np.full((per_group, k), -1, dtype=np.int64)
+        if mine:
+            sub = np.concatenate([q[b * block:(b + 1) * block] for b in mine], axis=0)
+            dd, rr = self.rows.search(sub, k, block)
+            d_l[: dd.shape[0]], r_l[: rr.shape[0]] = dd, rr
+        dev = torch.device("cuda", self.device) if self.backend == "nccl" else torch.device("cpu")
+        pk = torch.from_numpy(np.stack([d_l.view(np.int64), r_l])).to(dev)
+        ga = torch.empty((self.layout.world,) + tuple(pk.shape), dtype=torch.int64, device=dev)
+        self._dist.all_gather_into_tensor(ga.view(-1), pk.view(-1))
+        g = ga.cpu().numpy()
+        out_d = np.full((B, k), np.nan)
+        out_r = np.full((B, k), -1, dtype=np.int64)
+        for b in range(n_blocks):
+            src = (b % Q) * self.layout.row_shards  # any rank of the owning group holds the merged list: take its first
+            pos = (b // Q) * block
+            n = min(block, B - b * block)
+            out_d[b * block:b * block + n] = g[src, 0, pos:pos + n].view(np.float64)
+            out_r[b * block:b * block + n] = g[src, 1, pos:pos + n]
+        return out_d, out_r
+
+    def close(self) -> None:
+        self.rows.close()
+
+
+class _SingleShard:
+    """A group of one rank: the whole corpus in one index, no exchange."""
+
+    def __init__(self, dim, metric, device, index_factory):
+        if index_factory is None:
+            from .index import Mi355Index
+
+            index_factory = Mi355Index
+        self.index = index_factory(dim, metric, device)
+        self.world, self.rank = 1, 0
+
+    def add_local(self, rows, global_row0: int) -> None:
+        if int(global_row0) != 0 and len(self.index) == 0:
+            self.index.set_option("row_offset", int(global_row0))
+        self.index.add(rows)
+
+    def search(self, q, k: int, block: int = 1024):
+        return self.index.search(q, k)
 
     def close(self) -> None:
         self.index.close()

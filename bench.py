@@ -1,11 +1,17 @@
 #!/usr/bin/env python3
 """bench.py -- queries/sec of the Vector Search hot path on N MI355X (BASELINE.json metric).
 
-Workload (config.workload): synthetic fp32 corpus, d=768, N=10M rows TOTAL (row-sharded over the
-ranks: strong scaling), L2-normalised N(0,1) rows; a "step" = one pass of the hot path over one
-block of 1024 queries: exact cosine top-10 of every query against the whole corpus (screen + exact
-re-score + select on every shard, then all-gather of the per-shard top-k and the merge when N > 1).
-Queries and corpus are resident in HBM before the timed region; outputs stay on the device.
+Workload (config.workload): synthetic fp32 corpus, d=768, N=10M rows TOTAL, L2-normalised N(0,1) rows; a "step" =
+one pass of the hot path over one block of 1024 queries per query group: exact cosine top-10 of every query against
+the whole corpus (screen + exact re-score + select).  Queries and corpus are resident in HBM before the timed
+region; outputs stay on the device.
+
+N > 1 (--layout): the ranks form R row shards x Q query groups.  'auto' cuts the corpus into only as many row shards
+as it needs to fit (10 M rows x 5.4 KB = 54 GB of one GPU's 288 GB: R = 1), so every rank holds the corpus and each of
+the Q = N ranks serves ITS OWN query block per step -- independent units, no data-path collective, weak scaling in
+queries.  '--layout rows' is the row-sharded form (every rank the same block against 1/N of the rows, all-gather of
+the per-shard top-k + merge: strong scaling); 'RxQ' mixes the two (the exchange stays inside a group of R ranks).
+`value` = queries all ranks answered / max-over-ranks time in every layout.
 
 Launch: `python bench.py --gpus 1` or, for N > 1,
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`
@@ -63,6 +69,11 @@ def parse_args():
     ap.add_argument("--prefilter16", type=int, default=None, help="0/1: bf16 second screen inside the prune (default: library default)")
     ap.add_argument("--metric", choices=["cosine", "ip"], default="cosine", help="cosine (headline) or inner product")
     ap.add_argument("--screen-form", type=int, default=None, help="developer A/B: 0 = first form of k_screen256, 1 = second form")
+    ap.add_argument("--layout", default="auto",
+                    help="ranks as (row shards R) x (query groups Q): 'auto' = fewest row shards whose shard fits in 60 %% of "
+                         "one GPU's HBM (N=10M, d=768 -> 1 x world: every rank holds the corpus and serves its own query "
+                         "blocks, no data-path collective), 'rows' = world x 1 (every rank the same block, all-gather + "
+                         "merge), 'queries' = 1 x world, or 'RxQ'")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the all-gather + merge path even at world size 1 (exercises the multi-GPU code on one GPU)")
     ap.add_argument("--comm", choices=["torch", "lib"], default="torch",
@@ -265,19 +276,26 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    use_dist = world > 1 or args.force_dist
-    if use_dist:
+    from autorag_research_amd.sharded import GridLayout
+
+    n_total, d, B, k = args.rows, args.dim, args.block, args.k
+    layout = GridLayout.parse(args.layout, world, rank, n_total, d, torch.cuda.mem_get_info(device)[1])
+    R, QG = layout.row_shards, layout.query_groups
+    have_pg = world > 1 or args.force_dist          # a process group exists (timing barrier, max over ranks)
+    use_dist = R > 1 or args.force_dist             # the search itself has an exchange step (row shards)
+    row_group = None
+    if have_pg:
         import torch.distributed as dist  # noqa: PLC0415
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
+        row_group = layout.make_row_group(dist)      # None: the whole world (or a single rank)
 
-    n_total, d, B, k = args.rows, args.dim, args.block, args.k
     n_chunks = (n_total + CHUNK_ROWS - 1) // CHUNK_ROWS
-    # contiguous chunk range per rank
-    c_lo = n_chunks * rank // world
-    c_hi = n_chunks * (rank + 1) // world
+    # contiguous chunk range per row shard
+    c_lo = n_chunks * layout.shard // R
+    c_hi = n_chunks * (layout.shard + 1) // R
     row_lo = min(n_total, c_lo * CHUNK_ROWS)
     row_hi = min(n_total, c_hi * CHUNK_ROWS)
     n_local = row_hi - row_lo
@@ -324,6 +342,7 @@ def main() -> None:
     keep_parts = []
     keep_rows = 0
     want_sample = rank == 0 and world == 1 and not args.no_cpu_baseline
+    gworld = R if not args.force_dist else max(R, 1)  # ranks in one all-gather
     for c in range(c_lo, c_hi):
         rows = min(CHUNK_ROWS, n_total - c * CHUNK_ROWS)
         x = gen_chunk(c, rows)
@@ -349,7 +368,7 @@ def main() -> None:
     out_dist = packed[0].view(torch.float64)
     out_rows = packed[1]
     if use_dist:
-        packed_all2 = [torch.empty((world, 2, B, k), device=device, dtype=torch.int64) for _ in range(2)]
+        packed_all2 = [torch.empty((gworld, 2, B, k), device=device, dtype=torch.int64) for _ in range(2)]
         packed_all = packed_all2[0]
         fin_dist2 = [torch.empty((B, k), device=device, dtype=torch.float64) for _ in range(2)]
         fin_rows2 = [torch.empty((B, k), device=device, dtype=torch.int64) for _ in range(2)]
@@ -357,13 +376,14 @@ def main() -> None:
         comm_stream = torch.cuda.Stream(device)
         gather_done = [None, None]
         if args.comm == "lib":  # the library's own communicator: the unique id travels through torch's store
-            uid = [pkg.Mi355Index.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            idx.comm_init(rank, world, uid[0])
+            first = layout.group_ranks()[0]      # one RCCL communicator per group of row shards
+            uid = [pkg.Mi355Index.comm_unique_id() if rank == first else None]
+            dist.broadcast_object_list(uid, src=first, group=row_group)
+            idx.comm_init(layout.shard, gworld, uid[0])
     stream = torch.cuda.current_stream().cuda_stream
 
     def step(i: int):
-        q = qpool[i % n_pool]
+        q = qpool[(i * QG + layout.group) % n_pool]   # every query group serves its own block of the pool
         if not use_dist:
             idx.search_device(q.data_ptr(), B, k, out_dist.data_ptr(), out_rows.data_ptr(), stream)
             return out_dist, out_rows
@@ -380,8 +400,8 @@ def main() -> None:
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(ready)
             # one all-gather of the packed [2,B,k] (distance bits, rows) block per rank, then the merge kernel
-            dist.all_gather_into_tensor(packed_all2[buf].view(-1), pk.view(-1))
-            idx.merge_topk_packed_device(packed_all2[buf].data_ptr(), world, B, k, fin_dist2[buf].data_ptr(),
+            dist.all_gather_into_tensor(packed_all2[buf].view(-1), pk.view(-1), group=row_group)
+            idx.merge_topk_packed_device(packed_all2[buf].data_ptr(), gworld, B, k, fin_dist2[buf].data_ptr(),
                                          fin_rows2[buf].data_ptr(), comm_stream.cuda_stream)
             gather_done[buf] = torch.cuda.Event()
             gather_done[buf].record(comm_stream)
@@ -390,7 +410,7 @@ def main() -> None:
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
-    if use_dist:
+    if have_pg:
         dist.barrier()
     idx.reset_stats()
     idx.set_option("profile", 1)
@@ -399,12 +419,12 @@ def main() -> None:
     for i in range(args.steps):
         res = step(args.warmup + i)
     torch.cuda.synchronize()
-    if use_dist:
+    if have_pg:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     idx.set_option("profile", 0)
-    if use_dist:
+    if have_pg:
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -478,14 +498,16 @@ def main() -> None:
 
     result = {
         "metric": "queries/sec",
-        "value": round(args.steps * B / elapsed, 1),
+        "value": round(args.steps * B * QG / elapsed, 1),
         "unit": "queries/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(elapsed * 1e3 / args.steps, 3),
         "higher_is_better": True,
-        "scaling": "strong",
+        # per-GPU work is fixed when every rank holds the corpus and serves its own blocks; total work is fixed when every
+        # rank serves the same block against 1/world of the rows
+        "scaling": "weak" if R == 1 else ("strong" if QG == 1 else f"mixed ({layout.describe()})"),
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
@@ -496,8 +518,9 @@ def main() -> None:
             "rows_per_gpu": n_local,
             "dim": d,
             "k": k,
-            "queries_per_step": B,
-            "parallelism": f"row-shard x{world}" + ((" + all-gather top-k merge (" + ("library RCCL communicator" if args.comm == "lib"
+            "queries_per_step": B * QG,
+            "layout": {"row_shards": R, "query_groups": QG, "rule": args.layout},
+            "parallelism": f"{layout.describe()}" + ((" + all-gather top-k merge (" + ("library RCCL communicator" if args.comm == "lib"
                             else "torch.distributed, overlapped with the next step on a second stream") + ")") if use_dist else ""),
             "arithmetic": ("int8" if i8 else "bf16") + " MFMA screen over a normalised shadow corpus (rigorous "
                           "per-query error bound), exact fp32 chain re-score, float8 distance (results bit-exact vs "
@@ -535,18 +558,18 @@ def main() -> None:
             pd_, pr_ = pk[0].view(torch.float64), pk[1]
             idx.search_device(q_plant.data_ptr(), B, kk, pd_.data_ptr(), pr_.data_ptr(), stream)
             if use_dist:
-                pall = torch.empty((world, 2, B, kk), device=device, dtype=torch.int64)
-                dist.all_gather_into_tensor(pall.view(-1), pk.view(-1))
+                pall = torch.empty((gworld, 2, B, kk), device=device, dtype=torch.int64)
+                dist.all_gather_into_tensor(pall.view(-1), pk.view(-1), group=row_group)
                 fd = torch.empty((B, kk), device=device, dtype=torch.float64)
                 fr = torch.empty((B, kk), device=device, dtype=torch.int64)
-                idx.merge_topk_packed_device(pall.data_ptr(), world, B, kk, fd.data_ptr(), fr.data_ptr(), stream)
+                idx.merge_topk_packed_device(pall.data_ptr(), gworld, B, kk, fd.data_ptr(), fr.data_ptr(), stream)
                 pr_ = fr
         else:
             idx.search_device(q_plant.data_ptr(), B, k, out_dist.data_ptr(), out_rows.data_ptr(), stream)
             pr_ = out_rows
             if use_dist:
-                dist.all_gather_into_tensor(packed_all.view(-1), packed.view(-1))
-                idx.merge_topk_packed_device(packed_all.data_ptr(), world, B, k, fin_dist.data_ptr(), fin_rows.data_ptr(),
+                dist.all_gather_into_tensor(packed_all.view(-1), packed.view(-1), group=row_group)
+                idx.merge_topk_packed_device(packed_all.data_ptr(), gworld, B, k, fin_dist.data_ptr(), fin_rows.data_ptr(),
                                              stream)
                 pr_ = fin_rows
         torch.cuda.synchronize()
@@ -627,7 +650,7 @@ def main() -> None:
         assert (np.diff(rd_, axis=1) >= 0).all(), "distances not ascending"
         assert rr_.min() >= 0 and rr_.max() < n_total
     idx.close()
-    if use_dist:
+    if have_pg:
         dist.destroy_process_group()
     if rank == 0:
         # RCCL writes its version banner through C stdio; on a pipe that buffer would be flushed at exit, AFTER the

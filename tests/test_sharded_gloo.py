@@ -108,3 +108,68 @@ def test_merge_and_bounds_unit():
     assert orr.tolist() == [[3, 7, 4, 9]] and od[0, :4].tolist() == [0.1, 0.1, 0.2, 0.5]
     od, orr = merge_topk_host(d, r, 6)
     assert orr.tolist() == [[3, 7, 4, 9, 11, -1]] and np.isnan(od[0, 4]) and np.isnan(od[0, 5])
+
+
+def _grid_worker(rank: int, world: int, port: int, out_dir: str):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from helpers import OracleIndex
+    from autorag_research_amd.sharded import GridLayout, GridSearcher
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(77)
+    n, d, B, k = 2203, 40, 23, 7
+    C = rng.standard_normal((n, d)).astype(np.float32)
+    C[3] = C[2100]  # cross-shard exact tie
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    out = {}
+    for spec in ("rows", "queries", "2x2", "1x4"):
+        lay = GridLayout.parse(spec, world, rank)
+        g = GridSearcher(d, lay, "cosine", index_factory=OracleIndex)
+        lo, hi = g.local_rows(n, granule=100)
+        g.add_local(C[lo:hi], lo)
+        dd, rr = g.search(Q, k, block=4)  # 6 blocks dealt to the groups; the last one is ragged (3 queries)
+        out[f"d_{spec}"], out[f"r_{spec}"] = dd, rr
+        out[f"lay_{spec}"] = np.array([lay.shard, lay.group, lo, hi])
+        g.close()
+    np.savez(os.path.join(out_dir, f"g{rank}.npz"), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grid_layouts_equal_unsharded(tmp_path, oracle):
+    """world 4 over gloo: rows-only (4x1), queries-only (1x4) and the mixed 2x2 grid give every rank the unsharded result."""
+    import torch.multiprocessing as mp
+
+    from autorag_research_amd.sharded import GridLayout, auto_row_shards, resident_bytes_per_row
+
+    world, port = 4, _free_port()
+    mp.spawn(_grid_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(77)
+    n, d, B, k = 2203, 40, 23, 7
+    C = rng.standard_normal((n, d)).astype(np.float32)
+    C[3] = C[2100]
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    rd, rr = oracle.topk_search(C, Q, k)
+    for rank in range(world):
+        z = np.load(tmp_path / f"g{rank}.npz")
+        for spec in ("rows", "queries", "2x2", "1x4"):
+            assert np.array_equal(z[f"r_{spec}"], rr), (rank, spec)
+            assert np.array_equal(z[f"d_{spec}"].view(np.uint64), rd.view(np.uint64)), (rank, spec)
+        shard, group, lo, hi = z["lay_2x2"]
+        assert (shard, group) == (rank % 2, rank // 2)
+        assert (lo, hi) == ((0, 1100) if shard == 0 else (1100, 2203))
+        assert tuple(z["lay_queries"][2:]) == (0, n)  # one shard: every rank holds the whole corpus
+    # the auto rule: fewest row shards whose shard fits in the HBM fraction
+    per_row = resident_bytes_per_row(768)
+    assert per_row == 4 * 768 + 2 * 768 + 768 + 5
+    hbm = 288 * 10**9
+    assert auto_row_shards(10_000_000, 768, 8, hbm) == 1
+    assert auto_row_shards(60_000_000, 768, 8, hbm) == 2
+    assert auto_row_shards(500_000_000, 768, 8, hbm) == 8
+    assert GridLayout.parse("auto", 8, 5, 10_000_000, 768, hbm).describe() == "1 row shard(s) x 8 query group(s)"
+    with pytest.raises(ValueError):
+        GridLayout(8, 0, 3)
