@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "mi355dr_search_sharded_device", "mi355dr_set_option", "mi355dr_get_stat",
     "mi355dr_reset_stats", "mi355dr_timer_start", "mi355dr_timer_stop", "mi355dr_synchronize",
     "mi355dr_dev_alloc", "mi355dr_dev_free", "mi355dr_dev_upload", "mi355dr_dev_download",
-    "mi355dr_debug_screen_dense", "mi355dr_debug_screen_bound", "mi355dr_debug_rescore",
+    "mi355dr_debug_screen_dense", "mi355dr_debug_screen_bound", "mi355dr_debug_i8_state", "mi355dr_debug_rescore",
 ]
 
 
@@ -162,6 +162,8 @@ def load() -> ctypes.CDLL:
     L.mi355dr_debug_screen_dense.argtypes = [vp, f32p, c_int, i64, i64, f32p]
     L.mi355dr_debug_screen_bound.restype = c_int
     L.mi355dr_debug_screen_bound.argtypes = [vp, f32p, c_int, f32p]
+    L.mi355dr_debug_i8_state.restype = c_int
+    L.mi355dr_debug_i8_state.argtypes = [vp, f32p, c_int, f32p, f32p, i64, i64, f32p, f32p]
     L.mi355dr_debug_rescore.restype = c_int
     L.mi355dr_debug_rescore.argtypes = [vp, f32p, c_int, i32p, i64p, i64, f32p, f64p]
     _lib = L

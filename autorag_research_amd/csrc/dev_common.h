@@ -37,10 +37,10 @@ struct QueryState {
     int32_t* thr_row;   // [Bpad] ... and its row
     int* status;        // [Bpad]
     // screen bound and int8-screen state
-    float* E;           // [Bpad] rigorous bound on |screen value - exact cosine| for this query (both screen dtypes)
+    float* E;           // [Bpad] exact cosine <= candidate value + E.  bf16 screen: the whole bound; int8: its per-query part
     float* E16;         // [Bpad] the bf16 bound of this query whatever the active screen (second screen inside k_prune)
-    float* sc;          // [Bpad] int8 screen: value of one accumulator unit, S_q * S_c  (1 for the bf16 screen)
-    int* thr_i;         // [Bpad] int8 screen: emit iff acc >= thr_i  (conservative integer image of thr)
+    float* sc;          // [Bpad] int8 screen: the query's step S_q  (1 for the bf16 screen)
+    float* kq;          // [Bpad] int8 screen: factor on a row group's residual norm, 1.0001 + 3 e_q
     int8_t* qhat8;      // [Bpad, dpad8] int8 quantised normalised queries
 };
 
@@ -56,26 +56,43 @@ __host__ __device__ inline float bf16_screen_bound(float e_q, float e_c, int d) 
 }
 
 // ---- int8 screen quantisation (DESIGN.md "int8 screen bound") ----
-// Normalised rows are quantised with ONE step for the whole corpus, S_c = kI8Z / (127 sqrt(d)): a unit vector's
-// rms component is 1/sqrt(d), so +-127 steps span kI8Z "sigmas" and the rounding residual has norm
-// ~ S_c sqrt(d/12) = kI8Z / (127 sqrt(12)) = 0.01364, independent of d.  Rows whose measured residual norm exceeds
-// kI8ResidualLimit (clipped outlier components) are "loose": they are left out of the int8 shadow and re-scored
-// for every query like irregular rows; if there are more than kIrrCap of them the index keeps the bf16 screen.
+// Normalised rows c_hat are quantised per GROUP of kI8GroupRows = 32 consecutive rows (one 32x32 MFMA accumulator block is
+// 32 rows x 32 queries, so a block has ONE step and the epilogue reads it with a scalar load): S_g = (largest |component|
+// over the group's rows) / 127, c8 = round(c_hat / S_g) -- nothing is clipped, and the residual norm |c_hat - S_g c8| of
+// every row is MEASURED at build time; the group keeps e_g = the largest of them (~ S_g sqrt(d/12)).  A unit Gaussian row of
+// d = 768 peaks at ~3.5 sigma, a group of 32 at ~4.4 sigma: e_g ~ 0.010 -- against 0.0136 (and the 0.0150 limit the bound
+// had to use) for the one corpus-wide 6-sigma step of round 1.  Rows with an outlier component (|component| sqrt(d) > kI8Z)
+// would coarsen their whole group: they are "loose" -- left out of the int8 shadow (all-zero row, flag 1) and re-scored for
+// every query like irregular rows; with more than kIrrCap of them the index keeps the bf16 screen.
+// Queries: one step per query, S_q = max|q_hat| / 127, residual norm e_q measured.
+// Bound: q_hat.c_hat - (S_q q8).(S_g c8) = q~.e_c + e_q.c~ + e_q.e_c  ->  |..| <= e_q + e_c + 3 e_q e_c, split into
+//   a per-query part   E_q  = 1.0001 e_q + 4 d 2^-24 + 2^-16 + 4e-6        (st.E: what k_prune adds to a candidate's value)
+//   a per-pair part    e_g * kq,  kq = 1.0001 + 3 e_q                       (added to the screen value by the epilogue)
+// so a candidate carries v = S_q S_g acc + e_g kq and  exact cosine <= v + E_q;  it is emitted iff v >= thr = tau - E_q.
+// (4e-6: the epilogue's three fp32 roundings -- |acc| < 2^24 converts exactly below d = 1040, the product S_q S_g, the fma.)
 constexpr float kI8Z = 6.0f;
-constexpr float kI8ResidualLimit = 0.0150f;
-__host__ __device__ inline float i8_corpus_step(int d) { return kI8Z / (127.0f * sqrtf((float)d)); }
-// E_q = 1.0001 (e_q + e_lim) + 3 e_q e_lim + 4 d 2^-24 + 2^-16   (e_q = measured residual norm of the query, inflated)
-__host__ __device__ inline float i8_screen_bound(float e_q, int d) {
-    return 1.0001f * (e_q + kI8ResidualLimit) + 3.0f * e_q * kI8ResidualLimit + 4.0f * (float)d * 5.9604645e-8f +
-           1.5258789e-5f;
+constexpr int kI8GroupRows = 32;
+struct I8Group {  // [ceil(rows / 32)]
+    float step;   // S_g
+    float err;    // e_g (inflated by 1e-3 for its own rounding)
+};
+__host__ __device__ inline float i8_row_peak_limit(int d) { return kI8Z / sqrtf((float)d); }
+__host__ __device__ inline float i8_query_bound(float e_q, int d) {
+    return 1.0001f * e_q + 4.0f * (float)d * 5.9604645e-8f + 1.5258789e-5f + 4.0e-6f;
 }
-// conservative integer threshold: every acc with acc * sc >= thr satisfies acc >= i8_threshold(thr, sc)
-__device__ __forceinline__ int i8_threshold(float thr, float sc) {
-    if (!(sc > 0.0f) || thr != thr) return 0x7FFFFFFF;      // never emits (|acc| < 2^24)
-    const float x = floorf(thr / sc) - 1.0f;
-    if (x <= -2.0e9f) return -0x7FFFFFFF - 1;
-    if (x >= 2.0e9f) return 0x7FFFFFFF;
-    return (int)x;
+__host__ __device__ inline float i8_pair_factor(float e_q) { return 1.0001f + 3.0f * e_q; }
+// conservative integer threshold of one accumulator block: every acc with fl(fma((float)acc, m, ek)) >= th has acc >= the
+// result (m = S_q S_g >= 0, ek = e_g kq).  Hit path only, for lanes whose own float test passed (callers AND the lane's
+// `any` into every compare: a NaN threshold converts to 0 here).  Branch-free: v_cvt_i32_f32 saturates, so -inf (emit
+// everything; an all-zero block, m = 0, whose ek passes) becomes INT_MIN.
+//   fl(fma) >= th  only if  acc m + ek >= th - |th| 2^-24;   rcp: 1 ulp, the subtraction and the products 1/2 ulp each.
+__device__ __forceinline__ int i8_block_threshold(float th, float m, float ek) {
+    const float r = __builtin_amdgcn_rcpf(m);
+    const float x = (th - ek) * r;
+    const float y = floorf(x - fabsf(x) * 4.8e-7f - fabsf(th) * (1.2e-7f * r) - 2.0f);
+    int out;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(out) : "v"(y));
+    return out;
 }
 
 __device__ __forceinline__ float bits_f(uint32_t u) { return __uint_as_float(u); }

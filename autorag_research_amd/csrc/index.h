@@ -43,6 +43,7 @@ struct mi355dr_index {
     int dpad8 = 0;
     int8_t* shadow8 = nullptr;     // [cap_rows, dpad8]
     uint8_t* flag8 = nullptr;      // [cap_rows]
+    mi355::I8Group* grp8 = nullptr;  // [cap_rows / 32] int8 step + residual norm per group of 32 rows
     int32_t* irr8_rows = nullptr;  // [kIrrCap] irregular + loose rows
     int* irr8_count = nullptr;
     int irr8_n = 0;
@@ -82,6 +83,7 @@ struct mi355dr_index {
     int screen_form = 1;  // 1: k_screen256b (two-K-step prefetch, split epilogue), 0: k_screen256 (first form, kept for A/B)
     int64_t chunk0_rows = 1024;
     int64_t chunk_growth = 3;
+    int64_t small_chunk_rows = 16384;  // chunks up to this many rows go through the 128x128 kernel (dense hits: per-lane appends)
     int cap = mi355::kCandCap;
 
     // stats

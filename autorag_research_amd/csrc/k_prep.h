@@ -1,7 +1,7 @@
 // k_prep.h -- corpus-side and query-side preparation kernels.
 //   k_row_nrm2      |c|^2 per stored row, exact k-ascending fp32 chain (pgvector's `normb`, oracle.c orc_dot)
 //   k_build_shadow  bf16 shadow row  c_hat = bf16_rn(c / |c|)  streamed by the screen kernel
-//   k_build_shadow8 int8 shadow row  round(c / |c| / S_c)  (+ loose-row detection) for the int8 screen
+//   k_build_shadow8 int8 shadow rows round(c / |c| / S_g), one step per group of 32 rows (+ loose-row detection)
 //   k_prep_queries  |q|^2, q_hat = bf16_rn(q / |q|) and its int8 form, per-query bound, search state reset
 #pragma once
 #include "dev_common.h"
@@ -99,50 +99,99 @@ __device__ __forceinline__ float block256_reduce(float v, bool is_max, float* sh
     return is_max ? fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3])) : (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-// grid: n blocks of 256 threads (one row each).  c8 = clamp(round(c_hat / S_c), +-127); the residual norm
-// |c_hat - S_c c8| is measured (inflated by 1e-3 for its own rounding): a row above kI8ResidualLimit, or an
-// irregular one, gets an all-zero int8 row, flag 1, and a slot in irr8_rows (re-scored for every query).
+// grid: one block of 256 threads per GROUP of kI8GroupRows = 32 rows, groups [g0, g0 + gridDim.x) (dev_common.h: "int8
+// screen quantisation").  Wave w owns rows 8w .. 8w+7 of the group.  Pass 1: every row's peak |c_hat_k|; a row is loose
+// when it is irregular or its peak is above i8_row_peak_limit(d).  The group's step S_g = (largest peak of its tight rows)
+// / 127.  Pass 2: c8 = round(c_hat / S_g) for the tight rows (all-zero rows for the loose ones and for rows >= n_total),
+// the residual norm |c_hat - S_g c8| measured per row, e_g = the largest.  A group is always rebuilt whole: when a later
+// add() lands in a partly filled group its old rows are requantised with the new step.  Loose rows are registered in
+// irr8_rows once -- only rows >= first_new (the rows this add() brought) are appended.
 __global__ __launch_bounds__(256) void k_build_shadow8(const float* __restrict__ rows, const float* __restrict__ nrm2,
-                                                        int64_t row0, int64_t n, int d, int dpad8, float step,
+                                                        int64_t g0, int64_t n_total, int64_t first_new, int d, int dpad8,
                                                         int8_t* __restrict__ shadow8, uint8_t* __restrict__ flag8,
-                                                        int32_t* __restrict__ irr8_rows, int* __restrict__ irr8_count) {
-    __shared__ float sh[4];
-    const int64_t i = row0 + blockIdx.x;
-    if (i >= row0 + n) return;
-    const float n2 = nrm2[i];
-    const bool regular = norm_is_regular(n2);
-    const float rc = regular ? 1.0f / sqrtf(n2) : 0.0f;
-    const float inv_step = 1.0f / step;
-    const float* r = rows + i * (int64_t)d;
-    int8_t* s = shadow8 + i * (int64_t)dpad8;
-    float e2 = 0.0f;
-    for (int k = threadIdx.x; k < d; k += blockDim.x) {
-        const float ch = r[k] * rc;
-        const float qv = fminf(fmaxf(rintf(ch * inv_step), -127.0f), 127.0f);
-        const float e = __builtin_fmaf(-step, qv, ch);
-        e2 = __builtin_fmaf(e, e, e2);
-    }
-    e2 = block256_reduce(e2, false, sh);
-    const bool loose = !regular || !(sqrtf(e2) * 1.001f <= kI8ResidualLimit);
-    for (int k = threadIdx.x; k < dpad8; k += blockDim.x) {
-        int8_t v = 0;
-        if (k < d && !loose) v = (int8_t)fminf(fmaxf(rintf(r[k] * rc * inv_step), -127.0f), 127.0f);
-        s[k] = v;
-    }
-    if (threadIdx.x == 0) {
-        flag8[i] = loose ? 1 : 0;
-        if (loose) {
-            const int slot = atomicAdd(irr8_count, 1);
-            if (slot < kIrrCap) irr8_rows[slot] = (int32_t)i;
+                                                        I8Group* __restrict__ grp, int32_t* __restrict__ irr8_rows,
+                                                        int* __restrict__ irr8_count) {
+    __shared__ float s_peak[kI8GroupRows];
+    __shared__ float s_err[kI8GroupRows];
+    __shared__ float s_step;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t g = g0 + blockIdx.x;
+    const int64_t row_g = g * kI8GroupRows;
+    const float peak_limit = i8_row_peak_limit(d);
+    for (int j = 0; j < 8; ++j) {
+        const int lr = wave * 8 + j;
+        const int64_t i = row_g + lr;
+        float peak = -1.0f;  // < 0: not a tight row
+        if (i < n_total) {
+            const float n2 = nrm2[i];
+            if (norm_is_regular(n2)) {
+                const float rc = 1.0f / sqrtf(n2);
+                const float* r = rows + i * (int64_t)d;
+                float mx = 0.0f;
+                for (int k = lane; k < d; k += kWave) mx = fmaxf(mx, fabsf(r[k] * rc));
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+                if (mx <= peak_limit) peak = mx;  // (NaN components compare false: loose)
+            }
         }
+        if (lane == 0) s_peak[lr] = peak;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float mx = 0.0f;
+        for (int j = 0; j < kI8GroupRows; ++j) mx = fmaxf(mx, s_peak[j]);
+        s_step = mx * (1.0f / 127.0f) * 1.0000005f;  // rounded up: peak / step <= 127 exactly
+    }
+    __syncthreads();
+    const float step = s_step;
+    const float inv_step = step > 0.0f ? 1.0f / step : 0.0f;
+    for (int j = 0; j < 8; ++j) {
+        const int lr = wave * 8 + j;
+        const int64_t i = row_g + lr;
+        if (i >= n_total) {  // (rows past the end of the index: their shadow rows stay as allocated, all zero)
+            if (lane == 0) s_err[lr] = 0.0f;
+            continue;
+        }
+        const bool tight = s_peak[lr] >= 0.0f && step > 0.0f;
+        const float rc = tight ? 1.0f / sqrtf(nrm2[i]) : 0.0f;
+        const float* r = rows + i * (int64_t)d;
+        int8_t* s = shadow8 + i * (int64_t)dpad8;
+        float e2 = 0.0f;
+        for (int k = lane; k < dpad8; k += kWave) {
+            float qv = 0.0f;
+            if (k < d && tight) {
+                const float ch = r[k] * rc;
+                qv = fminf(fmaxf(rintf(ch * inv_step), -127.0f), 127.0f);
+                const float e = __builtin_fmaf(-step, qv, ch);
+                e2 = __builtin_fmaf(e, e, e2);
+            }
+            s[k] = (int8_t)qv;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) e2 += __shfl_xor(e2, o);
+        if (lane == 0) {
+            s_err[lr] = tight ? sqrtf(e2) * 1.001f : 0.0f;
+            flag8[i] = tight ? 0 : 1;
+            if (!tight && i >= first_new) {
+                const int slot = atomicAdd(irr8_count, 1);
+                if (slot < kIrrCap) irr8_rows[slot] = (int32_t)i;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float mx = 0.0f;
+        for (int j = 0; j < kI8GroupRows; ++j) mx = fmaxf(mx, s_err[j]);
+        grp[g].step = step;
+        grp[g].err = mx;
     }
 }
 
-// grid: Bpad blocks of 64 threads.  i8_step > 0: also prepare the int8 screen (qhat8, sc, thr_i, E from the
+// grid: Bpad blocks of 64 threads.  i8 != 0: also prepare the int8 screen (qhat8, sc, kq, E from the
 // measured query residual); otherwise the bf16 screen: E from the measured query residual and bf16_ec, the largest
 // residual norm of the stored rows.
 __global__ __launch_bounds__(64) void k_prep_queries(const float* __restrict__ q, int B, int d, int dpad, int metric,
-                                                      QueryState st, int dpad8, float i8_step, float bf16_ec) {
+                                                      QueryState st, int dpad8, int i8, float bf16_ec) {
     extern __shared__ float qs[];  // [d]
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
@@ -159,10 +208,10 @@ __global__ __launch_bounds__(64) void k_prep_queries(const float* __restrict__ q
             st.status[b] = 0;
             st.E[b] = bf16_screen_bound(0.00390625f, bf16_ec, d);
             st.E16[b] = st.E[b];
-            st.sc[b] = 1.0f;
-            st.thr_i[b] = 0x7FFFFFFF;
+            st.sc[b] = 0.0f;
+            st.kq[b] = 1.0f;
         }
-        if (i8_step > 0.0f)
+        if (i8)
             for (int k = lane; k < dpad8; k += kWave) st.qhat8[(int64_t)b * dpad8 + k] = 0;
         return;
     }
@@ -187,9 +236,9 @@ __global__ __launch_bounds__(64) void k_prep_queries(const float* __restrict__ q
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) eq2 += __shfl_xor(eq2, o);
-    float E = bf16_screen_bound(sqrtf(eq2) * 1.001f, bf16_ec, d), sc = 1.0f;
+    float E = bf16_screen_bound(sqrtf(eq2) * 1.001f, bf16_ec, d), sc = 1.0f, kq = 1.0f;
     const float E16 = E;
-    if (i8_step > 0.0f) {
+    if (i8) {
         // per-query step S_q = max|q_hat| / 127, residual norm measured like the corpus side
         float mx = 0.0f;
         for (int k = lane; k < d; k += kWave) mx = fmaxf(mx, fabsf(qs[k] * rq));
@@ -211,17 +260,19 @@ __global__ __launch_bounds__(64) void k_prep_queries(const float* __restrict__ q
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) e2 += __shfl_xor(e2, o);
-        E = i8_screen_bound(sqrtf(e2) * 1.001f, d);
-        sc = sq * i8_step;
+        const float e_q = sqrtf(e2) * 1.001f;
+        E = i8_query_bound(e_q, d);
+        kq = i8_pair_factor(e_q);
+        sc = sq;
     }
     if (lane == 0) {
         st.qn[b] = acc;
         st.E[b] = E;
         st.E16[b] = E16;
         st.sc[b] = sc;
+        st.kq[b] = kq;
         // cosine screen cannot rank an irregular query: park it (never emits) and flag it for the scan path
         // (metric 2 = test hook: every query screens with thresholds at -inf)
-        st.thr_i[b] = (regular || metric == 2) ? (-0x7FFFFFFF - 1) : 0x7FFFFFFF;
         st.thr[b] = (regular || metric == 2) ? -__builtin_inff() : __builtin_inff();
         st.cnt[b] = 0;
         st.best_n[b] = 0;

@@ -43,9 +43,10 @@ constexpr int kScreenLds = 2 * 2 * kTileBytes;         // 64 KiB: 2 buffers x (A
 struct ScreenArgs {
     const void* shadow;      // [rows_pad, row_bytes]  bf16 (2 B/element) or int8 shadow rows
     const void* qhat;        // [Bpad, row_bytes]      same element type
-    const float* thr;        // [Bpad]  bf16 screen: emit iff t >= thr
-    const int* thr_i;        // [Bpad]  int8 screen: emit iff acc >= thr_i
-    const float* sc;         // [Bpad]  int8 screen: candidate value = acc * sc
+    const float* thr;        // [Bpad]  emit iff v >= thr  (bf16: v = t; int8: v = S_q S_g acc + e_g kq, dev_common.h)
+    const float* sc;         // [Bpad]  int8 screen: the query's step S_q
+    const float* kq;         // [Bpad]  int8 screen: factor on the row group's residual norm
+    const I8Group* grp;      // [rows_pad / 32]  int8 screen: step and residual norm of every group of 32 rows
     const uint8_t* flag8;    // [rows]  int8 screen: 1 = row is not in the int8 shadow (read by the emit-all epilogue only)
     int* cnt;                // [Bpad]
     int32_t* cand_row;       // [Bpad, cap]
@@ -80,11 +81,26 @@ __device__ __forceinline__ f32x16 screen_mfma(bf16x8 fa, bf16x8 fb, f32x16 acc) 
     }
 }
 
+// int8 screen: the two per-lane constants of one 32x32 accumulator block (32 rows = one I8Group, 32 queries = the lanes):
+// v = fma((float)acc, m, ek).  `g` is wave-uniform (a scalar load), sq / kq are the lane's query.
+struct I8Blk {
+    float m, ek;
+};
+__device__ __forceinline__ I8Blk i8_blk(const I8Group g, float sq, float kq) { return I8Blk{g.step * sq, g.err * kq}; }
+__device__ __forceinline__ float i8_value(int acc, const I8Blk& b) { return __builtin_fmaf((float)acc, b.m, b.ek); }
+// the group record of the block whose first row is row0 (a multiple of 32), through the scalar data cache: the address is
+// wave-uniform, and the constant address space tells the compiler that nothing in this kernel writes it
+__device__ __forceinline__ I8Group i8_group_of(const I8Group* grp, int64_t row0) {
+    typedef const __attribute__((address_space(4))) float cfloat;
+    cfloat* p = (cfloat*)(const float*)(grp + (row0 >> 5));
+    return I8Group{p[0], p[1]};
+}
+
 // Fused epilogue of one 32x32 accumulator block, shared by both screen kernels.  C/D layout: column (query) =
 // lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5); rbase = first row of the block + 4*(lane>>5).
 template <bool I8>
 __device__ __forceinline__ void screen_emit_block(const ScreenArgs& a, f32x16 acc, int q, int64_t rbase, float th,
-                                                  int thi) {
+                                                  I8Blk blk) {
     // fast path (almost always): one max over the lane's 16 rows and one compare
     bool any;
     if constexpr (I8) {
@@ -92,7 +108,7 @@ __device__ __forceinline__ void screen_emit_block(const ScreenArgs& a, f32x16 ac
         int m = v[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) m = max(m, v[r]);
-        any = m >= thi;
+        any = i8_value(m, blk) >= th;
     } else {
         float m = acc[0];
 #pragma unroll
@@ -107,20 +123,18 @@ __device__ __forceinline__ void screen_emit_block(const ScreenArgs& a, f32x16 ac
     for (int r = 0; r < 16; ++r) {
         const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
         bool hit;
-        if constexpr (I8) hit = __builtin_bit_cast(i32x16, acc)[r] >= thi;
+        if constexpr (I8) hit = i8_value(__builtin_bit_cast(i32x16, acc)[r], blk) >= th;
         else hit = acc[r] >= th;
         if (hit && row < a.row_end) mask |= 1u << r;
     }
     if (mask == 0) return;
     int slot = atomicAdd(&a.cnt[q], __builtin_popcount(mask));
-    float sc = 1.0f;
-    if constexpr (I8) sc = a.sc[q];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         if ((mask >> r) & 1u) {
             if (slot < a.cap) {
                 float val;
-                if constexpr (I8) val = (float)__builtin_bit_cast(i32x16, acc)[r] * sc;
+                if constexpr (I8) val = i8_value(__builtin_bit_cast(i32x16, acc)[r], blk);
                 else val = acc[r];
                 a.cand_row[(int64_t)q * a.cap + slot] = (int32_t)(rbase + (r & 3) + 8 * (r >> 2));
                 a.cand_val[(int64_t)q * a.cap + slot] = val;
@@ -156,21 +170,27 @@ __device__ __forceinline__ void wave_queue_flush(const ScreenArgs& a, const int3
     }
 }
 
-template <bool I8>
-__device__ __forceinline__ void screen_queue_block(const ScreenArgs& a, f32x16 acc, int q, int rbase, int row_end,
-                                                   float th, int thi, float sc, int32_t* que, int& que_n) {
+// FLAG = false: a full queue falls back to a direct global append (a returning atomic: k_screen256, first form);
+// FLAG = true: it only flags the query in `status` (no returning atomic inside the K loop: k_screen256b) -- the host
+// re-screens flagged queries with the tighter bound.
+template <bool I8, bool FLAG>
+__device__ __forceinline__ void screen_queue_block(const ScreenArgs& a, int* status, f32x16 acc, int q, int rbase,
+                                                   int row_end, float th, I8Blk blk, int32_t* que, int& que_n) {
     // maxima of the four groups of four registers first (same 15 max operations as one flat reduction): the append
     // path below skips a whole group with one compare
     bool any, gany[4];
+    int thi = 0;
     if constexpr (I8) {
         const i32x16 v = __builtin_bit_cast(i32x16, acc);
         int g[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) g[i] = max(max(v[4 * i], v[4 * i + 1]), max(v[4 * i + 2], v[4 * i + 3]));
-        any = max(max(g[0], g[1]), max(g[2], g[3])) >= thi;
+        any = i8_value(max(max(g[0], g[1]), max(g[2], g[3])), blk) >= th;
         if (__builtin_amdgcn_ballot_w64(any) == 0) return;  // wave-uniform: almost always taken
+        // hit path: the block's integer threshold (conservative image of the float test above), then integer compares
+        thi = i8_block_threshold(th, blk.m, blk.ek);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) gany[i] = g[i] >= thi;
+        for (int i = 0; i < 4; ++i) gany[i] = any && g[i] >= thi;
     } else {
         float g[4];
 #pragma unroll
@@ -196,7 +216,7 @@ __device__ __forceinline__ void screen_queue_block(const ScreenArgs& a, f32x16 a
         for (int ri = 0; ri < 4; ++ri) {
             const int r = 4 * gi + ri;
             bool hit;
-            if constexpr (I8) hit = __builtin_bit_cast(i32x16, acc)[r] >= thi;
+            if constexpr (I8) hit = any && __builtin_bit_cast(i32x16, acc)[r] >= thi;
             else hit = acc[r] >= th;
             if (__builtin_amdgcn_ballot_w64(hit) == 0) continue;  // wave-uniform
             const int row = rbase + (r & 3) + 8 * (r >> 2);
@@ -206,12 +226,14 @@ __device__ __forceinline__ void screen_queue_block(const ScreenArgs& a, f32x16 a
                 const unsigned e = (unsigned)que_n +
                                    __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
                 float val;
-                if constexpr (I8) val = (float)__builtin_bit_cast(i32x16, acc)[r] * sc;
+                if constexpr (I8) val = i8_value(__builtin_bit_cast(i32x16, acc)[r], blk);
                 else val = acc[r];
                 if (e < (unsigned)kWaveQueueCap) {
                     asm volatile("ds_write_b32 %0, %1" ::"v"(a_q + 4u * e), "v"(q) : "memory");
                     asm volatile("ds_write_b32 %0, %1" ::"v"(a_r + 4u * e), "v"(row) : "memory");
                     asm volatile("ds_write_b32 %0, %1" ::"v"(a_v + 4u * e), "v"(val) : "memory");
+                } else if constexpr (FLAG) {  // queue full: the query is re-screened by the host
+                    __hip_atomic_fetch_or(&status[q], kStOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {  // queue full (a burst of hits inside one tile): direct global append, slow but correct
                     const int slot = atomicAdd(&a.cnt[q], 1);
                     if (slot < a.cap) {
@@ -227,14 +249,14 @@ __device__ __forceinline__ void screen_queue_block(const ScreenArgs& a, f32x16 a
 
 // first chunk: every (query,row) becomes a candidate at slot row-row0 (counts are set by the host)
 template <bool I8>
-__device__ __forceinline__ void screen_emit_all_block(const ScreenArgs& a, f32x16 acc, int q, int64_t rbase, float sc) {
+__device__ __forceinline__ void screen_emit_all_block(const ScreenArgs& a, f32x16 acc, int q, int64_t rbase, I8Blk blk) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
         if (row < a.row_end) {
             float val;
             if constexpr (I8) {
-                val = a.flag8[row] ? __builtin_nanf("") : (float)__builtin_bit_cast(i32x16, acc)[r] * sc;
+                val = a.flag8[row] ? __builtin_nanf("") : i8_value(__builtin_bit_cast(i32x16, acc)[r], blk);
             } else {
                 val = acc[r];
             }
@@ -345,13 +367,15 @@ __global__ __launch_bounds__(256, 2) void k_screen(ScreenArgs a) {
     for (int j = 0; j < 2; ++j) {
         const int q = q0 + 64 * wc + 32 * j + (lane & 31);
         const float th = a.thr[q];
-        const int thi = I8 ? a.thr_i[q] : 0;
-        const float sc = (I8 && a.emit_all) ? a.sc[q] : 1.0f;
+        const float sq = I8 ? a.sc[q] : 1.0f, kq = I8 ? a.kq[q] : 1.0f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int64_t rbase = tile_row0 + 64 * wr + 32 * i + 4 * (lane >> 5);
-            if (a.emit_all) screen_emit_all_block<I8>(a, acc[i][j], q, rbase, sc);  // wave-uniform branch
-            else screen_emit_block<I8>(a, acc[i][j], q, rbase, th, thi);
+            const int64_t row0 = tile_row0 + 64 * wr + 32 * i;  // wave-uniform: one row group per block
+            const int64_t rbase = row0 + 4 * (lane >> 5);
+            I8Blk blk{1.0f, 0.0f};
+            if constexpr (I8) blk = i8_blk(i8_group_of(a.grp, row0), sq, kq);
+            if (a.emit_all) screen_emit_all_block<I8>(a, acc[i][j], q, rbase, blk);  // wave-uniform branch
+            else screen_emit_block<I8>(a, acc[i][j], q, rbase, th, blk);
         }
     }
 }

@@ -134,14 +134,13 @@ __global__ __launch_bounds__(512, 2) void k_screen256(ScreenArgs a) {
         offB = r * kRowB + ((g ^ ((r >> 1) & 7)) << 4);
     }
     // ---- per-workgroup constants of the epilogue (frozen for the launch): no vector-memory loads later
-    float th[2], scq[2];
-    int thi[2];
+    float th[2], scq[2], kqq[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int q = q0 + 64 * wc + 32 * j + (lane & 31);
         th[j] = a.thr[q];
-        thi[j] = I8 ? a.thr_i[q] : 0;
         scq[j] = I8 ? a.sc[q] : 1.0f;
+        kqq[j] = I8 ? a.kq[q] : 1.0f;
     }
 
     f32x16 acc[2][2][2];  // [row half i][row block rb][query half j]
@@ -260,8 +259,11 @@ __global__ __launch_bounds__(512, 2) void k_screen256(ScreenArgs a) {
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int rb = 0; rb < 2; ++rb) {
-                        const int rbase = tile_row0 + 128 * wr + 64 * i + 32 * rb + 4 * (lane_e >> 5);
-                        screen_queue_block<I8>(a, acc[i][rb][j], q, rbase, row_end, th[j], thi[j], scq[j], que, que_n);
+                        const int row0 = tile_row0 + 128 * wr + 64 * i + 32 * rb;  // wave-uniform: one row group
+                        const int rbase = row0 + 4 * (lane_e >> 5);
+                        I8Blk blk{1.0f, 0.0f};
+                        if constexpr (I8) blk = i8_blk(i8_group_of(a.grp, row0), scq[j], kqq[j]);
+                        screen_queue_block<I8, false>(a, nullptr, acc[i][rb][j], q, rbase, row_end, th[j], blk, que, que_n);
                     }
             }
         }

@@ -37,61 +37,6 @@ struct ScreenArgs2 : ScreenArgs {
     int* status;  // [Bpad] per-query status bits (kStOverflow is set when a wave's queue overflows)
 };
 
-template <bool I8>
-__device__ __forceinline__ void screen_queue_block2(const ScreenArgs2& a, f32x16 acc, int q, int rbase, int row_end,
-                                                    float th, int thi, float sc, int32_t* que, int& que_n) {
-    bool any, gany[4];
-    if constexpr (I8) {
-        const i32x16 v = __builtin_bit_cast(i32x16, acc);
-        int g[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) g[i] = max(max(v[4 * i], v[4 * i + 1]), max(v[4 * i + 2], v[4 * i + 3]));
-        any = max(max(g[0], g[1]), max(g[2], g[3])) >= thi;
-        if (__builtin_amdgcn_ballot_w64(any) == 0) return;  // wave-uniform: almost always taken
-#pragma unroll
-        for (int i = 0; i < 4; ++i) gany[i] = g[i] >= thi;
-    } else {
-        float g[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) g[i] = fmaxf(fmaxf(acc[4 * i], acc[4 * i + 1]), fmaxf(acc[4 * i + 2], acc[4 * i + 3]));
-        any = fmaxf(fmaxf(g[0], g[1]), fmaxf(g[2], g[3])) >= th;
-        if (__builtin_amdgcn_ballot_w64(any) == 0) return;  // wave-uniform: almost always taken
-#pragma unroll
-        for (int i = 0; i < 4; ++i) gany[i] = g[i] >= th;
-    }
-    const unsigned a_q = lds_addr(que), a_r = a_q + 4u * kWaveQueueCap, a_v = a_q + 8u * kWaveQueueCap;
-#pragma unroll
-    for (int gi = 0; gi < 4; ++gi) {
-        if (__builtin_amdgcn_ballot_w64(gany[gi]) == 0) continue;  // wave-uniform: no hit in this group of four
-#pragma unroll
-        for (int ri = 0; ri < 4; ++ri) {
-            const int r = 4 * gi + ri;
-            bool hit;
-            if constexpr (I8) hit = __builtin_bit_cast(i32x16, acc)[r] >= thi;
-            else hit = acc[r] >= th;
-            if (__builtin_amdgcn_ballot_w64(hit) == 0) continue;  // wave-uniform
-            const int row = rbase + (r & 3) + 8 * (r >> 2);
-            hit = hit && row < row_end;
-            const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
-            if (hit) {
-                const unsigned e = (unsigned)que_n +
-                                   __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
-                float val;
-                if constexpr (I8) val = (float)__builtin_bit_cast(i32x16, acc)[r] * sc;
-                else val = acc[r];
-                if (e < (unsigned)kWaveQueueCap) {
-                    asm volatile("ds_write_b32 %0, %1" ::"v"(a_q + 4u * e), "v"(q) : "memory");
-                    asm volatile("ds_write_b32 %0, %1" ::"v"(a_r + 4u * e), "v"(row) : "memory");
-                    asm volatile("ds_write_b32 %0, %1" ::"v"(a_v + 4u * e), "v"(val) : "memory");
-                } else {  // queue full: the query is re-screened by the host (no returning atomic in the K loop)
-                    __hip_atomic_fetch_or(&a.status[q], kStOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            que_n += __builtin_popcountll(bal);  // may run past the capacity: the flush clamps
-        }
-    }
-}
-
 // ---- one 1-KiB piece (U = 0,1) of half-tile type S into ring parity `par`; src = the half-tile's first row + K offset
 // LDS-DMA with the source address split as the hardware takes it: a wave-uniform 64-bit base in SGPRs + a 32-bit
 // per-lane offset (the "saddr" form of global_load).  The builtin form adds the two into a 64-bit VGPR pair per lane
@@ -168,19 +113,18 @@ __global__ __launch_bounds__(512, 2) void k_screen256b(ScreenArgs2 a) {
         const int r = wc * 32 + (lane & 31);
         offB = r * kRowB + ((g ^ ((r >> 1) & 7)) << 4);
     }
-    float th[2], scq[2];
-    int thi[2];
+    float th[2], scq[2], kqq[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int q = q0 + 64 * wc + 32 * j + (lane & 31);
         th[j] = a.thr[q];
-        thi[j] = I8 ? a.thr_i[q] : 0;
         scq[j] = I8 ? a.sc[q] : 1.0f;
+        kqq[j] = I8 ? a.kq[q] : 1.0f;
     }
     // These loads must be complete IN THE COMPILER'S BOOKS before the first LDS-DMA is issued: its waitcnt insertion does
     // not see the counted asm waits below, and would otherwise put s_waitcnt vmcnt(0) in front of the first use of a
     // threshold -- inside the K loop, draining the whole prefetch (tests/test_build_pipeline.py checks the ISA).
-    asm volatile("" ::"v"(th[0]), "v"(th[1]), "v"(thi[0]), "v"(thi[1]), "v"(scq[0]), "v"(scq[1]));
+    asm volatile("" ::"v"(th[0]), "v"(th[1]), "v"(kqq[0]), "v"(kqq[1]), "v"(scq[0]), "v"(scq[1]));
 
     // accumulators start at "never a hit": the first tile's phase 1 tests quadrant (1,0) of a tile that does not exist
     f32x16 acc[2][2][2];  // [row half i][row block rb][query half j]
@@ -227,16 +171,42 @@ __global__ __launch_bounds__(512, 2) void k_screen256b(ScreenArgs2 a) {
         _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                              \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[I][rb][J][r] = 0.0f;                   \
     } while (0)
-// threshold test of quadrant (I,J) of the tile whose first row is ROW0
-#define KB_TEST(I, J, ROW0)                                                                           \
+// threshold test of quadrant (I,J) of the tile whose first row is ROW0; G[rb] = the row-group records of its two blocks
+#define KB_TEST(I, J, ROW0, G)                                                                        \
     do {                                                                                              \
         int lane_e = lane;                                                                            \
         asm volatile("" : "+v"(lane_e));                                                              \
         const int q__ = q0 + 64 * wc + 32 * (J) + (lane_e & 31);                                      \
         _Pragma("unroll") for (int rb = 0; rb < 2; ++rb) {                                            \
             const int rbase__ = (ROW0) + 128 * wr + 64 * (I) + 32 * rb + 4 * (lane_e >> 5);           \
-            screen_queue_block2<I8>(a, acc[I][rb][J], q__, rbase__, row_end, th[J], thi[J], scq[J], que, que_n); \
+            I8Blk blk__{1.0f, 0.0f};                                                                  \
+            if constexpr (I8) blk__ = i8_blk((G)[rb], scq[J], kqq[J]);                                \
+            screen_queue_block<I8, true>(a, a.status, acc[I][rb][J], q__, rbase__, row_end, th[J], blk__, que, que_n); \
         }                                                                                             \
+    } while (0)
+// int8: the four row-group records of this wave's rows of tile ROW0 (rows 128 wr + 32 (2 I + rb)) -- scalar loads.
+// They are issued in EVERY K-step, for the tile of the NEXT K-step, at the end of phase 3's LOAD half, and waited for (by
+// the compiler: KB_GROUPS_LANDED is a use) at the end of its MFMA half -- a barrier and eight MFMAs later, the one MFMA
+// half without counted LDS waits: a scalar load that may or may not be in flight (one
+// under `if (first)`) makes the compiler turn the counted lgkmcnt waits in front of the next MFMAs into lgkmcnt(0) -- in
+// every K-step (measured: -4 %).  Half 1 of the outgoing records is kept for the quadrant tested one K-step late.
+#define KB_LOAD_GROUPS(ROW0)                                                                          \
+    do {                                                                                              \
+        if constexpr (I8) {                                                                           \
+            KB_PIN();                                                                                 \
+            gprev[0] = gcur[1][0];                                                                    \
+            gprev[1] = gcur[1][1];                                                                    \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                             \
+                _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                      \
+                    gcur[i][rb] = i8_group_of(a.grp, (int64_t)(ROW0) + 128 * wr + 64 * i + 32 * rb);  \
+            KB_PIN();                                                                                 \
+        }                                                                                             \
+    } while (0)
+#define KB_GROUPS_LANDED()                                                                            \
+    do {                                                                                              \
+        if constexpr (I8)                                                                             \
+            asm volatile("" ::"s"(gcur[0][0].step), "s"(gcur[0][0].err), "s"(gcur[0][1].step), "s"(gcur[0][1].err), \
+                         "s"(gcur[1][0].step), "s"(gcur[1][0].err), "s"(gcur[1][1].step), "s"(gcur[1][1].err));     \
     } while (0)
 #define KB_WAIT_VM_N()                                                                                \
     do {                                                                                              \
@@ -247,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void k_screen256b(ScreenArgs2 a) {
 // One phase.  LOAD half: READS (ds_reads first), then the pieces of this phase's half-tile that are not issued inside the
 // MFMA half, EXTRA (accumulator zeroing / threshold tests at tile boundaries), the counted DMA wait (WAIT = 1) | barrier |
 // MFMA half: 8 MFMAs on quadrant (I,J), the remaining DMA pieces between them | barrier.
-#define KB_PHASE(READS, SS, SPAR, SSRC, SVOFF, EXTRA, WAIT, I, J, FB)                                  \
+#define KB_PHASE(READS, SS, SPAR, SSRC, SVOFF, EXTRA, WAIT, I, J, FB, MIDA, MIDB)                      \
     do {                                                                                              \
         constexpr int SS__ = (SS);                                                                    \
         const int spar__ = (SPAR);                                                                    \
@@ -280,7 +250,9 @@ __global__ __launch_bounds__(512, 2) void k_screen256b(ScreenArgs2 a) {
             if constexpr (NM == 1) {                                                                  \
                 if (kk == 1) { KB_PIN(); KB_STG(1); KB_PIN(); }                                       \
             }                                                                                         \
+            if (kk == 1) { MIDA; }                                                                    \
         }                                                                                             \
+        MIDB;                                                                                         \
         if (!(ABL & 4)) __builtin_amdgcn_s_setprio(0);                                                \
         if (TAIL == 0) {                                                                              \
             MI355_TR_STAMP(tr_on, tr_addr);                                                           \
@@ -339,6 +311,9 @@ __global__ __launch_bounds__(512, 2) void k_screen256b(ScreenArgs2 a) {
     unsigned tr_addr = lds_addr(smem + kTraceOff + group * (kTraceStamps * 8));
     unsigned long long tr_l = 0;
     int row0_cur = (a.ct0 + ctl) * kT2, row0_prev = row0_cur;  // rows < 2^31 (checked by the host)
+    I8Group gcur[2][2] = {}, gprev[2] = {};  // [row half i][row block rb]; gprev: half 1 of the previous tile (tested one K-step late)
+    KB_LOAD_GROUPS(row0_cur);
+    KB_GROUPS_LANDED();
     for (;;) {
         const bool first = t == 0, last = t + 1 == T;
         if (first && que_n > kWaveQueueCap / 2) {  // wave-uniform, rare: this wave stalls on vector memory once
@@ -349,16 +324,18 @@ __global__ __launch_bounds__(512, 2) void k_screen256b(ScreenArgs2 a) {
         // phase 0: quadrant (0,0); stage B1 of K-step g+1
         KB_PHASE(KB_READ_B(0, par, fb0); if constexpr (FAN) KB_READ_A0_PART(par, 2, 0, fa); else KB_READ_A(0, par), 2, par ^ 1,
                  baseB + half_B + c1_k, voffB,
-                 if (first) KB_ZERO(0, 0), 1, 0, 0, fb0);
+                 if (first) KB_ZERO(0, 0), 1, 0, 0, fb0, , );
         // phase 1: quadrant (0,1); stage A1 of K-step g+1; the previous tile's last quadrant is tested here
         KB_PHASE(KB_READ_B(1, par, fb1), 3, par ^ 1, c1_base + half_A + c1_k, voffA,
-                 if (first) { KB_TEST(1, 0, row0_prev); KB_ZERO(0, 1); } if (last) KB_TEST(0, 0, row0_cur), 1, 0, 1, fb1);
+                 if (first) { KB_TEST(1, 0, row0_prev, gprev); KB_ZERO(0, 1); } if (last) KB_TEST(0, 0, row0_cur, gcur[0]), 1, 0, 1, fb1, , );
         // phase 2: quadrant (1,1); stage A0 of K-step g+2 (its slot was read in phase 0 of this K-step)
         KB_PHASE(KB_READ_A(1, par), 0, par, c2_base + c2_k, voffA,
-                 if (first) KB_ZERO(1, 1); if (last) KB_TEST(0, 1, row0_cur), FAN ? 1 : 0, 1, 1, fb1);
+                 if (first) KB_ZERO(1, 1); if (last) KB_TEST(0, 1, row0_cur, gcur[0]), FAN ? 1 : 0, 1, 1, fb1, , );
         // phase 3: quadrant (1,0); stage B0 of K-step g+2
         KB_PHASE(if constexpr (FAN) KB_READ_A0_PART(par ^ 1, 0, 0, fan), 1, par, baseB + c2_k, voffB,
-                 if (first) KB_ZERO(1, 0); if (last) KB_TEST(1, 1, row0_cur), 1, 1, 0, fb0);
+                 if (first) KB_ZERO(1, 0); if (last) KB_TEST(1, 1, row0_cur, gcur[1]);
+                 if constexpr (!(ABL & 4096)) { if (!(ABL & 8192) || last) KB_LOAD_GROUPS((a.ct0 + c1_ctl) * kT2); }, 1, 1, 0, fb0,
+                 , if constexpr (!(ABL & 4096)) { if constexpr ((ABL & 16384) != 0) KB_PIN(); KB_GROUPS_LANDED(); });
 
         par ^= 1;
         ++gk;
@@ -377,7 +354,7 @@ __global__ __launch_bounds__(512, 2) void k_screen256b(ScreenArgs2 a) {
             ++t;
         }
     }
-    KB_TEST(1, 0, row0_prev);  // the last tile's last quadrant
+    KB_TEST(1, 0, row0_prev, gprev);  // the last tile's last quadrant
     if (group == 0) MI355_BARRIER();  // balance the stagger barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the dummy prefetches must land before the LDS is freed
     if ((ABL & 16) && blockIdx.x == 0 && (wave & 3) == 0) {  // dump the trace
@@ -393,6 +370,8 @@ __global__ __launch_bounds__(512, 2) void k_screen256b(ScreenArgs2 a) {
 #undef KB_PIN
 #undef KB_ZERO
 #undef KB_TEST
+#undef KB_LOAD_GROUPS
+#undef KB_GROUPS_LANDED
 #undef KB_WAIT_VM_N
 #undef KB_PHASE
 #undef KB_ADVANCE

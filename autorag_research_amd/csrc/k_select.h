@@ -330,7 +330,6 @@ __device__ void prune_body(const PruneArgs& a, char* smem) {
                         if (a.metric == 0) {
                             const float th = float_below((float)((1.0 - key_to_dist(wk)) - (double)E));
                             a.st.thr[q] = th;
-                            a.st.thr_i[q] = i8_threshold(th, a.st.sc[q]);
                         } else {
                             // a row can only beat dot_k > 0 if its cosine is at least dot_k / (|q| cmax)
                             const double dk = -key_to_dist(wk);
@@ -338,7 +337,6 @@ __device__ void prune_body(const PruneArgs& a, char* smem) {
                             if (dk > 0.0 && den > 0.0 && den < 1e300) {
                                 const float th = float_below((float)(dk / den * (1.0 - 4e-6) - (double)E));
                                 a.st.thr[q] = th;
-                                a.st.thr_i[q] = i8_threshold(th, a.st.sc[q]);
                             }
                         }
                     }
@@ -479,7 +477,6 @@ __device__ void prune_body(const PruneArgs& a, char* smem) {
             if (a.metric == 0 && wk != kKeyNaN && !(a.st.status[q] & kStIrregular)) {
                 const float th = float_below((float)((1.0 - key_to_dist(wk)) - (double)E));
                 a.st.thr[q] = th;
-                a.st.thr_i[q] = i8_threshold(th, a.st.sc[q]);
             }
         }
     }

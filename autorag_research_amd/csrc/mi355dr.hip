@@ -39,14 +39,16 @@ int ensure_capacity(mi355dr_index* idx, int64_t want_rows) {
     float* nrm2 = nullptr;
     int8_t* shadow8 = nullptr;
     uint8_t* flag8 = nullptr;
-    {   // all five or none: a failed allocation must not leak the ones before it
+    I8Group* grp8 = nullptr;
+    {   // all six or none: a failed allocation must not leak the ones before it
         hipError_t e = hipMalloc(&rows, (size_t)new_cap * idx->dim * sizeof(float));
         if (e == hipSuccess) e = hipMalloc(&shadow, (size_t)new_cap * idx->dpad * sizeof(uint16_t));
         if (e == hipSuccess) e = hipMalloc(&nrm2, (size_t)new_cap * sizeof(float));
         if (e == hipSuccess) e = hipMalloc(&shadow8, (size_t)new_cap * idx->dpad8);
         if (e == hipSuccess) e = hipMalloc(&flag8, (size_t)new_cap);
+        if (e == hipSuccess) e = hipMalloc(&grp8, (size_t)(new_cap / kI8GroupRows) * sizeof(I8Group));
         if (e != hipSuccess) {
-            for (void* p : {(void*)rows, (void*)shadow, (void*)nrm2, (void*)shadow8, (void*)flag8})
+            for (void* p : {(void*)rows, (void*)shadow, (void*)nrm2, (void*)shadow8, (void*)flag8, (void*)grp8})
                 if (p) (void)hipFree(p);
             HIPCHECK(idx, e);
         }
@@ -54,6 +56,7 @@ int ensure_capacity(mi355dr_index* idx, int64_t want_rows) {
     HIPCHECK(idx, hipMemsetAsync(shadow, 0, (size_t)new_cap * idx->dpad * sizeof(uint16_t), idx->stream));
     HIPCHECK(idx, hipMemsetAsync(shadow8, 0, (size_t)new_cap * idx->dpad8, idx->stream));
     HIPCHECK(idx, hipMemsetAsync(flag8, 0, (size_t)new_cap, idx->stream));
+    HIPCHECK(idx, hipMemsetAsync(grp8, 0, (size_t)(new_cap / kI8GroupRows) * sizeof(I8Group), idx->stream));
     if (idx->n > 0) {
         HIPCHECK(idx, hipMemcpyAsync(rows, idx->rows, (size_t)idx->n * idx->dim * sizeof(float),
                                      hipMemcpyDeviceToDevice, idx->stream));
@@ -64,6 +67,8 @@ int ensure_capacity(mi355dr_index* idx, int64_t want_rows) {
         HIPCHECK(idx, hipMemcpyAsync(shadow8, idx->shadow8, (size_t)idx->n * idx->dpad8, hipMemcpyDeviceToDevice,
                                      idx->stream));
         HIPCHECK(idx, hipMemcpyAsync(flag8, idx->flag8, (size_t)idx->n, hipMemcpyDeviceToDevice, idx->stream));
+        HIPCHECK(idx, hipMemcpyAsync(grp8, idx->grp8, (size_t)((idx->n + kI8GroupRows - 1) / kI8GroupRows) * sizeof(I8Group),
+                                     hipMemcpyDeviceToDevice, idx->stream));
     }
     HIPCHECK(idx, hipStreamSynchronize(idx->stream));
     if (idx->rows) (void)hipFree(idx->rows);
@@ -71,8 +76,10 @@ int ensure_capacity(mi355dr_index* idx, int64_t want_rows) {
     if (idx->nrm2) (void)hipFree(idx->nrm2);
     if (idx->shadow8) (void)hipFree(idx->shadow8);
     if (idx->flag8) (void)hipFree(idx->flag8);
+    if (idx->grp8) (void)hipFree(idx->grp8);
     idx->shadow8 = shadow8;
     idx->flag8 = flag8;
+    idx->grp8 = grp8;
     idx->rows = rows;
     idx->shadow = shadow;
     idx->nrm2 = nrm2;
@@ -96,7 +103,7 @@ int ensure_qstate(mi355dr_index* idx) {
     HIPCHECK(idx, hipMalloc(&idx->st.E, B * sizeof(float)));
     HIPCHECK(idx, hipMalloc(&idx->st.E16, B * sizeof(float)));
     HIPCHECK(idx, hipMalloc(&idx->st.sc, B * sizeof(float)));
-    HIPCHECK(idx, hipMalloc(&idx->st.thr_i, B * sizeof(int)));
+    HIPCHECK(idx, hipMalloc(&idx->st.kq, B * sizeof(float)));
     HIPCHECK(idx, hipMalloc(&idx->st.qhat8, B * idx->dpad8));
     HIPCHECK(idx, hipMalloc(&idx->qdev, B * idx->dim * sizeof(float)));
     HIPCHECK(idx, hipMalloc(&idx->cand_row, B * kCandCap * sizeof(int32_t)));
@@ -228,7 +235,7 @@ int launch_prune(mi355dr_index* idx, hipStream_t s, int nblocks, const int* qlis
 
 int launch_prep(mi355dr_index* idx, hipStream_t s, int B, int Bpad, int metric) {
     hipLaunchKernelGGL(k_prep_queries, dim3(Bpad), dim3(64), (size_t)idx->dim * sizeof(float), s, idx->qdev, B, idx->dim,
-                       idx->dpad, metric, idx->st, idx->dpad8, use_i8(idx) ? i8_corpus_step(idx->dim) : 0.0f, idx->bf16_ec);
+                       idx->dpad, metric, idx->st, idx->dpad8, use_i8(idx) ? 1 : 0, idx->bf16_ec);
     HIPCHECK(idx, hipGetLastError());
     return MI355DR_OK;
 }
@@ -236,7 +243,6 @@ int launch_prep(mi355dr_index* idx, hipStream_t s, int B, int Bpad, int metric) 
 // tile edge used for a block of B queries: the 256x256 ping-pong kernel from 129 queries up, else 128x128
 inline int screen_tile(int B) { return B > kTileN ? kT2 : kTileM; }
 
-constexpr int64_t kSmallChunkRows = 16384;
 constexpr int kRetryLevels = 2;  // re-screens of an overflowed query (bf16, growth/2, then growth 0.25) before the exact scan
 
 // launch one screen pass over rows [r0, r_end) (r0 a multiple of the tile edge)
@@ -249,15 +255,16 @@ int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t 
     // the emit-all first chunk always goes through the 128x128 kernel (k_screen256 has no emit-all epilogue)
     // ... and so do chunks of a few thousand rows: their thresholds are still so low that a good part of the tile is a
     // hit, which the per-lane global append of k_screen handles better than k_screen256's small per-wave queues
-    const int tile = (emit_all || r_end - r0 <= kSmallChunkRows) ? kTileM : screen_tile(B);
+    const int tile = (emit_all || r_end - r0 <= idx->small_chunk_rows) ? kTileM : screen_tile(B);
     const bool i8 = use_i8(idx);
     ScreenArgs2 sa{};
     sa.status = idx->st.status;
     sa.shadow = i8 ? (const void*)idx->shadow8 : (const void*)idx->shadow;
     sa.qhat = i8 ? (const void*)idx->st.qhat8 : (const void*)idx->st.qhat;
     sa.thr = idx->st.thr;
-    sa.thr_i = idx->st.thr_i;
     sa.sc = idx->st.sc;
+    sa.kq = idx->st.kq;
+    sa.grp = idx->grp8;
     sa.flag8 = idx->flag8;
     sa.cnt = idx->st.cnt;
     sa.cand_row = idx->cand_row;
@@ -317,7 +324,7 @@ int run_screen(mi355dr_index* idx, hipStream_t s, int B, int k) {
         }
         // the first chunk has no threshold yet: it keeps every row (direct stores) as long as it fits the buffer
         CHECK(launch_screen(idx, s, B, done, end, idx->cap, emit_all));
-        const bool big = !emit_all && end - done > kSmallChunkRows && screen_tile(B) == kT2;
+        const bool big = !emit_all && end - done > idx->small_chunk_rows && screen_tile(B) == kT2;
         if (idx->profile) {
             HIPCHECK(idx, hipEventRecord(ev.b, s));
             ev.big = big ? 1 : 0;
@@ -596,7 +603,7 @@ void mi355dr_destroy(mi355dr_index* idx) {
     (void)hipSetDevice(idx->device);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
     void* ptrs[] = {idx->n2max_dev, idx->bf16_res2_dev, idx->retry_q[0], idx->retry_dist[0], idx->retry_rows[0], idx->retry_map[0], idx->retry_q[1],
-                    idx->retry_dist[1], idx->retry_rows[1], idx->retry_map[1], idx->shadow8, idx->flag8, idx->irr8_rows, idx->irr8_count, idx->st.E, idx->st.E16, idx->st.sc, idx->st.thr_i,
+                    idx->retry_dist[1], idx->retry_rows[1], idx->retry_map[1], idx->shadow8, idx->flag8, idx->grp8, idx->irr8_rows, idx->irr8_count, idx->st.E, idx->st.E16, idx->st.sc, idx->st.kq,
                     idx->st.qhat8,
                     idx->rows, idx->shadow, idx->nrm2, idx->irr_rows, idx->irr_count, idx->st.qn, idx->st.qhat,
                     idx->st.thr, idx->st.cnt, idx->st.best_n, idx->st.best_key, idx->st.best_row, idx->st.thr_key,
@@ -651,9 +658,16 @@ static int add_rows_impl(mi355dr_index* idx, const float* rows, int64_t n, hipMe
         hipLaunchKernelGGL(k_build_shadow, dim3((unsigned)m), dim3(256), 0, s, idx->rows, idx->nrm2, first, m, idx->dim,
                            idx->dpad, idx->shadow, idx->irr_rows, idx->irr_count, idx->bf16_res2_dev);
         HIPCHECK(idx, hipGetLastError());
-        hipLaunchKernelGGL(k_build_shadow8, dim3((unsigned)m), dim3(256), 0, s, idx->rows, idx->nrm2, first, m, idx->dim,
-                           idx->dpad8, i8_corpus_step(idx->dim), idx->shadow8, idx->flag8, idx->irr8_rows, idx->irr8_count);
-        HIPCHECK(idx, hipGetLastError());
+    }
+    {   // int8 shadow: whole groups of 32 rows, from the (possibly partly filled) group the first new row falls into
+        const int64_t g_lo = idx->n / kI8GroupRows, g_hi = (idx->n + n + kI8GroupRows - 1) / kI8GroupRows;
+        for (int64_t g0 = g_lo; g0 < g_hi; g0 += kBuildSlice) {
+            const int64_t m = std::min(kBuildSlice, g_hi - g0);
+            hipLaunchKernelGGL(k_build_shadow8, dim3((unsigned)m), dim3(256), 0, s, idx->rows, idx->nrm2, g0, idx->n + n,
+                               idx->n, idx->dim, idx->dpad8, idx->shadow8, idx->flag8, idx->grp8, idx->irr8_rows,
+                               idx->irr8_count);
+            HIPCHECK(idx, hipGetLastError());
+        }
     }
     int irr = 0, irr8 = 0;
     HIPCHECK(idx, hipMemcpyAsync(&irr, idx->irr_count, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -798,6 +812,9 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
     } else if (k == "chunk_growth") {
         if (value < 1) return fail(idx, MI355DR_E_INVALID, "chunk_growth must be >= 1");
         idx->chunk_growth = value;
+    } else if (k == "small_chunk_rows") {
+        if (value < 0) return fail(idx, MI355DR_E_INVALID, "small_chunk_rows must be >= 0");
+        idx->small_chunk_rows = value;
     } else if (k == "round_a") {
         if (value < 0 || value > 64) return fail(idx, MI355DR_E_INVALID, "round_a must be in [0,64]");
         idx->round_a = (int)value;
@@ -849,7 +866,8 @@ int mi355dr_get_stat(mi355dr_index* idx, const char* key, int64_t* out) {
     else if (k == "loose_rows") *out = idx->irr8_n;
     else if (k == "screen_dtype_active") *out = use_i8(idx) ? MI355DR_SCREEN_I8 : MI355DR_SCREEN_BF16;
     else if (k == "hbm_bytes_resident")
-        *out = idx->cap_rows * ((int64_t)idx->dim * 4 + (int64_t)idx->dpad * 2 + (int64_t)idx->dpad8 + 5);
+        *out = idx->cap_rows * ((int64_t)idx->dim * 4 + (int64_t)idx->dpad * 2 + (int64_t)idx->dpad8 + 5) +
+               idx->cap_rows / kI8GroupRows * (int64_t)sizeof(I8Group);
     else return fail(idx, MI355DR_E_INVALID, "unknown stat: " + k);
     return MI355DR_OK;
 }
@@ -959,6 +977,32 @@ int mi355dr_debug_screen_bound(mi355dr_index* idx, const float* queries, int B, 
     CHECK(launch_prep(idx, s, B, (int)round_up(B, screen_tile(B)), idx->metric));
     HIPCHECK(idx, hipMemcpyAsync(out_E, idx->st.E, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, s));
     HIPCHECK(idx, hipStreamSynchronize(s));
+    return MI355DR_OK;
+}
+
+int mi355dr_debug_i8_state(mi355dr_index* idx, const float* queries, int B, float* out_sq, float* out_kq, int64_t g0,
+                           int64_t n_groups, float* out_step, float* out_err) {
+    if (!idx || !queries || !out_sq || !out_kq || !out_step || !out_err) return fail(idx, MI355DR_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (B <= 0 || B > kQBlockMax) return fail(idx, MI355DR_E_INVALID, "need 1<=B<=1024");
+    if (g0 < 0 || n_groups < 0 || (g0 + n_groups) * kI8GroupRows > idx->cap_rows)
+        return fail(idx, MI355DR_E_INVALID, "group range outside the index");
+    if (!use_i8(idx)) return fail(idx, MI355DR_E_UNSUPPORTED, "the int8 screen is not active");
+    HIPCHECK(idx, hipSetDevice(idx->device));
+    CHECK(ensure_qstate(idx));
+    hipStream_t s = idx->stream;
+    HIPCHECK(idx, hipMemcpyAsync(idx->qdev, queries, (size_t)B * idx->dim * sizeof(float), hipMemcpyHostToDevice, s));
+    CHECK(launch_prep(idx, s, B, (int)round_up(B, screen_tile(B)), idx->metric));
+    HIPCHECK(idx, hipMemcpyAsync(out_sq, idx->st.sc, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHECK(idx, hipMemcpyAsync(out_kq, idx->st.kq, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, s));
+    std::vector<I8Group> gr((size_t)n_groups);
+    if (n_groups > 0)
+        HIPCHECK(idx, hipMemcpyAsync(gr.data(), idx->grp8 + g0, (size_t)n_groups * sizeof(I8Group), hipMemcpyDeviceToHost, s));
+    HIPCHECK(idx, hipStreamSynchronize(s));
+    for (int64_t i = 0; i < n_groups; ++i) {
+        out_step[i] = gr[(size_t)i].step;
+        out_err[i] = gr[(size_t)i].err;
+    }
     return MI355DR_OK;
 }
 

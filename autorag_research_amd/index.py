@@ -299,8 +299,20 @@ class Mi355Index:
                                                             int(n), ptr(out, ctypes.c_float)))
         return out
 
+    def debug_i8_state(self, queries, g0: int, n_groups: int) -> tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
+        """int8 screen: (S_q [B], kq [B], S_g [n_groups], e_g [n_groups]) -- screen value = S_q S_g (q8.c8) + e_g kq."""
+        q = f32c(queries)
+        sq = np.empty(q.shape[0], dtype=np.float32)
+        kq = np.empty(q.shape[0], dtype=np.float32)
+        st = np.empty(n_groups, dtype=np.float32)
+        er = np.empty(n_groups, dtype=np.float32)
+        check(self._h, self._lib.mi355dr_debug_i8_state(self._h, ptr(q, ctypes.c_float), q.shape[0], ptr(sq, ctypes.c_float),
+                                                        ptr(kq, ctypes.c_float), int(g0), int(n_groups),
+                                                        ptr(st, ctypes.c_float), ptr(er, ctypes.c_float)))
+        return sq, kq, st, er
+
     def debug_screen_bound(self, queries) -> np.ndarray:
-        """Per-query rigorous bound E on |screen value - exact cosine| for the active screen dtype."""
+        """Per-query bound E of the active screen dtype: exact cosine <= screen value + E."""
         q = f32c(queries)
         out = np.empty(q.shape[0], dtype=np.float32)
         check(self._h, self._lib.mi355dr_debug_screen_bound(self._h, ptr(q, ctypes.c_float), q.shape[0],

@@ -202,8 +202,13 @@ int mi355dr_dev_download(mi355dr_index* idx, void* dst_host, const void* src_dev
 /* ---- test hooks (used by tests/ only; exercise the production kernels on small inputs) ----
  * dense screen values t[b, r] for rows [row0,row0+n): runs the screen kernel with thresholds at -inf. */
 int mi355dr_debug_screen_dense(mi355dr_index* idx, const float* queries, int B, int64_t row0, int64_t n, float* out_t);
-/* the per-query screen bound E (|screen value - exact cosine| <= E) of the active screen dtype */
+/* the per-query screen bound E of the active screen dtype: exact cosine <= screen value + E  (bf16 screen: also
+ * |screen value - exact cosine| <= E; int8 screen: the screen value already carries its row group's share of the bound) */
 int mi355dr_debug_screen_bound(mi355dr_index* idx, const float* queries, int B, float* out_E);
+/* int8 screen: per query the step S_q and the factor kq = 1.0001 + 3 e_q; per group of 32 rows [g0, g0 + n_groups) the
+ * step S_g and the measured residual norm e_g.  Screen value of (query, row) = S_q S_g (q8 . c8) + e_g kq. */
+int mi355dr_debug_i8_state(mi355dr_index* idx, const float* queries, int B, float* out_sq, float* out_kq, int64_t g0,
+                           int64_t n_groups, float* out_step, float* out_err);
 /* exact fp32 chain + distance for explicit (query,row) pairs, computed by the re-score device code */
 int mi355dr_debug_rescore(mi355dr_index* idx, const float* queries, int B, const int32_t* pair_q,
                           const int64_t* pair_row, int64_t n_pairs, float* out_dot, double* out_dist);

@@ -101,8 +101,9 @@ def test_bf16_bound_holds_on_low_dimensional_aligned_data(pkg, d):
 
 @pytest.mark.parametrize("d,B", [(768, 130), (384, 3), (100, 17), (1000, 40)])
 def test_int8_screen_values_and_bound(pkg, d, B):
-    """the int8 MFMA screen (v_mfma_i32_32x32x32_i8, exact int32 accumulate) == numpy emulation of the quantised
-    product, and |t - exact cosine| <= the per-query bound E the library uses to cut candidates."""
+    """the int8 MFMA screen (v_mfma_i32_32x32x32_i8, exact int32 accumulate; one step per group of 32 rows) == numpy
+    emulation of the quantised product + the group's share of the bound, and exact cosine <= value + E (the per-query part
+    of the bound the library cuts candidates with)."""
     rng = np.random.default_rng(17 + d)
     n = 1500
     C = rng.standard_normal((n, d)).astype(np.float32) * rng.uniform(0.1, 10, size=(n, 1)).astype(np.float32)
@@ -110,36 +111,46 @@ def test_int8_screen_values_and_bound(pkg, d, B):
     Q[0] *= 1e3
     with pkg.Mi355Index(d) as idx:
         idx.set_option("screen_dtype", "i8")
-        idx.add(C)
+        idx.add(C[:700])
+        idx.add(C[700:])  # 700 = 21 groups + 28 rows: the second add() lands in a partly filled group and rebuilds it
         assert idx.stat("screen_dtype_active") == 2
-        # the residual norm concentrates with d: at d >= 384 no Gaussian row is loose, at d = 100 about 1 % are
-        # (they are left out of the int8 shadow: NaN here, re-scored for every query in a search)
-        loose = idx.stat("loose_rows")
-        assert loose == 0 if d >= 384 else loose < 60
+        # Gaussian rows have no component beyond 6 sigma: nothing is loose
+        assert idx.stat("loose_rows") == 0
         E = idx.debug_screen_bound(Q).astype(np.float64)
-        assert (E > 0.015).all() and (E < 0.035).all()
-        step_c = np.float32(6.0) / (np.float32(127.0) * np.sqrt(np.float32(d)))
+        n_groups = (n + 31) // 32
+        sq, kq, step_g, err_g = (x.astype(np.float64) for x in idx.debug_i8_state(Q, 0, n_groups))
+        ch_all = C.astype(np.float64) / np.linalg.norm(C.astype(np.float64), axis=1, keepdims=True)
+        peak = np.abs(ch_all).max(axis=1)
+        peak_g = np.array([peak[g * 32:(g + 1) * 32].max() for g in range(n_groups)])
+        assert np.allclose(step_g, peak_g / 127.0, rtol=2e-6, atol=0)  # one step per group: its largest component / 127
+        # per-query part ~ the query's own rounding residual; per-group part ~ S_g sqrt(d/12)
+        assert (E > 0.003).all() and (E < 0.012).all()
+        assert np.allclose(err_g, step_g * np.sqrt(d / 12.0), rtol=0.2)
+        assert (kq > 1.0).all() and (kq < 1.05).all()
         qh = (Q.astype(np.float64) / np.linalg.norm(Q.astype(np.float64), axis=1, keepdims=True))
         step_q = np.abs(qh).max(axis=1, keepdims=True) / 127.0
+        assert np.allclose(sq, step_q[:, 0], rtol=2e-6, atol=0)
         q8 = np.clip(np.rint(qh / step_q), -127, 127)
         for row0, cnt in [(0, 1500), (256, 300), (1024, 476)]:
             t = idx.debug_screen_dense(Q, row0, cnt).astype(np.float64)
+            assert not np.isnan(t).any(), "some (query,row) pairs were never produced by the kernel"
             sub = C[row0:row0 + cnt].astype(np.float64)
-            ch = sub / np.linalg.norm(sub, axis=1, keepdims=True)
-            c8 = np.clip(np.rint(ch / float(step_c)), -127, 127)
-            ref = (q8 @ c8.T) * step_q * float(step_c)
-            missing = np.isnan(t)
-            assert (missing == missing[0:1]).all(), "a row is either in the int8 shadow for every query or for none"
-            assert missing[0].sum() <= loose, "some (query,row) pairs were never produced by the kernel"
-            keep = ~missing[0]
-            t, ref, sub = t[:, keep], ref[:, keep], sub[keep]
+            ch = ch_all[row0:row0 + cnt]
+            sg = step_g[np.arange(row0, row0 + cnt) // 32]
+            eg = err_g[np.arange(row0, row0 + cnt) // 32]
+            c8 = np.clip(np.rint(ch / sg[:, None]), -127, 127)
+            # the measured residual norm of every row is inside its group's record
+            assert (np.linalg.norm(ch - c8 * sg[:, None], axis=1) <= eg * (1 + 1e-6) + 1e-7).all()
+            ref = (q8 @ c8.T) * step_q * sg[None, :] + kq[:, None] * eg[None, :]
             # the device normalises in fp32, so a few components round to the neighbouring step: each flip moves
             # the integer accumulator by <= 127 units
-            unit = step_q * float(step_c)
+            unit = step_q * sg[None, :]
             assert (np.abs(t - ref) <= 4 * 127 * unit + 1e-6).all()
             assert np.abs(t - ref).mean() < 1e-5
             cos = (Q.astype(np.float64) @ sub.T) / (np.linalg.norm(Q.astype(np.float64), axis=1)[:, None]
                                                      * np.linalg.norm(sub, axis=1)[None, :])
-            assert (np.abs(t - cos) <= E[:, None]).all()
-            # the bound is not vacuous: typical error is a fair fraction of it
-            assert np.abs(t - cos).max() > 0.05 * E.min()
+            # what the cut relies on: the value is an upper bound of the cosine up to the per-query part ...
+            assert (cos <= t + E[:, None]).all()
+            # ... and not a vacuous one: it never overshoots by more than the whole two-sided bound
+            assert (t - cos <= E[:, None] + 2.0 * kq[:, None] * eg[None, :] + 1e-6).all()
+            assert np.abs(t - kq[:, None] * eg[None, :] - cos).max() > 0.05 * (E.min() + eg.min())

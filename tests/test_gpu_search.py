@@ -161,16 +161,17 @@ def test_schedule_adapts_to_k(pkg, oracle, k, expect_dtype):
 
 
 def test_overflow_is_rescreened_before_the_exact_scan(pkg, oracle):
-    """a dense neighbourhood (3000 rows within ~0.02 cosine of each other around the query) overflows the candidate
-    list under the int8 bound (2E = 0.046 covers all of them) but not under the bf16 bound (2E = 0.016): those queries
-    are re-screened with bf16, nobody pays the exact scan, results unchanged; AUTO then stays with bf16 for the index"""
+    """a dense neighbourhood (4600 rows within ~0.02 cosine of each other around the query) overflows the candidate
+    list under the int8 bound (E ~ 0.017 keeps ~90 % of them, ~3000 in the last chunk against 2048 slots) but not under
+    the bf16 bound (E ~ 0.008, smaller chunks): those queries are re-screened with bf16, nobody pays the exact scan,
+    results unchanged; AUTO then stays with bf16 for the index"""
     rng = np.random.default_rng(4)
     n, d, B, k = 60_000, 256, 64, 10
     C = rng.standard_normal((n, d)).astype(np.float32)
     v = rng.standard_normal(d).astype(np.float32)
     v /= np.linalg.norm(v)
     # cluster: v + noise of growing size -> cosines to v spread evenly over about [0.975, 0.995]
-    m = 3000
+    m = 4600
     amp = np.sqrt(1.0 / np.linspace(0.995, 0.975, m) ** 2 - 1.0).astype(np.float32)
     noise = rng.standard_normal((m, d)).astype(np.float32)
     noise -= (noise @ v)[:, None] * v[None, :]

@@ -92,25 +92,30 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)k_screen256<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
     CK(hipFuncSetAttribute((const void*)k_screen256b<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
     CK(hipFuncSetAttribute((const void*)k_screen256b<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
-#define SB_FORMS(X) X(3136) X(3072) X(3104) X(3140)
+#define SB_FORMS(X) X(3136) X(7232)
 #define SB_ATTR(A) CK(hipFuncSetAttribute((const void*)k_screen256b<A, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
     SB_FORMS(SB_ATTR)
     int* status;
     CK(hipMalloc(&status, Bpad * 4));
     CK(hipMemset(status, 0, Bpad * 4));
-    // int8 variants (1128 / 1256) reuse the same buffers as raw bytes: rows of dpad8 = round_up(d,128) int8;
-    // timing only (the integer thresholds are parked at INT_MAX)
+    // int8 variants (1128 / 1256) reuse the same buffers as raw bytes: rows of dpad8 = round_up(d,128) int8.  The
+    // harness bytes are uniform in [-128,127] -> acc ~ N(0, d * 5461^2): with S_q = 1 and one group step 1 / (d * 5461)
+    // for every row group the int8 screen value is N(0, 1/d) like the bf16 one, so both kinds share the float thresholds
     const int dpad8 = (d + 127) / 128 * 128;
-    int* thr_i;
-    float* scv;
+    float *scv, *kqv;
     uint8_t* flag8;
-    CK(hipMalloc(&thr_i, Bpad * 4));
+    I8Group* grp;
     CK(hipMalloc(&scv, Bpad * 4));
+    CK(hipMalloc(&kqv, Bpad * 4));
     CK(hipMalloc(&flag8, Npad));
     CK(hipMemset(flag8, 0, Npad));
+    CK(hipMalloc(&grp, (size_t)(Npad / 32) * sizeof(I8Group)));
     {
-        std::vector<int> hi(Bpad, 0x7FFFFFFF);
-        CK(hipMemcpy(thr_i, hi.data(), Bpad * 4, hipMemcpyHostToDevice));
+        std::vector<float> one(Bpad, 1.0f);
+        CK(hipMemcpy(scv, one.data(), Bpad * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(kqv, one.data(), Bpad * 4, hipMemcpyHostToDevice));
+        std::vector<I8Group> hg((size_t)(Npad / 32), I8Group{1.0f / ((float)d * 5461.0f), 0.0f});
+        CK(hipMemcpy(grp, hg.data(), hg.size() * sizeof(I8Group), hipMemcpyHostToDevice));
     }
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
@@ -127,8 +132,9 @@ int main(int argc, char** argv) {
         sa.cand_val = cval;
         const bool i8 = variant >= 1000;
         if (i8) variant -= 1000;
-        sa.thr_i = thr_i;
         sa.sc = scv;
+        sa.kq = kqv;
+        sa.grp = grp;
         sa.flag8 = flag8;
         sa.row_bytes = i8 ? dpad8 : dpad * 2;
         sa.ksteps = sa.row_bytes / 128;
@@ -226,11 +232,6 @@ int main(int argc, char** argv) {
         if (getenv("SWEEP")) {
             for (float z : {4.6f, 4.2f, 3.9f, 3.5f, 3.0f}) {
                 hipLaunchKernelGGL(k_fillf, dim3((Bpad + 255) / 256), dim3(256), 0, 0, thr, B, z / sqrtf((float)d));
-                {   // int8 variants: the harness bytes are uniform in [-128,127] -> acc ~ N(0, d * 5461^2)
-                    std::vector<int> hi(Bpad, 0x7FFFFFFF);
-                    for (int q = 0; q < B; ++q) hi[q] = (int)(z * sqrtf((float)d) * 5461.0f);
-                    CK(hipMemcpy(thr_i, hi.data(), Bpad * 4, hipMemcpyHostToDevice));
-                }
                 float bz = 1e30f;
                 for (int r = 0; r < 3; ++r) {
                     CK(hipMemset(cnt, 0, Bpad * 4));
@@ -248,19 +249,10 @@ int main(int argc, char** argv) {
                 for (int q = 0; q < B; ++q) tot += hc[q];
                 printf("   z=%.1f: %.3f ms, %lld hits (%.2e of pairs)\n", z, bz, tot, (double)tot / ((double)N * B));
             }
-            std::vector<int> hi(Bpad, 0x7FFFFFFF);
-            CK(hipMemcpy(thr_i, hi.data(), Bpad * 4, hipMemcpyHostToDevice));
         }
         // (2) finite threshold: collect candidates
         const float T0 = 4.6f / sqrtf((float)d);  // ~4.6 sigma
         hipLaunchKernelGGL(k_fillf, dim3((Bpad + 255) / 256), dim3(256), 0, 0, thr, B, T0);
-        {   // int8 variants: bytes uniform in [-128,127] -> acc ~ N(0, d * 5461^2); same 4.6 sigma
-            std::vector<int> hi(Bpad, 0x7FFFFFFF);
-            for (int q = 0; q < B; ++q) hi[q] = (int)(4.6f * sqrtf((float)d) * 5461.0f);
-            CK(hipMemcpy(thr_i, hi.data(), Bpad * 4, hipMemcpyHostToDevice));
-            std::vector<float> one(Bpad, 1.0f);
-            CK(hipMemcpy(scv, one.data(), Bpad * 4, hipMemcpyHostToDevice));
-        }
         CK(hipMemset(cnt, 0, Bpad * 4));
         launch(variant);
         CK(hipDeviceSynchronize());
@@ -281,8 +273,6 @@ int main(int argc, char** argv) {
         sets.push_back(s);
         set_kind.push_back(variant >= 1000 ? 1 : 0);
         {
-            std::vector<int> hi(Bpad, 0x7FFFFFFF);
-            CK(hipMemcpy(thr_i, hi.data(), Bpad * 4, hipMemcpyHostToDevice));
             std::vector<int> hs(Bpad);
             CK(hipMemcpy(hs.data(), status, Bpad * 4, hipMemcpyDeviceToHost));
             long long fl = 0;

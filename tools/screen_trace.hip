@@ -25,17 +25,19 @@ int main(int argc, char** argv) {
     const int B = 1024, d = 768, dpad8 = 768;
     char *shadow, *qhat;
     float *thr, *scv, *cval;
-    int *thr_i, *cnt, *status;
+    int *cnt, *status;
+    float* kqv;
+    I8Group* grp;
     int32_t* crow;
     uint8_t* flag8;
     CK(hipMalloc(&shadow, (size_t)N * dpad8)); CK(hipMalloc(&qhat, (size_t)B * dpad8));
-    CK(hipMalloc(&thr, B * 4)); CK(hipMalloc(&scv, B * 4)); CK(hipMalloc(&thr_i, B * 4)); CK(hipMalloc(&cnt, B * 4));
+    CK(hipMalloc(&thr, B * 4)); CK(hipMalloc(&scv, B * 4)); CK(hipMalloc(&kqv, B * 4)); CK(hipMalloc(&cnt, B * 4));
+    CK(hipMalloc(&grp, (size_t)(N / 32 + 8) * sizeof(I8Group))); CK(hipMemset(grp, 0, (size_t)(N / 32 + 8) * sizeof(I8Group)));
+    CK(hipMemset(scv, 0, B * 4)); CK(hipMemset(kqv, 0, B * 4));
     CK(hipMalloc(&status, B * 4)); CK(hipMalloc(&crow, (size_t)B * 2048 * 4)); CK(hipMalloc(&cval, (size_t)B * 2048 * 4));
     CK(hipMalloc(&flag8, N)); CK(hipMemset(flag8, 0, N)); CK(hipMemset(cnt, 0, B * 4)); CK(hipMemset(status, 0, B * 4));
     hipLaunchKernelGGL(k_fill8, dim3((unsigned)(((size_t)N * dpad8 / 4 + 255) / 256)), dim3(256), 0, 0, (uint32_t*)shadow, (size_t)N * dpad8 / 4, 1ull);
     hipLaunchKernelGGL(k_fill8, dim3((unsigned)(((size_t)B * dpad8 / 4 + 255) / 256)), dim3(256), 0, 0, (uint32_t*)qhat, (size_t)B * dpad8 / 4, 2ull);
-    std::vector<int> hi(B, 0x7FFFFFFF);
-    CK(hipMemcpy(thr_i, hi.data(), B * 4, hipMemcpyHostToDevice));
     std::vector<float> inf(B, INFINITY);
     CK(hipMemcpy(thr, inf.data(), B * 4, hipMemcpyHostToDevice));
     unsigned long long* trace;
@@ -48,7 +50,7 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)k_screen256b<1108, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     CK(hipFuncSetAttribute((const void*)k_screen256b<1112, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     ScreenArgs2 sa{};
-    sa.status = status; sa.shadow = shadow; sa.qhat = qhat; sa.thr = thr; sa.thr_i = thr_i; sa.sc = scv; sa.flag8 = flag8;
+    sa.status = status; sa.shadow = shadow; sa.qhat = qhat; sa.thr = thr; sa.sc = scv; sa.kq = kqv; sa.grp = grp; sa.flag8 = flag8;
     sa.cnt = cnt; sa.cand_row = crow; sa.cand_val = cval; sa.row_bytes = dpad8; sa.ksteps = dpad8 / 128; sa.cap = 2048;
     sa.ct0 = 0; sa.row_end = N; sa.n_ctiles = (int)(N / 256); sa.n_qtiles = B / 256;
     const unsigned grid = screen256_grid(sa.n_ctiles, sa.n_qtiles);
