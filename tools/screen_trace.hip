@@ -46,7 +46,7 @@ int main(int argc, char** argv) {
     const int lds = 163840;
     CK(hipFuncSetAttribute((const void*)k_screen256<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     CK(hipFuncSetAttribute((const void*)k_screen256b<1040, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    CK(hipFuncSetAttribute((const void*)k_screen256b<1104, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CK(hipFuncSetAttribute((const void*)k_screen256b<3152, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     CK(hipFuncSetAttribute((const void*)k_screen256b<1108, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     CK(hipFuncSetAttribute((const void*)k_screen256b<1112, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     ScreenArgs2 sa{};
@@ -56,7 +56,7 @@ int main(int argc, char** argv) {
     const unsigned grid = screen256_grid(sa.n_ctiles, sa.n_qtiles);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const bool brief = argc > 2;
-    for (int form = 0; form < 6; ++form) {
+    for (int form = 3; form < 4; ++form) {
         float ms = 0;
         for (int rep = 0; rep < 3; ++rep) {
             CK(hipMemset(trace, 0, 2 * kTraceStamps * 8));
@@ -64,7 +64,7 @@ int main(int argc, char** argv) {
             if (form == 0) hipLaunchKernelGGL((k_screen256<16, true>), dim3(grid), dim3(512), lds, 0, (ScreenArgs)sa);
             else if (form == 1) hipLaunchKernelGGL((k_screen256b<16, true>), dim3(grid), dim3(512), lds, 0, sa);
             else if (form == 2) hipLaunchKernelGGL((k_screen256b<1040, true>), dim3(grid), dim3(512), lds, 0, sa);   // NM = 2, TAIL = 1
-            else if (form == 3) hipLaunchKernelGGL((k_screen256b<1104, true>), dim3(grid), dim3(512), lds, 0, sa);   // NM = 2
+            else if (form == 3) hipLaunchKernelGGL((k_screen256b<3152, true>), dim3(grid), dim3(512), lds, 0, sa);   // NM = 2
             else if (form == 4) hipLaunchKernelGGL((k_screen256b<1108, true>), dim3(grid), dim3(512), lds, 0, sa);  // NM = 2, TAIL = 2
             else hipLaunchKernelGGL((k_screen256b<1112, true>), dim3(grid), dim3(512), lds, 0, sa);                 // NM = 2, no setprio
             CK(hipGetLastError());
