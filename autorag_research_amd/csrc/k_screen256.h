@@ -35,7 +35,10 @@ namespace mi355 {
 constexpr int kT2 = 256;                        // tile edge (rows and queries)
 constexpr int kHalfBytes = 128 * kRowB;         // 16 KiB
 constexpr int kRingBytes = 8 * kHalfBytes;     // ring of 8 half-tiles
-constexpr int kScreen256Lds = kRingBytes + 8 * kWaveQueueCap * 12;  // + one candidate queue per wave
+constexpr int kRecOff = kRingBytes + 8 * kWaveQueueCap * 12;  // + one candidate queue per wave
+constexpr int kRecBytes = 4 * 256;  // + 4 slots x 256 B of int8 row-group records (k_screen256c); 128 + 30 + 1 KiB of 160
+constexpr int kScreen256Lds = kRecOff + kRecBytes;
+static_assert(kScreen256Lds <= 160 * 1024, "LDS per workgroup");
 
 // persistent grid: 8 XCDs x L workgroups, L = the largest multiple of n_qtiles that fits the 32 CUs of an XCD
 // (fewer when the chunk has fewer tiles)
@@ -48,7 +51,7 @@ __host__ __device__ inline unsigned screen256_grid(int n_ctiles, int n_qtiles) {
 // ---- developer timeline trace (tools/screen_bench, ABL bit 4): waves 0 and 4 of workgroup 0 stamp s_memtime at four
 // points of every phase of K-steps [kTraceG0, kTraceG0 + kTraceSteps) into the 2 KiB of LDS behind the queues.
 constexpr int kTraceG0 = 24, kTraceSteps = 6, kTraceStamps = kTraceSteps * 16;
-constexpr int kTraceOff = kRingBytes + 8 * kWaveQueueCap * 12;  // == kScreen256Lds
+constexpr int kTraceOff = kRingBytes;  // (developer trace: over the first wave's queue -- traced launches park the thresholds)
 __device__ unsigned long long* g_trace_out;  // [2][kTraceStamps], set with hipMemcpyToSymbol
 // stamp with the scalar-memory wait (only where no LDS read is outstanding or a full lgkmcnt(0) is due anyway)
 #define MI355_TR_STAMP(ON, ADDR)                                                                       \

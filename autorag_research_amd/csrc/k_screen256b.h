@@ -46,6 +46,11 @@ __device__ __forceinline__ void glds16_saddr(const char* sbase, unsigned voff, u
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst)
                  : "memory");
 }
+// 256 B (one dword per lane) through the same path: the int8 row-group records of a tile (k_screen256c)
+__device__ __forceinline__ void glds4_saddr(const char* sbase, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
 template <int S, bool SADDR>
 __device__ __forceinline__ void kb_stage(char* smem, int wave, int par, const char* src, const unsigned (&voff)[2], int u) {
     char* const dst = smem + (4 * par + S) * kHalfBytes + (2 * wave + u) * 1024;

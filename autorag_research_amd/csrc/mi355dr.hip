@@ -6,7 +6,7 @@
 #include "k_scan.h"
 #include "k_screen.h"
 #include "k_screen256.h"
-#include "k_screen256b.h"
+#include "k_screen256c.h"
 #include "k_select.h"
 
 using namespace mi355;
@@ -140,6 +140,10 @@ int ensure_qstate(mi355dr_index* idx) {
     HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen256b<kScreen256bAbl, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kScreen256Lds));
     HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen256b<kScreen256bAbl, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kScreen256Lds));
+    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen256c<kScreen256cAbl, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kScreen256Lds));
+    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen256c<kScreen256cAbl, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kScreen256Lds));
     HIPCHECK(idx, hipFuncSetAttribute((const void*)k_merge_topk, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kSortMax * 12));
@@ -281,7 +285,10 @@ int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t 
     const int64_t grid = round_up(sa.n_ctiles, 8) * sa.n_qtiles;
     if (tile == kT2) {
         const unsigned g2 = screen256_grid(sa.n_ctiles, sa.n_qtiles);  // persistent: <= one workgroup per CU
-        if (idx->screen_form == 1) {
+        if (idx->screen_form == 2) {
+            if (i8) hipLaunchKernelGGL((k_screen256c<kScreen256cAbl, true>), dim3(g2), dim3(512), kScreen256Lds, s, sa);
+            else hipLaunchKernelGGL((k_screen256c<kScreen256cAbl, false>), dim3(g2), dim3(512), kScreen256Lds, s, sa);
+        } else if (idx->screen_form == 1) {
             if (i8) hipLaunchKernelGGL((k_screen256b<kScreen256bAbl, true>), dim3(g2), dim3(512), kScreen256Lds, s, sa);
             else hipLaunchKernelGGL((k_screen256b<kScreen256bAbl, false>), dim3(g2), dim3(512), kScreen256Lds, s, sa);
         } else {
@@ -572,6 +579,10 @@ int mi355dr_create(mi355dr_index** out, int device_id, int dim, int metric) {
     mi355dr_index* idx = new mi355dr_index();
     idx->device = device_id;
     idx->dim = dim;
+    if (const char* e = getenv("MI355DR_SCREEN_FORM")) {  // developer override of the `screen_form` default (A/B, test sweeps)
+        const int f = atoi(e);
+        if (f >= 0 && f <= 2) idx->screen_form = f;
+    }
     idx->dpad = (int)round_up(dim, kStepK);
     idx->dpad8 = (int)round_up(dim, kRowB);
     idx->metric = metric;
@@ -821,7 +832,7 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
     } else if (k == "prefilter16") {
         idx->prefilter16 = value != 0;
     } else if (k == "screen_form") {
-        if (value < 0 || value > 1) return fail(idx, MI355DR_E_INVALID, "screen_form must be 0 or 1");
+        if (value < 0 || value > 2) return fail(idx, MI355DR_E_INVALID, "screen_form must be 0, 1 or 2");
         idx->screen_form = (int)value;
     } else if (k == "cand_cap") {
         if (value < 16 || value > kCandCap) return fail(idx, MI355DR_E_INVALID, "cand_cap must be in [16,2048]");

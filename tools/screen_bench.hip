@@ -14,7 +14,7 @@
 #include "dev_common.h"
 #include "k_screen.h"
 #include "k_screen256.h"
-#include "k_screen256b.h"
+#include "k_screen256c.h"
 
 using namespace mi355;
 
@@ -95,6 +95,11 @@ int main(int argc, char** argv) {
 #define SB_FORMS(X) X(3136) X(7232)
 #define SB_ATTR(A) CK(hipFuncSetAttribute((const void*)k_screen256b<A, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
     SB_FORMS(SB_ATTR)
+#define SC_FORMS(X) X(1024) X(1028)
+#define SC_ATTR(A) CK(hipFuncSetAttribute((const void*)k_screen256c<A, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
+    SC_FORMS(SC_ATTR)
+    CK(hipFuncSetAttribute((const void*)k_screen256c<kScreen256cAbl, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
+    CK(hipFuncSetAttribute((const void*)k_screen256c<kScreen256cAbl, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
     int* status;
     CK(hipMalloc(&status, Bpad * 4));
     CK(hipMemset(status, 0, Bpad * 4));
@@ -130,7 +135,7 @@ int main(int argc, char** argv) {
         sa.cnt = cnt;
         sa.cand_row = crow;
         sa.cand_val = cval;
-        const bool i8 = variant >= 1000;
+        const bool i8 = variant >= 1000 && variant != 200000;  // (200000 = third form bf16, 201000 + ABL = third form int8)
         if (i8) variant -= 1000;
         sa.sc = scv;
         sa.kq = kqv;
@@ -152,7 +157,13 @@ int main(int argc, char** argv) {
             sa.n_qtiles = (B + 255) / 256;
             int64_t grid = screen256_grid(sa.n_ctiles, sa.n_qtiles);
             if (getenv("GRIDDIV")) grid = grid / atoi(getenv("GRIDDIV")) / 8 / sa.n_qtiles * 8 * sa.n_qtiles;  // fewer CUs busy
-            if (variant >= 300) {  // second form (k_screen256b): 300 + ABL
+            if (variant >= 200000) {  // third form (k_screen256c): 200000 + ABL (+1000 for int8)
+                const int abl = variant - 200000;
+                if (!i8) hipLaunchKernelGGL((k_screen256c<kScreen256cAbl, false>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa);
+#define SC_LAUNCH(A) else if (abl == A) hipLaunchKernelGGL((k_screen256c<A, true>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa);
+                SC_FORMS(SC_LAUNCH)
+                else hipLaunchKernelGGL((k_screen256c<kScreen256cAbl, true>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa);
+            } else if (variant >= 300) {  // second form (k_screen256b): 300 + ABL
                 const int abl = variant - 300;
                 if (!i8) hipLaunchKernelGGL((k_screen256b<0, false>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa);
 #define SB_LAUNCH(A) else if (abl == A) hipLaunchKernelGGL((k_screen256b<A, true>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa);
