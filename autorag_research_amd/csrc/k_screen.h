@@ -170,6 +170,81 @@ __device__ __forceinline__ void wave_queue_flush(const ScreenArgs& a, const int3
     }
 }
 
+// The append path of k_screen256c, OUT OF LINE: one copy per kernel instead of one per test site.  Inlined at the 12 test
+// sites of that kernel's K-step it made the loop body ~60 KB of code -- the hot path hopping over a dozen cold blocks, more
+// than the instruction cache holds -- and cost 20 % of the kernel although it almost never runs.  A call spills the caller's
+// live registers around the call site only, i.e. on the rare path.  Returns the wave's new queue fill.
+template <bool I8>
+__device__ __attribute__((noinline)) int screen_queue_hits(f32x16 acc, int any_i, int q, int rbase, int row_end, float th,
+                                                            float m, float ek, unsigned a_q, int que_n, int* status) {
+    const bool any = any_i != 0;
+    bool gany[4];
+    int thi = 0;
+    if constexpr (I8) {
+        const i32x16 v = __builtin_bit_cast(i32x16, acc);
+        thi = i8_block_threshold(th, m, ek);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            gany[i] = any && max(max(v[4 * i], v[4 * i + 1]), max(v[4 * i + 2], v[4 * i + 3])) >= thi;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            gany[i] = fmaxf(fmaxf(acc[4 * i], acc[4 * i + 1]), fmaxf(acc[4 * i + 2], acc[4 * i + 3])) >= th;
+    }
+    const unsigned a_r = a_q + 4u * kWaveQueueCap, a_v = a_q + 8u * kWaveQueueCap;
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+        if (__builtin_amdgcn_ballot_w64(gany[gi]) == 0) continue;  // wave-uniform: no hit in this group of four
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+            const int r = 4 * gi + ri;
+            bool hit;
+            if constexpr (I8) hit = any && __builtin_bit_cast(i32x16, acc)[r] >= thi;
+            else hit = acc[r] >= th;
+            if (__builtin_amdgcn_ballot_w64(hit) == 0) continue;  // wave-uniform
+            const int row = rbase + (r & 3) + 8 * (r >> 2);
+            hit = hit && row < row_end;
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
+            if (hit) {
+                const unsigned e = (unsigned)que_n +
+                                   __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+                float val;
+                if constexpr (I8) val = __builtin_fmaf((float)__builtin_bit_cast(i32x16, acc)[r], m, ek);
+                else val = acc[r];
+                if (e < (unsigned)kWaveQueueCap) {
+                    asm volatile("ds_write_b32 %0, %1" ::"v"(a_q + 4u * e), "v"(q) : "memory");
+                    asm volatile("ds_write_b32 %0, %1" ::"v"(a_r + 4u * e), "v"(row) : "memory");
+                    asm volatile("ds_write_b32 %0, %1" ::"v"(a_v + 4u * e), "v"(val) : "memory");
+                } else {  // queue full: the query is re-screened by the host
+                    __hip_atomic_fetch_or(&status[q], kStOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            que_n += __builtin_popcountll(bal);  // may run past the capacity: the flush clamps
+        }
+    }
+    return que_n;
+}
+// the test itself, inline: 15 max + the compare; the call only when some lane passes
+template <bool I8>
+__device__ __forceinline__ void screen_test_block(int* status, f32x16 acc, int q, int rbase, int row_end, float th, I8Blk blk,
+                                                  int32_t* que, int& que_n) {
+    bool any;
+    if constexpr (I8) {
+        const i32x16 v = __builtin_bit_cast(i32x16, acc);
+        int g[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[i] = max(max(v[4 * i], v[4 * i + 1]), max(v[4 * i + 2], v[4 * i + 3]));
+        any = i8_value(max(max(g[0], g[1]), max(g[2], g[3])), blk) >= th;
+    } else {
+        float g[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[i] = fmaxf(fmaxf(acc[4 * i], acc[4 * i + 1]), fmaxf(acc[4 * i + 2], acc[4 * i + 3]));
+        any = fmaxf(fmaxf(g[0], g[1]), fmaxf(g[2], g[3])) >= th;
+    }
+    if (__builtin_amdgcn_ballot_w64(any) == 0) return;  // wave-uniform: almost always taken
+    que_n = screen_queue_hits<I8>(acc, any ? 1 : 0, q, rbase, row_end, th, blk.m, blk.ek, lds_addr(que), que_n, status);
+}
+
 // FLAG = false: a full queue falls back to a direct global append (a returning atomic: k_screen256, first form);
 // FLAG = true: it only flags the query in `status` (no returning atomic inside the K loop: k_screen256b) -- the host
 // re-screens flagged queries with the tighter bound.

@@ -91,7 +91,6 @@ __global__ __launch_bounds__(512, 2) void k_screen256c(ScreenArgs2 a) {
     f32x16 zero16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
-    bf16x8 fA[2][2][2], fB[2][2];  // [buffer][i][rb], [buffer][j]: fragments of one K sub-step, double-buffered
     const int T = a.ksteps;
     const int kend = T * kRowB;
     const unsigned rec_lds = lds_addr(smem + kRecOff);
@@ -106,47 +105,6 @@ __global__ __launch_bounds__(512, 2) void k_screen256c(ScreenArgs2 a) {
     } while (0)
 
 #define KC_PIN() __builtin_amdgcn_sched_barrier(0)
-// the 6 fragment reads of K sub-step KK of the K-step in ring parity PAR into buffer BUF
-#define KC_READ(BUF, PAR, KK)                                                                         \
-    do {                                                                                              \
-        const char* s__ = smem + (4 * (PAR)) * kHalfBytes;                                            \
-        if constexpr ((ABL & 2) != 0) {                                                               \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                             \
-                fB[BUF][j] = __builtin_bit_cast(bf16x8, *(const uint4*)(s__ + (1 + j) * kHalfBytes + (offB ^ ((KK) * 32)))); \
-        }                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                 \
-            _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                          \
-                fA[BUF][i][rb] = __builtin_bit_cast(bf16x8, *(const uint4*)(s__ + (i ? 3 : 0) * kHalfBytes + (offA[rb] ^ ((KK) * 32)))); \
-        if constexpr ((ABL & 2) == 0) {                                                               \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                             \
-                fB[BUF][j] = __builtin_bit_cast(bf16x8, *(const uint4*)(s__ + (1 + j) * kHalfBytes + (offB ^ ((KK) * 32)))); \
-        }                                                                                             \
-    } while (0)
-// the 8 MFMAs of one K sub-step on the fragments in buffer BUF
-#define KC_MFMA(BUF)                                                                                  \
-    do {                                                                                              \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                 \
-            _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                          \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                         \
-                    acc[i][rb][j] = screen_mfma<I8>(fA[BUF][i][rb], fB[BUF][j], acc[i][rb][j]);       \
-    } while (0)
-// one interleaved K sub-step: reads of the next sub-step first, then the MFMAs; the scheduler is told to alternate
-#define KC_SUBSTEP(BUF, PAR, KKNEXT)                                                                  \
-    do {                                                                                              \
-        KC_READ((BUF) ^ 1, PAR, KKNEXT);                                                              \
-        KC_MFMA(BUF);                                                                                 \
-        if constexpr ((ABL & 1) != 0) { /* burst: all six reads, then the eight MFMAs */              \
-            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                        \
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                        \
-        } else {                                                                                      \
-            _Pragma("unroll") for (int s__ = 0; s__ < 6; ++s__) {                                     \
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); /* one DS read  */                 \
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* one MFMA     */                 \
-            }                                                                                         \
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                        \
-        }                                                                                             \
-        KC_PIN();                                                                                     \
-    } while (0)
 
     // staging cursor: position of the NEXT K-step to stage = (tile base, K offset, K-steps done in that tile); past the
     // last tile it stays on it (dummy re-stage of valid memory, drained before the exit)
@@ -175,49 +133,82 @@ __global__ __launch_bounds__(512, 2) void k_screen256c(ScreenArgs2 a) {
             else KC_REC_STAGE(RECPOS);                                                                \
         }                                                                                             \
     } while (0)
-// One K sub-step, written out: the 6 fragment reads of sub-step KKNEXT of ring parity RPAR into buffer BUF^1 and up to
-// three DMA pieces [P0, P0+NP) of the K-step being staged (parity SPAR) between the 8 MFMAs on buffer BUF.
-// Order: reads B0 B1 | A00 A01 | A10 | A11 in front of the MFMA pairs (0,0) (0,1) (1,0) (1,1); one DMA piece behind
-// each of the first NP pairs.
-#define KC_STEP(BUF, RPAR, KKNEXT, SPAR, P0, NP, RECPOS, ZERO)                                        \
+// ---- I-major K-step: 8 micro-steps m = 4 I + kk of 4 MFMAs each -- first the row half I = 0 over the four K sub-steps,
+// then I = 1 -- so that a finished tile's blocks are tested UNDER MFMAs of the other row half: I = 0 (final after micro-step 3
+// of the tile's last K-step) during micro-steps 4..7 of that K-step, I = 1 during micro-steps 0..3 of the next tile's first
+// K-step.  (All eight tests after the last MFMA, both waves of every SIMD at once, idled the matrix pipe for 20 % of the
+// kernel.)  The query fragments of a K-step stay in registers (fBk, 8 x 16 B), the row fragments go through a ring of four
+// micro-steps (fAq), read two micro-steps ahead.
+#define KC_RD_A(SLOT, I, RPAR, KK)                                                                    \
     do {                                                                                              \
-        const char* r__ = smem + (4 * (RPAR)) * kHalfBytes;                                           \
-        _Pragma("unroll") for (int g__ = 0; g__ < 4; ++g__) {                                         \
-            const int i__ = g__ >> 1, rb__ = g__ & 1;                                                 \
-            if (g__ == 0) {                                                                           \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                         \
-                    fB[(BUF) ^ 1][j] = __builtin_bit_cast(bf16x8, *(const uint4*)(r__ + (1 + j) * kHalfBytes + (offB ^ ((KKNEXT) * 32)))); \
-            } else if (g__ == 1) {                                                                    \
-                _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                      \
-                    fA[(BUF) ^ 1][0][rb] = __builtin_bit_cast(bf16x8, *(const uint4*)(r__ + (offA[rb] ^ ((KKNEXT) * 32)))); \
-            } else {                                                                                  \
-                fA[(BUF) ^ 1][1][g__ - 2] = __builtin_bit_cast(bf16x8, *(const uint4*)(r__ + 3 * kHalfBytes + (offA[g__ - 2] ^ ((KKNEXT) * 32)))); \
-            }                                                                                         \
-            KC_PIN();                                                                                 \
+        const char* r__ = smem + (4 * (RPAR) + ((I) ? 3 : 0)) * kHalfBytes;                           \
+        _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                              \
+            fAq[SLOT][rb] = __builtin_bit_cast(bf16x8, *(const uint4*)(r__ + (offA[rb] ^ ((KK) * 32)))); \
+    } while (0)
+#define KC_RD_B(RPAR, KK)                                                                             \
+    do {                                                                                              \
+        const char* r__ = smem + (4 * (RPAR) + 1) * kHalfBytes;                                       \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                 \
+            fBk[KK][j] = __builtin_bit_cast(bf16x8, *(const uint4*)(r__ + j * kHalfBytes + (offB ^ ((KK) * 32)))); \
+    } while (0)
+// reads for micro-step M2 (0..9; 8, 9 = micro-steps 0, 1 of the next K-step, other ring parity)
+#define KC_PREFETCH(M2)                                                                               \
+    do {                                                                                              \
+        constexpr int m2__ = (M2) & 7;                                                                \
+        const int rp__ = (M2) >= 8 ? (par ^ 1) : par;                                                 \
+        if (m2__ < 4) KC_RD_B(rp__, m2__ & 3);                                                        \
+        KC_RD_A(m2__ & 3, m2__ >> 2, rp__, m2__ & 3);                                                 \
+    } while (0)
+#define KC_MM(M, ZERO)                                                                                \
+    do {                                                                                              \
+        _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                              \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                             \
-                acc[i__][rb__][j] = screen_mfma<I8>(fA[BUF][i__][rb__], fB[BUF][j], (ZERO) ? zero16 : acc[i__][rb__][j]); \
-            KC_PIN();                                                                                 \
-            if (g__ < (NP)) {                                                                         \
-                KC_PIECE(SPAR, (P0) + g__, RECPOS);                                                   \
-                KC_PIN();                                                                             \
+                acc[(M) >> 2][rb][j] = screen_mfma<I8>(fAq[(M) & 3][rb], fBk[(M) & 3][j], (ZERO) ? zero16 : acc[(M) >> 2][rb][j]); \
+    } while (0)
+// test block (I, RB, J) of the tile whose first row is ROW0, records slot RSLOT
+#define KC_TEST1(I, RB, J, ROW0, RSLOT)                                                               \
+    do {                                                                                              \
+        if constexpr ((ABL & 4) == 0) {                                                               \
+            int lane_e = lane;                                                                        \
+            asm volatile("" : "+v"(lane_e));                                                          \
+            const int q__ = q0 + 64 * wc + 32 * (J) + (lane_e & 31);                                  \
+            const int rbase__ = (ROW0) + 128 * wr + 64 * (I) + 32 * (RB) + 4 * (lane_e >> 5);         \
+            I8Blk blk__{1.0f, 0.0f};                                                                  \
+            if constexpr (I8) {                                                                       \
+                const I8Group g__ = ((const I8Group*)(smem + kRecOff + ((RSLOT) & 3) * 256))[4 * wr + 2 * (I) + (RB)]; \
+                blk__ = i8_blk(g__, scq[J], kqq[J]);                                                  \
             }                                                                                         \
+            screen_test_block<I8>(a.status, acc[I][RB][J], q__, rbase__, row_end, th[J], blk__, que, que_n); \
         }                                                                                             \
     } while (0)
+// one micro-step: [reads for M + 2] [4 MFMAs] [DMA pieces P0, P0 + 1 (NP of them)] [one block test]
+#define KC_MICRO(M, ZERO, SPAR, P0, NP, RECPOS)                                                       \
+    do {                                                                                              \
+        KC_PREFETCH((M) + 2);                                                                         \
+        KC_PIN();                                                                                     \
+        KC_MM(M, ZERO);                                                                               \
+        KC_PIN();                                                                                     \
+        _Pragma("unroll") for (int p__ = 0; p__ < (NP); ++p__) KC_PIECE(SPAR, (P0) + p__, RECPOS);    \
+        KC_PIN();                                                                                     \
+    } while (0)
 
-    // ---- prologue: K-step 0 completely into parity 0, the first three pieces of K-step 1 into parity 1; K-step 0 landed
-    // and visible; first fragments
+    bf16x8 fAq[4][2], fBk[4][2];
+    // ---- prologue: K-step 0 completely into parity 0, the first four pieces of K-step 1 into parity 1; K-step 0 landed
+    // and visible; fragments of micro-steps 0 and 1
 #pragma unroll
     for (int p = 0; p < 9; ++p) KC_PIECE(0, p, 0);
     KC_ADVANCE();
 #pragma unroll
-    for (int p = 0; p < 3; ++p) KC_PIECE(1, p, 1);
-    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // K-step 0 (+ its records) has landed (this wave's pieces)
+    for (int p = 0; p < 4; ++p) KC_PIECE(1, p, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // K-step 0 (+ its records) has landed (this wave's pieces)
     MI355_BARRIER();
-    KC_READ(0, 0, 0);
+    int par = 0, t = 0;
+    KC_PREFETCH(0);
+    KC_PREFETCH(1);
 
     const int row_end = (int)a.row_end;
-    int par = 0, t = 0;
-    int row0_cur = (a.ct0 + ctl) * kT2;  // rows < 2^31 (checked by the host)
+    int row0_cur = (a.ct0 + ctl) * kT2, row0_prev = row0_cur;  // rows < 2^31 (checked by the host)
+    bool have_prev = false;  // a finished tile's row half 1 is waiting for its tests
     for (;;) {
         const bool first = t == 0, last = t + 1 == T;
         if (first && que_n > kWaveQueueCap / 2) {  // wave-uniform, rare: this wave stalls on vector memory once
@@ -225,57 +216,47 @@ __global__ __launch_bounds__(512, 2) void k_screen256c(ScreenArgs2 a) {
             wave_queue_flush(a, que, min(que_n, kWaveQueueCap));
             que_n = 0;
         }
-        // K-step g = gpos, ring parity par.  The K-step being staged: g+1 (pieces 3..8, into par^1) in sub-steps 0 and 1, then
-        // g+2 (pieces 0..2, into par) behind the barrier of sub-step 3 -- three LDS-DMA instructions per sub-step: all nine
-        // in one sub-step (8 waves x 9 through the one texture-address path of the CU) held the matrix pipe up for 20 %.
-        // (a tile's first sub-step starts from C = 0 -- an inline constant of the MFMA -- instead of zeroing 128 registers)
-        if (first) {
-            asm volatile("; first sub-step of a tile");
-            KC_STEP(0, par, 1, par ^ 1, 3, 3, gpos + 1, true);
+        // K-step g = gpos, ring parity par.  Staging: pieces 4..8 of K-step g+1 (into par^1) in micro-steps 0..2, pieces 0..3
+        // of K-step g+2 (into par) behind the hand-over in micro-steps 6, 7: at most two LDS-DMA instructions per micro-step
+        // (all nine at once -- 8 waves x 9 through the one texture-address path of the CU -- held the matrix pipe up).
+        const bool tp = first && have_prev;  // test the previous tile's row half 1 under this K-step's row half 0
+        if (first) {  // (a tile's first MFMA per block starts from C = 0 -- an inline constant -- instead of zeroing registers)
+            asm volatile("; first K-step of a tile");
+            KC_MICRO(0, true, par ^ 1, 4, 2, gpos + 1);
         } else {
-            KC_STEP(0, par, 1, par ^ 1, 3, 3, gpos + 1, false);
+            KC_MICRO(0, false, par ^ 1, 4, 2, gpos + 1);
         }
-        KC_STEP(1, par, 2, par ^ 1, 6, 3, gpos + 1, false);
+        if (tp) KC_TEST1(1, 0, 0, row0_prev, gpos - 1);
+        KC_MICRO(1, false, par ^ 1, 6, 2, gpos + 1);
+        if (tp) KC_TEST1(1, 0, 1, row0_prev, gpos - 1);
+        KC_MICRO(2, false, par ^ 1, 8, 1, gpos + 1);
         KC_ADVANCE();
-        KC_STEP(0, par, 3, par, 0, 0, 0, false);
-        // ---- sub-step 3: hand-over of the ring
+        if (tp) KC_TEST1(1, 1, 0, row0_prev, gpos - 1);
+        KC_MICRO(3, false, par, 0, 0, 0);
+        if (tp) KC_TEST1(1, 1, 1, row0_prev, gpos - 1);
+        if (first) {
+            asm volatile("; first K-step of a tile, row half 1");
+            KC_MICRO(4, true, par, 0, 0, 0);
+        } else {
+            KC_MICRO(4, false, par, 0, 0, 0);
+        }
+        if (last) KC_TEST1(0, 0, 0, row0_cur, gpos);
+        KC_MICRO(5, false, par, 0, 0, 0);
+        if (last) KC_TEST1(0, 0, 1, row0_cur, gpos);
+        // ---- hand-over of the ring: every read of K-step g has been issued (the last ones in micro-step 5)
         if constexpr ((ABL & 32) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of K-step g+1 have landed
-        else if constexpr ((ABL & 64) == 0) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");  // (probe: one K-step more)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // ... and its last fragments of K-step g are in registers
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and its last fragments of K-step g are in registers
         if constexpr ((ABL & 8) == 0) MI355_BARRIER();
         KC_PIN();
-        KC_STEP(1, par ^ 1, 0, par, 0, 3, gpos + 2, false);  // reads: sub-step 0 of K-step g+1; pieces 0..2 of K-step g+2
+        KC_MICRO(6, false, par, 0, 2, gpos + 2);
+        if (last) KC_TEST1(0, 1, 0, row0_cur, gpos);
+        KC_MICRO(7, false, par, 2, 2, gpos + 2);
+        if (last) KC_TEST1(0, 1, 1, row0_cur, gpos);
         par ^= 1;
-        if (last && (ABL & 4)) {
-            if (ctl + cstep >= a.n_ctiles) break;
-            ctl += cstep;
-            row0_cur = (a.ct0 + ctl) * kT2;
-            t = 0;
-        } else if (last) {
-            // ---- the tile is complete: threshold tests of its eight blocks (k_screen.h: screen_queue_block)
-            int lane_e = lane;
-            asm volatile("" : "+v"(lane_e));
-            I8Group gcur[2][2] = {};
-            if constexpr (I8) {  // this tile's records: staged two K-steps ago (or by the prologue), published by the barriers since
-                const I8Group* rp = (const I8Group*)(smem + kRecOff + (gpos & 3) * 256) + 4 * wr;
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int rb = 0; rb < 2; ++rb) gcur[i][rb] = rp[2 * i + rb];
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int q = q0 + 64 * wc + 32 * j + (lane_e & 31);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int rb = 0; rb < 2; ++rb) {
-                        const int rbase = row0_cur + 128 * wr + 64 * i + 32 * rb + 4 * (lane_e >> 5);
-                        I8Blk blk{1.0f, 0.0f};
-                        if constexpr (I8) blk = i8_blk(gcur[i][rb], scq[j], kqq[j]);
-                        screen_queue_block<I8, true>(a, a.status, acc[i][rb][j], q, rbase, row_end, th[j], blk, que, que_n);
-                    }
-            }
+        ++gpos;
+        if (last) {
+            row0_prev = row0_cur;
+            have_prev = true;
             if (ctl + cstep >= a.n_ctiles) break;
             ctl += cstep;
             row0_cur = (a.ct0 + ctl) * kT2;
@@ -283,18 +264,24 @@ __global__ __launch_bounds__(512, 2) void k_screen256c(ScreenArgs2 a) {
         } else {
             ++t;
         }
-        ++gpos;
     }
+    // the last tile's row half 1
+    KC_TEST1(1, 0, 0, row0_prev, gpos - 1);
+    KC_TEST1(1, 0, 1, row0_prev, gpos - 1);
+    KC_TEST1(1, 1, 0, row0_prev, gpos - 1);
+    KC_TEST1(1, 1, 1, row0_prev, gpos - 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the dummy prefetches must land before the LDS is freed
     wave_queue_flush(a, que, min(que_n, kWaveQueueCap));
 
+#undef KC_RD_A
+#undef KC_RD_B
+#undef KC_PREFETCH
+#undef KC_MM
+#undef KC_TEST1
+#undef KC_MICRO
 #undef KC_PIN
-#undef KC_READ
-#undef KC_MFMA
-#undef KC_SUBSTEP
 #undef KC_ADVANCE
 #undef KC_PIECE
-#undef KC_STEP
 #undef KC_REC_STAGE
 }
 

@@ -2,7 +2,7 @@
 # third form (k_screen256c): parked timing vs the second form, then correctness with MI355DR_SCREEN_FORM=2, then the bench line
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/j15; mkdir -p $OUT
-for r in 1 2; do VARIANTS=4436,202024,202028,202040 ROUNDS=11 timeout 300 tools/bin/screen_bench 9999872 1024 768 5 2>&1 | tail -4; done
+for r in 1 2; do VARIANTS=4436,202024,202028 ROUNDS=11 timeout 300 tools/bin/screen_bench 9999872 1024 768 5 2>&1 | tail -4; done
 echo "== sweep c"; VARIANTS=202024 SWEEP=1 timeout 300 tools/bin/screen_bench 9999872 1024 768 5 2>&1 | grep -v threshold
 echo "== candidate sets equal?"; VARIANTS=4436,202024 timeout 300 tools/bin/screen_bench 1048576 1024 768 2 2>&1 | tail -3
 echo "== bf16"; VARIANTS=600,200000 timeout 300 tools/bin/screen_bench 4194304 1024 768 3 2>&1 | tail -6
