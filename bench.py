@@ -470,7 +470,8 @@ def main() -> None:
     ubench = (MFMA_I8_UBENCH_TOPS["32x32x32"] if i8 else MFMA_BF16_UBENCH_TF)
     roof = {
         "bound": "mfma",
-        "kernel": ("k_screen256b" if B > 128 else "k_screen") + ("<int8>" if i8 else "<bf16>"),
+        "kernel": (("k_screen256", "k_screen256b", "k_screen256c", "k_screen256d")[idx.stat("screen_form")] if B > 128
+                   else "k_screen") + ("<int8>" if i8 else "<bf16>"),
         "op": "int8 multiply-add ops (v_mfma_i32_32x32x32_i8)" if i8 else "bf16 flops (v_mfma_f32_32x32x16_bf16)",
         "achieved": round(alg_flops / screen_s / 1e12, 2) if screen_s > 0 else None,
         "peak": peak,

@@ -130,3 +130,33 @@ def test_screen128_double_buffering(screen_asm, i8):
     last_issue = max(i for i in gl if i < mf[0])
     assert not any("vmcnt" in o for o in ops[last_issue:mf[-1]] if o.startswith("s_waitcnt"))
     assert not any(o.startswith("scratch_") for o in ops)
+
+
+@pytest.mark.parametrize("i8", [False, True])
+def test_screen256c_structure(screen_asm, i8):
+    """Third form (the one the library launches): free-running waves -- one workgroup barrier per K-step, every fragment read
+    issued two micro-steps ahead under counted LDS waits, nine (int8: + the row-group records) LDS-DMA pieces per K-step spread
+    over the micro-steps, the append path out of line (one copy, reached by a call), no scratch."""
+    names = [n for n in screen_asm if "k_screen256cILi" in n and n.endswith(f"ELb{int(i8)}EEEvNS_11ScreenArgs2E")]
+    assert len(names) == 1, sorted(screen_asm)
+    ops = screen_asm[names[0]]
+    want = "v_mfma_i32_32x32x32_i8" if i8 else "v_mfma_f32_32x32x16_bf16"
+    mf = [o for o in ops if o.startswith("v_mfma")]
+    # 8 micro-steps of 4 MFMAs; the two micro-steps that open a tile exist twice (C = 0 as an inline constant)
+    assert len(mf) == 40 and all(o.startswith(want) for o in mf)
+    assert sum(o.rstrip().endswith(", 0") for o in mf) == 8
+    assert not any(o.startswith("scratch_") for o in ops), "register spill in the screen kernel"
+    loop = _loop_blocks(ops)
+    assert sum(o.startswith("s_barrier") for o in loop) == 1
+    dma = [o for o in loop if o.startswith("global_load_lds_dwordx4")]
+    assert len(dma) == 8 and all(", s[" in o for o in dma), dma
+    assert len([o for o in loop if o.startswith("global_load_lds_dword ")]) == (1 if i8 else 0)
+    assert not any(o.startswith("s_load") for o in loop)  # (a scalar load in flight would turn counted LDS waits into lgkmcnt(0))
+    counted = [o for o in loop if o.startswith("s_waitcnt") and "lgkmcnt(" in o and "lgkmcnt(0)" not in o]
+    assert len(counted) >= 6, counted
+    # the hand-over: this wave's pieces of the next K-step have landed, its fragments are in registers
+    i_bar = next(i for i, o in enumerate(loop) if o.startswith("s_barrier"))
+    before = loop[max(0, i_bar - 12):i_bar]
+    assert any(_is_vm0(o) for o in before) and any(o.startswith("s_waitcnt") and "lgkmcnt(0)" in o for o in before)
+    # the append path is a call
+    assert any(o.startswith("s_swappc_b64") for o in ops)

@@ -14,7 +14,7 @@
 #include "dev_common.h"
 #include "k_screen.h"
 #include "k_screen256.h"
-#include "k_screen256c.h"
+#include "k_screen256d.h"
 
 using namespace mi355;
 
@@ -98,6 +98,10 @@ int main(int argc, char** argv) {
 #define SC_FORMS(X) X(1024) X(1028)
 #define SC_ATTR(A) CK(hipFuncSetAttribute((const void*)k_screen256c<A, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
     SC_FORMS(SC_ATTR)
+#define SD_FORMS(X) X(0) X(16) X(32)
+#define SD_ATTR(A) CK(hipFuncSetAttribute((const void*)k_screen256d<A, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
+    SD_FORMS(SD_ATTR)
+    CK(hipFuncSetAttribute((const void*)k_screen256d<kScreen256dAbl, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
     CK(hipFuncSetAttribute((const void*)k_screen256c<kScreen256cAbl, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
     CK(hipFuncSetAttribute((const void*)k_screen256c<kScreen256cAbl, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
     int* status;
@@ -135,7 +139,7 @@ int main(int argc, char** argv) {
         sa.cnt = cnt;
         sa.cand_row = crow;
         sa.cand_val = cval;
-        const bool i8 = variant >= 1000 && variant != 200000;  // (200000 = third form bf16, 201000 + ABL = third form int8)
+        const bool i8 = variant >= 1000 && variant != 200000 && variant != 300000;  // (x00000 = bf16, x01000 + ABL = int8)
         if (i8) variant -= 1000;
         sa.sc = scv;
         sa.kq = kqv;
@@ -157,7 +161,13 @@ int main(int argc, char** argv) {
             sa.n_qtiles = (B + 255) / 256;
             int64_t grid = screen256_grid(sa.n_ctiles, sa.n_qtiles);
             if (getenv("GRIDDIV")) grid = grid / atoi(getenv("GRIDDIV")) / 8 / sa.n_qtiles * 8 * sa.n_qtiles;  // fewer CUs busy
-            if (variant >= 200000) {  // third form (k_screen256c): 200000 + ABL (+1000 for int8)
+            if (variant >= 300000) {  // fourth form (k_screen256d): 300000 + ABL (+1000 for int8)
+                const int abl = variant - 300000;
+                if (!i8) hipLaunchKernelGGL((k_screen256d<kScreen256dAbl, false>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa);
+#define SD_LAUNCH(A) else if (abl == A) hipLaunchKernelGGL((k_screen256d<A, true>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa);
+                SD_FORMS(SD_LAUNCH)
+                else hipLaunchKernelGGL((k_screen256d<kScreen256dAbl, true>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa);
+            } else if (variant >= 200000) {  // third form (k_screen256c): 200000 + ABL (+1000 for int8)
                 const int abl = variant - 200000;
                 if (!i8) hipLaunchKernelGGL((k_screen256c<kScreen256cAbl, false>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa);
 #define SC_LAUNCH(A) else if (abl == A) hipLaunchKernelGGL((k_screen256c<A, true>), dim3((unsigned)grid), dim3(512), kScreen256Lds, 0, sa);
