@@ -1,6 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-# does the corpus stream's HBM latency bound the staging?  small corpora stay in the 256 MB Infinity Cache between launches
-for n in 131072 262144 1048576 9999872; do
-echo "== N=$n"; VARIANTS=4436,202024,202028 ROUNDS=21 timeout 300 tools/bin/screen_bench $n 1024 768 5 2>&1 | tail -3
+# third form: 202024 default ; 202280 = early release ; 202792 = early release + the two waves of a SIMD issue DMA in alternate micro-steps
+echo "== candidate sets equal?"; VARIANTS=4436,202792 timeout 120 tools/bin/screen_bench 1048576 1024 768 2 2>&1 | grep "candidate set"
+for r in 1 2; do
+VARIANTS=202024,202280,202792 ROUNDS=11 timeout 300 tools/bin/screen_bench 9999872 1024 768 5 2>&1 | tail -3
 done
