@@ -104,9 +104,17 @@ def cpu_shape_baselines(Cs: np.ndarray, Qs: np.ndarray, k: int, metric: str, n_t
     C = np.ascontiguousarray(Cs[:S])
     Q = np.ascontiguousarray(Qs[:1024])
     inv = 1.0 / np.linalg.norm(C, axis=1) if metric == "cosine" else None
-    try:
-        from threadpoolctl import threadpool_info
+    # BLAS and torch size their pools from the logical CPUs they see (256 on the GPU boxes); the cgroup grants a 16-CPU quota:
+    # both are held to the quota the oracle uses, so that `cores` is what the figure was measured on
+    from oracle import cpu_ref as _cr
 
+    quota = max(1, int(_cr.num_threads()))
+    torch.set_num_threads(quota)
+    blas_limit = None
+    try:
+        from threadpoolctl import threadpool_info, threadpool_limits
+
+        blas_limit = threadpool_limits(limits=quota, user_api="blas")
         blas_threads = max([t.get("num_threads", 1) for t in threadpool_info() if t.get("user_api") == "blas"] or [1])
     except Exception:  # noqa: BLE001
         blas_threads = None
@@ -157,6 +165,8 @@ def cpu_shape_baselines(Cs: np.ndarray, Qs: np.ndarray, k: int, metric: str, n_t
                 "cores": torch.get_num_threads(),
                 "sample": f"the same, ONE query per call (how the reference's pipeline calls its engine: "
                           f"pipelines/retrieval/vector_search.py:157-169), 16 calls over C[{S}], {t:.2f} s, scaled to N={n_total}"})
+    if blas_limit is not None:
+        blas_limit.restore_original_limits()
     return out
 
 
