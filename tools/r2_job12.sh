@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-# third form: 202024 default ; 202280 = early release ; 202792 = early release + the two waves of a SIMD issue DMA in alternate micro-steps
-echo "== candidate sets equal?"; VARIANTS=4436,202792 timeout 120 tools/bin/screen_bench 1048576 1024 768 2 2>&1 | grep "candidate set"
+# third form, timing ablations: 202024 full | 202026 no fragment reads (MFMA on stale registers) + staging | 202040 reads + MFMA, no staging
+# | 202042 MFMA only
 for r in 1 2; do
-VARIANTS=202024,202280,202792 ROUNDS=11 timeout 300 tools/bin/screen_bench 9999872 1024 768 5 2>&1 | tail -3
+VARIANTS=202024,202026,202040,202042 ROUNDS=11 timeout 300 tools/bin/screen_bench 9999872 1024 768 5 2>&1 | tail -4
 done
