@@ -350,18 +350,17 @@ __global__ __launch_bounds__(kMsThreads, 2) void k_maxsim16(Ms16Args a) {
                 if ((p + 2) % npp == 0) finish_block();
             }
         }
-        for (int qi = 0; qi < a.nq_launch; ++qi) {
-            float accd = 0.0f;
-            for (int j = 0; j < a.q_len[qi]; ++j) {
-                const int c = a.q_col0[qi] + j;
-                float v = 0.0f;
+        for (int qi = 0; qi < a.nq_launch; ++qi) {  // (masked butterfly sum over the query's column blocks: see k_maxsim16_d128)
+            const int cb0 = a.q_col0[qi] >> 5, len = a.q_len[qi];
+            float part = 0.0f;
 #pragma unroll
-                for (int cbi = 0; cbi < 4; ++cbi)
-                    if (cbi == (c >> 5)) v = run[cbi];
-                v = __shfl(v, c & 31, kWave);
-                accd = accd + (-v);
+            for (int cbi = 0; cbi < 4; ++cbi) {
+                const int j = (cbi - cb0) * 32 + (lane & 31);
+                if (cbi >= cb0 && j < len) part += run[cbi];
             }
-            if (lane == 0) a.dist[(int64_t)qi * a.n_docs + doc] = b1 > b0 ? accd : __uint_as_float(0x7FC00000u);
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) part += __shfl_xor(part, o, kWave);
+            if (lane == 0) a.dist[(int64_t)qi * a.n_docs + doc] = b1 > b0 ? -part : __uint_as_float(0x7FC00000u);
         }
     }
 }
@@ -379,58 +378,89 @@ __global__ __launch_bounds__(kMsThreads, 2) void k_maxsim16_d128(Ms16Args a) {
     __syncthreads();
     const uint4* const ql = qs + lane;
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // The wave's kMsDocsPerWave documents are walked as ONE stream of 32-token blocks: the first block of the next document
+    // is requested while the last block of the current one is multiplied (a text document is ~3 blocks: with the pipeline
+    // restarted per document, every document paid one exposed HBM round trip).
+    int64_t dq[kMsDocsPerWave], db0[kMsDocsPerWave], dnb[kMsDocsPerWave];
+#pragma unroll
     for (int dw = 0; dw < kMsDocsPerWave; ++dw) {
-        const int64_t doc = ((int64_t)dw * gridDim.x + blockIdx.x) * 4 + wave;
-        if (doc >= a.n_docs) break;
-        const int64_t b0 = a.blk_off[doc], b1 = a.blk_off[doc + 1];
-        float run[NCB];
+        dq[dw] = ((int64_t)dw * gridDim.x + blockIdx.x) * 4 + wave;
+        const bool live = dq[dw] < a.n_docs;
+        db0[dw] = live ? a.blk_off[dq[dw]] : 0;
+        dnb[dw] = live ? a.blk_off[dq[dw] + 1] - db0[dw] : 0;
+        if (!live) dq[dw] = -1;
+    }
+    uint4 pa[8], pb[8];
+    auto load = [&](uint4(&dst)[8], const uint4* src) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[i] = src[i * 64];
+    };
+    float run[NCB];
+    auto block = [&](const uint4(&fr)[8]) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ms_bf16x8, fr[0]),
+                                                                 __builtin_bit_cast(ms_bf16x8, ql[(cb * 8) * 64]), zero, 0, 0, 0);
+#pragma unroll
+            for (int i = 1; i < 8; ++i)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ms_bf16x8, fr[i]),
+                                                              __builtin_bit_cast(ms_bf16x8, ql[(cb * 8 + i) * 64]), acc, 0, 0, 0);
+            float m = acc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+            run[cb] = fmaxf(run[cb], m);  // (the two halves of the wave are combined once per doc, below)
+        }
+    };
+    auto blk_ptr = [&](int dw, int64_t p) { return a.tok16 + (db0[dw] + p) * (8 * 64) + lane; };
+    // first block of the first non-empty document
+    int parity = 0;
+    {
+        const uint4* first = nullptr;
+#pragma unroll
+        for (int f = kMsDocsPerWave - 1; f >= 0; --f)
+            if (dnb[f] > 0) first = blk_ptr(f, 0);
+        if (first) load(pa, first);
+    }
+#pragma unroll
+    for (int dw = 0; dw < kMsDocsPerWave; ++dw) {
+        const int64_t doc = dq[dw];
+        if (doc < 0) break;
+        const uint4* first_next = nullptr;  // first block of the next non-empty document of this wave
+#pragma unroll
+        for (int f = kMsDocsPerWave - 1; f > dw; --f)
+            if (dnb[f] > 0) first_next = blk_ptr(f, 0);
+        const int64_t nb = dnb[dw];
 #pragma unroll
         for (int c = 0; c < NCB; ++c) run[c] = -__builtin_inff();
-        const uint4* blk = a.tok16 + b0 * (8 * 64) + lane;
-        uint4 pa[8], pb[8];
-        auto load = [&](uint4(&dst)[8], const uint4* src) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) dst[i] = src[i * 64];
-        };
-        auto block = [&](const uint4(&fr)[8]) {
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) {
-                f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ms_bf16x8, fr[0]),
-                                                                     __builtin_bit_cast(ms_bf16x8, ql[(cb * 8) * 64]), zero, 0, 0, 0);
-#pragma unroll
-                for (int i = 1; i < 8; ++i)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ms_bf16x8, fr[i]),
-                                                                  __builtin_bit_cast(ms_bf16x8, ql[(cb * 8 + i) * 64]), acc, 0, 0, 0);
-                float m = acc[0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
-                run[cb] = fmaxf(run[cb], m);  // (the two halves of the wave are combined once per doc, below)
-            }
-        };
-        const int64_t nb = b1 - b0;
-        if (nb > 0) load(pa, blk);
-        for (int64_t p = 0; p < nb; p += 2) {
-            if (p + 1 < nb) load(pb, blk + (p + 1) * (8 * 64));
-            block(pa);
-            if (p + 1 < nb) {
-                if (p + 2 < nb) load(pa, blk + (p + 2) * (8 * 64));
+        for (int64_t p = 0; p < nb; ++p) {
+            // the block after this one: the next of this document, or the first of the next non-empty one
+            const uint4* nxt = p + 1 < nb ? blk_ptr(dw, p + 1) : first_next;
+            if (parity == 0) {
+                if (nxt) load(pb, nxt);
+                block(pa);
+            } else {
+                if (nxt) load(pa, nxt);
                 block(pb);
             }
+            parity ^= 1;
         }
 #pragma unroll
         for (int c = 0; c < NCB; ++c) run[c] = fmaxf(run[c], __shfl_xor(run[c], 32, kWave));
+        // per query: the sum of its columns' maxima.  A query owns whole column blocks (its columns start at a multiple of 32),
+        // so this is a masked sum over the 32 lanes of its blocks: 5 butterfly steps instead of one shuffle per query token
+        // (the serial form -- 128 dependent shuffles per document -- was most of this kernel's time on 3-block documents).
+        // The order of the fp32 additions differs from the exact kernel's; the screen's bound covers any order (e_acc).
         for (int qi = 0; qi < a.nq_launch; ++qi) {
-            float accd = 0.0f;
-            for (int j = 0; j < a.q_len[qi]; ++j) {
-                const int c = a.q_col0[qi] + j;
-                float v = 0.0f;
+            const int cb0 = a.q_col0[qi] >> 5, len = a.q_len[qi];
+            float part = 0.0f;
 #pragma unroll
-                for (int cbi = 0; cbi < NCB; ++cbi)
-                    if (cbi == (c >> 5)) v = run[cbi];
-                v = __shfl(v, c & 31, kWave);
-                accd = accd + (-v);
+            for (int cbi = 0; cbi < NCB; ++cbi) {
+                const int j = (cbi - cb0) * 32 + (lane & 31);  // this lane's column of block cbi as a token index of query qi
+                if (cbi >= cb0 && j < len) part += run[cbi];
             }
-            if (lane == 0) a.dist[(int64_t)qi * a.n_docs + doc] = nb > 0 ? accd : __uint_as_float(0x7FC00000u);
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) part += __shfl_xor(part, o, kWave);
+            if (lane == 0) a.dist[(int64_t)qi * a.n_docs + doc] = nb > 0 ? -part : __uint_as_float(0x7FC00000u);
         }
     }
 }
