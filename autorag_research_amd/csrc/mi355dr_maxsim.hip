@@ -55,8 +55,8 @@ struct MultiVecStore {
     double tok16_norm_max = 0.0;   // largest norm of a bf16-rounded token
     double tok_res_max = 0.0;      // largest residual norm |d - bf16(d)| of a token
     bool finite = true;            // every stored value is finite (else: no screen)
-    uint4* qfrag = nullptr;        // [4 * nkk * 64] query fragments of one launch
-    float* dist16 = nullptr;       // [4, cap_docs] screen distances
+    uint4* qfrag = nullptr;        // [8 * nkk * 64] query fragments of one screen launch (two groups of <= 4 queries)
+    float* dist16 = nullptr;       // [8, cap_docs] screen distances (rows 4..7: the group screened ahead)
     int32_t* cand_list = nullptr;  // [kMsCandCap]
     float* cand_dist = nullptr;    // [kMsCandCap]
     int* cand_ctl = nullptr;       // [2]: count, overflow flag
@@ -269,13 +269,13 @@ typedef __bf16 ms_bf16x8 __attribute__((ext_vector_type(8)));
 struct Ms16Args {
     const uint4* tok16;
     const int64_t* blk_off;
-    const uint4* qfrag;     // [4][nkk][64]
+    const uint4* qfrag;     // [column blocks][nkk][64]
     float* dist;            // [nq_launch, n_docs]
     int64_t n_docs;
     int nkk;
     int nq_launch;
-    int q_col0[4];
-    int q_len[4];
+    int q_col0[8];          // (k_maxsim16_d128 serves two groups of <= 4 queries per launch: rows 0..3 and 4..7)
+    int q_len[8];
 };
 
 __device__ __forceinline__ void ms16_load_piece(uint4 (&a)[8], const uint4* blk, int piece, int nkk, int lane) {
@@ -977,7 +977,7 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
     // scratch
     if (!m->qtok) {
         HIPCHECK(idx, hipMalloc(&m->qtok, (size_t)kMsCols * dp * sizeof(float)));
-        HIPCHECK(idx, hipMalloc(&m->qfrag, lds16));
+        HIPCHECK(idx, hipMalloc(&m->qfrag, 2 * lds16));
         HIPCHECK(idx, hipMalloc(&m->out_d, 4 * kKMax * sizeof(float)));
         HIPCHECK(idx, hipMalloc(&m->out_r, 4 * kKMax * sizeof(int64_t)));
         HIPCHECK(idx, hipMalloc(&m->cand_list, 4 * kMsCandCap * sizeof(int32_t)));
@@ -990,6 +990,10 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
         HIPCHECK(idx, hipFuncSetAttribute((const void*)k_maxsim, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (lds16 <= 160 * 1024)
             HIPCHECK(idx, hipFuncSetAttribute((const void*)k_maxsim16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+        HIPCHECK(idx, hipFuncSetAttribute((const void*)k_maxsim16_d128<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 8192));
+        HIPCHECK(idx, hipFuncSetAttribute((const void*)k_maxsim16_d128<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 8192));
+        HIPCHECK(idx, hipFuncSetAttribute((const void*)k_maxsim16_d128<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 7 * 8192));
+        HIPCHECK(idx, hipFuncSetAttribute((const void*)k_maxsim16_d128<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192));
         HIPCHECK(idx, hipFuncSetAttribute((const void*)k_topk_segments, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           kSegSort * 12));
     }
@@ -997,7 +1001,7 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
         if (m->dist) (void)hipFree(m->dist);
         if (m->dist16) (void)hipFree(m->dist16);
         HIPCHECK(idx, hipMalloc(&m->dist, (size_t)4 * m->cap_docs * sizeof(float)));
-        HIPCHECK(idx, hipMalloc(&m->dist16, (size_t)4 * m->cap_docs * sizeof(float)));
+        HIPCHECK(idx, hipMalloc(&m->dist16, (size_t)8 * m->cap_docs * sizeof(float)));
         for (int i = 0; i < 2; ++i) {
             if (m->sel[i]) (void)hipFree(m->sel[i]);
             HIPCHECK(idx, hipMalloc(&m->sel[i], (size_t)4 * ((m->cap_docs + kMsSelSeg - 1) / kMsSelSeg) * kMsFastK * sizeof(uint32_t)));
@@ -1023,7 +1027,7 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
     // bf16 round-to-nearest: unit roundoff 2^-8 per operand -> 2^-7 + 2^-16 per product
     const double eps = std::ldexp(1.0, -7) + std::ldexp(1.0, -15) + 3.0 * d * std::ldexp(1.0, -24);
     // pinned staging (pageable copies are synchronous and cost ~20 us each)
-    const size_t qimg_n = (size_t)kMsCols * dp, qf16_n = (size_t)4 * nkk * 64 * 8;
+    const size_t qimg_n = (size_t)kMsCols * dp, qf16_n = (size_t)8 * nkk * 64 * 8;
     const size_t need_stage = qimg_n * 4 + qf16_n * 2 + 4 * kKMax * 12 + 64;
     if (m->stage_bytes < need_stage) {
         if (m->stage_host) (void)hipHostFree(m->stage_host);
@@ -1052,10 +1056,67 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
         size_t size() const { return n; }
         uint16_t& operator[](size_t i) { return p[i]; }
     } qf16{qf16_p, qf16_n};
+    // one group = up to 4 queries whose 32-padded token counts fit 128 columns.  pack() writes the group's bf16 fragments at
+    // column base `fcol0` of qf16 (fcol0 < 0: none) and, with `img`, its fp32 image for the exact kernel into qimg.
+    struct Group {
+        int nql = 0, col = 0, b_end = 0;
+        int q_col0[4] = {0, 0, 0, 0}, q_len[4] = {0, 0, 0, 0};
+        double two_e[4] = {0, 0, 0, 0};
+        bool finite = true;
+    };
+    auto pack = [&](int b0, int fcol0, bool img) {
+        Group g;
+        int bb = b0;
+        while (bb < B && g.nql < 4) {
+            const int nq = q_offsets[bb + 1] - q_offsets[bb];
+            const int need = (int)round_up(std::max(nq, 1), 32);
+            if (g.col + need > kMsCols) break;
+            g.q_col0[g.nql] = g.col;
+            g.q_len[g.nql] = nq;
+            double norm_sum = 0.0, res_sum = 0.0;
+            for (int j = 0; j < nq; ++j) {
+                const float* sv = qtok + (int64_t)(q_offsets[bb] + j) * d;
+                if (img) {
+                    float* dst = &qimg[(size_t)(g.col + j) * dp];
+                    for (int c = 0; c < dp; ++c) {
+                        const int oc = ms_perm(c);
+                        dst[c] = oc < d ? sv[oc] : 0.0f;
+                    }
+                }
+                // bf16 fragment of the same column: block cb = column / 32, lane = (column & 31) + 32 * half
+                double n2 = 0.0, r2 = 0.0;
+                const int cc = fcol0 + g.col + j;
+                for (int c = 0; c < d; ++c) {
+                    if (!std::isfinite(sv[c])) g.finite = false;
+                    const uint16_t h = host_bf16_rn(sv[c]);
+                    const double x = sv[c], x16 = host_bf16_to_f32(h);
+                    n2 += x * x;
+                    r2 += (x - x16) * (x - x16);
+                    if (fcol0 >= 0) {
+                        const int kk = c / 16, half = (c % 16) / 8, jj = c % 8;
+                        qf16[((((size_t)(cc >> 5) * nkk + kk) * 64) + (cc & 31) + 32 * half) * 8 + jj] = h;
+                    }
+                }
+                norm_sum += std::sqrt(n2);
+                res_sum += std::sqrt(r2);
+            }
+            // per token pair: |q16.d16 - q.d| <= |r_q||d16| + |q||r_d| with the residuals MEASURED (round-to-nearest leaves
+            // about half of the a-priori 2^-8 |x|), + fp32 accumulation of both dot products and of the per-doc sums
+            const double e_pair = res_sum * m->tok16_norm_max + norm_sum * m->tok_res_max;
+            const double e_acc = (3.0 * d + 2.0 * nq) * std::ldexp(1.0, -24) * m->tok_norm_max * norm_sum;
+            g.two_e[g.nql] = 2.0 * std::min(e_pair + e_acc, (eps + 2.0 * nq * std::ldexp(1.0, -24)) * m->tok_norm_max * norm_sum) *
+                             (1.0 + 1e-6);
+            g.col += need;
+            ++g.nql;
+            ++bb;
+        }
+        g.b_end = bb;
+        return g;
+    };
     int b = 0;
+    int pre_first = -1;  // first query of the group whose screen distances already sit in rows 4..7 of dist16
     while (b < B) {
         HIPCHECK(idx, hipStreamSynchronize(s));  // the staging buffers are free again
-        // pack queries into one launch while their 32-padded token counts fit 128 columns (max 4 queries)
         MsArgs a{};
         a.tok = m->tok;
         a.blk_off = m->blk_off;
@@ -1066,55 +1127,29 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
         a.doc_list = nullptr;
         a.n_items_dev = nullptr;
         a.dpad = dp;
+        const bool pre = pre_first == b;  // this group was screened together with the previous one
         std::fill(qimg.begin(), qimg.end(), 0.0f);
-        std::fill(qf16.begin(), qf16.end(), (uint16_t)0);
-        int col = 0, nql = 0, first = b;
-        bool q_finite = true;
-        double two_e[4] = {0, 0, 0, 0};
-        while (b < B && nql < 4) {
-            const int nq = q_offsets[b + 1] - q_offsets[b];
-            const int need = (int)round_up(std::max(nq, 1), 32);
-            if (col + need > kMsCols) break;
-            a.q_col0[nql] = col;
-            a.q_len[nql] = nq;
-            double norm_sum = 0.0, res_sum = 0.0;
-            for (int j = 0; j < nq; ++j) {
-                float* dst = &qimg[(size_t)(col + j) * dp];
-                const float* sv = qtok + (int64_t)(q_offsets[b] + j) * d;
-                for (int c = 0; c < dp; ++c) {
-                    const int oc = ms_perm(c);
-                    dst[c] = oc < d ? sv[oc] : 0.0f;
-                }
-                // bf16 fragment of the same column: block cb = (col+j)/32, lane = ((col+j)&31) + 32*half
-                double n2 = 0.0, r2 = 0.0;
-                const int cc = col + j;
-                for (int c = 0; c < d; ++c) {
-                    if (!std::isfinite(sv[c])) q_finite = false;
-                    const uint16_t h = host_bf16_rn(sv[c]);
-                    const double x = sv[c], x16 = host_bf16_to_f32(h);
-                    n2 += x * x;
-                    r2 += (x - x16) * (x - x16);
-                    const int kk = c / 16, half = (c % 16) / 8, jj = c % 8;
-                    qf16[((((size_t)(cc >> 5) * nkk + kk) * 64) + (cc & 31) + 32 * half) * 8 + jj] = h;
-                }
-                norm_sum += std::sqrt(n2);
-                res_sum += std::sqrt(r2);
-            }
-            // per token pair: |q16.d16 - q.d| <= |r_q||d16| + |q||r_d| with the residuals MEASURED (round-to-nearest leaves
-            // about half of the a-priori 2^-8 |x|), + fp32 accumulation of both dot products and of the per-doc sums
-            const double e_pair = res_sum * m->tok16_norm_max + norm_sum * m->tok_res_max;
-            const double e_acc = (3.0 * d + 2.0 * nq) * std::ldexp(1.0, -24) * m->tok_norm_max * norm_sum;
-            two_e[nql] = 2.0 * std::min(e_pair + e_acc, (eps + 2.0 * nq * std::ldexp(1.0, -24)) * m->tok_norm_max * norm_sum) *
-                         (1.0 + 1e-6);
-            col += need;
-            ++nql;
-            ++b;
+        if (!pre) std::fill(qf16.begin(), qf16.end(), (uint16_t)0);
+        const int first = b;
+        const Group G = pack(b, pre ? -1 : 0, true);
+        b = G.b_end;
+        const int nql = G.nql, col = G.col;
+        const bool q_finite = G.finite;
+        double two_e[4];
+        for (int qi = 0; qi < 4; ++qi) {
+            a.q_col0[qi] = G.q_col0[qi];
+            a.q_len[qi] = G.q_len[qi];
+            two_e[qi] = G.two_e[qi];
         }
         a.nq_launch = nql;
         HIPCHECK(idx, hipMemcpyAsync(m->qtok, qimg.data(), qimg.size() * sizeof(float), hipMemcpyHostToDevice, s));
         const bool screen = idx->maxsim_screen && m->finite && q_finite && lds16 <= 160 * 1024;
-        if (screen) {
-            HIPCHECK(idx, hipMemcpyAsync(m->qfrag, qf16.data(), qf16.size() * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+        float* dist16 = m->dist16;  // this group's screen distances: [4, n_docs]
+        if (screen && pre) {
+            dist16 = m->dist16 + 4 * m->n_docs;
+            pre_first = -1;
+        } else if (screen) {
+            pre_first = -1;
             Ms16Args sa{};
             sa.tok16 = m->tok16;
             sa.blk_off = m->blk_off;
@@ -1127,20 +1162,43 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
                 sa.q_col0[qi] = a.q_col0[qi];
                 sa.q_len[qi] = a.q_len[qi];
             }
-            const int ncb_launch = (col + 31) / 32;
+            int ncb_launch = (col + 31) / 32;
+            // The screen is HBM-bound on the token stream: the NEXT group (<= 4 more queries) rides the same pass in column blocks
+            // 4..7 and rows 4..7 of dist16 (dims <= 128, the single-launch selection path); its turn then starts at the selection.
+            if (nkk == 8 && k <= kMsFastK && b < B) {
+                const Group H = pack(b, kMsCols, false);
+                if (H.nql > 0 && H.finite) {
+                    for (int qi = 0; qi < 4; ++qi) {
+                        sa.q_col0[4 + qi] = kMsCols + H.q_col0[qi];
+                        sa.q_len[4 + qi] = H.q_len[qi];
+                    }
+                    sa.nq_launch = 4 + H.nql;  // (rows nql..3: zero-length queries, their rows are never read)
+                    ncb_launch = 4 + (H.col + 31) / 32;
+                    pre_first = b;
+                } else {  // (the fragments pack() may have written for H are not used: clear them)
+                    std::fill(qf16.begin() + (size_t)4 * nkk * 64 * 8, qf16.end(), (uint16_t)0);
+                }
+            }
+            HIPCHECK(idx, hipMemcpyAsync(m->qfrag, qf16.data(), (size_t)std::max(ncb_launch, 4) * nkk * 64 * 8 * sizeof(uint16_t),
+                                         hipMemcpyHostToDevice, s));
             if (nkk == 8) {  // dims <= 128: the compile-time-unrolled form, only as many column blocks as the pass has
                 const size_t l16 = (size_t)ncb_launch * 8 * 64 * sizeof(uint4);
                 switch (ncb_launch) {
                     case 1: hipLaunchKernelGGL(k_maxsim16_d128<1>, dim3(grid_all), dim3(kMsThreads), l16, s, sa); break;
                     case 2: hipLaunchKernelGGL(k_maxsim16_d128<2>, dim3(grid_all), dim3(kMsThreads), l16, s, sa); break;
                     case 3: hipLaunchKernelGGL(k_maxsim16_d128<3>, dim3(grid_all), dim3(kMsThreads), l16, s, sa); break;
-                    default: hipLaunchKernelGGL(k_maxsim16_d128<4>, dim3(grid_all), dim3(kMsThreads), l16, s, sa); break;
+                    case 4: hipLaunchKernelGGL(k_maxsim16_d128<4>, dim3(grid_all), dim3(kMsThreads), l16, s, sa); break;
+                    case 5: hipLaunchKernelGGL(k_maxsim16_d128<5>, dim3(grid_all), dim3(kMsThreads), l16, s, sa); break;
+                    case 6: hipLaunchKernelGGL(k_maxsim16_d128<6>, dim3(grid_all), dim3(kMsThreads), l16, s, sa); break;
+                    case 7: hipLaunchKernelGGL(k_maxsim16_d128<7>, dim3(grid_all), dim3(kMsThreads), l16, s, sa); break;
+                    default: hipLaunchKernelGGL(k_maxsim16_d128<8>, dim3(grid_all), dim3(kMsThreads), l16, s, sa); break;
                 }
             } else {
                 hipLaunchKernelGGL(k_maxsim16, dim3(grid_all), dim3(kMsThreads), lds16, s, sa);
             }
             HIPCHECK(idx, hipGetLastError());
         } else {
+            pre_first = -1;
             hipLaunchKernelGGL(k_maxsim, dim3(grid_all), dim3(kMsThreads), lds, s, a);
             HIPCHECK(idx, hipGetLastError());
         }
@@ -1154,7 +1212,7 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
             while (true) {  // k best screen distances per 1024-entry segment, until one segment is left
                 const int64_t nseg = (n_in + kMsSelSeg - 1) / kMsSelSeg;
                 hipLaunchKernelGGL(k_ms_select, dim3((unsigned)nseg, nql), dim3(kWave), 0, s,
-                                   first_stage ? m->dist16 : nullptr, m->blk_off, first_stage ? nullptr : m->sel[cur ^ 1], n_in,
+                                   first_stage ? dist16 : nullptr, m->blk_off, first_stage ? nullptr : m->sel[cur ^ 1], n_in,
                                    first_stage ? m->n_docs : sel_stride, k, m->sel[cur], sel_stride);
                 HIPCHECK(idx, hipGetLastError());
                 first_stage = false;
@@ -1169,7 +1227,7 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
             }
             HIPCHECK(idx, hipMemcpyAsync(m->two_e_dev, te, sizeof(te), hipMemcpyHostToDevice, s));
             HIPCHECK(idx, hipMemsetAsync(m->cand_ctl, 0, 8 * sizeof(int), s));
-            hipLaunchKernelGGL(k_ms_candidates_y, dim3((unsigned)((m->n_docs + 255) / 256), nql), dim3(256), 0, s, m->dist16,
+            hipLaunchKernelGGL(k_ms_candidates_y, dim3((unsigned)((m->n_docs + 255) / 256), nql), dim3(256), 0, s, dist16,
                                m->n_docs, m->blk_off, m->n_docs, m->sel[cur], sel_stride, k, m->two_e_dev, m->cand_list,
                                kMsCandCap, m->cand_ctl);
             HIPCHECK(idx, hipGetLastError());
@@ -1219,12 +1277,12 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
                 HIPCHECK(idx, hipGetLastError());
             } else if (screen) {
                 // screen top-k -> candidates -> exact kernel on the candidates -> exact top-k
-                CHECK(ms_topk(idx, m, s, m->dist16 + (int64_t)qi * m->n_docs, m->n_docs, k, seg, nullptr, nullptr, &cur));
+                CHECK(ms_topk(idx, m, s, dist16 + (int64_t)qi * m->n_docs, m->n_docs, k, seg, nullptr, nullptr, &cur));
                 HIPCHECK(idx, hipMemsetAsync(m->cand_ctl, 0, 2 * sizeof(int), s));
                 float te = (float)two_e[qi];
                 if ((double)te < two_e[qi]) te = std::nextafter(te, INFINITY);
                 hipLaunchKernelGGL(k_ms_candidates, dim3((unsigned)((m->n_docs + 255) / 256)), dim3(256), 0, s,
-                                   m->dist16 + (int64_t)qi * m->n_docs, m->blk_off, m->n_docs, m->pk[cur], k, te, m->cand_list,
+                                   dist16 + (int64_t)qi * m->n_docs, m->blk_off, m->n_docs, m->pk[cur], k, te, m->cand_list,
                                    kMsCandCap, m->cand_ctl);
                 HIPCHECK(idx, hipGetLastError());
                 MsArgs c = a;

@@ -174,13 +174,14 @@ def run_maxsim(args, n_docs: int, tokens: str, nq: int, steps: int, warmup: int,
     """MaxSim top-k (VectorChord `@#`) on a synthetic multi-vector store built ON THE DEVICE (token vectors generated in
     HBM, handed to the index by pointer: mi355dr_add_multivec_device).  `tokens` = "text" (ColBERT-like: U{32..180} vectors
     per doc) or "page" (ColPali-like: 1030 patch vectors per doc); d = 128, unit-norm vectors, seed 777.
-    A step = one block of 4 queries x `nq` query vectors against every document: bf16 MFMA screen over the bf16 fragment
-    copy (HBM-bound), exact fp32 MFMA kernel on the candidates; wall clock includes H2D of the queries and D2H of [4,k]."""
+    A step = one call with 8 queries x `nq` query vectors against every document: ONE bf16 MFMA screen pass over the bf16
+    fragment copy (HBM-bound) serves both groups of 4, then per group the selection and the exact fp32 MFMA kernel on the
+    candidates; wall clock includes H2D of the queries and D2H of [8,k]."""
     import torch
 
     import autorag_research_amd as pkg
 
-    d, qblock, k = 128, 4, args.k
+    d, qblock, k = 128, 8, args.k
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     rng = np.random.default_rng(777)
     lens = rng.integers(32, 181, size=n_docs) if tokens == "text" else np.full((n_docs,), 1030, dtype=np.int64)
@@ -218,7 +219,7 @@ def run_maxsim(args, n_docs: int, tokens: str, nq: int, steps: int, warmup: int,
     el = time.perf_counter() - t0
     assert (np.diff(res[0], axis=1) >= 0).all()
     blocks = int(((lens + 31) // 32).sum())
-    alg_bytes = float(lens.sum()) * d * 4 * steps                # fp32 token rows read once per 4-query pass
+    alg_bytes = float(lens.sum()) * d * 4 * steps                # fp32 token rows read once per 8-query pass
     streamed = float(blocks) * 32 * d * 2 * steps                # bf16 fragment store the screen streams
     flops = 2.0 * (qblock * nq) * blocks * 32 * d * steps        # what the screen issues (32-row padded docs)
     screened, cands, fb = idx.stat("maxsim_screened"), idx.stat("maxsim_candidates"), idx.stat("maxsim_fallbacks")
