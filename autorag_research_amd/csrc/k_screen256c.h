@@ -31,6 +31,12 @@ namespace mi355 {
 
 constexpr int kScreen256cAbl = 1024;  // SADDR (the only staging form this kernel has)
 
+// LDS-DMA pieces per micro-step slot {5, 6, 7 | 0, 1, 2, 3, 4} for schedule id (0 = what the library runs; the others are the
+// A/B of tools/r2_job21.sh: +1.5 ... +5 %.  More pieces right behind the hand-over, or a thinner, longer spread: both lose.)
+__host__ __device__ constexpr int kc_sched(int id, int slot) {
+    constexpr int t[4][8] = {{2, 2, 0, 2, 2, 1, 0, 0}, {2, 2, 0, 1, 1, 1, 1, 1}, {1, 1, 1, 1, 1, 2, 2, 0}, {2, 2, 0, 2, 1, 1, 1, 0}};
+    return t[id][slot];
+}
 template <int ABL, bool I8>
 __global__ __launch_bounds__(512, 2) void k_screen256c(ScreenArgs2 a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -122,14 +128,17 @@ __global__ __launch_bounds__(512, 2) void k_screen256c(ScreenArgs2 a) {
             }                                                                                         \
         }                                                                                             \
     } while (0)
-// piece P (0..8) of the cursor's K-step into ring parity PAR: A0 A0 B0 | B0 B1 B1 | A1 A1 records
+// piece P (0..8) of the cursor's K-step into ring parity PAR.  Issue order: the corpus half-tiles first (A0 A0 A1 A1), then
+// the query half-tiles (B0 B0 B1 B1), then the records -- the pieces that may have to come from HBM get the longest lead
+// (-1.6 % against A0 B0 | B1 A1).  
 #define KC_PIECE(PAR, P, RECPOS)                                                                      \
     do {                                                                                              \
         if constexpr ((ABL & 16) == 0) {                                                              \
-            if ((P) == 0 || (P) == 1) kb_stage<0, true>(smem, wave, PAR, c_base + c_k, voffA, (P) & 1);           \
-            else if ((P) == 2 || (P) == 3) kb_stage<1, true>(smem, wave, PAR, baseB + c_k, voffB, (P) & 1);        \
-            else if ((P) == 4 || (P) == 5) kb_stage<2, true>(smem, wave, PAR, baseB + half_B + c_k, voffB, (P) & 1); \
-            else if ((P) == 6 || (P) == 7) kb_stage<3, true>(smem, wave, PAR, c_base + half_A + c_k, voffA, (P) & 1); \
+            const int c__ = (P);                                                                      \
+            if (c__ == 0 || c__ == 1) kb_stage<0, true>(smem, wave, PAR, c_base + c_k, voffA, c__ & 1);            \
+            else if (c__ == 2 || c__ == 3) kb_stage<3, true>(smem, wave, PAR, c_base + half_A + c_k, voffA, c__ & 1); \
+            else if (c__ == 4 || c__ == 5) kb_stage<1, true>(smem, wave, PAR, baseB + c_k, voffB, c__ & 1);        \
+            else if (c__ == 6 || c__ == 7) kb_stage<2, true>(smem, wave, PAR, baseB + half_B + c_k, voffB, c__ & 1); \
             else KC_REC_STAGE(RECPOS);                                                                \
         }                                                                                             \
     } while (0)
@@ -192,6 +201,12 @@ __global__ __launch_bounds__(512, 2) void k_screen256c(ScreenArgs2 a) {
         KC_PIN();                                                                                     \
     } while (0)
 
+    // pieces per micro-step 5, 6, 7 (behind the hand-over) | 0, 1, 2, 3, 4 (next K-step); bits 7, 8: the schedule id
+    constexpr int kSched = (ABL >> 7) & 3;
+    constexpr int kN5 = kc_sched(kSched, 0), kN6 = kc_sched(kSched, 1), kN7 = kc_sched(kSched, 2), kN0 = kc_sched(kSched, 3),
+                  kN1 = kc_sched(kSched, 4), kN2 = kc_sched(kSched, 5), kN3 = kc_sched(kSched, 6), kN4 = kc_sched(kSched, 7);
+    constexpr int kNLate = kN5 + kN6 + kN7;
+    static_assert(kNLate + kN0 + kN1 + kN2 + kN3 + kN4 == 9, "nine pieces per K-step");
     constexpr int kPF = (ABL & 2048) ? 2 : 3;  // fragment reads run this many micro-steps ahead (3: -1.7 % against 2, bit 11)
     bf16x8 fAq[4][2], fBk[4][2];
     // ---- prologue: K-step 0 completely into parity 0, the first four pieces of K-step 1 into parity 1; K-step 0 landed
@@ -200,8 +215,10 @@ __global__ __launch_bounds__(512, 2) void k_screen256c(ScreenArgs2 a) {
     for (int p = 0; p < 9; ++p) KC_PIECE(0, p, 0);
     KC_ADVANCE();
 #pragma unroll
-    for (int p = 0; p < 4; ++p) KC_PIECE(1, p, 1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // K-step 0 (+ its records) has landed (this wave's pieces)
+    for (int p = 0; p < kNLate; ++p) KC_PIECE(1, p, 1);
+    if constexpr (kNLate == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (kNLate == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // K-step 0 (+ its records) has landed (this wave's pieces)
     MI355_BARRIER();
     int par = 0, t = 0;
     KC_PREFETCH(0);
@@ -219,28 +236,27 @@ __global__ __launch_bounds__(512, 2) void k_screen256c(ScreenArgs2 a) {
             que_n = 0;
         }
         // K-step g = gpos, ring parity par.  Staging: pieces 4..8 of K-step g+1 (into par^1) in micro-steps 0..2, pieces 0..3
-        // of K-step g+2 (into par) behind the hand-over in micro-steps 6, 7: at most two LDS-DMA instructions per micro-step
+        // of K-step g+2 (into par) behind the hand-over in micro-steps 5, 6: at most two LDS-DMA instructions per micro-step
         // (all nine at once -- 8 waves x 9 through the one texture-address path of the CU -- held the matrix pipe up).
         const bool tp = first && have_prev;  // test the previous tile's row half 1 under this K-step's row half 0
         if (first) {  // (a tile's first MFMA per block starts from C = 0 -- an inline constant -- instead of zeroing registers)
             asm volatile("; first K-step of a tile");
-            KC_MICRO(0, true, par ^ 1, 4, 2, gpos + 1);
+            KC_MICRO(0, true, par ^ 1, kNLate, kN0, gpos + 1);
         } else {
-            KC_MICRO(0, false, par ^ 1, 4, 2, gpos + 1);
+            KC_MICRO(0, false, par ^ 1, kNLate, kN0, gpos + 1);
         }
         if (tp) KC_TEST1(1, 0, 0, row0_prev, gpos - 1);
-        KC_MICRO(1, false, par ^ 1, 6, 2, gpos + 1);
+        KC_MICRO(1, false, par ^ 1, kNLate + kN0, kN1, gpos + 1);
         if (tp) KC_TEST1(1, 0, 1, row0_prev, gpos - 1);
-        KC_MICRO(2, false, par ^ 1, 8, 1, gpos + 1);
-        KC_ADVANCE();
+        KC_MICRO(2, false, par ^ 1, kNLate + kN0 + kN1, kN2, gpos + 1);
         if (tp) KC_TEST1(1, 1, 0, row0_prev, gpos - 1);
-        KC_MICRO(3, false, par, 0, 0, 0);
+        KC_MICRO(3, false, par ^ 1, kNLate + kN0 + kN1 + kN2, kN3, gpos + 1);
         if (tp) KC_TEST1(1, 1, 1, row0_prev, gpos - 1);
         if (first) {
             asm volatile("; first K-step of a tile, row half 1");
-            KC_MICRO(4, true, par, 0, 0, 0);
+            KC_MICRO(4, true, par ^ 1, kNLate + kN0 + kN1 + kN2 + kN3, kN4, gpos + 1);
         } else {
-            KC_MICRO(4, false, par, 0, 0, 0);
+            KC_MICRO(4, false, par ^ 1, kNLate + kN0 + kN1 + kN2 + kN3, kN4, gpos + 1);
         }
         if (last) KC_TEST1(0, 0, 0, row0_cur, gpos);
 #define KC_HANDOVER()                                                                                 \
@@ -251,13 +267,14 @@ __global__ __launch_bounds__(512, 2) void k_screen256c(ScreenArgs2 a) {
         KC_PIN();                                                                                     \
     } while (0)
         // ---- hand-over of the ring: every read of K-step g has been issued (the last ones kPF micro-steps before the end)
+        KC_ADVANCE();
         if constexpr (kPF == 3) KC_HANDOVER();
-        KC_MICRO(5, false, par, 0, kPF == 3 ? 2 : 0, gpos + 2);
+        KC_MICRO(5, false, par, 0, kPF == 3 ? kN5 : 0, gpos + 2);
         if (last) KC_TEST1(0, 0, 1, row0_cur, gpos);
         if constexpr (kPF == 2) KC_HANDOVER();
-        KC_MICRO(6, false, par, kPF == 3 ? 2 : 0, 2, gpos + 2);
+        KC_MICRO(6, false, par, kPF == 3 ? kN5 : 0, kPF == 3 ? kN6 : 2, gpos + 2);
         if (last) KC_TEST1(0, 1, 0, row0_cur, gpos);
-        KC_MICRO(7, false, par, 2, kPF == 3 ? 0 : 2, gpos + 2);
+        KC_MICRO(7, false, par, kPF == 3 ? kN5 + kN6 : 2, kPF == 3 ? kN7 : 2, gpos + 2);
 #undef KC_HANDOVER
         if (last) KC_TEST1(0, 1, 1, row0_cur, gpos);
         par ^= 1;
