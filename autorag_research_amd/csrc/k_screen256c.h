@@ -163,10 +163,12 @@ __global__ __launch_bounds__(512, 2) void k_screen256c(ScreenArgs2 a) {
 // reads for micro-step M2 (0..9; 8, 9 = micro-steps 0, 1 of the next K-step, other ring parity)
 #define KC_PREFETCH(M2)                                                                               \
     do {                                                                                              \
-        constexpr int m2__ = (M2) & 7;                                                                \
-        const int rp__ = (M2) >= 8 ? (par ^ 1) : par;                                                 \
-        if (m2__ < 4) KC_RD_B(rp__, m2__ & 3);                                                        \
-        KC_RD_A(m2__ & 3, m2__ >> 2, rp__, m2__ & 3);                                                 \
+        if constexpr ((ABL & 1) == 0) {  /* (bit 0: timing build without fragment reads) */            \
+            constexpr int m2__ = (M2) & 7;                                                            \
+            const int rp__ = (M2) >= 8 ? (par ^ 1) : par;                                             \
+            if (m2__ < 4) KC_RD_B(rp__, m2__ & 3);                                                    \
+            KC_RD_A(m2__ & 3, m2__ >> 2, rp__, m2__ & 3);                                             \
+        }                                                                                             \
     } while (0)
 #define KC_MM(M, ZERO)                                                                                \
     do {                                                                                              \
@@ -209,6 +211,12 @@ __global__ __launch_bounds__(512, 2) void k_screen256c(ScreenArgs2 a) {
     static_assert(kNLate + kN0 + kN1 + kN2 + kN3 + kN4 == 9, "nine pieces per K-step");
     constexpr int kPF = (ABL & 2048) ? 2 : 3;  // fragment reads run this many micro-steps ahead (3: -1.7 % against 2, bit 11)
     bf16x8 fAq[4][2], fBk[4][2];
+    if constexpr ((ABL & 1) != 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" : "=v"(fAq[i][j]), "=v"(fBk[i][j]));
+    }
     // ---- prologue: K-step 0 completely into parity 0, the first four pieces of K-step 1 into parity 1; K-step 0 landed
     // and visible; fragments of micro-steps 0 and 1
 #pragma unroll
