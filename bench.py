@@ -80,6 +80,9 @@ def parse_args():
     ap.add_argument("--comm", choices=["torch", "lib"], default="torch",
                     help="N > 1: all-gather through torch.distributed (RCCL, overlapped with the next step's search on a second "
                          "stream) or through the library's own RCCL communicator (mi355dr_search_sharded_device)")
+    ap.add_argument("--row-sharded-leg", action="store_true",
+                    help="also measure the fully row-sharded layout (world x 1) after the main run and report it under "
+                         "extra.row_sharded (default at world > 1 when the main layout is not already that one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (planted-answer nDCG, PCIe-inclusive "
                                                            "rate, BLAS / torch / B=1 CPU baselines)")
@@ -267,6 +270,84 @@ def main_maxsim(args) -> None:
     if "cpu_baseline" in r:
         out["cpu_baseline"] = r["cpu_baseline"]
     print(json.dumps(out))
+
+
+def row_sharded_leg(args, torch, pkg, dist, device, local_rank, rank, world, qpool, ref_block, make_chunk) -> dict:
+    """BASELINE.json's config C3 as named -- the corpus row-sharded over ALL ranks, every rank answering the SAME query block
+    against its 1/world of the rows, one packed all-gather + k_merge_topk per step (overlapped with the next step's search)
+    -- measured after the main run on a second, shard-sized index, and checked against the main layout's answer."""
+    n_total, d, B, k = args.rows, args.dim, args.block, args.k
+    n_chunks = (n_total + CHUNK_ROWS - 1) // CHUNK_ROWS
+    c_lo, c_hi = n_chunks * rank // world, n_chunks * (rank + 1) // world
+    row_lo = min(n_total, c_lo * CHUNK_ROWS)
+    n_local = min(n_total, c_hi * CHUNK_ROWS) - row_lo
+    idx = pkg.Mi355Index(d, args.metric, device=local_rank)
+    idx.reserve(n_local)
+    idx.set_option("row_offset", row_lo)
+    idx.set_option("screen_dtype", args.screen)
+    for c in range(c_lo, c_hi):
+        x = make_chunk(c, min(CHUNK_ROWS, n_total - c * CHUNK_ROWS))
+        torch.cuda.synchronize()
+        idx.add_device(x.data_ptr(), x.shape[0])
+        del x
+    torch.cuda.synchronize()
+    n_pool = qpool.shape[0]
+    stream = torch.cuda.current_stream().cuda_stream
+    comm_stream = torch.cuda.Stream(device)
+    packed2 = [torch.empty((2, B, k), device=device, dtype=torch.int64) for _ in range(2)]
+    all2 = [torch.empty((world, 2, B, k), device=device, dtype=torch.int64) for _ in range(2)]
+    fin2 = [torch.empty((2, B, k), device=device, dtype=torch.int64) for _ in range(2)]
+    done = [None, None]
+
+    def step(i: int):
+        buf = i & 1
+        if done[buf] is not None:
+            torch.cuda.current_stream().wait_event(done[buf])
+        pk = packed2[buf]
+        idx.search_device(qpool[i % n_pool].data_ptr(), B, k, pk[0].data_ptr(), pk[1].data_ptr(), stream)
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(ready)
+            dist.all_gather_into_tensor(all2[buf].view(-1), pk.view(-1))
+            idx.merge_topk_packed_device(all2[buf].data_ptr(), world, B, k, fin2[buf][0].data_ptr(), fin2[buf][1].data_ptr(),
+                                         comm_stream.cuda_stream)
+            done[buf] = torch.cuda.Event()
+            done[buf].record(comm_stream)
+        return fin2[buf]
+
+    out0 = step(0)
+    torch.cuda.synchronize()
+    identical = bool(torch.equal(out0, ref_block)) if ref_block is not None else None
+    steps = max(4, min(args.steps, 20))
+    step(1)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(2 + i)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    agree = torch.tensor([1.0 if identical in (True, None) else 0.0], device=device, dtype=torch.float64)
+    dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+    idx.close()
+    return {
+        "layout": f"{world} row shards x 1 query group (every rank: the same {B}-query block against {n_local} of the "
+                  f"{n_total} rows; one packed all-gather + k_merge_topk per step on a second stream)",
+        "scaling": "strong",
+        "queries_per_s": round(steps * B / elapsed, 1),
+        "ms_per_step": round(elapsed * 1e3 / steps, 3),
+        "steps": steps,
+        "identical_to_main_layout": bool(agree.item() == 1.0) if ref_block is not None else None,
+        "note": "NOT `value`: the default layout answers independent query blocks on replicas when the corpus fits one GPU "
+                "(DESIGN.md section 5)",
+    }
 
 
 def main() -> None:
@@ -664,7 +745,42 @@ def main() -> None:
         rd_, rr_ = res[0].cpu().numpy(), res[1].cpu().numpy()
         assert (np.diff(rd_, axis=1) >= 0).all(), "distances not ascending"
         assert rr_.min() >= 0 and rr_.max() < n_total
+    want_leg = args.row_sharded_leg or (world > 1 and R != world and not args.no_extras)
+    ref_block = None
+    if want_leg:
+        # the main layout's answer for block 0 of the pool: the row-sharded leg must reproduce it bit for bit
+        ref_block = torch.empty((2, B, k), device=device, dtype=torch.int64)
+        if use_dist:
+            idx.search_device(qpool[0].data_ptr(), B, k, packed[0].data_ptr(), packed[1].data_ptr(), stream)
+            dist.all_gather_into_tensor(packed_all.view(-1), packed.view(-1), group=row_group)
+            idx.merge_topk_packed_device(packed_all.data_ptr(), gworld, B, k, ref_block[0].data_ptr(), ref_block[1].data_ptr(),
+                                         stream)
+        else:
+            idx.search_device(qpool[0].data_ptr(), B, k, ref_block[0].data_ptr(), ref_block[1].data_ptr(), stream)
+        torch.cuda.synchronize()
     idx.close()
+    if want_leg:
+        if not have_pg:
+            import torch.distributed as dist  # noqa: PLC0415
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
+            have_pg = True
+
+        def plant(c: int, x):
+            sel = (p_pos_t >= c * CHUNK_ROWS) & (p_pos_t < c * CHUNK_ROWS + x.shape[0])
+            if bool(sel.any()):
+                x[p_pos_t[sel] - c * CHUNK_ROWS] = p_vec[sel]
+            return x
+
+        try:
+            leg = row_sharded_leg(args, torch, pkg, dist, device, local_rank, rank, world, qpool, ref_block,
+                                  lambda c, rows: plant(c, gen_chunk(c, rows)))
+        except Exception as e:  # noqa: BLE001 - a secondary figure must not take the headline line down with it
+            leg = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
+            result["extra"]["row_sharded"] = leg
     if have_pg:
         dist.destroy_process_group()
     if rank == 0:
