@@ -182,23 +182,49 @@ __device__ __forceinline__ uint32_t f32_order_key(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// number of keys >= x over the whole wave (wave-uniform result): 16 ballots + scalar popcounts, no shuffles
-__device__ __forceinline__ int wave_count_ge(const uint32_t (&key)[kSelPerLane], uint32_t x) {
+// number of keys >= x over the wave's first NS slots per lane (wave-uniform result): NS ballots + scalar popcounts, no
+// shuffles.  Entry e of a list lives in slot e / 64 of lane e % 64, so a list of n entries only occupies its first
+// ceil(n / 64) slots -- the others hold 0 ("absent", below every real key) and need not be looked at.
+template <int NS>
+__device__ __forceinline__ int wave_count_ge_n(const uint32_t (&key)[kSelPerLane], uint32_t x) {
     int c = 0;
 #pragma unroll
-    for (int j = 0; j < kSelPerLane; ++j) c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(key[j] >= x));
+    for (int j = 0; j < NS; ++j) c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(key[j] >= x));
     return c;
 }
-
-// the n-th largest key of the wave's 64*16 keys (1 <= n <= number of keys): bitwise construction of the largest
-// x with count(key >= x) >= n.  32 rounds of wave_count_ge.
-__device__ __forceinline__ uint32_t wave_nth_largest(const uint32_t (&key)[kSelPerLane], int n) {
+// the n-th largest key among the first NS slots (1 <= n <= number of keys): bitwise construction of the largest
+// x with count(key >= x) >= n.  32 rounds of wave_count_ge_n.
+template <int NS>
+__device__ __forceinline__ uint32_t wave_nth_largest_n(const uint32_t (&key)[kSelPerLane], int n) {
     uint32_t x = 0;
     for (int b = 31; b >= 0; --b) {
         const uint32_t t = x | (1u << b);
-        if (wave_count_ge(key, t) >= n) x = t;
+        if (wave_count_ge_n<NS>(key, t) >= n) x = t;
     }
     return x;
+}
+// the same for a list of `entries` entries (wave-uniform): the smallest instantiation that covers its slots.  A prune of
+// the headline pass selects among ~250 new candidates, then among ~40 and ~70 exact scores: 4, 1 and 2 slots, not 16.
+__device__ __forceinline__ int wave_count_ge(const uint32_t (&key)[kSelPerLane], uint32_t x, int entries) {
+    if (entries <= kWave) return wave_count_ge_n<1>(key, x);
+    if (entries <= 2 * kWave) return wave_count_ge_n<2>(key, x);
+    if (entries <= 4 * kWave) return wave_count_ge_n<4>(key, x);
+    if (entries <= 8 * kWave) return wave_count_ge_n<8>(key, x);
+    return wave_count_ge_n<kSelPerLane>(key, x);
+}
+__device__ __forceinline__ uint32_t wave_nth_largest(const uint32_t (&key)[kSelPerLane], int n, int entries) {
+    if (entries <= kWave) return wave_nth_largest_n<1>(key, n);
+    if (entries <= 2 * kWave) return wave_nth_largest_n<2>(key, n);
+    if (entries <= 4 * kWave) return wave_nth_largest_n<4>(key, n);
+    if (entries <= 8 * kWave) return wave_nth_largest_n<8>(key, n);
+    return wave_nth_largest_n<kSelPerLane>(key, n);
+}
+
+__device__ __forceinline__ int wave_count_ge(const uint32_t (&key)[kSelPerLane], uint32_t x) {
+    return wave_count_ge_n<kSelPerLane>(key, x);
+}
+__device__ __forceinline__ uint32_t wave_nth_largest(const uint32_t (&key)[kSelPerLane], int n) {
+    return wave_nth_largest_n<kSelPerLane>(key, n);
 }
 
 // descending sort of (value, payload) pairs

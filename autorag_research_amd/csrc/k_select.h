@@ -171,7 +171,7 @@ __device__ void prune_body(const PruneArgs& a, char* smem) {
             for (int k = lane; k < a.d; k += kWave) qs[k] = a.q[(int64_t)q * a.d + k];
             if (a.shadow16 != nullptr)
                 for (int k = lane; k < a.dpad; k += kWave) q16[k] = bf16_bits_to_f32(a.st.qhat[(int64_t)q * a.dpad + k]);
-            const int n_cand = wave_count_ge(key, 1u);
+            const int n_cand = wave_count_ge(key, 1u, n_new);
             // wave-local exact re-score of the candidates listed in R[0..n) -> SK/SR[dst..]
             auto rescore_list = [&](int n, int dst) {
                 for (int base = 0; base < n; base += kWave) {
@@ -191,6 +191,7 @@ __device__ void prune_body(const PruneArgs& a, char* smem) {
                 int n = 0;
 #pragma unroll
                 for (int j = 0; j < kSelPerLane; ++j) {
+                    if (j * kWave >= n_new) break;  // wave-uniform: the list ends before this slot
                     const bool want = key[j] >= x && key[j] != 0 && !((in_a >> j) & 1u);
                     const unsigned long long bal = __builtin_amdgcn_ballot_w64(want);
                     const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32),
@@ -208,7 +209,7 @@ __device__ void prune_body(const PruneArgs& a, char* smem) {
             const int wantA = min(n_cand, min(kWave, max(a.k, a.round_a > 0 ? a.round_a : max(32, 2 * a.k))));
             int nA = 0;
             if (wantA > 0) {
-                const uint32_t xA = wave_nth_largest(key, wantA);
+                const uint32_t xA = wave_nth_largest(key, wantA, n_new);
                 nA = compact(xA, kWave, true);
                 wave_sync();
                 rescore_list(nA, n_best);
@@ -233,8 +234,8 @@ __device__ void prune_body(const PruneArgs& a, char* smem) {
                         if (e < n1 && SK[e] != kKeyNaN) kk = f32_order_key(sim_of_dist(a.metric, key_to_dist(SK[e])));
                         sk[j] = kk;
                     }
-                    if (wave_count_ge(sk, 1u) >= a.k) {
-                        const uint32_t xs = wave_nth_largest(sk, a.k);
+                    if (wave_count_ge(sk, 1u, n1) >= a.k) {
+                        const uint32_t xs = wave_nth_largest(sk, a.k, n1);
                         const float kth = __uint_as_float((xs & 0x80000000u) ? (xs & 0x7FFFFFFFu) : ~xs);  // invert the key
                         // cosine: candidates carry v, exact <= v + E.  inner product: they carry the upper bound itself.
                         cut = a.metric == 0 ? kth - E * 1.001f - 2e-6f : kth - fabsf(kth) * 4e-6f - 1e-30f;
@@ -287,10 +288,11 @@ __device__ void prune_body(const PruneArgs& a, char* smem) {
                     if (e < n_tot) kk = SK[e] == kKeyNaN ? 1u : f32_order_key(sim_of_dist(a.metric, key_to_dist(SK[e])));
                     sk[j] = kk;  // every real similarity (order key >= 0x007FFFFF) ranks above the NaN class 1 and "absent" 0
                 }
-                const uint32_t xs = wave_nth_largest(sk, a.k);
+                const uint32_t xs = wave_nth_largest(sk, a.k, n_tot);
                 n_sel = 0;
 #pragma unroll
                 for (int j = 0; j < kSelPerLane; ++j) {
+                    if (j * kWave >= n_tot) break;  // wave-uniform
                     const bool want = sk[j] >= xs && sk[j] != 0;
                     const unsigned long long bal = __builtin_amdgcn_ballot_w64(want);
                     const int pos = n_sel + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32),
