@@ -293,6 +293,16 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// The row pointers of a batch travel between lanes as integers (__shfl), so the compiler no longer knows their address
+// space and would gather with FLAT loads -- which count on lgkmcnt as well as vmcnt: every LDS wait of the chain then also
+// waits for the pieces in flight and the prefetch is worth nothing.  Rows live in global memory: say so.
+typedef float f32x4_native __attribute__((ext_vector_type(4)));
+typedef const f32x4_native __attribute__((address_space(1)))* gmem_f4;
+__device__ __forceinline__ float4 load_gmem_f4(const float* p) {
+    const f32x4_native v = *(gmem_f4)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // One 64-column piece of the 64 rows, held in registers between issue and commit so the HBM/L2 latency
 // of piece p+1 (and p+2) overlaps the chain over piece p.
 struct StagePiece {
@@ -314,13 +324,45 @@ __device__ __forceinline__ void stage_rows_init(StageRows& sr, const float* my_r
     }
 }
 
+// The same, with idle slots (nullptr) pointed at a live lane's row: every lane then loads from a valid address and a piece
+// that lies inside the rows (k0 + 64 <= d) needs no per-load predicate -- 16 x (address add + load) instead of 16 x
+// (compare, exec mask, branch, add, load, restore).  At one wave per SIMD the issue of these instructions, not the memory,
+// is what a piece costs.  Returns false when no lane has a row (the caller keeps the predicated path).
+__device__ __forceinline__ bool stage_rows_init_dense(StageRows& sr, const float* my_row, int lane) {
+    const unsigned long long live = __builtin_amdgcn_ballot_w64(my_row != nullptr);
+    if (live == 0) {
+        stage_rows_init(sr, my_row, lane);
+        return false;
+    }
+    const int src = __builtin_ctzll(live);
+    unsigned long long a = (unsigned long long)my_row;
+    unsigned plo = (unsigned)(a & 0xFFFFFFFFull), phi = (unsigned)(a >> 32);
+    const unsigned flo = __shfl(plo, src, kWave), fhi = __shfl(phi, src, kWave);
+    if (my_row == nullptr) {
+        plo = flo;
+        phi = fhi;
+    }
+    const int sub = lane >> 4;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const unsigned lo = __shfl(plo, g * 4 + sub, kWave), hi = __shfl(phi, g * 4 + sub, kWave);
+        sr.r[g] = (const float*)(((unsigned long long)hi << 32) | lo);
+    }
+    return true;
+}
+__device__ __forceinline__ void stage_issue_dense(StagePiece& p, const StageRows& sr, int k0, int lane) {
+    const int c4 = (lane & 15) * 4;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) p.v[g] = load_gmem_f4(sr.r[g] + k0 + c4);
+}
+
 // d % 4 == 0: lane (sub = lane>>4, c4 = 4*(lane&15)) loads 16 B of row 4g+sub for g = 0..15 -- one
 // global_load_dwordx4 covers 4 rows x 256 B, all 16 loads are independent and issued back to back.
 __device__ __forceinline__ void stage_issue(StagePiece& p, const StageRows& sr, int k0, int d, int lane) {
     const int c4 = (lane & 15) * 4;
 #pragma unroll
     for (int g = 0; g < 16; ++g)
-        p.v[g] = (sr.r[g] != nullptr && k0 + c4 < d) ? *(const float4*)(sr.r[g] + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        p.v[g] = (sr.r[g] != nullptr && k0 + c4 < d) ? load_gmem_f4(sr.r[g] + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 __device__ __forceinline__ void stage_commit(float* tile, const StagePiece& p, int lane) {
     wave_sync();  // previous readers of the tile are done
@@ -391,16 +433,20 @@ __device__ __forceinline__ float staged_dot(float* tile, const float* my_row, co
     if ((d & 3) == 0) {
         StageRows sr;
         StagePiece p0, p1;
-        stage_rows_init(sr, my_row, lane);
-        stage_issue(p0, sr, 0, d, lane);
-        if (kStageCols < d) stage_issue(p1, sr, kStageCols, d, lane);
+        const bool dense = stage_rows_init_dense(sr, my_row, lane);
+        auto issue = [&](StagePiece& p, int k0) __attribute__((always_inline)) {
+            if (dense && k0 + kStageCols <= d) stage_issue_dense(p, sr, k0, lane);  // wave-uniform
+            else stage_issue(p, sr, k0, d, lane);
+        };
+        issue(p0, 0);
+        if (kStageCols < d) issue(p1, kStageCols);
         for (int k0 = 0; k0 < d; k0 += 2 * kStageCols) {
             stage_commit(tile, p0, lane);
-            if (k0 + 2 * kStageCols < d) stage_issue(p0, sr, k0 + 2 * kStageCols, d, lane);
+            if (k0 + 2 * kStageCols < d) issue(p0, k0 + 2 * kStageCols);
             acc = chain_piece(tile, lane, qv + k0, min(kStageCols, d - k0), acc);
             if (k0 + kStageCols < d) {
                 stage_commit(tile, p1, lane);
-                if (k0 + 3 * kStageCols < d) stage_issue(p1, sr, k0 + 3 * kStageCols, d, lane);
+                if (k0 + 3 * kStageCols < d) issue(p1, k0 + 3 * kStageCols);
                 acc = chain_piece(tile, lane, qv + k0 + kStageCols, min(kStageCols, d - k0 - kStageCols), acc);
             }
         }

@@ -55,7 +55,7 @@ __host__ __device__ inline size_t prune_lds_bytes(int d, int threads, int sortma
 }
 
 template <int THREADS, int SORT>
-__device__ void prune_body(const PruneArgs& a, char* smem);
+__device__ __forceinline__ void prune_body(const PruneArgs& a, char* smem);
 
 template <int THREADS, int SORT>
 __global__ __launch_bounds__(THREADS) void k_prune(PruneArgs a) {
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(THREADS) void k_prune(PruneArgs a) {
 }
 
 template <int THREADS, int SORT>
-__device__ void prune_body(const PruneArgs& a, char* smem) {
+__device__ __forceinline__ void prune_body(const PruneArgs& a, char* smem) {
     constexpr int kWaves = THREADS / kWave;
     uint64_t* SK = (uint64_t*)smem;
     int32_t* SR = (int32_t*)(smem + (size_t)SORT * 8);
@@ -173,7 +173,7 @@ __device__ void prune_body(const PruneArgs& a, char* smem) {
                 for (int k = lane; k < a.dpad; k += kWave) q16[k] = bf16_bits_to_f32(a.st.qhat[(int64_t)q * a.dpad + k]);
             const int n_cand = wave_count_ge(key, 1u, n_new);
             // wave-local exact re-score of the candidates listed in R[0..n) -> SK/SR[dst..]
-            auto rescore_list = [&](int n, int dst) {
+            auto rescore_list = [&](int n, int dst) __attribute__((always_inline)) {
                 for (int base = 0; base < n; base += kWave) {
                     const int e = base + lane;
                     const bool live = e < n;
