@@ -137,7 +137,7 @@ __device__ __forceinline__ void ms_load_piece(float4 (&a)[16], const float* row,
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int k0 = chunk * 128 + i * 8;
-        a[i] = k0 < dpad ? *(const float4*)(row + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        a[i] = k0 < dpad ? load_gmem_f4(row + k0) : make_float4(0.f, 0.f, 0.f, 0.f);  // (global, not FLAT: dev_common.h)
     }
 }
 
