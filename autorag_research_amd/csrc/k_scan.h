@@ -66,14 +66,22 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
 
     StageRows sr, sq;
     StagePiece p0, p1, q0, q1;
+    // idle slots read a live lane's row (their products are never looked at): pieces inside the rows need no per-load
+    // predicate (dev_common.h, stage_rows_init_dense)
+    bool dense = false;
+    auto issue = [&](StagePiece& p, const StageRows& r, int k0) __attribute__((always_inline)) {
+        if (dense && k0 + kStageCols <= d) stage_issue_dense(p, r, k0, lane);  // wave-uniform
+        else stage_issue(p, r, k0, d, lane);
+    };
     if (vec) {
-        stage_rows_init(sr, rp, lane);
-        stage_rows_init(sq, qp, lane);
-        stage_issue(p0, sr, 0, d, lane);
-        stage_issue(q0, sq, 0, d, lane);
+        const bool dr = stage_rows_init_dense(sr, rp, lane);
+        const bool dq = stage_rows_init_dense(sq, qp, lane);
+        dense = dr && dq;
+        issue(p0, sr, 0);
+        issue(q0, sq, 0);
         if (kStageCols < d) {
-            stage_issue(p1, sr, kStageCols, d, lane);
-            stage_issue(q1, sq, kStageCols, d, lane);
+            issue(p1, sr, kStageCols);
+            issue(q1, sq, kStageCols);
         }
     }
     const int h = lane >> 5;
@@ -105,8 +113,8 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
             commit_q(q0);
             wave_sync();
             if (k0 + 2 * kStageCols < d) {
-                stage_issue(p0, sr, k0 + 2 * kStageCols, d, lane);
-                stage_issue(q0, sq, k0 + 2 * kStageCols, d, lane);
+                issue(p0, sr, k0 + 2 * kStageCols);
+                issue(q0, sq, k0 + 2 * kStageCols);
             }
             mfma_piece();
             if (k0 + kStageCols < d) {
@@ -114,8 +122,8 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
                 commit_q(q1);
                 wave_sync();
                 if (k0 + 3 * kStageCols < d) {
-                    stage_issue(p1, sr, k0 + 3 * kStageCols, d, lane);
-                    stage_issue(q1, sq, k0 + 3 * kStageCols, d, lane);
+                    issue(p1, sr, k0 + 3 * kStageCols);
+                    issue(q1, sq, k0 + 3 * kStageCols);
                 }
                 mfma_piece();
             }
