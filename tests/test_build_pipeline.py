@@ -31,7 +31,7 @@ def _kernel_bodies(asm: str) -> dict[str, list[str]]:
 
 
 @pytest.fixture(scope="module")
-def screen_asm(tmp_path_factory):
+def lib_asm_text(tmp_path_factory):
     hipcc = Path("/opt/rocm/bin/hipcc")
     if not hipcc.exists():
         pytest.skip("hipcc not available")
@@ -39,7 +39,12 @@ def screen_asm(tmp_path_factory):
     cmd = [str(hipcc), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", f"-I{ROOT / 'include'}",
            f"-I{CSRC}", str(CSRC / "mi355dr.hip"), "-S", "--cuda-device-only", "-o", str(out)]
     subprocess.run(cmd, check=True, capture_output=True, timeout=900)
-    return _kernel_bodies(out.read_text())
+    return out.read_text()
+
+
+@pytest.fixture(scope="module")
+def screen_asm(lib_asm_text):
+    return _kernel_bodies(lib_asm_text)
 
 
 def _is_vm0(op: str) -> bool:
@@ -162,3 +167,26 @@ def test_screen256c_structure(screen_asm, i8):
     assert any(_is_vm0(o) for o in before) and any(o.startswith("s_waitcnt") and "lgkmcnt(0)" in o for o in before)
     # the append path is a call
     assert any(o.startswith("s_swappc_b64") for o in ops)
+
+
+def _whole_kernel(asm: str, name: str) -> tuple[list[str], str]:
+    """(instructions, .amdhsa descriptor text) of one kernel."""
+    a = asm.index(f"\n{name}:")
+    b = asm.index(".end_amdhsa_kernel", a)
+    body = asm[a:b]
+    ops = [ln.strip() for ln in body.split("\n") if ln.strip() and not ln.strip().startswith((";", "."))]
+    return ops, body[body.index(".amdhsa_kernel"):]
+
+
+@pytest.mark.parametrize("name", ["_ZN5mi3557k_pruneILi64ELi1024EEEvNS_9PruneArgsE", "_ZN5mi3556k_scanENS_8ScanArgsE"])
+def test_gather_kernels_use_global_loads_and_no_stack(lib_asm_text, name):
+    """The re-score gathers rebuild their row pointers from shuffled integers; without the address-space cast of
+    dev_common.h (load_gmem_f4) the compiler emits FLAT loads, which count on lgkmcnt as well as vmcnt -- every LDS wait
+    of the chain then drains the prefetched pieces.  And k_prune's body must stay inlined: as a function its argument
+    struct lives on the stack."""
+    ops, desc = _whole_kernel(lib_asm_text, name)
+    wide_flat = [o for o in ops if o.startswith("flat_load_dwordx4")]
+    assert not wide_flat, f"{len(wide_flat)} FLAT 16-byte loads in {name}"
+    assert sum(o.startswith("global_load_dwordx4") for o in ops) >= 32
+    assert ".amdhsa_private_segment_fixed_size 0" in desc, "stack use (spills or an out-of-line body)"
+    assert not any(o.startswith(("scratch_", "s_swappc")) for o in ops)
