@@ -77,6 +77,7 @@ struct mi355dr_index {
     int maxsim_screen = 1; // 1: bf16 MFMA screen + exact re-score of the candidates, 0: exact kernel over every doc
     int64_t row_offset = 0;
     int round_a = 0;      // k_prune: rows re-scored before the cut is known (0 = max(32, 2k)); tuning option "round_a"
+    int screen_stream = 1;  // query blocks of at most 64: k_screen_stream instead of k_screen (option "screen_stream", A/B and tests)
     int prefilter16 = 0;  // int8 screen: bf16 second screen of the surviving candidates inside k_prune (option "prefilter16";
                           // off: measured +1.4 % at 1.25 M rows, +0.2 % at 10 M -- the prune is bound by batch latency, not bytes)
     int profile = 0;

@@ -7,6 +7,7 @@
 #include "k_screen.h"
 #include "k_screen256.h"
 #include "k_screen256d.h"
+#include "k_screen_stream.h"
 #include "k_select.h"
 
 using namespace mi355;
@@ -133,6 +134,13 @@ int ensure_qstate(mi355dr_index* idx) {
     }
     HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreenLds));
     HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreenLds));
+    {
+        const int stream_lds = kStreamQueryBytesMax + kStreamStages * kStreamStageBytes;
+        HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen_stream<false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, stream_lds));
+        HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen_stream<true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, stream_lds));
+        HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen_stream<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, stream_lds));
+        HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen_stream<true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, stream_lds));
+    }
     HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen256<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kScreen256Lds));
     HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen256<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -302,6 +310,16 @@ int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t 
             if (i8) hipLaunchKernelGGL((k_screen256<0, true>), dim3(g2), dim3(512), kScreen256Lds, s, (ScreenArgs)sa);
             else hipLaunchKernelGGL((k_screen256<0, false>), dim3(g2), dim3(512), kScreen256Lds, s, (ScreenArgs)sa);
         }
+    } else if (!emit_all && idx->screen_stream && B <= 64 && sa.ksteps >= 1 &&
+               (B <= 32 ? 32 : 64) * sa.row_bytes <= kStreamQueryBytesMax) {
+        // small query blocks: the streaming form (resident query block, deep row ring, one persistent workgroup per CU)
+        const int nq = B <= 32 ? 32 : 64;
+        const unsigned gs = (unsigned)std::min(sa.n_ctiles, 256);
+        const size_t lds = screen_stream_lds(nq, sa.row_bytes);
+        if (i8 && nq == 32) hipLaunchKernelGGL((k_screen_stream<true, 32>), dim3(gs), dim3(256), lds, s, (ScreenArgs)sa);
+        else if (i8) hipLaunchKernelGGL((k_screen_stream<true, 64>), dim3(gs), dim3(256), lds, s, (ScreenArgs)sa);
+        else if (nq == 32) hipLaunchKernelGGL((k_screen_stream<false, 32>), dim3(gs), dim3(256), lds, s, (ScreenArgs)sa);
+        else hipLaunchKernelGGL((k_screen_stream<false, 64>), dim3(gs), dim3(256), lds, s, (ScreenArgs)sa);
     } else {
         if (i8) hipLaunchKernelGGL(k_screen<true>, dim3((unsigned)grid), dim3(256), kScreenLds, s, (ScreenArgs)sa);
         else hipLaunchKernelGGL(k_screen<false>, dim3((unsigned)grid), dim3(256), kScreenLds, s, (ScreenArgs)sa);
@@ -830,6 +848,8 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
     } else if (k == "chunk_growth") {
         if (value < 1) return fail(idx, MI355DR_E_INVALID, "chunk_growth must be >= 1");
         idx->chunk_growth = value;
+    } else if (k == "screen_stream") {
+        idx->screen_stream = value != 0;
     } else if (k == "small_chunk_rows") {
         if (value < 0) return fail(idx, MI355DR_E_INVALID, "small_chunk_rows must be >= 0");
         idx->small_chunk_rows = value;

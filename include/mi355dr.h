@@ -175,7 +175,9 @@ int mi355dr_search_sharded_device(mi355dr_index* idx, const float* queries_dev, 
  * options: "path" (MI355DR_PATH_*), "screen_dtype" (MI355DR_SCREEN_*), "row_offset", "profile" (0/1: HIP-event
  *          timing of the dominant kernel), "chunk0_rows", "chunk_growth", "cand_cap", "prefilter16" (1: int8 screen only, a bf16 second
  *          screen of the surviving candidates before the exact re-score; default 0, same results), "maxsim_screen" (1: bf16 MFMA screen
- *          over every doc + exact re-score of the candidates [default], 0: exact kernel over every doc; same results).
+ *          over every doc + exact re-score of the candidates [default], 0: exact kernel over every doc; same results),
+ *          "screen_stream" (1 [default]: query blocks of at most 64 are screened by the streaming kernel -- resident query
+ *          block, ring of row stages --, 0: by the tile kernel; same results).
  * stats:   "screen_launches", "screen_ns" (profile=1), "screen_rows" (all screen launches) and their k_screen256 share
  *          "screen256_launches", "screen256_ns", "screen256_rows"; "candidates", "rescored",
  *          "fallback_queries" (queries recomputed by the exact scan), "retry_queries" (queries whose candidate list

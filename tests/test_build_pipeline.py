@@ -190,3 +190,23 @@ def test_gather_kernels_use_global_loads_and_no_stack(lib_asm_text, name):
     assert sum(o.startswith("global_load_dwordx4") for o in ops) >= 32
     assert ".amdhsa_private_segment_fixed_size 0" in desc, "stack use (spills or an out-of-line body)"
     assert not any(o.startswith(("scratch_", "s_swappc")) for o in ops)
+
+
+@pytest.mark.parametrize("nq", [32, 64])
+@pytest.mark.parametrize("i8", [False, True])
+def test_screen_stream_ring_stays_in_flight(screen_asm, i8, nq):
+    """k_screen_stream's stage loop: the counted wait, one barrier, the four LDS-DMA pieces of the stage five ahead, the
+    fragment reads and MFMAs -- and no full vmcnt(0) anywhere between the wait and the last MFMA (the compiler puts one
+    in front of the first use of a value it loaded itself: the per-query constants are therefore used before the loop)."""
+    name = f"_ZN5mi35515k_screen_streamILb{int(i8)}ELi{nq}EEEvNS_10ScreenArgsE"
+    ops = screen_asm[name]
+    w = [i for i, o in enumerate(ops) if o.startswith("s_waitcnt") and "vmcnt(16)" in o]
+    assert len(w) == 1, "one counted wait: the head of the stage loop"
+    mf = [i for i, o in enumerate(ops) if o.startswith("v_mfma") and i > w[0]]
+    nj = nq // 32
+    assert len(mf) == 4 * nj
+    body = ops[w[0]:mf[-1] + 1]
+    assert sum(o.startswith("s_barrier") for o in body) == 1
+    assert sum(o.startswith("global_load_lds_dwordx4") for o in body) == 4
+    assert sum(o.startswith("ds_read_b128") for o in body) == 4 * (1 + nj)
+    assert not any(_is_vm0(o) for o in body)

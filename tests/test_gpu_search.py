@@ -144,6 +144,29 @@ def test_persistent_screen_shapes(pkg, oracle, screen, n, d, B, k):
         assert idx.stat("fallback_queries") == 0
 
 
+@pytest.mark.parametrize("screen", SCREENS)
+@pytest.mark.parametrize("n,d,B,k", [(30000, 768, 1, 10), (20000, 768, 33, 10), (9000, 100, 64, 5), (50000, 384, 17, 20),
+                                      (3000, 1536, 32, 10), (2100, 2048, 5, 10)])
+def test_small_query_blocks_streaming_screen(pkg, oracle, screen, n, d, B, k):
+    """Query blocks of at most 64 go through k_screen_stream (resident query block, ring of row stages, persistent
+    workgroups) when the query image fits its 48 KiB, else through k_screen: same results either way, equal to the oracle's.
+    Shapes: one and two query blocks of 32, a ragged last corpus tile, d that needs padding, d whose query image does not fit."""
+    rng = np.random.default_rng(n * 7 + d + B)
+    C = rng.standard_normal((n, d)).astype(np.float32)
+    C *= rng.uniform(0.1, 5.0, size=(n, 1)).astype(np.float32)
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    res = []
+    for stream in (1, 0):
+        with pkg.Mi355Index(d) as idx:
+            idx.set_option("screen_dtype", screen)
+            idx.set_option("path", "screen")
+            idx.set_option("screen_stream", stream)
+            idx.add(C)
+            res.append(_check(idx, oracle, C, Q, k))
+            assert idx.stat("fallback_queries") == 0
+    assert np.array_equal(res[0][1], res[1][1])
+
+
 @pytest.mark.parametrize("k,expect_dtype", [(10, 2), (24, 2), (26, 1), (100, 1), (400, 1)])
 def test_schedule_adapts_to_k(pkg, oracle, k, expect_dtype):
     """the wider int8 bound keeps ~16x k candidates per chunk, the bf16 bound ~3x: AUTO keeps int8 for small k only and
