@@ -86,6 +86,7 @@ struct mi355dr_index {
     int screen_form = 2;
     int64_t chunk0_rows = 1024;
     int64_t chunk_growth = 3;
+    int chunk_growth_set = 0;  // the option was set by the caller: no small-block override
     int64_t small_chunk_rows = 16384;  // chunks up to this many rows go through the 128x128 kernel (dense hits: per-lane appends)
     int cap = mi355::kCandCap;
 

@@ -198,6 +198,7 @@ void drain_events(mi355dr_index* idx) {  // call only after the stream was synch
 // the screen's bound widens the tail it has to keep: measured ~4-5 for the bf16 bound and ~14-16 for the int8 bound on
 // Gaussian data.  The chunk growth is capped so that this stays inside what one prune of the one-wave kernel holds.
 constexpr double kInflationBf16 = 5.0, kInflationI8 = 16.0;
+constexpr double kSmallBlockBudget = 1.6;  // (the measured inflations are ~4 and ~9-10: the budget above carries that much slack)
 inline double growth_budget(const mi355dr_index* idx, int k, bool i8) {
     const int room = k < kPruneSmallSort / 2 ? kPruneSmallSort - k : idx->cap;  // (large k: the general prune, whole buffer)
     return 0.6 * std::min(room, idx->cap) / ((double)k * (i8 ? kInflationI8 : kInflationBf16));
@@ -339,6 +340,10 @@ int run_screen(mi355dr_index* idx, hipStream_t s, int B, int k) {
     int64_t kept_all_below = 0;  // rows the emit-all first chunk already turned into candidates
     int64_t chunk = std::max<int64_t>(tile, std::min<int64_t>(idx->chunk0_rows, idx->cap));
     double growth = std::max(0.25, std::min((double)idx->chunk_growth, growth_budget(idx, k, use_i8(idx))));
+    // small query blocks: a pass is one stream over the shadow rows plus one latency-bound re-score launch per chunk, and an
+    // append costs nothing -- fewer, larger chunks (the k-dependent budget alone bounds the growth: x7 per step at k = 10)
+    if (B <= 64 && idx->retry_level == 0 && idx->chunk_growth_set == 0)
+        growth = std::max(growth, std::min(8.0, growth_budget(idx, k, use_i8(idx)) * kSmallBlockBudget));
     if (idx->retry_level == 1) growth = std::max(0.25, growth * 0.5);
     if (idx->retry_level >= 2) growth = 0.25;  // (every chunk then holds <= 20 % of the rows: a dense neighbourhood is split up)
     const bool i8 = use_i8(idx);
@@ -848,6 +853,7 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
     } else if (k == "chunk_growth") {
         if (value < 1) return fail(idx, MI355DR_E_INVALID, "chunk_growth must be >= 1");
         idx->chunk_growth = value;
+        idx->chunk_growth_set = 1;
     } else if (k == "screen_stream") {
         idx->screen_stream = value != 0;
     } else if (k == "small_chunk_rows") {
