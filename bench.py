@@ -691,6 +691,23 @@ def main() -> None:
                                              "note": "mi355dr_search: pageable host queries in (H2D), float8 distances + "
                                                      "int64 rows out (D2H), one blocking call per step; NOT `value`"}
 
+    if rank == 0 and world == 1 and not args.no_extras:
+        # (2b) the reference's own call shape: ONE query per call (pipelines/retrieval/vector_search.py:157-169), through the
+        # host entry point (H2D of the query, D2H of its k results, one blocking call per query)
+        q1 = [qpool[0, i:i + 1].cpu().numpy() for i in range(8)]
+        for i in range(3):
+            idx.search(q1[i], k)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n1 = 24
+        for i in range(n1):
+            idx.search(q1[i % 8], k)
+        t1 = (time.perf_counter() - t1) / n1
+        result["extra"]["one_query_per_call"] = {
+            "ms_per_call": round(t1 * 1e3, 3), "queries_per_s": round(1.0 / t1, 1),
+            "note": "mi355dr_search with B = 1 (k_screen_stream: the int8 shadow streamed once per call, DESIGN.md 4.1d); "
+                    "the CPU figure for the same call shape is cpu_baselines[kind = 'torch-cpu, B=1 call shape']; NOT `value`"}
+
     if rank == 0 and world == 1 and not args.no_extras and args.data == "gaussian":
         # (3) the multi-vector half of the path (configs C4 / C5) at SURVEY 8(d) sizes, as secondary figures of the same run
         result["maxsim"] = {
