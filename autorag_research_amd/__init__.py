@@ -12,7 +12,7 @@ metrics.py (retrieval metrics), embeddings.py (embedding interfaces), shards.py 
 chunked load), sharded.py (row-sharded multi-GPU search).
 """
 
-__version__ = "0.1.0"
+__version__ = "0.3.0"
 
 from .index import Mi355Index  # noqa: F401
 from ._native import NativeError  # noqa: F401

@@ -81,9 +81,6 @@ struct mi355dr_index {
     int prefilter16 = 0;  // int8 screen: bf16 second screen of the surviving candidates inside k_prune (option "prefilter16";
                           // off: measured +1.4 % at 1.25 M rows, +0.2 % at 10 M -- the prune is bound by batch latency, not bytes)
     int profile = 0;
-    // large-block screen kernel: 2 = k_screen256c (free-running waves, one barrier per K-step; the default), 3 = k_screen256d (the
-    // same on a ring of four half-K-step stages), 1 = k_screen256b (ping-pong, two-K-step prefetch), 0 = k_screen256 (first form)
-    int screen_form = 2;
     int64_t chunk0_rows = 1024;
     int64_t chunk_growth = 3;
     int chunk_growth_set = 0;  // the option was set by the caller: no small-block override

@@ -25,7 +25,7 @@
 //   lgkmcnt waits that keep one sub-step of fragment reads in flight into lgkmcnt(0): DESIGN.md 4.1b.)
 // LDS: the ring of 8 half-tile slots (2 parities x A0 B0 B1 A1), the per-wave candidate queues, 1 KiB of records.
 #pragma once
-#include "k_screen256b.h"
+#include "k_screen256_common.h"
 
 namespace mi355 {
 

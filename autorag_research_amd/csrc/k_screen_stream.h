@@ -14,7 +14,7 @@
 // Past the last stage of its last tile a workgroup keeps re-staging that tile (valid memory) so that the number of pieces
 // in flight -- what the counted wait relies on -- stays constant; drained before the exit.
 #pragma once
-#include "k_screen256b.h"
+#include "k_screen256_common.h"
 
 namespace mi355 {
 

@@ -5,8 +5,7 @@
 #include "k_prep.h"
 #include "k_scan.h"
 #include "k_screen.h"
-#include "k_screen256.h"
-#include "k_screen256d.h"
+#include "k_screen256c.h"
 #include "k_screen_stream.h"
 #include "k_select.h"
 
@@ -141,18 +140,6 @@ int ensure_qstate(mi355dr_index* idx) {
         HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen_stream<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, stream_lds));
         HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen_stream<true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, stream_lds));
     }
-    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen256<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      kScreen256Lds));
-    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen256<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      kScreen256Lds));
-    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen256b<kScreen256bAbl, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      kScreen256Lds));
-    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen256b<kScreen256bAbl, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      kScreen256Lds));
-    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen256d<kScreen256dAbl, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      kScreen256Lds));
-    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen256d<kScreen256dAbl, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      kScreen256Lds));
     HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen256c<kScreen256cAbl, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kScreen256Lds));
     HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen256c<kScreen256cAbl, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -298,19 +285,8 @@ int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t 
     const int64_t grid = round_up(sa.n_ctiles, 8) * sa.n_qtiles;
     if (tile == kT2) {
         const unsigned g2 = screen256_grid(sa.n_ctiles, sa.n_qtiles);  // persistent: <= one workgroup per CU
-        if (idx->screen_form == 3) {
-            if (i8) hipLaunchKernelGGL((k_screen256d<kScreen256dAbl, true>), dim3(g2), dim3(512), kScreen256Lds, s, sa);
-            else hipLaunchKernelGGL((k_screen256d<kScreen256dAbl, false>), dim3(g2), dim3(512), kScreen256Lds, s, sa);
-        } else if (idx->screen_form == 2) {
-            if (i8) hipLaunchKernelGGL((k_screen256c<kScreen256cAbl, true>), dim3(g2), dim3(512), kScreen256Lds, s, sa);
-            else hipLaunchKernelGGL((k_screen256c<kScreen256cAbl, false>), dim3(g2), dim3(512), kScreen256Lds, s, sa);
-        } else if (idx->screen_form == 1) {
-            if (i8) hipLaunchKernelGGL((k_screen256b<kScreen256bAbl, true>), dim3(g2), dim3(512), kScreen256Lds, s, sa);
-            else hipLaunchKernelGGL((k_screen256b<kScreen256bAbl, false>), dim3(g2), dim3(512), kScreen256Lds, s, sa);
-        } else {
-            if (i8) hipLaunchKernelGGL((k_screen256<0, true>), dim3(g2), dim3(512), kScreen256Lds, s, (ScreenArgs)sa);
-            else hipLaunchKernelGGL((k_screen256<0, false>), dim3(g2), dim3(512), kScreen256Lds, s, (ScreenArgs)sa);
-        }
+        if (i8) hipLaunchKernelGGL((k_screen256c<kScreen256cAbl, true>), dim3(g2), dim3(512), kScreen256Lds, s, sa);
+        else hipLaunchKernelGGL((k_screen256c<kScreen256cAbl, false>), dim3(g2), dim3(512), kScreen256Lds, s, sa);
     } else if (!emit_all && idx->screen_stream && B <= 64 && sa.ksteps >= 1 &&
                (B <= 32 ? 32 : 64) * sa.row_bytes <= kStreamQueryBytesMax) {
         // small query blocks: the streaming form (resident query block, deep row ring, one persistent workgroup per CU)
@@ -609,10 +585,6 @@ int mi355dr_create(mi355dr_index** out, int device_id, int dim, int metric) {
     mi355dr_index* idx = new mi355dr_index();
     idx->device = device_id;
     idx->dim = dim;
-    if (const char* e = getenv("MI355DR_SCREEN_FORM")) {  // developer override of the `screen_form` default (A/B, test sweeps)
-        const int f = atoi(e);
-        if (f >= 0 && f <= 3) idx->screen_form = f;
-    }
     idx->dpad = (int)round_up(dim, kStepK);
     idx->dpad8 = (int)round_up(dim, kRowB);
     idx->metric = metric;
@@ -864,9 +836,6 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
         idx->round_a = (int)value;
     } else if (k == "prefilter16") {
         idx->prefilter16 = value != 0;
-    } else if (k == "screen_form") {
-        if (value < 0 || value > 3) return fail(idx, MI355DR_E_INVALID, "screen_form must be 0..3");
-        idx->screen_form = (int)value;
     } else if (k == "cand_cap") {
         if (value < 16 || value > kCandCap) return fail(idx, MI355DR_E_INVALID, "cand_cap must be in [16,2048]");
         idx->cap = (int)value;
@@ -908,7 +877,6 @@ int mi355dr_get_stat(mi355dr_index* idx, const char* key, int64_t* out) {
     else if (k == "maxsim_fallbacks") *out = idx->s_ms_fallbacks;
     else if (k == "irregular_rows") *out = idx->irr_n;
     else if (k == "loose_rows") *out = idx->irr8_n;
-    else if (k == "screen_form") *out = idx->screen_form;
     else if (k == "screen_dtype_active") *out = use_i8(idx) ? MI355DR_SCREEN_I8 : MI355DR_SCREEN_BF16;
     else if (k == "hbm_bytes_resident")
         *out = idx->cap_rows * ((int64_t)idx->dim * 4 + (int64_t)idx->dpad * 2 + (int64_t)idx->dpad8 + 5) +

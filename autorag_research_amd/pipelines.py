@@ -4,7 +4,7 @@ Mirrors, name for name and signature for signature:
   VectorSearchPipelineConfig / VectorSearchRetrievalPipeline          pipelines/retrieval/vector_search.py:19-191
   ImageVectorSearchPipelineConfig / ImageVectorSearchRetrievalPipeline pipelines/retrieval/image_vector_search.py:22-139
   BaseRetrievalPipeline (retrieve / run / abstract hooks)              pipelines/retrieval/base.py:49-199
-Discovery: entry-point group "autorag_research.pipelines" -> this package's `plugin` module, YAML
+Discovery: entry-point group "autorag_research.pipelines" -> this PACKAGE (the registry scans its directory), YAML
 `retrieval/mi355_vector_search.yaml` with `_target_: autorag_research_amd.pipelines.Mi355VectorSearchPipelineConfig`
 (reference plugin_registry.py:199-255, docs/plugins/retrieval-pipeline.md).
 

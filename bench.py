@@ -68,7 +68,6 @@ def parse_args():
     ap.add_argument("--round-a", type=int, default=None, help="k_prune: rows re-scored before the cut is known (tuning)")
     ap.add_argument("--prefilter16", type=int, default=None, help="0/1: bf16 second screen inside the prune (default: library default)")
     ap.add_argument("--metric", choices=["cosine", "ip"], default="cosine", help="cosine (headline) or inner product")
-    ap.add_argument("--screen-form", type=int, default=None, help="developer A/B: 0 = first form of k_screen256, 1 = second form")
     ap.add_argument("--small-chunk", type=int, default=None, help="override small_chunk_rows (developer sweep)")
     ap.add_argument("--layout", default="auto",
                     help="ranks as (row shards R) x (query groups Q): 'auto' = fewest row shards whose shard fits in 60 %% of "
@@ -405,8 +404,6 @@ def main() -> None:
         idx.set_option("prefilter16", args.prefilter16)
     if args.round_a is not None:
         idx.set_option("round_a", args.round_a)
-    if args.screen_form is not None:
-        idx.set_option("screen_form", args.screen_form)
     if args.small_chunk is not None:
         idx.set_option("small_chunk_rows", args.small_chunk)
     aniso = synth.Anisotropic(torch, d, device) if args.data == "anisotropic" else None
@@ -562,7 +559,7 @@ def main() -> None:
     ubench = (MFMA_I8_UBENCH_TOPS["32x32x32"] if i8 else MFMA_BF16_UBENCH_TF)
     roof = {
         "bound": "mfma",
-        "kernel": (("k_screen256", "k_screen256b", "k_screen256c", "k_screen256d")[idx.stat("screen_form")] if B > 128
+        "kernel": ("k_screen256c" if B > 128
                    else "k_screen") + ("<int8>" if i8 else "<bf16>"),
         "op": "int8 multiply-add ops (v_mfma_i32_32x32x32_i8)" if i8 else "bf16 flops (v_mfma_f32_32x32x16_bf16)",
         "achieved": round(alg_flops / screen_s / 1e12, 2) if screen_s > 0 else None,

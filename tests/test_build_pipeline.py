@@ -51,77 +51,10 @@ def _is_vm0(op: str) -> bool:
     return op.startswith("s_waitcnt") and "vmcnt(0)" in op
 
 
-@pytest.mark.parametrize("i8", [False, True])
-def test_screen256_keeps_dma_in_flight(screen_asm, i8):
-    name = f"_ZN5mi35511k_screen256ILi0ELb{int(i8)}EEEvNS_10ScreenArgsE"
-    ops = screen_asm[name]
-    mf = [i for i, o in enumerate(ops) if o.startswith("v_mfma")]
-    # one K-step body (4 quadrants x 8 MFMAs) serves every K-step of every tile; the compiler may peel or unroll it
-    assert len(mf) % 32 == 0 and 32 <= len(mf) <= 96
-    copies = len(mf) // 32
-    want = "v_mfma_i32_32x32x32_i8" if i8 else "v_mfma_f32_32x32x16_bf16"
-    assert all(ops[i].startswith(want) for i in mf)
-    # the K-step body: from the first LDS-DMA issue after the prologue's barrier to the last MFMA
-    gl = [i for i, o in enumerate(ops) if o.startswith("global_load_lds")]
-    body_start = max(i for i in gl if i < mf[0]) - 1
-    body = ops[body_start:mf[-1]]
-    assert not any(_is_vm0(o) for o in body), "the K-step waits for ALL outstanding LDS-DMA loads"
-    assert sum(o.startswith("s_waitcnt") and "vmcnt(4)" in o for o in body) == 4 * copies
-    assert sum(o.startswith("global_load_lds") for o in body) >= 8 * copies - 1  # (the first issue may sit just above)
-    # the hit path's queue stores must not be preceded by a vector-memory wait (the compiler adds one for LDS
-    # accesses it can see; they are inline asm for that reason)
-    for i, o in enumerate(ops):
-        if o.startswith("ds_write_b32"):
-            assert not any("vmcnt" in p for p in ops[max(0, i - 6):i] if p.startswith("s_waitcnt")), ops[i - 6:i + 1]
-    assert not any(o.startswith("scratch_") for o in ops), "register spill in the screen kernel"
-    # ... and must not be followed by a wait for themselves: a hit stalls the whole workgroup for as long as this path
-    # takes (DESIGN 4.1 "what a hit costs"); LDS operations of one wave execute in order, the flush reads them later
-    writes = [i for i, o in enumerate(ops) if o.startswith("ds_write_b32")]
-    assert writes and len(writes) % 3 == 0
-    for i in writes[2::3]:  # the last store of every (query, row, value) entry
-        assert not any(p.startswith("s_waitcnt") and "lgkmcnt(0)" in p for p in ops[i + 1:i + 5]), ops[i:i + 6]
-
-
 def _loop_blocks(ops: list[str]) -> list[str]:
     """The instructions between the first and the last MFMA (the persistent K loop incl. its cold branches)."""
     mf = [i for i, o in enumerate(ops) if o.startswith("v_mfma")]
     return ops[mf[0]:mf[-1] + 1]
-
-
-@pytest.mark.parametrize("i8", [False, True])
-def test_screen256b_pipeline(screen_asm, i8):
-    """Second form (the one the library launches): one K-step body; LDS-DMA issued BETWEEN the MFMAs through the
-    SGPR-base + 32-bit-offset form; counted waits vmcnt(6) in front of all four barriers; the only full vector-memory
-    wait inside the loop is the queue flush's (returning atomics, rare)."""
-    names = [n for n in screen_asm if "k_screen256bILi" in n and n.endswith(f"ELb{int(i8)}EEEvNS_11ScreenArgs2E")]
-    assert len(names) == 1, sorted(screen_asm)
-    ops = screen_asm[names[0]]
-    want = "v_mfma_i32_32x32x32_i8" if i8 else "v_mfma_f32_32x32x16_bf16"
-    mf = [o for o in ops if o.startswith("v_mfma")]
-    assert len(mf) == 32 and all(o.startswith(want) for o in mf)
-    assert not any(o.startswith("scratch_") for o in ops), "register spill in the screen kernel"
-    loop = _loop_blocks(ops)
-    glds = [o for o in loop if o.startswith("global_load_lds_dwordx4")]
-    assert len(glds) == 8 and all(", s[" in o for o in glds), glds  # saddr form: `v_off, s[base:base+1]`
-    assert sum(o.startswith("s_waitcnt") and "vmcnt(6)" in o for o in ops) == 4  # one per phase, the first above the first MFMA
-    # a vmcnt(0) inside the loop is allowed only next to the flush's global atomic
-    for i, o in enumerate(loop):
-        if _is_vm0(o):
-            assert any(p.startswith("global_atomic") for p in loop[max(0, i - 4):i]), loop[max(0, i - 6):i + 1]
-    # every MFMA quadrant: the two DMA pieces sit between MFMAs, not in the LOAD half
-    idx = [i for i, o in enumerate(loop) if o.startswith("v_mfma")]
-    for q in range(4):
-        seg = loop[idx[8 * q]:idx[8 * q + 7] + 1]
-        assert sum(o.startswith("global_load_lds") for o in seg) == 2, seg
-    # the hit path's queue stores are inline asm: no vector-memory wait in front of them, no LDS wait behind them
-    writes = [i for i, o in enumerate(ops) if o.startswith("ds_write_b32")]
-    assert writes and len(writes) % 3 == 0
-    for i in writes:
-        assert not any("vmcnt" in p for p in ops[max(0, i - 6):i] if p.startswith("s_waitcnt")), ops[i - 6:i + 1]
-    for i in writes[2::3]:
-        assert not any(p.startswith("s_waitcnt") and "lgkmcnt(0)" in p for p in ops[i + 1:i + 5]), ops[i:i + 6]
-    # a wave's queue overflow flags the query (no returning atomic): a non-returning global OR
-    assert any(o.startswith("global_atomic_or ") and "sc0" not in o for o in ops)
 
 
 @pytest.mark.parametrize("i8", [False, True])

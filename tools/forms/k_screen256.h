@@ -28,25 +28,9 @@
 //    global candidate lists when it fills up and when the workgroup is done.
 //  * The emit-all first chunk is not handled here (the host runs it through k_screen).
 #pragma once
-#include "k_screen.h"
+#include "k_screen256_common.h"
 
 namespace mi355 {
-
-constexpr int kT2 = 256;                        // tile edge (rows and queries)
-constexpr int kHalfBytes = 128 * kRowB;         // 16 KiB
-constexpr int kRingBytes = 8 * kHalfBytes;     // ring of 8 half-tiles
-constexpr int kRecOff = kRingBytes + 8 * kWaveQueueCap * 12;  // + one candidate queue per wave
-constexpr int kRecBytes = 4 * 256;  // + 4 slots x 256 B of int8 row-group records (k_screen256c); 128 + 30 + 1 KiB of 160
-constexpr int kScreen256Lds = kRecOff + kRecBytes;
-static_assert(kScreen256Lds <= 160 * 1024, "LDS per workgroup");
-
-// persistent grid: 8 XCDs x L workgroups, L = the largest multiple of n_qtiles that fits the 32 CUs of an XCD
-// (fewer when the chunk has fewer tiles)
-__host__ __device__ inline unsigned screen256_grid(int n_ctiles, int n_qtiles) {
-    const int lmax = (32 / n_qtiles) * n_qtiles;
-    const int need = ((n_ctiles + 7) / 8) * n_qtiles;
-    return 8u * (unsigned)(need < lmax ? need : lmax);
-}
 
 // ---- developer timeline trace (tools/screen_bench, ABL bit 4): waves 0 and 4 of workgroup 0 stamp s_memtime at four
 // points of every phase of K-steps [kTraceG0, kTraceG0 + kTraceSteps) into the 2 KiB of LDS behind the queues.
@@ -71,13 +55,6 @@ __device__ unsigned long long* g_trace_out;  // [2][kTraceStamps], set with hipM
             asm volatile("ds_write_b64 %0, %1" ::"v"(ADDR), "v"(T) : "memory");                        \
             ADDR += 8;                                                                                 \
         }                                                                                              \
-    } while (0)
-
-#define MI355_BARRIER()                      \
-    do {                                     \
-        __builtin_amdgcn_sched_barrier(0);   \
-        __builtin_amdgcn_s_barrier();        \
-        __builtin_amdgcn_sched_barrier(0);   \
     } while (0)
 
 // ABL: developer ablation switches for tools/screen_bench (0 in the library): bit0 = skip the ds_reads after

@@ -33,31 +33,6 @@
 
 namespace mi355 {
 
-struct ScreenArgs2 : ScreenArgs {
-    int* status;  // [Bpad] per-query status bits (kStOverflow is set when a wave's queue overflows)
-};
-
-// ---- one 1-KiB piece (U = 0,1) of half-tile type S into ring parity `par`; src = the half-tile's first row + K offset
-// LDS-DMA with the source address split as the hardware takes it: a wave-uniform 64-bit base in SGPRs + a 32-bit
-// per-lane offset (the "saddr" form of global_load).  The builtin form adds the two into a 64-bit VGPR pair per lane
-// (one v_lshl_add_u64 per piece, and twice the address payload from the register file to the texture addresser).  M0 =
-// LDS destination of the wave's 1-KiB piece; it is written in the same statement (the compiler does not preserve it).
-__device__ __forceinline__ void glds16_saddr(const char* sbase, unsigned voff, unsigned lds_dst) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst)
-                 : "memory");
-}
-// 256 B (one dword per lane) through the same path: the int8 row-group records of a tile (k_screen256c)
-__device__ __forceinline__ void glds4_saddr(const char* sbase, unsigned voff, unsigned lds_dst) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst)
-                 : "memory");
-}
-template <int S, bool SADDR>
-__device__ __forceinline__ void kb_stage(char* smem, int wave, int par, const char* src, const unsigned (&voff)[2], int u) {
-    char* const dst = smem + (4 * par + S) * kHalfBytes + (2 * wave + u) * 1024;
-    if constexpr (SADDR) glds16_saddr(src, voff[u], lds_addr(dst));
-    else glds16(src + voff[u], dst);
-}
-
 // ABL (developer switches for tools/screen_bench / screen_trace, 0 in the library):
 //   bit2 (4)   no s_setprio            bit3 (8)   wait for the ds_reads before the barrier instead of after it
 //   bit4 (16)  timeline trace          bit5 (32)  NM = 1: the second 1-KiB piece of every half-tile is issued inside the

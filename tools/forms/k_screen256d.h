@@ -23,6 +23,7 @@
 //   final after micro-step 7 and tested in micro-steps 0, 1 of the next tile's first K-step (its registers restart from
 //   C = 0 in micro-step 2).  Append path out of line (k_screen.h: screen_queue_hits).
 #pragma once
+#include "k_screen256b.h"
 #include "k_screen256c.h"
 
 namespace mi355 {

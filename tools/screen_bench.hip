@@ -1,5 +1,5 @@
 // tools/screen_bench.hip -- developer micro-benchmark of the screen kernels (not part of the library).
-// Builds: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -Iautorag_research_amd/csrc tools/screen_bench.hip -o gpurun_out/screen_bench
+// Builds: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -Iautorag_research_amd/csrc -Itools/forms tools/screen_bench.hip -o gpurun_out/screen_bench
 // Runs each variant on synthetic bf16 rows: (1) pure compute (thresholds = +inf), (2) with a finite
 // threshold, comparing the appended candidate sets between variants.
 #include <hip/hip_runtime.h>

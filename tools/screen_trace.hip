@@ -1,6 +1,6 @@
 // tools/screen_trace.hip -- developer probe: per-phase timeline of the 256x256 screen kernels (s_memtime stamps of
 // waves 0 and 4 of workgroup 0, K-steps 24..29), first form vs second form, int8.  Not part of the library.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -Iautorag_research_amd/csrc tools/screen_trace.hip -o tools/bin/screen_trace
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -Iautorag_research_amd/csrc -Itools/forms tools/screen_trace.hip -o tools/bin/screen_trace
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
