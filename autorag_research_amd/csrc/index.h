@@ -81,6 +81,9 @@ struct mi355dr_index {
     int prefilter16 = 0;  // int8 screen: bf16 second screen of the surviving candidates inside k_prune (option "prefilter16";
                           // off: measured +1.4 % at 1.25 M rows, +0.2 % at 10 M -- the prune is bound by batch latency, not bytes)
     int profile = 0;
+    int starter = 1;          // pass schedule: sampled threshold estimator instead of the smallest chunks (option "starter", A/B and tests)
+    int prune_companion = 0;  // 1: always launch the general-form prune behind the one-wave form (option "prune_companion")
+    int chunk0_set = 0;       // the first chunk's size was set by the caller: emit-all ladder, no starter
     int64_t chunk0_rows = 1024;
     int64_t chunk_growth = 3;
     int chunk_growth_set = 0;  // the option was set by the caller: no small-block override
@@ -89,7 +92,7 @@ struct mi355dr_index {
 
     // stats
     int64_t s_screen_launches = 0, s_screen_ns = 0, s_screen_rows = 0, s_fallback_queries = 0, s_chunks = 0,
-            s_passes = 0, s_candidates = 0, s_rescored = 0;
+            s_passes = 0, s_candidates = 0, s_rescored = 0, s_starters = 0;
     int64_t s_big_launches = 0, s_big_ns = 0, s_big_rows = 0;  // the k_screen256 share of the three above
     int64_t s_retry_queries = 0;  // queries whose candidate list overflowed and that were re-screened with the bf16 bound
     int64_t s_ms_screened = 0, s_ms_candidates = 0, s_ms_fallbacks = 0;  // MaxSim: queries screened, docs re-scored, full re-runs

@@ -59,8 +59,11 @@ struct ScreenArgs {
     int n_qtiles;   // query tiles
     int64_t row_end;  // rows >= row_end are not part of this chunk (tile padding)
     int64_t row0;     // first row of this chunk
-    int emit_all;     // first chunk: every (query,row) is a candidate -> direct store at slot row-row0, no atomics
+    int emit_all;     // 1 = first chunk: every (query,row) is a candidate -> direct store at slot row-row0, no atomics;
+                      // 2 = starter (k_screen only): per query and 64-row slab ONLY the largest value, at slot (slab index)
 };
+constexpr int kEmitAll = 1, kEmitSlabMax = 2;
+constexpr int kSlabRows = 64;  // rows of one wave's sub-tile in k_screen: the starter keeps one candidate per slab and query
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -341,6 +344,63 @@ __device__ __forceinline__ void screen_emit_all_block(const ScreenArgs& a, f32x1
     }
 }
 
+// Starter (run_screen: "sampled threshold estimator"): the wave's 64 rows x 64 queries sub-tile -> for each of its queries
+// the LARGEST value over the 64 rows and its row, stored at slot (slab index) of the query's list: no thresholds, no
+// atomics, S / 64 candidates per query from a sample of S rows.  The exact re-score of the best of them (k_prune,
+// thr_only) gives a first threshold that is valid whatever the sample missed: any k exact scores bound the k-th best
+// from below.  int8: v = fma((float)acc, m, ek) is monotone in acc (m >= 0), so a block's largest value comes from its
+// largest accumulator.  acc[i] = the two row blocks of query block j.
+template <bool I8>
+__device__ __forceinline__ void screen_emit_slab_max(const ScreenArgs& a, const f32x16 (&acc)[2], int q, int64_t slab_row0,
+                                                     int lane, const I8Blk (&blk)[2]) {
+    float best = -__builtin_inff();
+    int64_t best_row = slab_row0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int64_t rbase = slab_row0 + 32 * i + 4 * (lane >> 5);
+        int br = 0;
+        float bv;
+        if constexpr (I8) {
+            const i32x16 v = __builtin_bit_cast(i32x16, acc[i]);
+            int m = v[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r)
+                if (v[r] > m) {
+                    m = v[r];
+                    br = r;
+                }
+            bv = i8_value(m, blk[i]);
+        } else {
+            float m = acc[i][0];
+            if (!(m == m)) m = -__builtin_inff();  // (NaN image of an irregular row: never a maximum)
+#pragma unroll
+            for (int r = 1; r < 16; ++r)
+                if (acc[i][r] > m) {
+                    m = acc[i][r];
+                    br = r;
+                }
+            bv = m;
+        }
+        const int64_t row = rbase + (br & 3) + 8 * (br >> 2);
+        if (row < a.row_end && bv > best) {
+            best = bv;
+            best_row = row;
+        }
+    }
+    // the other half of the wave holds the other 32 rows of the same query column
+    const float ov = __shfl_xor(best, 32, kWave);
+    const int orow = __shfl_xor((int)best_row, 32, kWave);
+    if (ov > best || (ov == best && orow < (int)best_row)) {
+        best = ov;
+        best_row = orow;
+    }
+    if (lane < 32) {
+        const int64_t slot = (slab_row0 - a.row0) / kSlabRows;
+        a.cand_row[(int64_t)q * a.cap + slot] = (int32_t)best_row;
+        a.cand_val[(int64_t)q * a.cap + slot] = best;
+    }
+}
+
 template <bool I8>
 __global__ __launch_bounds__(256, 2) void k_screen(ScreenArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -438,6 +498,22 @@ __global__ __launch_bounds__(256, 2) void k_screen(ScreenArgs a) {
     }
 
     // ---- fused epilogue: threshold test, rare append
+    if (a.emit_all == kEmitSlabMax) {  // wave-uniform: the starter's form
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = q0 + 64 * wc + 32 * j + (lane & 31);
+            const float sq = I8 ? a.sc[q] : 1.0f, kq = I8 ? a.kq[q] : 1.0f;
+            const int64_t slab_row0 = tile_row0 + 64 * wr;
+            I8Blk blk[2] = {{1.0f, 0.0f}, {1.0f, 0.0f}};
+            if constexpr (I8) {
+                blk[0] = i8_blk(i8_group_of(a.grp, slab_row0), sq, kq);
+                blk[1] = i8_blk(i8_group_of(a.grp, slab_row0 + 32), sq, kq);
+            }
+            const f32x16 col[2] = {acc[0][j], acc[1][j]};
+            screen_emit_slab_max<I8>(a, col, q, slab_row0, lane, blk);
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int q = q0 + 64 * wc + 32 * j + (lane & 31);
@@ -449,7 +525,7 @@ __global__ __launch_bounds__(256, 2) void k_screen(ScreenArgs a) {
             const int64_t rbase = row0 + 4 * (lane >> 5);
             I8Blk blk{1.0f, 0.0f};
             if constexpr (I8) blk = i8_blk(i8_group_of(a.grp, row0), sq, kq);
-            if (a.emit_all) screen_emit_all_block<I8>(a, acc[i][j], q, rbase, blk);  // wave-uniform branch
+            if (a.emit_all == kEmitAll) screen_emit_all_block<I8>(a, acc[i][j], q, rbase, blk);  // wave-uniform branch
             else screen_emit_block<I8>(a, acc[i][j], q, rbase, th, blk);
         }
     }

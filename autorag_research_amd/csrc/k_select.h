@@ -35,6 +35,14 @@ struct PruneArgs {
     // `qlist` (exact path) = one workgroup per query as before.
     int* skip_list;
     int skip_parity;
+    // starter (run_screen): the candidates are a SAMPLE (one per slab of the first rows) -- re-score the best-looking ones,
+    // publish the threshold their k-th best exact score gives, and keep NOTHING: the rows are screened again by the first
+    // regular chunk.  One-wave form only.
+    int thr_only;
+    // no general-form companion launch behind this one: a query the one-wave form cannot hold (more than its 1024 entries,
+    // a candidate list beyond its capacity) is flagged kStOverflow -- re-screened by the host with the tighter bound --
+    // instead of being handed over.
+    int one_wave_only;
 };                         // (the screen bound is per query: st.E[q])
 
 // Two instantiations share the code: a small one (1 wave, <= 1024 entries, ~36 KiB LDS, 4 workgroups
@@ -105,6 +113,13 @@ __device__ __forceinline__ void prune_body(const PruneArgs& a, char* smem) {
     const int n_best = a.st.best_n[q];
     if (raw_cnt == 0) return;  // nothing new; kept list and thresholds stay as they are
     auto leave_for_general = [&]() {  // one-wave form: hand the query over
+        if (a.one_wave_only) {
+            if (tid == 0) {
+                a.st.status[q] |= kStOverflow;
+                a.st.cnt[q] = 0;
+            }
+            return;
+        }
         if (list_mode && tid == 0) {
             const int i = atomicAdd(&a.skip_list[a.skip_parity], 1);
             a.skip_list[2 + a.skip_parity * kQBlockMax + i] = q;
@@ -222,7 +237,7 @@ __device__ __forceinline__ void prune_body(const PruneArgs& a, char* smem) {
             wave_sync();
             int n1 = n_best + nA;
             int nB = 0;
-            if (n_cand > nA) {
+            if (n_cand > nA && !a.thr_only) {
                 // ---- cut = (k-th largest exact similarity over kept U round A) - E: as float, rounded down
                 float cut = -__builtin_inff(), cut16 = -__builtin_inff();
                 if (n1 >= a.k) {
@@ -317,17 +332,20 @@ __device__ __forceinline__ void prune_body(const PruneArgs& a, char* smem) {
             __syncthreads();
             bitonic_asc_key_row(K2, R2, np);
             const int n_keep = min(a.k, n_sel);
-            for (int i = lane; i < n_keep; i += kWave) {
-                bkey[i] = K2[i];
-                brow[i] = R2[i];
-            }
+            if (!a.thr_only)
+                for (int i = lane; i < n_keep; i += kWave) {
+                    bkey[i] = K2[i];
+                    brow[i] = R2[i];
+                }
             if (lane == 0) {
-                a.st.best_n[q] = n_keep;
+                if (!a.thr_only) a.st.best_n[q] = n_keep;
                 a.st.cnt[q] = 0;
                 if (n_keep >= a.k) {
                     const uint64_t wk = K2[a.k - 1];
-                    a.st.thr_key[q] = wk;
-                    a.st.thr_row[q] = R2[a.k - 1];
+                    if (!a.thr_only) {  // (the exact path's threshold speaks for KEPT rows)
+                        a.st.thr_key[q] = wk;
+                        a.st.thr_row[q] = R2[a.k - 1];
+                    }
                     if (wk != kKeyNaN && !(a.st.status[q] & kStIrregular)) {
                         if (a.metric == 0) {
                             const float th = float_below((float)((1.0 - key_to_dist(wk)) - (double)E));

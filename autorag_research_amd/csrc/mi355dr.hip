@@ -201,8 +201,11 @@ inline bool use_i8(const mi355dr_index* idx) {
            growth_budget(idx, idx->k_now, true) >= 1.5;
 }
 
-int launch_prune(mi355dr_index* idx, hipStream_t s, int nblocks, const int* qlist, int k, int exact) {
+int launch_prune(mi355dr_index* idx, hipStream_t s, int nblocks, const int* qlist, int k, int exact, bool thr_only = false,
+                 bool one_wave_only = false) {
     PruneArgs pa{};
+    pa.thr_only = thr_only ? 1 : 0;
+    pa.one_wave_only = one_wave_only ? 1 : 0;
     pa.rows = idx->rows;
     pa.nrm2 = idx->nrm2;
     pa.q = idx->qdev;
@@ -231,6 +234,7 @@ int launch_prune(mi355dr_index* idx, hipStream_t s, int nblocks, const int* qlis
     hipLaunchKernelGGL((k_prune<kPruneSmallThreads, kPruneSmallSort>), dim3(nblocks), dim3(kPruneSmallThreads),
                        prune_lds_bytes(idx->dim, kPruneSmallThreads, kPruneSmallSort, pa.shadow16 ? idx->dpad : 0), s, pa);
     HIPCHECK(idx, hipGetLastError());
+    if (one_wave_only) return MI355DR_OK;  // (what the one-wave form cannot hold is flagged for the host's re-screen)
     hipLaunchKernelGGL((k_prune<kPruneBigThreads, kPruneBigSort>), dim3(list_mode ? std::min(nblocks, 64) : nblocks),
                        dim3(kPruneBigThreads), prune_lds_bytes(idx->dim, kPruneBigThreads, kPruneBigSort, 0), s, pa);
     HIPCHECK(idx, hipGetLastError());
@@ -255,7 +259,8 @@ __global__ void k_set_counts(int* cnt, int n, int v) {
     if (i < n) cnt[i] = v;
 }
 
-int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t r_end, int cap, bool emit_all) {
+int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t r_end, int cap, int emit_mode) {
+    const bool emit_all = emit_mode != 0;  // (both special epilogues live in k_screen)
     // the emit-all first chunk always goes through the 128x128 kernel (k_screen256 has no emit-all epilogue)
     // ... and so do chunks of a few thousand rows: their thresholds are still so low that a good part of the tile is a
     // hit, which the per-lane global append of k_screen handles better than k_screen256's small per-wave queues
@@ -281,7 +286,7 @@ int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t 
     sa.n_qtiles = (int)(round_up(B, tile) / tile);
     sa.row_end = r_end;
     sa.row0 = r0;
-    sa.emit_all = emit_all ? 1 : 0;
+    sa.emit_all = emit_mode;
     const int64_t grid = round_up(sa.n_ctiles, 8) * sa.n_qtiles;
     if (tile == kT2) {
         const unsigned g2 = screen256_grid(sa.n_ctiles, sa.n_qtiles);  // persistent: <= one workgroup per CU
@@ -302,53 +307,117 @@ int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t 
         else hipLaunchKernelGGL(k_screen<false>, dim3((unsigned)grid), dim3(256), kScreenLds, s, (ScreenArgs)sa);
     }
     HIPCHECK(idx, hipGetLastError());
-    if (emit_all) {  // every row of the chunk was stored at slot row-r0 for every query
-        hipLaunchKernelGGL(k_set_counts, dim3((B + 255) / 256), dim3(256), 0, s, idx->st.cnt, B, (int)(r_end - r0));
+    if (emit_all) {  // every row of the chunk (starter: every slab's best row) was stored at its own slot for every query
+        const int per_query = emit_mode == kEmitSlabMax ? (int)((r_end - r0 + kSlabRows - 1) / kSlabRows) : (int)(r_end - r0);
+        hipLaunchKernelGGL(k_set_counts, dim3((B + 255) / 256), dim3(256), 0, s, idx->st.cnt, B, per_query);
         HIPCHECK(idx, hipGetLastError());
     }
     return MI355DR_OK;
 }
 
+// ---- the pass schedule --------------------------------------------------------------------------------------------
+// Thresholds are frozen during a launch, so the corpus is walked in geometrically growing chunks, each followed by the exact
+// re-score + select of what it appended (k_prune), which publishes the next chunk's thresholds.  Round 3:
+//  * STARTER instead of the three smallest chunks (k <= kStarterKMax, first attempt only): one k_screen launch over the first
+//    S <= 16 k rows that keeps, per query, the best value of every 64-row slab (S / 64 candidates, no thresholds, no atomics)
+//    + one k_prune (thr_only) that re-scores the best-looking of them exactly and publishes the threshold their k-th best
+//    gives -- valid whatever the sample missed -- and keeps nothing; the first regular chunk then starts at row 0.  Two
+//    launches (~80 us) where the ladder 1 024 -> 4 096 -> 16 384 took six (~290 us), at every shard size.
+//  * The chunk ends are PLANNED: n = the fewest steps of ratio <= 1 + growth from the starter's sample (or the emit-all first
+//    chunk) to the end, then one uniform ratio (N / S)^(1/n) -- no short last chunk with a prune of its own.
+//  * No general-form companion behind the one-wave prune while k is small: what it cannot hold is flagged and re-screened.
+constexpr int kStarterKMax = 32;          // the starter's round A re-scores max(32, 2k) <= 64 rows: one batch of the one-wave form
+constexpr int64_t kStarterRows = 16384;   // sample size (256 slabs); a corpus must hold at least 4 samples
+struct PassPlan {
+    int64_t sample = 0;          // > 0: starter over rows [0, sample)
+    std::vector<int64_t> ends;   // chunk ends, ascending, last = n; the first chunk starts at 0 (starter) or is the emit-all one
+    bool emit_all_first = false;
+};
+PassPlan plan_pass(const mi355dr_index* idx, int B, int k, double growth) {
+    PassPlan p;
+    const int64_t n = idx->n;
+    const int tile = screen_tile(B);
+    int64_t seen = 0;  // rows whose k-th best the first planned chunk's threshold comes from
+    if (idx->starter && k <= kStarterKMax && idx->retry_level == 0 && idx->chunk0_set == 0 && n >= 4 * 1024) {
+        p.sample = std::min<int64_t>(kStarterRows, n / 4) / kTileM * kTileM;
+        seen = p.sample;
+    } else {
+        const int64_t c0 = std::min<int64_t>(n, round_up(std::max<int64_t>(tile, std::min<int64_t>(idx->chunk0_rows, idx->cap)), tile));
+        p.emit_all_first = c0 <= idx->cap;
+        p.ends.push_back(c0);
+        seen = c0;
+        if (c0 >= n) return p;
+    }
+    const double rmax = 1.0 + growth;
+    const double span = (double)n / (double)seen;
+    int steps = std::max(1, (int)std::ceil(std::log(span) / std::log(rmax) - 0.12));
+    const double r = std::pow(span, 1.0 / steps);
+    double pos = (double)seen;
+    int64_t prev = p.sample > 0 ? 0 : seen;
+    for (int i = 1; i <= steps; ++i) {
+        pos *= r;
+        int64_t end = i == steps ? n : std::min<int64_t>(n, round_up((int64_t)pos, tile));
+        if (end <= prev) continue;
+        p.ends.push_back(end);
+        prev = end;
+        if (end >= n) break;
+    }
+    if (p.ends.empty() || p.ends.back() < n) p.ends.push_back(n);
+    return p;
+}
+
 // screen path over all rows for the B queries prepared in idx->st / idx->qdev
 int run_screen(mi355dr_index* idx, hipStream_t s, int B, int k) {
-    const int tile = screen_tile(B);
-    int64_t done = 0;
     int64_t kept_all_below = 0;  // rows the emit-all first chunk already turned into candidates
-    int64_t chunk = std::max<int64_t>(tile, std::min<int64_t>(idx->chunk0_rows, idx->cap));
-    double growth = std::max(0.25, std::min((double)idx->chunk_growth, growth_budget(idx, k, use_i8(idx))));
+    double growth = std::max(0.25, idx->chunk_growth_set ? std::min((double)idx->chunk_growth, growth_budget(idx, k, use_i8(idx)))
+                                                         : growth_budget(idx, k, use_i8(idx)));
+    growth = std::min(growth, 8.0);
     // small query blocks: a pass is one stream over the shadow rows plus one latency-bound re-score launch per chunk, and an
     // append costs nothing -- fewer, larger chunks (the k-dependent budget alone bounds the growth: x7 per step at k = 10)
     if (B <= 64 && idx->retry_level == 0 && idx->chunk_growth_set == 0)
         growth = std::max(growth, std::min(8.0, growth_budget(idx, k, use_i8(idx)) * kSmallBlockBudget));
-    if (idx->retry_level == 1) growth = std::max(0.25, growth * 0.5);
+    if (idx->retry_level == 1) growth = std::max(0.25, std::min(growth, 3.0) * 0.5);
     if (idx->retry_level >= 2) growth = 0.25;  // (every chunk then holds <= 20 % of the rows: a dense neighbourhood is split up)
     const bool i8 = use_i8(idx);
     const int side_n = i8 ? idx->irr8_n : idx->irr_n;  // rows this screen cannot see
     constexpr int kSideMerge = 32;
     bool side_done = false;
-    while (done < idx->n) {
-        const int64_t end = std::min<int64_t>(idx->n, round_up(done + chunk, tile));
-        const bool emit_all = done == 0 && end <= idx->cap;
-        if (emit_all) kept_all_below = end;
+    const PassPlan plan = plan_pass(idx, B, k, growth);
+    // one-wave prune alone: small k, first attempt (a retry keeps the general form: it is the last screen before the exact scan)
+    const bool lean = plan.sample > 0 && idx->prune_companion == 0;
+    auto timed = [&](bool big, int64_t rows, auto&& launch) -> int {
         EventPair ev{};
         if (idx->profile) {
             ev = take_events(idx);
             HIPCHECK(idx, hipEventRecord(ev.a, s));
         }
-        // the first chunk has no threshold yet: it keeps every row (direct stores) as long as it fits the buffer
-        CHECK(launch_screen(idx, s, B, done, end, idx->cap, emit_all));
-        const bool big = !emit_all && end - done > idx->small_chunk_rows && screen_tile(B) == kT2;
+        CHECK(launch());
         if (idx->profile) {
             HIPCHECK(idx, hipEventRecord(ev.b, s));
             ev.big = big ? 1 : 0;
             idx->ev_pending.push_back(ev);
         }
         idx->s_screen_launches++;
-        idx->s_screen_rows += end - done;
+        idx->s_screen_rows += rows;
         if (big) {
             idx->s_big_launches++;
-            idx->s_big_rows += end - done;
+            idx->s_big_rows += rows;
         }
+        return MI355DR_OK;
+    };
+    if (plan.sample > 0) {
+        CHECK(timed(false, plan.sample, [&] { return launch_screen(idx, s, B, 0, plan.sample, idx->cap, kEmitSlabMax); }));
+        CHECK(launch_prune(idx, s, B, nullptr, k, /*exact=*/0, /*thr_only=*/true, /*one_wave_only=*/true));
+        idx->s_starters++;
+    }
+    int64_t done = 0;
+    for (size_t ci = 0; ci < plan.ends.size(); ++ci) {
+        const int64_t end = plan.ends[ci];
+        const bool emit_all = ci == 0 && plan.emit_all_first;
+        if (emit_all) kept_all_below = end;
+        // the first chunk has no threshold yet: it keeps every row (direct stores) as long as it fits the buffer
+        const bool big = !emit_all && end - done > idx->small_chunk_rows && screen_tile(B) == kT2;
+        CHECK(timed(big, end - done, [&] { return launch_screen(idx, s, B, done, end, idx->cap, emit_all ? kEmitAll : 0); }));
         idx->s_chunks++;
         if (end >= idx->n && side_n > 0 && side_n <= kSideMerge) {
             // rows this screen cannot see (irregular; for int8 also loose): a handful of them ride the LAST chunk's prune
@@ -358,15 +427,14 @@ int run_screen(mi355dr_index* idx, hipStream_t s, int B, int k) {
             HIPCHECK(idx, hipGetLastError());
             side_done = true;
         }
-        CHECK(launch_prune(idx, s, B, nullptr, k, /*exact=*/0));
+        CHECK(launch_prune(idx, s, B, nullptr, k, /*exact=*/0, false, lean));
         done = end;
-        chunk = std::max<int64_t>(tile, (int64_t)((double)done * growth));
     }
     if (side_n > 0 && !side_done) {
         hipLaunchKernelGGL(k_emit_irregular, dim3(B), dim3(64), 0, s, i8 ? idx->irr8_rows : idx->irr_rows, side_n, idx->st,
                            idx->cand_row, idx->cand_val, idx->cap, (int)kept_all_below);
         HIPCHECK(idx, hipGetLastError());
-        CHECK(launch_prune(idx, s, B, nullptr, k, 0));
+        CHECK(launch_prune(idx, s, B, nullptr, k, 0, false, lean));
     }
     idx->s_passes++;
     return MI355DR_OK;
@@ -822,6 +890,11 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
     } else if (k == "chunk0_rows") {
         if (value < 1) return fail(idx, MI355DR_E_INVALID, "chunk0_rows must be >= 1");
         idx->chunk0_rows = value;
+        idx->chunk0_set = 1;  // (an explicit first chunk means the emit-all ladder: no starter)
+    } else if (k == "starter") {
+        idx->starter = value != 0;
+    } else if (k == "prune_companion") {
+        idx->prune_companion = value != 0;
     } else if (k == "chunk_growth") {
         if (value < 1) return fail(idx, MI355DR_E_INVALID, "chunk_growth must be >= 1");
         idx->chunk_growth = value;
@@ -870,6 +943,7 @@ int mi355dr_get_stat(mi355dr_index* idx, const char* key, int64_t* out) {
     else if (k == "fallback_queries") *out = idx->s_fallback_queries;
     else if (k == "chunks") *out = idx->s_chunks;
     else if (k == "passes") *out = idx->s_passes;
+    else if (k == "starters") *out = idx->s_starters;
     else if (k == "retry_queries") *out = idx->s_retry_queries;
     else if (k == "i8_demoted") *out = idx->i8_demoted ? 1 : 0;
     else if (k == "maxsim_screened") *out = idx->s_ms_screened;
@@ -889,7 +963,7 @@ int mi355dr_reset_stats(mi355dr_index* idx) {
     if (!idx) return fail(nullptr, MI355DR_E_INVALID, "null index");
     std::lock_guard<std::mutex> g(idx->mu);
     idx->s_screen_launches = idx->s_screen_ns = idx->s_screen_rows = idx->s_fallback_queries = idx->s_chunks =
-        idx->s_passes = idx->s_big_launches = idx->s_big_ns = idx->s_big_rows = 0;
+        idx->s_passes = idx->s_big_launches = idx->s_big_ns = idx->s_big_rows = idx->s_starters = 0;
     idx->s_ms_screened = idx->s_ms_candidates = idx->s_ms_fallbacks = idx->s_retry_queries = 0;
     if (idx->stat_dev) {
         HIPCHECK(idx, hipSetDevice(idx->device));
@@ -958,7 +1032,7 @@ int mi355dr_debug_screen_dense(mi355dr_index* idx, const float* queries, int B, 
     HIPCHECK(idx, hipMemcpyAsync(idx->qdev, queries, (size_t)B * idx->dim * sizeof(float), hipMemcpyHostToDevice, s));
     const int Bpad = (int)round_up(B, screen_tile(B));
     CHECK(launch_prep(idx, s, B, Bpad, /*metric=*/2));  // test hook: thresholds at -inf for every query
-    CHECK(launch_screen(idx, s, B, row0, row0 + n, kCandCap, /*emit_all=*/false));
+    CHECK(launch_screen(idx, s, B, row0, row0 + n, kCandCap, /*emit_mode=*/0));
     std::vector<int> cnt(B);
     std::vector<int32_t> crow((size_t)B * kCandCap);
     std::vector<float> cval((size_t)B * kCandCap);

@@ -69,6 +69,8 @@ def parse_args():
     ap.add_argument("--prefilter16", type=int, default=None, help="0/1: bf16 second screen inside the prune (default: library default)")
     ap.add_argument("--metric", choices=["cosine", "ip"], default="cosine", help="cosine (headline) or inner product")
     ap.add_argument("--small-chunk", type=int, default=None, help="override small_chunk_rows (developer sweep)")
+    ap.add_argument("--starter", type=int, default=None, help="0/1: pass schedule with / without the sampled threshold estimator (A/B)")
+    ap.add_argument("--prune-companion", type=int, default=None, help="0/1: general-form prune launch behind every one-wave prune (A/B)")
     ap.add_argument("--layout", default="auto",
                     help="ranks as (row shards R) x (query groups Q): 'auto' = fewest row shards whose shard fits in 60 %% of "
                          "one GPU's HBM (N=10M, d=768 -> 1 x world: every rank holds the corpus and serves its own query "
@@ -406,6 +408,10 @@ def main() -> None:
         idx.set_option("round_a", args.round_a)
     if args.small_chunk is not None:
         idx.set_option("small_chunk_rows", args.small_chunk)
+    if args.starter is not None:
+        idx.set_option("starter", args.starter)
+    if args.prune_companion is not None:
+        idx.set_option("prune_companion", args.prune_companion)
     aniso = synth.Anisotropic(torch, d, device) if args.data == "anisotropic" else None
 
     def gen_chunk(c: int, rows: int):

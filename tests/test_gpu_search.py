@@ -167,6 +167,35 @@ def test_small_query_blocks_streaming_screen(pkg, oracle, screen, n, d, B, k):
     assert np.array_equal(res[0][1], res[1][1])
 
 
+@pytest.mark.parametrize("screen", SCREENS)
+@pytest.mark.parametrize("n,d,B,k", [(70_000, 768, 300, 10), (40_000, 128, 1024, 32), (9_000, 64, 20, 1), (300_000, 96, 64, 24)])
+def test_starter_pass_equals_ladder_pass(pkg, oracle, screen, n, d, B, k):
+    """round 3 pass schedule: a sampled threshold estimator (best value per 64-row slab of the first rows, exact re-score of
+    the best-looking ones, threshold only -- nothing kept) replaces the smallest chunks and the chunk ends are planned; the
+    result is the oracle's bit for bit, the same as the emit-all ladder's, whatever the sample holds -- here with the best
+    rows of some queries INSIDE the sample (re-screened, no duplicates), duplicated rows across the sample's edge, and
+    loose / zero rows in it."""
+    rng = np.random.default_rng(n + k)
+    C = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    C[5] = Q[0] * 3.0                       # the best row of query 0 sits in the sample
+    C[n - 1] = Q[0] * 3.0                   # ... and its exact duplicate at the far end (tie -> lower row first)
+    C[100:104] = Q[1][None, :] + 0.05 * rng.standard_normal((4, d)).astype(np.float32)   # four near-ties in ONE slab
+    C[7] = 0.0                              # zero row (irregular) in the sample
+    C[9, 3] = 40.0 * np.abs(C[9]).max()     # outlier component: loose row for the int8 shadow
+    res = []
+    for starter in (1, 0):
+        with pkg.Mi355Index(d) as idx:
+            idx.set_option("screen_dtype", screen)
+            idx.set_option("starter", starter)
+            idx.add(C)
+            idx.reset_stats()
+            res.append(_check(idx, oracle, C, Q, k))
+            assert idx.stat("starters") == starter * idx.stat("passes")
+            assert idx.stat("fallback_queries") == 0
+    assert np.array_equal(res[0][1], res[1][1])
+
+
 @pytest.mark.parametrize("k,expect_dtype", [(10, 2), (24, 2), (26, 1), (100, 1), (400, 1)])
 def test_schedule_adapts_to_k(pkg, oracle, k, expect_dtype):
     """the wider int8 bound keeps ~16x k candidates per chunk, the bf16 bound ~3x: AUTO keeps int8 for small k only and

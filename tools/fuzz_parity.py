@@ -66,6 +66,10 @@ def check_single(rng, case):
         opts["chunk0_rows"] = int(rng.choice([256, 512, 2048]))
     if rng.random() < 0.25:
         opts["prefilter16"] = 1
+    if rng.random() < 0.15:
+        opts["starter"] = 0
+    if rng.random() < 0.15:
+        opts["prune_companion"] = 1
     row_offset = int(rng.choice([0, 0, 12345, 2**33]))
     desc = f"single n={n} d={d} B={B} k={k} mode={mode} metric={metric} opts={opts} row_offset={row_offset}"
     import hashlib

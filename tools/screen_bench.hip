@@ -48,6 +48,23 @@ __global__ void k_fill(uint16_t* p, int64_t rows, int dpad, int d, uint64_t seed
     }
     p[i] = f32_to_bf16_rn(v);
 }
+// int8 data patterns (DATA env): does the matrix pipe's power -- the chip runs this kernel AT its power cap -- depend on the
+// operand values?  1 = Gaussian sigma 29 clipped to +-127 (what the library's shadows hold), 2 = zeros, 3 = Gaussian sigma 4,
+// 4 = |Gaussian| sigma 29 (non-negative), 5 = uniform full range, 6 = Gaussian sigma 29 with the low 2 bits cleared
+__global__ void k_fill8(int8_t* p, int64_t n, int mode, uint64_t seed) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t h = hash32(i * 4 + seed), h2 = hash32(i * 4 + 1 + seed);
+    const float u = ((h & 0xFFFF) + (h >> 16) + (h2 & 0xFFFF) + (h2 >> 16)) * (1.0f / 65536.0f) - 2.0f;  // var 1/3
+    const float g = u * sqrtf(3.0f);
+    int v = 0;
+    if (mode == 1) v = (int)rintf(fminf(fmaxf(g * 29.0f, -127.f), 127.f));
+    else if (mode == 3) v = (int)rintf(g * 4.0f);
+    else if (mode == 4) v = (int)rintf(fminf(fabsf(g) * 29.0f, 127.f));
+    else if (mode == 5) v = (int)(h & 0xFF) - 128;
+    else if (mode == 6) v = ((int)rintf(fminf(fmaxf(g * 29.0f, -127.f), 127.f))) & ~3;
+    p[i] = (int8_t)v;
+}
 __global__ void k_fillf(float* p, int n, float v) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -81,6 +98,12 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&cval, (size_t)Bpad * cap * 4));
     hipLaunchKernelGGL(k_fill, dim3((unsigned)((Npad * dpad + 255) / 256)), dim3(256), 0, 0, shadow, Npad, dpad, d, 1234ull);
     hipLaunchKernelGGL(k_fill, dim3((unsigned)(((int64_t)Bpad * dpad + 255) / 256)), dim3(256), 0, 0, qhat, (int64_t)Bpad, dpad, d, 99ull);
+    if (getenv("DATA")) {
+        const int mode = atoi(getenv("DATA"));
+        const int64_t nb = (int64_t)Npad * dpad * 2, nq = (int64_t)Bpad * dpad * 2;
+        hipLaunchKernelGGL(k_fill8, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, 0, (int8_t*)shadow, nb, mode, 1234ull);
+        hipLaunchKernelGGL(k_fill8, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, 0, (int8_t*)qhat, nq, getenv("QDATA") ? atoi(getenv("QDATA")) : mode, 99ull);
+    }
     CK(hipDeviceSynchronize());
     CK(hipFuncSetAttribute((const void*)k_screen<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreenLds));
     CK(hipFuncSetAttribute((const void*)k_screen<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreenLds));
