@@ -19,6 +19,19 @@ struct EventPair {
     int big;  // 1: the launch went to k_screen256 (the dominant kernel), 0: k_screen
 };
 struct MultiVecStore;  // mi355dr_maxsim.hip
+// one block between enqueue_block() and complete_block() (mi355dr.hip)
+struct Pending {
+    bool active = false;
+    hipEvent_t done = nullptr;
+    int* status_host = nullptr;   // pinned [kQBlockMax + 1]: the block's per-query status words + their OR
+    hipStream_t stream = nullptr;
+    const float* q_dev = nullptr; // the caller's queries (valid until the wait: a fix-up gathers from them)
+    int B = 0, k = 0, level = 0;
+    double* out_dist = nullptr;
+    int64_t* out_rows = nullptr;
+    bool used_screen = false, was_i8 = false;
+};
+constexpr int kPendingRing = 4;
 }  // namespace mi355
 
 struct mi355dr_index {
@@ -69,10 +82,15 @@ struct mi355dr_index {
     int retry_level = 0;   // > 0 while overflowed queries are re-screened: bf16 bound, slower chunk growth
     bool i8_demoted = false;  // AUTO saw the int8 bound overflow on this corpus' score distribution: bf16 from now on
     // buffers of the sub-block a search at retry level L re-screens (one set per level: the nested call owns the next)
-    float* retry_q[2] = {nullptr, nullptr};      // [kQBlockMax, dim] queries being re-screened
-    double* retry_dist[2] = {nullptr, nullptr};  // [kQBlockMax, kKMax]
-    int64_t* retry_rows[2] = {nullptr, nullptr};
-    int* retry_map[2] = {nullptr, nullptr};      // [kQBlockMax] position of each re-screened query in its block
+    float* retry_q[3] = {nullptr, nullptr, nullptr};      // [kQBlockMax, dim] queries being re-screened / re-scanned
+    double* retry_dist[3] = {nullptr, nullptr, nullptr};  // [kQBlockMax, kKMax]
+    int64_t* retry_rows[3] = {nullptr, nullptr, nullptr};
+    int* retry_map[3] = {nullptr, nullptr, nullptr};      // [kQBlockMax] position of each sub-block query in its block
+    // blocks in flight: sequence numbers [seq_done, seq_next) live in pend[seq % kPendingRing]; sub_pend[level]: the
+    // synchronous blocks of the fix-up levels
+    mi355::Pending pend[mi355::kPendingRing];
+    mi355::Pending sub_pend[4];
+    int64_t seq_next = 0, seq_done = 0;
     int k_now = 10;        // k of the search in progress (the screen element type and the chunk growth depend on it)
     int maxsim_screen = 1; // 1: bf16 MFMA screen + exact re-score of the candidates, 0: exact kernel over every doc
     int64_t row_offset = 0;

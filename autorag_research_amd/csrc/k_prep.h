@@ -190,11 +190,17 @@ __global__ __launch_bounds__(256) void k_build_shadow8(const float* __restrict__
 // grid: Bpad blocks of 64 threads.  i8 != 0: also prepare the int8 screen (qhat8, sc, kq, E from the
 // measured query residual); otherwise the bf16 screen: E from the measured query residual and bf16_ec, the largest
 // residual norm of the stored rows.
+// block 0 also re-arms the block's OR-ed status word and both hand-over counters of k_prune (two launches less per block)
 __global__ __launch_bounds__(64) void k_prep_queries(const float* __restrict__ q, int B, int d, int dpad, int metric,
-                                                      QueryState st, int dpad8, int i8, float bf16_ec) {
+                                                      QueryState st, int dpad8, int i8, float bf16_ec, int* status_or,
+                                                      int* prune_skip, int cnt0) {
     extern __shared__ float qs[];  // [d]
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
+    if (b == 0 && lane == 0) {
+        if (status_or) *status_or = 0;
+        if (prune_skip) prune_skip[0] = prune_skip[1] = 0;
+    }
     uint16_t* qh = st.qhat + (int64_t)b * dpad;
     if (b >= B) {  // padding rows of the last 128-query tile
         for (int k = lane; k < dpad; k += kWave) qh[k] = 0;
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(64) void k_prep_queries(const float* __restrict__ q
         // cosine screen cannot rank an irregular query: park it (never emits) and flag it for the scan path
         // (metric 2 = test hook: every query screens with thresholds at -inf)
         st.thr[b] = (regular || metric == 2) ? -__builtin_inff() : __builtin_inff();
-        st.cnt[b] = 0;
+        st.cnt[b] = cnt0;  // (> 0: the starter writes one candidate per slab at fixed slots)
         st.best_n[b] = 0;
         st.thr_key[b] = kKeyNaN;
         st.thr_row[b] = 0x7FFFFFFF;

@@ -169,8 +169,13 @@ EventPair take_events(mi355dr_index* idx) {
     return p;
 }
 
-void drain_events(mi355dr_index* idx) {  // call only after the stream was synchronised
+void drain_events(mi355dr_index* idx) {  // the pairs whose launch has finished (a later block's may still be in flight)
+    std::vector<EventPair> keep;
     for (auto& p : idx->ev_pending) {
+        if (hipEventQuery(p.b) == hipErrorNotReady) {
+            keep.push_back(p);
+            continue;
+        }
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             idx->s_screen_ns += (int64_t)(ms * 1e6);
@@ -178,7 +183,7 @@ void drain_events(mi355dr_index* idx) {  // call only after the stream was synch
         }
         idx->ev_pool.push_back(p);
     }
-    idx->ev_pending.clear();
+    idx->ev_pending.swap(keep);
 }
 
 // Candidates a chunk appends per query ~ k * (chunk / rows seen before) * inflation, where the inflation is how much
@@ -241,9 +246,11 @@ int launch_prune(mi355dr_index* idx, hipStream_t s, int nblocks, const int* qlis
     return MI355DR_OK;
 }
 
-int launch_prep(mi355dr_index* idx, hipStream_t s, int B, int Bpad, int metric) {
+int launch_prep(mi355dr_index* idx, hipStream_t s, int B, int Bpad, int metric, int cnt0 = 0) {
     hipLaunchKernelGGL(k_prep_queries, dim3(Bpad), dim3(64), (size_t)idx->dim * sizeof(float), s, idx->qdev, B, idx->dim,
-                       idx->dpad, metric, idx->st, idx->dpad8, use_i8(idx) ? 1 : 0, idx->bf16_ec);
+                       idx->dpad, metric, idx->st, idx->dpad8, use_i8(idx) ? 1 : 0, idx->bf16_ec, idx->status_or_dev,
+                       idx->prune_skip, cnt0);
+    idx->prune_parity = 0;
     HIPCHECK(idx, hipGetLastError());
     return MI355DR_OK;
 }
@@ -307,8 +314,9 @@ int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t 
         else hipLaunchKernelGGL(k_screen<false>, dim3((unsigned)grid), dim3(256), kScreenLds, s, (ScreenArgs)sa);
     }
     HIPCHECK(idx, hipGetLastError());
-    if (emit_all) {  // every row of the chunk (starter: every slab's best row) was stored at its own slot for every query
-        const int per_query = emit_mode == kEmitSlabMax ? (int)((r_end - r0 + kSlabRows - 1) / kSlabRows) : (int)(r_end - r0);
+    if (emit_mode == kEmitAll) {  // every row of the chunk was stored at slot row-r0 for every query
+        // (the starter's one-candidate-per-slab count is what k_prep_queries initialised the lists with: starter_count())
+        const int per_query = (int)(r_end - r0);
         hipLaunchKernelGGL(k_set_counts, dim3((B + 255) / 256), dim3(256), 0, s, idx->st.cnt, B, per_query);
         HIPCHECK(idx, hipGetLastError());
     }
@@ -357,6 +365,14 @@ PassPlan plan_pass(const mi355dr_index* idx, int B, int k, double growth) {
     for (int i = 1; i <= steps; ++i) {
         pos *= r;
         int64_t end = i == steps ? n : std::min<int64_t>(n, round_up((int64_t)pos, tile));
+        if (tile == kT2 && end < n) {
+            // whole rounds of the persistent grid: 8 XCDs x (32 / n_qtiles) corpus tiles are in flight at a time, and a chunk
+            // of 4.3 rounds costs 5 (k_screen256c's launches of 70 k rows ran at 1.6 ns per row against 0.68 in long ones)
+            const int n_qtiles = (int)(round_up(B, kT2) / kT2);
+            const int64_t round_rows = (int64_t)8 * (32 / n_qtiles) * kT2;
+            const int64_t len = end - prev;
+            if (len >= 2 * round_rows) end = std::min<int64_t>(n, prev + (len + round_rows / 2) / round_rows * round_rows);
+        }
         if (end <= prev) continue;
         p.ends.push_back(end);
         prev = end;
@@ -366,9 +382,9 @@ PassPlan plan_pass(const mi355dr_index* idx, int B, int k, double growth) {
     return p;
 }
 
-// screen path over all rows for the B queries prepared in idx->st / idx->qdev
-int run_screen(mi355dr_index* idx, hipStream_t s, int B, int k) {
-    int64_t kept_all_below = 0;  // rows the emit-all first chunk already turned into candidates
+inline int starter_count(const PassPlan& p) { return (int)((p.sample + kSlabRows - 1) / kSlabRows); }
+
+PassPlan make_plan(const mi355dr_index* idx, int B, int k) {
     double growth = std::max(0.25, idx->chunk_growth_set ? std::min((double)idx->chunk_growth, growth_budget(idx, k, use_i8(idx)))
                                                          : growth_budget(idx, k, use_i8(idx)));
     growth = std::min(growth, 8.0);
@@ -378,11 +394,17 @@ int run_screen(mi355dr_index* idx, hipStream_t s, int B, int k) {
         growth = std::max(growth, std::min(8.0, growth_budget(idx, k, use_i8(idx)) * kSmallBlockBudget));
     if (idx->retry_level == 1) growth = std::max(0.25, std::min(growth, 3.0) * 0.5);
     if (idx->retry_level >= 2) growth = 0.25;  // (every chunk then holds <= 20 % of the rows: a dense neighbourhood is split up)
+    return plan_pass(idx, B, k, growth);
+}
+
+// screen path over all rows for the B queries prepared in idx->st / idx->qdev (candidate counts initialised to
+// starter_count(plan) by k_prep_queries when the plan has a starter)
+int run_screen(mi355dr_index* idx, hipStream_t s, int B, int k, const PassPlan& plan) {
+    int64_t kept_all_below = 0;  // rows the emit-all first chunk already turned into candidates
     const bool i8 = use_i8(idx);
     const int side_n = i8 ? idx->irr8_n : idx->irr_n;  // rows this screen cannot see
     constexpr int kSideMerge = 32;
     bool side_done = false;
-    const PassPlan plan = plan_pass(idx, B, k, growth);
     // one-wave prune alone: small k, first attempt (a retry keeps the general form: it is the last screen before the exact scan)
     const bool lean = plan.sample > 0 && idx->prune_companion == 0;
     auto timed = [&](bool big, int64_t rows, auto&& launch) -> int {
@@ -518,8 +540,6 @@ int run_scan(mi355dr_index* idx, hipStream_t s, const std::vector<int>& qs, int 
     return MI355DR_OK;
 }
 
-__global__ void k_set_int(int* p, int v) { *p = v; }
-
 // rows `map[j]` of src -> row j of dst (d floats each)
 __global__ void k_gather_queries(const float* src, const int* map, int d, float* dst) {
     const int j = blockIdx.x;
@@ -534,18 +554,28 @@ __global__ void k_scatter_results(const double* sd, const int64_t* sr, const int
     }
 }
 
-// one block of B <= kQBlockMax device-resident queries -> device outputs [B,k]
-int search_block(mi355dr_index* idx, hipStream_t s, const float* q_dev, int B, int k, double* out_dist_dev,
-                 int64_t* out_rows_dev) {
+// ---- a block in flight -------------------------------------------------------------------------------------------------
+// Round 3: a block no longer ends with a host synchronisation.  enqueue_block() puts the whole pass on the stream -- prepare,
+// starter, chunks, finalize, a copy of the per-query status words into the block's own pinned buffer, an event -- and returns;
+// complete_block() waits for the event and only then looks at the status: queries that overflowed a candidate list are
+// re-screened (tighter bound, slower growth), queries the screen cannot rank are recomputed by the exact scan, each as a
+// sub-block of its own whose results are scattered into the block's outputs.  Between the two calls the caller may enqueue
+// the NEXT block (same stream): the GPU goes from one block's last kernel to the next one's first without waiting for the
+// host's round trip (~50 us per block: 0.6 % of the 10 M-row pass, 4 % at the 8-way shard size).  The per-search state is
+// single: blocks follow each other in stream order, and a fix-up (enqueued behind whatever is in flight) gathers its
+// queries from the CALLER's buffer, which therefore stays valid until the wait.
+int pending_alloc(mi355dr_index* idx, Pending& p) {
+    if (!p.status_host) HIPCHECK(idx, hipHostMalloc(&p.status_host, (kQBlockMax + 1) * sizeof(int)));
+    if (!p.done) HIPCHECK(idx, hipEventCreateWithFlags(&p.done, hipEventDisableTiming));
+    return MI355DR_OK;
+}
+
+int enqueue_block(mi355dr_index* idx, hipStream_t s, const float* q_dev, int B, int k, double* out_dist_dev,
+                  int64_t* out_rows_dev, Pending& p) {
     CHECK(ensure_qstate(idx));
+    CHECK(pending_alloc(idx, p));
     idx->k_now = k;
     const int Bpad = (int)round_up(B, screen_tile(B));
-    if (q_dev != idx->qdev)
-        HIPCHECK(idx, hipMemcpyAsync(idx->qdev, q_dev, (size_t)B * idx->dim * sizeof(float), hipMemcpyDeviceToDevice, s));
-    CHECK(launch_prep(idx, s, B, Bpad, idx->metric));
-    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, idx->status_or_dev, 0);
-    HIPCHECK(idx, hipMemsetAsync(idx->prune_skip, 0, 2 * sizeof(int), s));  // both hand-over counters of the prune
-    idx->prune_parity = 0;
     if (idx->screen_dtype == MI355DR_SCREEN_I8 && !i8_available(idx) && idx->path != MI355DR_PATH_SCAN)
         return fail(idx, MI355DR_E_UNSUPPORTED, "int8 screen unavailable: too many rows outside the residual limit");
     // (inner product rides the same cosine screens: thresholds become cos >= dot_k / (|q| cmax), see k_prune)
@@ -553,71 +583,125 @@ int search_block(mi355dr_index* idx, hipStream_t s, const float* q_dev, int B, i
     const bool use_screen = idx->n > 0 && screen_possible && idx->path != MI355DR_PATH_SCAN;
     if (idx->path == MI355DR_PATH_SCREEN && !screen_possible && idx->n > 0)
         return fail(idx, MI355DR_E_UNSUPPORTED, "screen path unavailable (metric or too many irregular rows)");
-    std::vector<int> todo;
+    if (q_dev != idx->qdev)
+        HIPCHECK(idx, hipMemcpyAsync(idx->qdev, q_dev, (size_t)B * idx->dim * sizeof(float), hipMemcpyDeviceToDevice, s));
+    PassPlan plan;
+    if (use_screen) plan = make_plan(idx, B, k);
+    // (also re-arms the status word and the prune's hand-over counters, and starts the lists at the starter's count)
+    CHECK(launch_prep(idx, s, B, Bpad, idx->metric, starter_count(plan)));
     if (idx->n > 0) {
         if (use_screen) {
-            CHECK(run_screen(idx, s, B, k));
+            CHECK(run_screen(idx, s, B, k, plan));
         } else {
-            todo.resize(B);
-            for (int i = 0; i < B; ++i) todo[i] = i;
-            CHECK(run_scan(idx, s, todo, k));
-            todo.clear();
+            std::vector<int> all(B);
+            for (int i = 0; i < B; ++i) all[i] = i;
+            CHECK(run_scan(idx, s, all, k));  // (blocks on the host only where a chunk larger than the buffer overflowed)
         }
     }
     hipLaunchKernelGGL(k_finalize, dim3(B), dim3(64), 0, s, idx->st, k, idx->row_offset, out_dist_dev, out_rows_dev,
                        idx->status_or_dev);
     HIPCHECK(idx, hipGetLastError());
-    HIPCHECK(idx, hipMemcpyAsync(idx->status_host + kQBlockMax, idx->status_or_dev, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHECK(idx, hipStreamSynchronize(s));
+    HIPCHECK(idx, hipMemcpyAsync(p.status_host, idx->st.status, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHECK(idx, hipMemcpyAsync(p.status_host + kQBlockMax, idx->status_or_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHECK(idx, hipEventRecord(p.done, s));
+    p.active = true;
+    p.stream = s;
+    p.q_dev = q_dev;
+    p.B = B;
+    p.k = k;
+    p.out_dist = out_dist_dev;
+    p.out_rows = out_rows_dev;
+    p.used_screen = use_screen;
+    p.was_i8 = use_screen && use_i8(idx);
+    p.level = idx->retry_level;
+    return MI355DR_OK;
+}
+
+int search_block(mi355dr_index* idx, hipStream_t s, const float* q_dev, int B, int k, double* out_dist_dev,
+                 int64_t* out_rows_dev);
+
+int complete_block(mi355dr_index* idx, Pending& p) {
+    if (!p.active) return MI355DR_OK;
+    p.active = false;
+    HIPCHECK(idx, hipEventSynchronize(p.done));
     drain_events(idx);
-    if (use_screen && idx->status_host[kQBlockMax] != 0) {
-        // some query overflowed its candidate buffer or has an irregular norm
-        HIPCHECK(idx, hipMemcpyAsync(idx->status_host, idx->st.status, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
-        HIPCHECK(idx, hipStreamSynchronize(s));
+    if (!p.used_screen || p.status_host[kQBlockMax] == 0) return MI355DR_OK;
+    // some query overflowed its candidate buffer or has an irregular norm
+    hipStream_t s = p.stream;
+    const int B = p.B, k = p.k, level = p.level;
+    std::vector<int> sub;  // [todo ... | retry ...]
+    int n_todo = 0;
+    {
         std::vector<int> retry;
-        const bool was_i8 = use_i8(idx);
         for (int i = 0; i < B; ++i) {
-            const int st = idx->status_host[i];
+            const int st = p.status_host[i];
             if (st == 0) continue;
             // an overflow at the first attempt is re-screened with the tighter bound and slower growth; whatever
             // overflows again, and every query the screen cannot rank (irregular norm), is recomputed exactly
-            if (idx->retry_level < kRetryLevels && !(st & kStIrregular)) retry.push_back(i);
-            else todo.push_back(i);
+            if (level < kRetryLevels && !(st & kStIrregular)) retry.push_back(i);
+            else sub.push_back(i);
         }
-        if (!todo.empty()) {
-            CHECK(run_scan(idx, s, todo, k));
-            hipLaunchKernelGGL(k_finalize, dim3(B), dim3(64), 0, s, idx->st, k, idx->row_offset, out_dist_dev,
-                               out_rows_dev, idx->status_or_dev);
-            HIPCHECK(idx, hipGetLastError());
-            HIPCHECK(idx, hipStreamSynchronize(s));
-        }
-        if (!retry.empty()) {
-            const int nr = (int)retry.size();
-            idx->s_retry_queries += nr;
-            if (was_i8 && idx->screen_dtype == MI355DR_SCREEN_AUTO && nr * 20 > B) idx->i8_demoted = true;
-            const int level = idx->retry_level;  // this call's level; the nested call runs at level + 1
-            if (!idx->retry_q[level]) {
-                HIPCHECK(idx, hipMalloc(&idx->retry_q[level], (size_t)kQBlockMax * idx->dim * sizeof(float)));
-                HIPCHECK(idx, hipMalloc(&idx->retry_dist[level], (size_t)kQBlockMax * kKMax * sizeof(double)));
-                HIPCHECK(idx, hipMalloc(&idx->retry_rows[level], (size_t)kQBlockMax * kKMax * sizeof(int64_t)));
-                HIPCHECK(idx, hipMalloc(&idx->retry_map[level], (size_t)kQBlockMax * sizeof(int)));
-            }
-            HIPCHECK(idx, hipMemcpyAsync(idx->retry_map[level], retry.data(), nr * sizeof(int), hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(k_gather_queries, dim3(nr), dim3(128), 0, s, idx->qdev, idx->retry_map[level], idx->dim,
-                               idx->retry_q[level]);
-            HIPCHECK(idx, hipGetLastError());
-            HIPCHECK(idx, hipStreamSynchronize(s));  // `retry` (pageable) was read by the copy
-            idx->retry_level = level + 1;
-            const int rc = search_block(idx, s, idx->retry_q[level], nr, k, idx->retry_dist[level], idx->retry_rows[level]);
-            idx->retry_level = level;
-            CHECK(rc);
-            hipLaunchKernelGGL(k_scatter_results, dim3(nr), dim3(128), 0, s, idx->retry_dist[level], idx->retry_rows[level],
-                               idx->retry_map[level], k, out_dist_dev, out_rows_dev);
-            HIPCHECK(idx, hipGetLastError());
-            HIPCHECK(idx, hipStreamSynchronize(s));
-        }
+        n_todo = (int)sub.size();
+        sub.insert(sub.end(), retry.begin(), retry.end());
     }
+    const int n_sub = (int)sub.size(), n_retry = n_sub - n_todo;
+    if (n_sub == 0) return MI355DR_OK;
+    if (!idx->retry_q[level]) {
+        HIPCHECK(idx, hipMalloc(&idx->retry_q[level], (size_t)kQBlockMax * idx->dim * sizeof(float)));
+        HIPCHECK(idx, hipMalloc(&idx->retry_dist[level], (size_t)kQBlockMax * kKMax * sizeof(double)));
+        HIPCHECK(idx, hipMalloc(&idx->retry_rows[level], (size_t)kQBlockMax * kKMax * sizeof(int64_t)));
+        HIPCHECK(idx, hipMalloc(&idx->retry_map[level], (size_t)kQBlockMax * sizeof(int)));
+    }
+    // both sub-blocks' queries are gathered from the caller's buffer BEFORE either runs (a nested search overwrites qdev)
+    HIPCHECK(idx, hipMemcpyAsync(idx->retry_map[level], sub.data(), n_sub * sizeof(int), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_gather_queries, dim3(n_sub), dim3(128), 0, s, p.q_dev, idx->retry_map[level], idx->dim,
+                       idx->retry_q[level]);
+    HIPCHECK(idx, hipGetLastError());
+    HIPCHECK(idx, hipStreamSynchronize(s));  // `sub` (pageable) was read by the copy
+    const int saved_level = idx->retry_level, saved_path = idx->path;
+    int rc = MI355DR_OK;
+    if (n_todo > 0) {  // guaranteed exact path
+        idx->retry_level = level + 1;  // (buffers of the next level; the scan itself never re-screens)
+        idx->path = MI355DR_PATH_SCAN;
+        rc = search_block(idx, s, idx->retry_q[level], n_todo, k, idx->retry_dist[level], idx->retry_rows[level]);
+        idx->path = saved_path;
+        idx->retry_level = saved_level;
+        CHECK(rc);
+    }
+    if (n_retry > 0) {
+        idx->s_retry_queries += n_retry;
+        if (p.was_i8 && idx->screen_dtype == MI355DR_SCREEN_AUTO && n_retry * 20 > B) idx->i8_demoted = true;
+        idx->retry_level = level + 1;
+        rc = search_block(idx, s, idx->retry_q[level] + (size_t)n_todo * idx->dim, n_retry, k,
+                          idx->retry_dist[level] + (size_t)n_todo * k, idx->retry_rows[level] + (size_t)n_todo * k);
+        idx->retry_level = saved_level;
+        CHECK(rc);
+    }
+    hipLaunchKernelGGL(k_scatter_results, dim3(n_sub), dim3(128), 0, s, idx->retry_dist[level], idx->retry_rows[level],
+                       idx->retry_map[level], k, p.out_dist, p.out_rows);
+    HIPCHECK(idx, hipGetLastError());
+    HIPCHECK(idx, hipStreamSynchronize(s));
     return MI355DR_OK;
+}
+
+// blocks still in flight (mi355dr_search_device_async) are finished before anything that is not the next block on the same
+// stream touches the per-search state or the corpus buffers
+int drain_pending(mi355dr_index* idx) {
+    int rc = MI355DR_OK;
+    while (idx->seq_done < idx->seq_next) {
+        const int r = complete_block(idx, idx->pend[idx->seq_done % kPendingRing]);
+        if (rc == MI355DR_OK) rc = r;
+        idx->seq_done++;
+    }
+    return rc;
+}
+
+// one block of B <= kQBlockMax device-resident queries -> device outputs [B,k], complete on return
+int search_block(mi355dr_index* idx, hipStream_t s, const float* q_dev, int B, int k, double* out_dist_dev,
+                 int64_t* out_rows_dev) {
+    Pending& p = idx->sub_pend[std::min(idx->retry_level, kRetryLevels + 1)];
+    CHECK(enqueue_block(idx, s, q_dev, B, k, out_dist_dev, out_rows_dev, p));
+    return complete_block(idx, p);
 }
 
 int check_search_args(mi355dr_index* idx, const void* q, int B, int k, const void* od, const void* orow) {
@@ -682,8 +766,15 @@ int mi355dr_create(mi355dr_index** out, int device_id, int dim, int metric) {
 void mi355dr_destroy(mi355dr_index* idx) {
     if (!idx) return;
     (void)hipSetDevice(idx->device);
+    (void)drain_pending(idx);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
-    void* ptrs[] = {idx->n2max_dev, idx->bf16_res2_dev, idx->retry_q[0], idx->retry_dist[0], idx->retry_rows[0], idx->retry_map[0], idx->retry_q[1],
+    for (Pending* pp : {&idx->pend[0], &idx->pend[1], &idx->pend[2], &idx->pend[3], &idx->sub_pend[0], &idx->sub_pend[1],
+                        &idx->sub_pend[2], &idx->sub_pend[3]}) {
+        if (pp->done) (void)hipEventDestroy(pp->done);
+        if (pp->status_host) (void)hipHostFree(pp->status_host);
+    }
+    void* ptrs[] = {idx->retry_q[2], idx->retry_dist[2], idx->retry_rows[2], idx->retry_map[2],
+                    idx->n2max_dev, idx->bf16_res2_dev, idx->retry_q[0], idx->retry_dist[0], idx->retry_rows[0], idx->retry_map[0], idx->retry_q[1],
                     idx->retry_dist[1], idx->retry_rows[1], idx->retry_map[1], idx->shadow8, idx->flag8, idx->grp8, idx->irr8_rows, idx->irr8_count, idx->st.E, idx->st.E16, idx->st.sc, idx->st.kq,
                     idx->st.qhat8,
                     idx->rows, idx->shadow, idx->nrm2, idx->irr_rows, idx->irr_count, idx->st.qn, idx->st.qhat,
@@ -715,6 +806,7 @@ int mi355dr_reserve(mi355dr_index* idx, int64_t n_rows) {
     HIPCHECK(idx, hipSetDevice(idx->device));
     if (n_rows < 0) return fail(idx, MI355DR_E_INVALID, "negative row count");
     if (n_rows >= (int64_t)1 << 31) return fail(idx, MI355DR_E_UNSUPPORTED, "more than 2^31-1 rows per index");
+    CHECK(drain_pending(idx));
     return ensure_capacity(idx, n_rows);
 }
 
@@ -726,6 +818,7 @@ static int add_rows_impl(mi355dr_index* idx, const float* rows, int64_t n, hipMe
     if (!rows) return fail(idx, MI355DR_E_INVALID, "rows is null");
     if (idx->n + n >= (int64_t)1 << 31) return fail(idx, MI355DR_E_UNSUPPORTED, "more than 2^31-1 rows per index");
     HIPCHECK(idx, hipSetDevice(idx->device));
+    CHECK(drain_pending(idx));
     CHECK(ensure_capacity(idx, idx->n + n));
     hipStream_t s = idx->stream;
     HIPCHECK(idx, hipMemcpyAsync(idx->rows + idx->n * idx->dim, rows, (size_t)n * idx->dim * sizeof(float), kind, s));
@@ -792,6 +885,7 @@ int mi355dr_search(mi355dr_index* idx, const float* queries, int B, int k, doubl
     CHECK(check_search_args(idx, queries, B, k, out_dist, out_rows));
     std::lock_guard<std::mutex> g(idx->mu);
     HIPCHECK(idx, hipSetDevice(idx->device));
+    CHECK(drain_pending(idx));
     CHECK(ensure_qstate(idx));
     hipStream_t s = idx->stream;
     for (int b0 = 0; b0 < B; b0 += kQBlockMax) {
@@ -808,18 +902,58 @@ int mi355dr_search(mi355dr_index* idx, const float* queries, int B, int k, doubl
     return MI355DR_OK;
 }
 
+static int search_device_async_locked(mi355dr_index* idx, const float* queries_dev, int B, int k, double* out_dist_dev,
+                                      int64_t* out_rows_dev, hipStream_t s, int64_t* ticket) {
+    // a block in flight on ANOTHER stream is finished first: the per-search state is shared and only stream order protects it
+    if (idx->seq_done < idx->seq_next && idx->pend[(idx->seq_next - 1) % kPendingRing].stream != s) CHECK(drain_pending(idx));
+    for (int b0 = 0; b0 < B; b0 += kQBlockMax) {
+        const int nb = std::min(kQBlockMax, B - b0);
+        if (idx->seq_next - idx->seq_done >= kPendingRing) {  // the ring is full: finish the oldest block
+            CHECK(complete_block(idx, idx->pend[idx->seq_done % kPendingRing]));
+            idx->seq_done++;
+        }
+        Pending& p = idx->pend[idx->seq_next % kPendingRing];
+        CHECK(enqueue_block(idx, s, queries_dev + (int64_t)b0 * idx->dim, nb, k, out_dist_dev + (int64_t)b0 * k,
+                            out_rows_dev + (int64_t)b0 * k, p));
+        idx->seq_next++;
+    }
+    if (ticket) *ticket = idx->seq_next;  // every block below this sequence number belongs to (or precedes) this call
+    return MI355DR_OK;
+}
+
+int mi355dr_search_device_async(mi355dr_index* idx, const float* queries_dev, int B, int k, double* out_dist_dev,
+                                int64_t* out_rows_dev, void* stream, int64_t* ticket) {
+    CHECK(check_search_args(idx, queries_dev, B, k, out_dist_dev, out_rows_dev));
+    if (!ticket) return fail(idx, MI355DR_E_INVALID, "ticket is null");
+    std::lock_guard<std::mutex> g(idx->mu);
+    HIPCHECK(idx, hipSetDevice(idx->device));
+    return search_device_async_locked(idx, queries_dev, B, k, out_dist_dev, out_rows_dev,
+                                      stream ? (hipStream_t)stream : idx->stream, ticket);
+}
+
+int mi355dr_search_wait(mi355dr_index* idx, int64_t ticket) {
+    if (!idx) return fail(nullptr, MI355DR_E_INVALID, "null index");
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (ticket < 0 || ticket > idx->seq_next) return fail(idx, MI355DR_E_INVALID, "unknown ticket");
+    HIPCHECK(idx, hipSetDevice(idx->device));
+    int rc = MI355DR_OK;
+    while (idx->seq_done < ticket) {
+        const int r = complete_block(idx, idx->pend[idx->seq_done % kPendingRing]);
+        if (rc == MI355DR_OK) rc = r;
+        idx->seq_done++;
+    }
+    return rc;
+}
+
 int mi355dr_search_device(mi355dr_index* idx, const float* queries_dev, int B, int k, double* out_dist_dev,
                           int64_t* out_rows_dev, void* stream) {
     CHECK(check_search_args(idx, queries_dev, B, k, out_dist_dev, out_rows_dev));
     std::lock_guard<std::mutex> g(idx->mu);
     HIPCHECK(idx, hipSetDevice(idx->device));
-    hipStream_t s = stream ? (hipStream_t)stream : idx->stream;
-    for (int b0 = 0; b0 < B; b0 += kQBlockMax) {
-        const int nb = std::min(kQBlockMax, B - b0);
-        CHECK(search_block(idx, s, queries_dev + (int64_t)b0 * idx->dim, nb, k, out_dist_dev + (int64_t)b0 * k,
-                           out_rows_dev + (int64_t)b0 * k));
-    }
-    return MI355DR_OK;
+    int64_t ticket = 0;
+    CHECK(search_device_async_locked(idx, queries_dev, B, k, out_dist_dev, out_rows_dev,
+                                     stream ? (hipStream_t)stream : idx->stream, &ticket));
+    return drain_pending(idx);
 }
 
 int mi355dr_merge_topk_device(mi355dr_index* idx, const double* dist_all_dev, const int64_t* rows_all_dev, int world,
@@ -873,6 +1007,10 @@ int mi355dr_merge_topk_packed_device(mi355dr_index* idx, const int64_t* packed_a
 int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
     if (!idx || !key) return fail(idx, MI355DR_E_INVALID, "null argument");
     std::lock_guard<std::mutex> g(idx->mu);
+    if (idx->seq_done < idx->seq_next) {  // (a fix-up of a block in flight must see the options it was enqueued under)
+        HIPCHECK(idx, hipSetDevice(idx->device));
+        CHECK(drain_pending(idx));
+    }
     const std::string k(key);
     if (k == "path") {
         if (value < 0 || value > 2) return fail(idx, MI355DR_E_INVALID, "path must be 0,1,2");
@@ -1027,6 +1165,7 @@ int mi355dr_debug_screen_dense(mi355dr_index* idx, const float* queries, int B, 
         return fail(idx, MI355DR_E_INVALID,
                     "debug_screen_dense: need 1<=B<=1024, 1<=n<=2048, row0 a multiple of the tile (128; 256 if B>128)");
     HIPCHECK(idx, hipSetDevice(idx->device));
+    CHECK(drain_pending(idx));
     CHECK(ensure_qstate(idx));
     hipStream_t s = idx->stream;
     HIPCHECK(idx, hipMemcpyAsync(idx->qdev, queries, (size_t)B * idx->dim * sizeof(float), hipMemcpyHostToDevice, s));
@@ -1058,6 +1197,7 @@ int mi355dr_debug_screen_bound(mi355dr_index* idx, const float* queries, int B, 
     std::lock_guard<std::mutex> g(idx->mu);
     if (B <= 0 || B > kQBlockMax) return fail(idx, MI355DR_E_INVALID, "need 1<=B<=1024");
     HIPCHECK(idx, hipSetDevice(idx->device));
+    CHECK(drain_pending(idx));
     CHECK(ensure_qstate(idx));
     hipStream_t s = idx->stream;
     HIPCHECK(idx, hipMemcpyAsync(idx->qdev, queries, (size_t)B * idx->dim * sizeof(float), hipMemcpyHostToDevice, s));
@@ -1076,6 +1216,7 @@ int mi355dr_debug_i8_state(mi355dr_index* idx, const float* queries, int B, floa
         return fail(idx, MI355DR_E_INVALID, "group range outside the index");
     if (!use_i8(idx)) return fail(idx, MI355DR_E_UNSUPPORTED, "the int8 screen is not active");
     HIPCHECK(idx, hipSetDevice(idx->device));
+    CHECK(drain_pending(idx));
     CHECK(ensure_qstate(idx));
     hipStream_t s = idx->stream;
     HIPCHECK(idx, hipMemcpyAsync(idx->qdev, queries, (size_t)B * idx->dim * sizeof(float), hipMemcpyHostToDevice, s));
@@ -1103,6 +1244,7 @@ int mi355dr_debug_rescore(mi355dr_index* idx, const float* queries, int B, const
         if (pair_q[i] < 0 || pair_q[i] >= B || pair_row[i] < 0 || pair_row[i] >= idx->n)
             return fail(idx, MI355DR_E_INVALID, "pair out of range");
     HIPCHECK(idx, hipSetDevice(idx->device));
+    CHECK(drain_pending(idx));
     CHECK(ensure_qstate(idx));
     hipStream_t s = idx->stream;
     HIPCHECK(idx, hipMemcpyAsync(idx->qdev, queries, (size_t)B * idx->dim * sizeof(float), hipMemcpyHostToDevice, s));

@@ -100,6 +100,22 @@ class Mi355Index:
                                                        ctypes.c_void_p(int(out_rows_ptr)),
                                                        ctypes.c_void_p(int(stream) if stream else None)))
 
+    def search_device_async(self, q_ptr: int, B: int, k: int, out_dist_ptr: int, out_rows_ptr: int,
+                            stream: int | None = None) -> int:
+        """Enqueue the search and return a ticket without synchronising (mi355dr_search_device_async): the outputs are
+        valid after `search_wait(ticket)`; the query and output buffers must stay untouched until then."""
+        t = ctypes.c_int64(0)
+        check(self._h, self._lib.mi355dr_search_device_async(self._h, ctypes.c_void_p(int(q_ptr)), int(B), int(k),
+                                                             ctypes.c_void_p(int(out_dist_ptr)),
+                                                             ctypes.c_void_p(int(out_rows_ptr)),
+                                                             ctypes.c_void_p(int(stream) if stream else None),
+                                                             ctypes.byref(t)))
+        return int(t.value)
+
+    def search_wait(self, ticket: int) -> None:
+        """Complete every block up to `ticket` (waits, then recomputes the rare queries the screen flagged)."""
+        check(self._h, self._lib.mi355dr_search_wait(self._h, int(ticket)))
+
     def merge_topk_device(self, dist_all_ptr: int, rows_all_ptr: int, world: int, B: int, k: int, out_dist_ptr: int,
                           out_rows_ptr: int, stream: int | None = None) -> None:
         check(self._h, self._lib.mi355dr_merge_topk_device(

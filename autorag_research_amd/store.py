@@ -226,18 +226,41 @@ class UowStore:
         if repo_name in self._tables:
             return self._tables[repo_name]
         ids, contents, single, multi = [], [], [], []
-        offset = 0
-        while True:
+
+        def take(c) -> None:
+            ids.append(c.id)
+            contents.append(getattr(c, "contents", None))
+            single.append(_as_vec(getattr(c, "embedding", None)))
+            multi.append(_as_vec(getattr(c, "embeddings", None)))
+
+        with self._svc._create_uow() as uow:
+            keyed = hasattr(getattr(uow, repo_name), "get_all_ids") and hasattr(getattr(uow, repo_name), "get_by_ids")
+        if keyed:
+            # page by ORDERED primary key (ChunkRepository.get_all_ids is `ORDER BY id`, orm/repository/chunk.py:123-136), then
+            # fetch each page by key: `get_all(limit, offset)` is a SELECT without ORDER BY, one transaction per page -- PostgreSQL
+            # promises no stable order across such statements, and a row seen twice or never would shift every row -> id mapping
             with self._svc._create_uow() as uow:
-                page = getattr(uow, repo_name).get_all(limit=self.EXPORT_PAGE, offset=offset)
-                for c in page:
-                    ids.append(c.id)
-                    contents.append(getattr(c, "contents", None))
-                    single.append(_as_vec(getattr(c, "embedding", None)))
-                    multi.append(_as_vec(getattr(c, "embeddings", None)))
-            if len(page) < self.EXPORT_PAGE:
-                break
-            offset += len(page)
+                all_ids = list(getattr(uow, repo_name).get_all_ids(limit=None, offset=0))
+            for p0 in range(0, len(all_ids), self.EXPORT_PAGE):
+                page_ids = all_ids[p0:p0 + self.EXPORT_PAGE]
+                with self._svc._create_uow() as uow:
+                    by_id = {c.id: c for c in getattr(uow, repo_name).get_by_ids(page_ids)}
+                    for i in page_ids:
+                        if i in by_id:  # (a row deleted between the two statements is simply absent)
+                            take(by_id[i])
+        else:
+            offset = 0
+            while True:
+                with self._svc._create_uow() as uow:
+                    page = getattr(uow, repo_name).get_all(limit=self.EXPORT_PAGE, offset=offset)
+                    for c in page:
+                        take(c)
+                if len(page) < self.EXPORT_PAGE:
+                    break
+                offset += len(page)
+        if len(set(ids)) != len(ids):
+            raise RuntimeError(f"{repo_name}: the export returned {len(ids) - len(set(ids))} duplicate primary keys "
+                               "(unordered paging over a table that changed?)")
         t = ChunkTable(ids=ids, contents=contents)
         d1 = next((v.shape[0] for v in single if v is not None), 0)
         if d1:

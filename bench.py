@@ -6,12 +6,16 @@ one pass of the hot path over one block of 1024 queries per query group: exact c
 the whole corpus (screen + exact re-score + select).  Queries and corpus are resident in HBM before the timed
 region; outputs stay on the device.
 
-N > 1 (--layout): the ranks form R row shards x Q query groups.  'auto' cuts the corpus into only as many row shards
-as it needs to fit (10 M rows x 5.4 KB = 54 GB of one GPU's 288 GB: R = 1), so every rank holds the corpus and each of
-the Q = N ranks serves ITS OWN query block per step -- independent units, no data-path collective, weak scaling in
-queries.  '--layout rows' is the row-sharded form (every rank the same block against 1/N of the rows, all-gather of
-the per-shard top-k + merge: strong scaling); 'RxQ' mixes the two (the exchange stays inside a group of R ranks).
-`value` = queries all ranks answered / max-over-ranks time in every layout.
+N > 1 (--layout): the ranks form R row shards x Q query groups.  The default is 'rows' -- BASELINE.json's configuration 3 as
+named: the corpus row-sharded over ALL ranks, every rank the same query block against its 1/N of the rows, ONE packed RCCL
+all-gather of the per-shard top-k + k_merge_topk per step inside the timed loop (on a second stream, under the next step's
+search): "scaling": "strong".  'auto' cuts the corpus into only as many row shards as it needs to fit (10 M rows x 5.4 KB =
+54 GB of one GPU's 288 GB: R = 1: replicas serving their own query blocks, no data-path collective, weak scaling);
+'RxQ' mixes the two (the exchange stays inside a group of R ranks).  `--replicated-leg` measures the 1 x N layout after the
+main run and reports it under extra.replicated.  `value` = queries all ranks answered / max-over-ranks time in every layout.
+
+Steps are software-pipelined through mi355dr_search_device_async / mi355dr_search_wait: block i + 1 is on the stream before
+the host waits for block i (every step's work, its wait included, lies inside the timed region).
 
 Launch: `python bench.py --gpus 1` or, for N > 1,
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`
@@ -71,11 +75,15 @@ def parse_args():
     ap.add_argument("--small-chunk", type=int, default=None, help="override small_chunk_rows (developer sweep)")
     ap.add_argument("--starter", type=int, default=None, help="0/1: pass schedule with / without the sampled threshold estimator (A/B)")
     ap.add_argument("--prune-companion", type=int, default=None, help="0/1: general-form prune launch behind every one-wave prune (A/B)")
-    ap.add_argument("--layout", default="auto",
-                    help="ranks as (row shards R) x (query groups Q): 'auto' = fewest row shards whose shard fits in 60 %% of "
-                         "one GPU's HBM (N=10M, d=768 -> 1 x world: every rank holds the corpus and serves its own query "
-                         "blocks, no data-path collective), 'rows' = world x 1 (every rank the same block, all-gather + "
-                         "merge), 'queries' = 1 x world, or 'RxQ'")
+    ap.add_argument("--layout", default="rows",
+                    help="ranks as (row shards R) x (query groups Q): 'rows' (default) = world x 1: the corpus row-sharded over "
+                         "all ranks, every rank the same block, RCCL all-gather + merge per step (BASELINE config 3); 'auto' = "
+                         "fewest row shards whose shard fits in 60 %% of one GPU's HBM (N=10M, d=768 -> 1 x world: replicas, "
+                         "no data-path collective); 'queries' = 1 x world; or 'RxQ'")
+    ap.add_argument("--replicated-leg", action="store_true",
+                    help="N > 1: also measure the replicated layout (1 x world, every rank the whole corpus and its own query "
+                         "block, no collective) after the main run and report it under extra.replicated")
+    ap.add_argument("--sync-steps", action="store_true", help="one blocking mi355dr_search_device per step (no async pipelining; A/B)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the all-gather + merge path even at world size 1 (exercises the multi-GPU code on one GPU)")
     ap.add_argument("--comm", choices=["torch", "lib"], default="torch",
@@ -83,7 +91,7 @@ def parse_args():
                          "stream) or through the library's own RCCL communicator (mi355dr_search_sharded_device)")
     ap.add_argument("--row-sharded-leg", action="store_true",
                     help="also measure the fully row-sharded layout (world x 1) after the main run and report it under "
-                         "extra.row_sharded (default at world > 1 when the main layout is not already that one)")
+                         "extra.row_sharded (only meaningful when the main layout is not already that one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (planted-answer nDCG, PCIe-inclusive "
                                                            "rate, BLAS / torch / B=1 CPU baselines)")
@@ -351,6 +359,115 @@ def row_sharded_leg(args, torch, pkg, dist, device, local_rank, rank, world, qpo
     }
 
 
+def replicated_leg(args, torch, pkg, dist, device, local_rank, rank, world, qpool, make_chunk) -> dict:
+    """The 1 x world layout next to the row-sharded `value`: every rank holds the WHOLE corpus (288 GB of HBM take ~32 M rows of
+    d = 768 with both screen copies) and answers its OWN query block per step -- independent units, no data-path collective,
+    weak scaling in queries."""
+    n_total, d, B, k = args.rows, args.dim, args.block, args.k
+    idx = pkg.Mi355Index(d, args.metric, device=local_rank)
+    idx.reserve(n_total)
+    idx.set_option("screen_dtype", args.screen)
+    for c in range((n_total + CHUNK_ROWS - 1) // CHUNK_ROWS):
+        x = make_chunk(c, min(CHUNK_ROWS, n_total - c * CHUNK_ROWS))
+        torch.cuda.synchronize()
+        idx.add_device(x.data_ptr(), x.shape[0])
+        del x
+    torch.cuda.synchronize()
+    n_pool = qpool.shape[0]
+    stream = torch.cuda.current_stream().cuda_stream
+    out2 = [torch.empty((2, B, k), device=device, dtype=torch.int64) for _ in range(2)]
+    steps = max(4, min(args.steps, 20))
+
+    def run(first, count):
+        pend = None
+        for i in range(first, first + count):
+            o = out2[i & 1]
+            t = idx.search_device_async(qpool[(i * world + rank) % n_pool].data_ptr(), B, k, o[0].data_ptr(), o[1].data_ptr(), stream)
+            if pend is not None:
+                idx.search_wait(pend)
+            pend = t
+        idx.search_wait(pend)
+
+    run(0, 2)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(2, steps)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    idx.close()
+    return {"layout": f"1 row shard x {world} query groups (replicas: every rank the whole corpus and its own {B}-query block, "
+                      "no data-path collective)", "scaling": "weak",
+            "queries_per_s": round(steps * B * world / float(tmax.item()), 1),
+            "ms_per_step": round(float(tmax.item()) * 1e3 / steps, 3), "steps": steps,
+            "note": "NOT `value`: BASELINE.json's configuration 3 is the row-sharded layout"}
+
+
+def block_size_table(idx, torch, qpool, d: int, k: int, n_rows: int, device) -> list:
+    """the same corpus pass with 1, 32 and 128 queries per call -- the HBM-bound regime (the pass is one stream over
+    the int8 shadow + the re-score launches; k_screen_stream / k_screen).  Device buffers, blocking calls."""
+    out = []
+    stream = torch.cuda.current_stream().cuda_stream
+    flat = qpool.reshape(-1, d)
+    od = torch.empty((128, k), device=device, dtype=torch.float64)
+    orr = torch.empty((128, k), device=device, dtype=torch.int64)
+    for b in (1, 32, 128):
+        for i in range(3):
+            idx.search_device(flat[i * b:(i + 1) * b].data_ptr(), b, k, od.data_ptr(), orr.data_ptr(), stream)
+        torch.cuda.synchronize()
+        n = 12
+        t = time.perf_counter()
+        for i in range(n):
+            idx.search_device(flat[(3 + i) * b:(4 + i) * b].data_ptr(), b, k, od.data_ptr(), orr.data_ptr(), stream)
+        torch.cuda.synchronize()
+        t = (time.perf_counter() - t) / n
+        out.append({"queries_per_call": b, "ms_per_call": round(t * 1e3, 3), "queries_per_s": round(b / t, 1),
+                    "algorithmic_GBps": round(n_rows * d * 4 / t / 1e9, 1)})
+    return out
+
+
+def small_corpus_line(args, torch, pkg, qpool, device, local_rank, n_rows: int) -> dict:
+    """SURVEY 8(d)'s second corpus size (N = 1 M) as a secondary figure of the same run: same generator, same 1024-query blocks."""
+    d, B, k = args.dim, args.block, args.k
+    idx = pkg.Mi355Index(d, args.metric, device=local_rank)
+    idx.reserve(n_rows)
+    idx.set_option("screen_dtype", args.screen)
+    for c in range((n_rows + CHUNK_ROWS - 1) // CHUNK_ROWS):
+        x = synth.gaussian_chunk(torch, c, min(CHUNK_ROWS, n_rows - c * CHUNK_ROWS), d, device)
+        torch.cuda.synchronize()
+        idx.add_device(x.data_ptr(), x.shape[0])
+        del x
+    stream = torch.cuda.current_stream().cuda_stream
+    out2 = [torch.empty((2, B, k), device=device, dtype=torch.int64) for _ in range(2)]
+    n_pool = qpool.shape[0]
+
+    def run(first, count):
+        pend = None
+        for i in range(first, first + count):
+            o = out2[i & 1]
+            t = idx.search_device_async(qpool[i % n_pool].data_ptr(), B, k, o[0].data_ptr(), o[1].data_ptr(), stream)
+            if pend is not None:
+                idx.search_wait(pend)
+            pend = t
+        idx.search_wait(pend)
+
+    run(0, 3)
+    torch.cuda.synchronize()
+    steps = 30
+    t = time.perf_counter()
+    run(3, steps)
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t) / steps
+    idx.close()
+    return {"rows": n_rows, "ms_per_step": round(t * 1e3, 3), "queries_per_s": round(B / t, 1),
+            "algorithmic_GBps": round(n_rows * d * 4 / t / 1e9, 1)}
+
+
 def main() -> None:
     args = parse_args()
     if args.workload == "maxsim":
@@ -480,33 +597,54 @@ def main() -> None:
             idx.comm_init(layout.shard, gworld, uid[0])
     stream = torch.cuda.current_stream().cuda_stream
 
-    def step(i: int):
-        q = qpool[(i * QG + layout.group) % n_pool]   # every query group serves its own block of the pool
+    def q_of(i: int):
+        return qpool[(i * QG + layout.group) % n_pool]   # every query group serves its own block of the pool
+
+    def finish(pend):
+        """Complete one enqueued block: wait (the library re-does the rare flagged queries here), then -- row shards -- one
+        all-gather of the packed [2,B,k] (distance bits, rows) block per rank + the merge kernel on the second stream."""
+        ticket, buf = pend
+        idx.search_wait(ticket)
         if not use_dist:
-            idx.search_device(q.data_ptr(), B, k, out_dist.data_ptr(), out_rows.data_ptr(), stream)
-            return out_dist, out_rows
-        buf = i & 1
-        if args.comm == "lib":
-            idx.search_sharded_device(q.data_ptr(), B, k, fin_dist2[buf].data_ptr(), fin_rows2[buf].data_ptr(), stream)
-            return fin_dist2[buf], fin_rows2[buf]
-        if gather_done[buf] is not None:
-            torch.cuda.current_stream().wait_event(gather_done[buf])  # the gather that read this block two steps ago
-        pk = packed2[buf]
-        idx.search_device(q.data_ptr(), B, k, pk[0].data_ptr(), pk[1].data_ptr(), stream)
-        ready = torch.cuda.Event()
-        ready.record()
+            return packed2[buf][0].view(torch.float64), packed2[buf][1]
         with torch.cuda.stream(comm_stream):
-            comm_stream.wait_event(ready)
-            # one all-gather of the packed [2,B,k] (distance bits, rows) block per rank, then the merge kernel
-            dist.all_gather_into_tensor(packed_all2[buf].view(-1), pk.view(-1), group=row_group)
+            dist.all_gather_into_tensor(packed_all2[buf].view(-1), packed2[buf].view(-1), group=row_group)
             idx.merge_topk_packed_device(packed_all2[buf].data_ptr(), gworld, B, k, fin_dist2[buf].data_ptr(),
                                          fin_rows2[buf].data_ptr(), comm_stream.cuda_stream)
             gather_done[buf] = torch.cuda.Event()
             gather_done[buf].record(comm_stream)
         return fin_dist2[buf], fin_rows2[buf]
 
-    for i in range(args.warmup):
-        step(i)
+    def run_steps(first: int, count: int):
+        """`count` steps, software-pipelined: block i + 1 is put on the stream BEFORE the host waits for block i, so the GPU
+        goes from one block's last kernel to the next one's first without the host's round trip; the all-gather + merge of
+        block i run on the second stream under block i + 1.  Every step's wait lies inside the caller's timed region."""
+        res = None
+        if use_dist and args.comm == "lib":   # the library's own communicator: blocking per step
+            for i in range(first, first + count):
+                buf = i & 1
+                idx.search_sharded_device(q_of(i).data_ptr(), B, k, fin_dist2[buf].data_ptr(), fin_rows2[buf].data_ptr(), stream)
+                res = (fin_dist2[buf], fin_rows2[buf])
+            return res
+        pend = None
+        for i in range(first, first + count):
+            buf = i & 1
+            if use_dist and gather_done[buf] is not None:
+                torch.cuda.current_stream().wait_event(gather_done[buf])  # the gather that read this block two steps ago
+            pk = packed2[buf]
+            if args.sync_steps:
+                idx.search_device(q_of(i).data_ptr(), B, k, pk[0].data_ptr(), pk[1].data_ptr(), stream)
+                res = finish((0, buf))
+                continue
+            t = idx.search_device_async(q_of(i).data_ptr(), B, k, pk[0].data_ptr(), pk[1].data_ptr(), stream)
+            if pend is not None:
+                res = finish(pend)
+            pend = (t, buf)
+        if pend is not None:
+            res = finish(pend)
+        return res
+
+    run_steps(0, args.warmup)
     torch.cuda.synchronize()
     if have_pg:
         dist.barrier()
@@ -514,8 +652,7 @@ def main() -> None:
     idx.set_option("profile", 1)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        res = step(args.warmup + i)
+    res = run_steps(args.warmup, args.steps)
     torch.cuda.synchronize()
     if have_pg:
         dist.barrier()
@@ -611,7 +748,7 @@ def main() -> None:
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"synthetic fp32 d={d} N={n_total} corpus (L2-normalised N(0,1)), {B}-query blocks, "
+            "workload": f"synthetic fp32 d={d} N={n_total} corpus ({'L2-normalised N(0,1)' if args.data == 'gaussian' else 'anisotropic stand-in for bge-base / BEIR nq: shared mean direction, power-law spectrum, near-duplicate clusters (synth.Anisotropic)'}), {B}-query blocks, "
                         f"exact {'cosine' if args.metric == 'cosine' else 'inner-product'} top-{k}",
             "rows_total": n_total,
             "rows_per_gpu": n_local,
@@ -619,8 +756,9 @@ def main() -> None:
             "k": k,
             "queries_per_step": B * QG,
             "layout": {"row_shards": R, "query_groups": QG, "rule": args.layout},
-            "parallelism": f"{layout.describe()}" + ((" + all-gather top-k merge (" + ("library RCCL communicator" if args.comm == "lib"
-                            else "torch.distributed, overlapped with the next step on a second stream") + ")") if use_dist else ""),
+            "parallelism": f"{layout.describe()}" + ((" + one packed RCCL all-gather of the per-shard top-k + k_merge_topk per step, inside the timed loop (" + ("library RCCL communicator" if args.comm == "lib"
+                            else "torch.distributed, on a second stream under the next step's search") + ")") if use_dist else ""),
+            "stepping": "blocking call per step" if args.sync_steps else "async: block i+1 enqueued before the wait for block i (mi355dr_search_device_async)",
             "arithmetic": ("int8" if i8 else "bf16") + " MFMA screen over a normalised shadow corpus (rigorous "
                           "per-query error bound), exact fp32 chain re-score, float8 distance (results bit-exact vs "
                           "CPU oracle)",
@@ -711,6 +849,12 @@ def main() -> None:
             "note": "mi355dr_search with B = 1 (k_screen_stream: the int8 shadow streamed once per call, DESIGN.md 4.1d); "
                     "the CPU figure for the same call shape is cpu_baselines[kind = 'torch-cpu, B=1 call shape']; NOT `value`"}
 
+    if rank == 0 and world == 1 and not args.no_extras:
+        # (2c) SURVEY 8(d): the HBM-bound regime (1 / 32 / 128 queries per call) and the second corpus size
+        result["extra"]["block_sizes"] = block_size_table(idx, torch, qpool, d, k, n_total, device)
+        if args.data == "gaussian" and n_total > 1_000_000:
+            result["extra"]["n_1m"] = small_corpus_line(args, torch, pkg, qpool, device, local_rank, 1_000_000)
+
     if rank == 0 and world == 1 and not args.no_extras and args.data == "gaussian":
         # (3) the multi-vector half of the path (configs C4 / C5) at SURVEY 8(d) sizes, as secondary figures of the same run
         result["maxsim"] = {
@@ -765,7 +909,7 @@ def main() -> None:
         rd_, rr_ = res[0].cpu().numpy(), res[1].cpu().numpy()
         assert (np.diff(rd_, axis=1) >= 0).all(), "distances not ascending"
         assert rr_.min() >= 0 and rr_.max() < n_total
-    want_leg = args.row_sharded_leg or (world > 1 and R != world and not args.no_extras)
+    want_leg = args.row_sharded_leg and (R != world or world == 1)
     ref_block = None
     if want_leg:
         # the main layout's answer for block 0 of the pool: the row-sharded leg must reproduce it bit for bit
@@ -801,6 +945,13 @@ def main() -> None:
             leg = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0:
             result["extra"]["row_sharded"] = leg
+    if args.replicated_leg and world > 1 and QG != world:
+        try:
+            leg = replicated_leg(args, torch, pkg, dist, device, local_rank, rank, world, qpool, gen_chunk)
+        except Exception as e:  # noqa: BLE001 - a secondary figure must not take the headline line down with it
+            leg = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
+            result["extra"]["replicated"] = leg
     if have_pg:
         dist.destroy_process_group()
     if rank == 0:

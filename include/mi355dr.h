@@ -97,6 +97,18 @@ int mi355dr_search(mi355dr_index* idx, const float* queries, int B, int k, doubl
  * Returns after the work is complete on that stream (it checks the device-side status word). */
 int mi355dr_search_device(mi355dr_index* idx, const float* queries_dev, int B, int k, double* out_dist_dev,
                           int64_t* out_rows_dev, void* stream);
+/* The same in two halves, so that consecutive blocks follow each other on the GPU without the host's round trip (the
+ * reference's caller issues its queries back to back: pipelines/retrieval/vector_search.py:157-169; here a page of query
+ * blocks).  _async puts the whole search on `stream` and returns a ticket without synchronising; the outputs are valid
+ * after mi355dr_search_wait(ticket) returned MI355DR_OK: it waits for the block(s), reads their status words and, in the
+ * rare case that a query overflowed a candidate list or cannot be screened, recomputes those queries (blocking) into the
+ * same output buffers.  queries_dev and the output buffers must stay valid and untouched until the wait.  Up to 4 blocks
+ * of 1024 queries may be in flight (a fifth first completes the oldest); blocks must be issued on ONE stream (a block on
+ * another stream first completes what is in flight).  mi355dr_search_wait(idx, t) completes every block up to ticket t;
+ * the synchronous entry points complete whatever is in flight first. */
+int mi355dr_search_device_async(mi355dr_index* idx, const float* queries_dev, int B, int k, double* out_dist_dev,
+                                int64_t* out_rows_dev, void* stream, int64_t* ticket);
+int mi355dr_search_wait(mi355dr_index* idx, int64_t ticket);
 
 /* ---- corpus + search (multi-vector, MaxSim) ----
  * vecs: host [sum_T, dim] fp32, offsets: [n_docs+1] (doc i owns rows offsets[i]..offsets[i+1]). */

@@ -357,6 +357,50 @@ def test_search_device_buffers_and_row_offset(pkg, oracle):
     assert np.array_equal(gr, rr + 1_000_000) and np.array_equal(gd, rd)
 
 
+@pytest.mark.parametrize("cand_cap", [2048, 24])
+def test_async_blocks_in_flight_equal_blocking_calls(pkg, oracle, cand_cap):
+    """mi355dr_search_device_async / mi355dr_search_wait: seven blocks issued back to back (the ring holds four: the fifth
+    completes the oldest), every one the oracle's answer -- also the blocks whose queries need the host's fix-ups AFTER later
+    blocks were enqueued behind them: a zero query (the screen cannot rank it: exact scan), and with a 24-slot candidate
+    buffer every query (overflow: re-screen, then exact scan).  Waits out of order and a blocking call in between."""
+    rng = np.random.default_rng(77)
+    n, d, k = 30_000, 128, 10
+    C = rng.standard_normal((n, d)).astype(np.float32)
+    sizes = [200, 1, 130, 64, 300, 7, 1024]
+    Qs = [rng.standard_normal((b, d)).astype(np.float32) for b in sizes]
+    Qs[2][5] = 0.0        # irregular query in block 2
+    Qs[4][0] = C[17]      # an exact hit
+    with pkg.Mi355Index(d) as idx:
+        idx.add(C)
+        idx.set_option("cand_cap", cand_cap)
+        bufs = []
+        for Q in Qs:
+            pq, od, orr = idx.dev_alloc(Q.nbytes), idx.dev_alloc(len(Q) * k * 8), idx.dev_alloc(len(Q) * k * 8)
+            idx.dev_upload(pq, Q)
+            bufs.append((pq, od, orr))
+        tickets = [idx.search_device_async(pq, len(Q), k, od, orr) for Q, (pq, od, orr) in zip(Qs, bufs)]
+        assert tickets == sorted(tickets)
+        idx.search_wait(tickets[2])                      # completes blocks 0..2
+        _check(idx, oracle, C, Qs[1], k)                 # a blocking call in between completes the rest first
+        idx.search_wait(tickets[-1])
+        idx.search_wait(tickets[0])                      # waiting again is a no-op
+        for Q, (pq, od, orr) in zip(Qs, bufs):
+            gd, gr = np.empty((len(Q), k)), np.empty((len(Q), k), dtype=np.int64)
+            idx.dev_download(od, gd)
+            idx.dev_download(orr, gr)
+            rd, rr = oracle.topk_search(C, Q, k)
+            assert np.array_equal(gr, rr)
+            ok = ~np.isnan(rd)
+            assert np.array_equal(np.isnan(gd), np.isnan(rd)) and np.array_equal(gd[ok].view(np.uint64), rd[ok].view(np.uint64))
+        if cand_cap == 24:
+            assert idx.stat("fallback_queries") + idx.stat("retry_queries") > 0
+        with pytest.raises(pkg.NativeError):
+            idx.search_wait(tickets[-1] + 5)
+        for b in bufs:
+            for ptr_ in b:
+                idx.dev_free(ptr_)
+
+
 def test_large_corpus_properties(pkg, oracle):
     """N = 2M x d=768 (6 GB fp32 + 3 GB shadow): size-independent properties + planted answers + oracle spot checks.
 

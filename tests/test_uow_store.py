@@ -119,3 +119,49 @@ def test_block_failure_falls_back_to_the_per_query_path(oracle, monkeypatch):
     stats = p.run(top_k=3, batch_size=4, max_retries=2, retry_delay=0.0)
     assert calls["block"] >= 1
     assert sorted(stats["failed_queries"]) == ["q3", "q_noemb"] and stats["total_queries"] == 5 and stats["total_results"] == 15
+
+
+def test_export_pages_by_ordered_primary_key():
+    """A repository with the reference's `get_all_ids` (ORDER BY id) + `get_by_ids` (an IN query: any order) is exported by
+    key -- every row once, in id order -- even when its unordered `get_all` pages would repeat and skip rows; duplicate keys
+    from an unordered fallback are refused."""
+    from autorag_research_amd.store import UowStore
+
+    rng = np.random.default_rng(0)
+    rows = [types.SimpleNamespace(id=i, contents=f"c{i}", embedding=rng.standard_normal(4).astype(np.float32), embeddings=None)
+            for i in range(23)]
+
+    class Repo:
+        def __init__(self, keyed):
+            self.calls = 0
+            if keyed:
+                self.get_all_ids = lambda limit=None, offset=0: sorted(r.id for r in rows)[offset:None if limit is None else offset + limit]
+                self.get_by_ids = lambda ids: [r for r in reversed(rows) if r.id in set(ids)]  # IN (...): arbitrary order
+
+        def get_all(self, limit=None, offset=None):  # unordered paging: every page starts over from a shuffled table
+            self.calls += 1
+            order = np.random.default_rng(self.calls).permutation(len(rows))
+            return [rows[i] for i in order][offset or 0:(offset or 0) + limit]
+
+    class Uow:
+        def __init__(self, repo):
+            self.chunks = repo
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    for keyed in (True, False):
+        repo = Repo(keyed)
+        svc = types.SimpleNamespace(_create_uow=lambda repo=repo: Uow(repo))
+        st = UowStore(svc)
+        st.EXPORT_PAGE = 5
+        if keyed:
+            t = st.chunks
+            assert t.ids == list(range(23)) and repo.calls == 0
+            assert np.array_equal(t.embedding, np.stack([r.embedding for r in rows]))
+        else:
+            with pytest.raises(RuntimeError, match="duplicate primary keys"):
+                st.chunks

@@ -1,12 +1,16 @@
 #!/bin/bash
-# round 3, pass schedule: parity suite, then starter on / off interleaved at the 10 M-row and the 8-way shard size, then the
-# one-step kernel timeline of both
+# round 3, pass schedule: parity suite, then starter on / off and async / blocking steps interleaved at the 10 M-row and the
+# 8-way shard size, then the one-step kernel timeline of both
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/r3a; mkdir -p $OUT
-timeout 1500 python -m pytest tests/test_gpu_search.py tests/test_gpu_kernels.py tests/test_gpu_fuzz.py tests/test_gpu_c2.py -x -q > $OUT/pytest.log 2>&1; tail -3 $OUT/pytest.log
-for rep in 1 2; do for st in 1 0; do for rows in 10000000 1250000; do
-python bench.py --rows $rows --steps 20 --warmup 3 --no-cpu-baseline --no-extras --starter $st 2>/dev/null | tail -1 | python -c "
-import sys,json; d=json.loads(sys.stdin.read()); print('starter',$st,'rows',$rows,'ms',d['ms_per_step'],'screen_ms',d['roofline'].get('all_screen_kernels_ms_per_step'),'cand',d['extra']['candidates_per_query_per_step'],'resc',d['extra']['rescored_per_query_per_step'],'fb',d['extra']['fallback_queries'])"
-done; done; done 2>&1 | tee $OUT/ab.log
-ROWS=10000000 BENCH_ARGS=--no-extras bash tools/step_timeline.sh > $OUT/timeline_10m.txt 2>&1; tail -40 $OUT/timeline_10m.txt
-ROWS=1250000 BENCH_ARGS=--no-extras bash tools/step_timeline.sh > $OUT/timeline_1250k.txt 2>&1; tail -30 $OUT/timeline_1250k.txt
+timeout 1500 python -m pytest tests/test_gpu_search.py tests/test_gpu_kernels.py tests/test_gpu_fuzz.py tests/test_gpu_c2.py tests/test_gpu_sharded.py tests/test_gpu_threads.py -x -q > $OUT/pytest.log 2>&1; tail -3 $OUT/pytest.log
+line() { python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print('$1','ms',d['ms_per_step'],'screen_ms',d['roofline'].get('all_screen_kernels_ms_per_step'),'cand',d['extra']['candidates_per_query_per_step'],'resc',d['extra']['rescored_per_query_per_step'],'fb',d['extra']['fallback_queries'])"; }
+for rep in 1 2; do for rows in 10000000 1250000; do
+python bench.py --rows $rows --steps 20 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | line "rows $rows default     "
+python bench.py --rows $rows --steps 20 --warmup 3 --no-cpu-baseline --no-extras --sync-steps 2>/dev/null | tail -1 | line "rows $rows sync-steps  "
+python bench.py --rows $rows --steps 20 --warmup 3 --no-cpu-baseline --no-extras --starter 0 --prune-companion 1 --sync-steps 2>/dev/null | tail -1 | line "rows $rows round2-like "
+done; done 2>&1 | tee $OUT/ab.log
+bash tools/shard_sizes.sh 2>&1 | tee $OUT/shard_sizes.log
+ROWS=10000000 BENCH_ARGS=--no-extras bash tools/step_timeline.sh > $OUT/timeline_10m.txt 2>&1; tail -32 $OUT/timeline_10m.txt
+ROWS=1250000 BENCH_ARGS=--no-extras bash tools/step_timeline.sh > $OUT/timeline_1250k.txt 2>&1; tail -28 $OUT/timeline_1250k.txt

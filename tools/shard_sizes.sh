@@ -2,6 +2,6 @@
 cd $GRAFT_REPO_ROOT
 export MASTER_ADDR=127.0.0.1 MASTER_PORT=29544 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0
 for rows in 10000000 5000000 2500000 1250000; do
-python bench.py --rows $rows --steps 20 --warmup 3 --no-cpu-baseline --force-dist 2>/dev/null | tail -1 | python -c "
+python bench.py --rows $rows --steps 20 --warmup 3 --no-cpu-baseline --no-extras --force-dist 2>/dev/null | tail -1 | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); print('rows',$rows,'ms',d['ms_per_step'],'qps',d['value'])"
 done
