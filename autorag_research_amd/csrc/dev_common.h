@@ -42,6 +42,7 @@ struct QueryState {
     float* sc;          // [Bpad] int8 screen: the query's step S_q  (1 for the bf16 screen)
     float* kq;          // [Bpad] int8 screen: factor on a row group's residual norm, 1.0001 + 3 e_q
     int8_t* qhat8;      // [Bpad, dpad8] int8 quantised normalised queries
+    int* carry;         // [Bpad] candidates at the head of the list that an earlier prune of this pass carried over (k_prune, defer_b)
 };
 
 // bf16 value (upper 16 bits) back to fp32
@@ -51,8 +52,14 @@ __device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) { return __uint_as
 // c16 + e_c exactly, so |q_hat.c_hat - q16.c16| <= |c16||e_q| + |q16||e_c| + |e_q||e_c| <= 1.0001 (e_q + e_c) + 3 e_q e_c;
 // + 8 d 2^-24 + 2^-16 for the fp32 normalisation, the MFMA's fp32 accumulation and the exact key's own rounding.
 // e_c = the largest residual norm over the stored rows.  Never above the a-priori 2^-7 + 2^-15 + 8 d 2^-24.
-__host__ __device__ inline float bf16_screen_bound(float e_q, float e_c, int d) {
-    return 1.0001f * (e_q + e_c) + 3.0f * e_q * e_c + 8.0f * (float)d * 5.9604645e-8f + 1.5258789e-5f;
+// Inner product (round 3): the shadows hold the rows THEMSELVES (not normalised), so the screen estimates <q_hat, c> =
+// dot / |q| and its threshold is dot_k / |q| - E: no row norm, no "largest row norm" in the threshold (round 2 screened the
+// cosine and asked for cos >= dot_k / (|q| cmax) - E: rows 2 % shorter than the longest one loosened it by 2 % OF THE COSINE,
+// an order of magnitude more than E -- every query of the C2 stand-in overflowed its candidate list).  The algebra is the
+// same with |c_hat| = 1 replaced by |c| <= cscale (the largest stored row norm, inflated): the residual norms e_c / e_g are
+// measured in the rows' own units, the query-side and rounding terms scale with cscale.  cscale = 1 for the cosine metric.
+__host__ __device__ inline float bf16_screen_bound(float e_q, float e_c, int d, float cscale = 1.0f) {
+    return 1.0001f * (e_q * cscale + e_c) + 3.0f * e_q * e_c + (8.0f * (float)d * 5.9604645e-8f + 1.5258789e-5f) * cscale;
 }
 
 // ---- int8 screen quantisation (DESIGN.md "int8 screen bound") ----

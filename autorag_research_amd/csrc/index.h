@@ -100,7 +100,12 @@ struct mi355dr_index {
                           // off: measured +1.4 % at 1.25 M rows, +0.2 % at 10 M -- the prune is bound by batch latency, not bytes)
     int profile = 0;
     int starter = 1;          // pass schedule: sampled threshold estimator instead of the smallest chunks (option "starter", A/B and tests)
-    int prune_companion = 0;  // 1: always launch the general-form prune behind the one-wave form (option "prune_companion")
+    // 1 (default): the general-form prune is launched behind every one-wave prune (4 us when it finds nothing to do); 0: the
+    // one-wave form alone, what it cannot hold (> 1024 entries) is flagged and re-screened -- measured at N = 10 M, k = 10: a few
+    // queries per block exceed the 1024 entries in some chunk, and their re-screen pass costs 0.25 ms per block (0.85 ms with
+    // carried survivors in the lists), against 20 us of companion launches
+    int prune_companion = 1;
+    int defer_round_b = 1;    // k_prune before the pass's last one carries the survivors of its cut over instead of re-scoring them
     int chunk0_set = 0;       // the first chunk's size was set by the caller: emit-all ladder, no starter
     int64_t chunk0_rows = 1024;
     int64_t chunk_growth = 3;

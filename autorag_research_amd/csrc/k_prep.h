@@ -40,16 +40,19 @@ __global__ __launch_bounds__(64) void k_row_nrm2(const float* __restrict__ rows,
 // emitted by the screen: NaN compares false) and are recorded in irr_rows for the exact side pass.  The residual norm
 // |c_hat - bf16(c_hat)| of every regular row is measured; res2_max keeps the largest squared one (bit pattern of a
 // non-negative float: unsigned max == float max) -- the corpus half of the bf16 screen bound.
+// absolute != 0 (inner-product metric): the shadow holds bf16_rn(c) itself -- the screen then estimates <q_hat, c> =
+// dot / |q| directly and no row norm enters the threshold (dev_common.h "inner product").
 __global__ __launch_bounds__(256) void k_build_shadow(const float* __restrict__ rows, const float* __restrict__ nrm2,
                                                        int64_t row0, int64_t n, int d, int dpad,
                                                        uint16_t* __restrict__ shadow, int32_t* __restrict__ irr_rows,
-                                                       int* __restrict__ irr_count, unsigned* __restrict__ res2_max) {
+                                                       int* __restrict__ irr_count, unsigned* __restrict__ res2_max,
+                                                       int absolute) {
     __shared__ float sh[4];
     const int64_t i = row0 + blockIdx.x;
     if (i >= row0 + n) return;
     const float n2 = nrm2[i];
     const bool regular = norm_is_regular(n2);
-    const float rc = regular ? 1.0f / sqrtf(n2) : 0.0f;
+    const float rc = regular ? (absolute ? 1.0f : 1.0f / sqrtf(n2)) : 0.0f;
     const float* r = rows + i * (int64_t)d;
     uint16_t* s = shadow + i * (int64_t)dpad;
     float e2 = 0.0f;
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(256) void k_build_shadow8(const float* __restrict__
                                                         int64_t g0, int64_t n_total, int64_t first_new, int d, int dpad8,
                                                         int8_t* __restrict__ shadow8, uint8_t* __restrict__ flag8,
                                                         I8Group* __restrict__ grp, int32_t* __restrict__ irr8_rows,
-                                                        int* __restrict__ irr8_count) {
+                                                        int* __restrict__ irr8_count, int absolute) {
     __shared__ float s_peak[kI8GroupRows];
     __shared__ float s_err[kI8GroupRows];
     __shared__ float s_step;
@@ -125,13 +128,15 @@ __global__ __launch_bounds__(256) void k_build_shadow8(const float* __restrict__
         if (i < n_total) {
             const float n2 = nrm2[i];
             if (norm_is_regular(n2)) {
-                const float rc = 1.0f / sqrtf(n2);
+                // absolute (inner product): the row itself is quantised; "outlier component" stays relative to its own norm
+                const float rc = absolute ? 1.0f : 1.0f / sqrtf(n2);
+                const float lim = absolute ? peak_limit * sqrtf(n2) : peak_limit;
                 const float* r = rows + i * (int64_t)d;
                 float mx = 0.0f;
                 for (int k = lane; k < d; k += kWave) mx = fmaxf(mx, fabsf(r[k] * rc));
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-                if (mx <= peak_limit) peak = mx;  // (NaN components compare false: loose)
+                if (mx <= lim) peak = mx;  // (NaN components compare false: loose)
             }
         }
         if (lane == 0) s_peak[lr] = peak;
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(256) void k_build_shadow8(const float* __restrict__
             continue;
         }
         const bool tight = s_peak[lr] >= 0.0f && step > 0.0f;
-        const float rc = tight ? 1.0f / sqrtf(nrm2[i]) : 0.0f;
+        const float rc = tight ? (absolute ? 1.0f : 1.0f / sqrtf(nrm2[i])) : 0.0f;
         const float* r = rows + i * (int64_t)d;
         int8_t* s = shadow8 + i * (int64_t)dpad8;
         float e2 = 0.0f;
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(256) void k_build_shadow8(const float* __restrict__
 // block 0 also re-arms the block's OR-ed status word and both hand-over counters of k_prune (two launches less per block)
 __global__ __launch_bounds__(64) void k_prep_queries(const float* __restrict__ q, int B, int d, int dpad, int metric,
                                                       QueryState st, int dpad8, int i8, float bf16_ec, int* status_or,
-                                                      int* prune_skip, int cnt0) {
+                                                      int* prune_skip, int cnt0, float cscale) {
     extern __shared__ float qs[];  // [d]
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
@@ -208,11 +213,12 @@ __global__ __launch_bounds__(64) void k_prep_queries(const float* __restrict__ q
             st.qn[b] = 0.0f;
             st.thr[b] = __builtin_inff();
             st.cnt[b] = 0;
+            st.carry[b] = 0;
             st.best_n[b] = 0;
             st.thr_key[b] = 0;
             st.thr_row[b] = -1;
             st.status[b] = 0;
-            st.E[b] = bf16_screen_bound(0.00390625f, bf16_ec, d);
+            st.E[b] = bf16_screen_bound(0.00390625f, bf16_ec, d, cscale);
             st.E16[b] = st.E[b];
             st.sc[b] = 0.0f;
             st.kq[b] = 1.0f;
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(64) void k_prep_queries(const float* __restrict__ q
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) eq2 += __shfl_xor(eq2, o);
-    float E = bf16_screen_bound(sqrtf(eq2) * 1.001f, bf16_ec, d), sc = 1.0f, kq = 1.0f;
+    float E = bf16_screen_bound(sqrtf(eq2) * 1.001f, bf16_ec, d, cscale), sc = 1.0f, kq = 1.0f;
     const float E16 = E;
     if (i8) {
         // per-query step S_q = max|q_hat| / 127, residual norm measured like the corpus side
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(64) void k_prep_queries(const float* __restrict__ q
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) e2 += __shfl_xor(e2, o);
         const float e_q = sqrtf(e2) * 1.001f;
-        E = i8_query_bound(e_q, d);
+        E = i8_query_bound(e_q, d) * cscale;
         kq = i8_pair_factor(e_q);
         sc = sq;
     }
@@ -281,6 +287,7 @@ __global__ __launch_bounds__(64) void k_prep_queries(const float* __restrict__ q
         // (metric 2 = test hook: every query screens with thresholds at -inf)
         st.thr[b] = (regular || metric == 2) ? -__builtin_inff() : __builtin_inff();
         st.cnt[b] = cnt0;  // (> 0: the starter writes one candidate per slab at fixed slots)
+        st.carry[b] = 0;
         st.best_n[b] = 0;
         st.thr_key[b] = kKeyNaN;
         st.thr_row[b] = 0x7FFFFFFF;

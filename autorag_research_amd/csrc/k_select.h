@@ -25,7 +25,7 @@ struct PruneArgs {
     int cap, d, k, metric;
     int exact;           // 0: screen candidates (re-score), 1: cand_val already holds the exact dot
     const uint8_t* flag8;  // int8 screen only (else nullptr): rows outside the int8 shadow
-    float cmax;            // inner-product metric: largest stored row norm (inflated); thresholds are cos >= dot_k / (|q| cmax)
+    float cscale;          // 1 (cosine) or the largest stored row norm, inflated (inner product): scale of the absolute slacks
     const uint16_t* shadow16;  // optional [n, dpad] bf16 shadow: second screen of round-B candidates (int8 screen, cosine)
     int dpad;
     int round_a;           // rows re-scored before the cut is known (0: max(32, 2k)); always at least k, at most 64
@@ -43,7 +43,27 @@ struct PruneArgs {
     // a candidate list beyond its capacity) is flagged kStOverflow -- re-screened by the host with the tighter bound --
     // instead of being handed over.
     int one_wave_only;
+    // not the last prune of the pass: the candidates that survive the cut are NOT re-scored now -- they move to the head of
+    // the query's candidate list (count left in st.cnt, st.carry) and meet the next chunk's candidates in the next prune,
+    // under its tighter cut; only the pass's last prune walks round B.  A prune before the last one then costs one gather
+    // round instead of two (the starter's 33 us against 57-67), and a survivor is re-scored at most once, under the final
+    // cut.  The threshold a deferring prune publishes comes from kept U round A alone: any k exact scores bound the k-th
+    // best from below.  One-wave form only (the general form re-scores everything it is handed).
+    int defer_b;
 };                         // (the screen bound is per query: st.E[q])
+
+// Similarity of an exact key in the SCREEN's units: the cosine itself, or dot / |q| (the inner-product shadows hold the rows
+// themselves and the queries normalised: dev_common.h "Inner product").  inv_qn = 1 / sqrt(|q|^2) in fp32; callers subtract
+// |u| 4e-6 for its roundings wherever the value is used as a lower bound.
+__device__ __forceinline__ float unit_sim(int metric, double dist, float inv_qn) {
+    return metric == 0 ? (float)(1.0 - dist) : (float)(-dist) * inv_qn;
+}
+// the screen threshold the k-th best exact key `dist_k` allows: every row of the final top-k has a screen value >= this
+__device__ __forceinline__ float screen_threshold(int metric, double dist_k, float E, float nq) {
+    if (metric == 0) return float_below((float)((1.0 - dist_k) - (double)E));
+    const double u = -dist_k / sqrt((double)nq);
+    return float_below((float)(u - fabs(u) * 4e-6 - (double)E));
+}
 
 // Two instantiations share the code: a small one (1 wave, <= 1024 entries, ~36 KiB LDS, 4 workgroups
 // per CU so that a whole 1024-query block is resident at once and the re-score latency overlaps across
@@ -146,8 +166,12 @@ __device__ __forceinline__ void prune_body(const PruneArgs& a, char* smem) {
     uint64_t* bkey = a.st.best_key + (int64_t)q * kKMax;
     int32_t* brow = a.st.best_row + (int64_t)q * kKMax;
     const float nq = a.st.qn[q];
+    const float inv_qn = 1.0f / sqrtf(nq);  // (inner product: exact dots -> the screen's units; an irregular |q| never screens)
     const float E = a.st.E[q];
-    if (tid == 0) a.stat[2 * q] += (unsigned long long)n_new;
+    if (tid == 0) {
+        a.stat[2 * q] += (unsigned long long)(n_new - a.st.carry[q]);  // (carried entries were counted when they were appended)
+        a.st.carry[q] = 0;
+    }
 
     int n_res;
     int n_base = n_best;  // kept entries carried into the final sort (truncated to k after round A)
@@ -168,18 +192,7 @@ __device__ __forceinline__ void prune_body(const PruneArgs& a, char* smem) {
                 if (e < n_new) {
                     const float v = cval[e];
                     if (v != v) kk = 0xFFFFFFFFu;  // "no bound": always re-scored
-                    else if (!(a.flag8 && a.flag8[crow[e]])) {  // (else: stale zero of a loose row)
-                        if (a.metric == 0) {
-                            kk = f32_order_key(v);
-                        } else {
-                            // inner product: rank by an UPPER bound of the dot product, (v + E) |q| |c| -- the exact dot
-                            // is cos_key * sqrt(nq * nc) with the same fp32 norms the cosine key is defined with
-                            const float vb = v + E;
-                            const float s = sqrtf(nq) * sqrtf(a.nrm2[crow[e]]);
-                            const float ub = vb >= 0.0f ? vb * s * 1.000002f + 1e-30f : vb * s * 0.999998f;
-                            kk = ub == ub ? f32_order_key(ub) : 0xFFFFFFFFu;
-                        }
-                    }
+                    else if (!(a.flag8 && a.flag8[crow[e]])) kk = f32_order_key(v);  // (else: stale zero of a loose row)
                 }
                 key[j] = kk;
             }
@@ -236,7 +249,7 @@ __device__ __forceinline__ void prune_body(const PruneArgs& a, char* smem) {
             kept_loaded = true;
             wave_sync();
             int n1 = n_best + nA;
-            int nB = 0;
+            int nB = 0, carried = 0;
             if (n_cand > nA && !a.thr_only) {
                 // ---- cut = (k-th largest exact similarity over kept U round A) - E: as float, rounded down
                 float cut = -__builtin_inff(), cut16 = -__builtin_inff();
@@ -253,7 +266,9 @@ __device__ __forceinline__ void prune_body(const PruneArgs& a, char* smem) {
                         const uint32_t xs = wave_nth_largest(sk, a.k, n1);
                         const float kth = __uint_as_float((xs & 0x80000000u) ? (xs & 0x7FFFFFFFu) : ~xs);  // invert the key
                         // cosine: candidates carry v, exact <= v + E.  inner product: they carry the upper bound itself.
-                        cut = a.metric == 0 ? kth - E * 1.001f - 2e-6f : kth - fabsf(kth) * 4e-6f - 1e-30f;
+                        // candidates carry v with exact <= v + E, in the screen's units (cosine; dot / |q|)
+                        const float ku = a.metric == 0 ? kth : kth * inv_qn;
+                        cut = ku - fabsf(ku) * (a.metric == 0 ? 0.0f : 4e-6f) - E * 1.001f - 2e-6f * a.cscale;
                         if (a.shadow16 != nullptr && a.metric == 0) cut16 = kth - a.st.E16[q] * 1.001f - 2e-6f;
                     }
                 }
@@ -261,6 +276,35 @@ __device__ __forceinline__ void prune_body(const PruneArgs& a, char* smem) {
                 const uint32_t xB = cut == -__builtin_inff() ? 1u : f32_order_key(cut);
                 nB = compact(xB, SORT, false);
                 wave_sync();
+                if (a.defer_b && cut != -__builtin_inff()) {  // (no cut yet -- fewer than k exact scores, k > 64 --: full round B)
+                    // carry the survivors: (row, value) of entry R[i] -> slot i of the list.  All loads, then all stores:
+                    // a slot may be another survivor's source.
+                    int32_t* crow_w = a.cand_row + (int64_t)q * a.cap;
+                    float* cval_w = a.cand_val + (int64_t)q * a.cap;
+                    int32_t cr[kSelPerLane];
+                    float cv[kSelPerLane];
+#pragma unroll
+                    for (int j = 0; j < kSelPerLane; ++j) {
+                        if (j * kWave >= nB) break;  // wave-uniform
+                        const int i = j * kWave + lane;
+                        if (i < nB) {
+                            cr[j] = crow[R[i]];
+                            cv[j] = cval[R[i]];
+                        }
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int j = 0; j < kSelPerLane; ++j) {
+                        if (j * kWave >= nB) break;
+                        const int i = j * kWave + lane;
+                        if (i < nB) {
+                            crow_w[i] = cr[j];
+                            cval_w[i] = cv[j];
+                        }
+                    }
+                    carried = nB;
+                    nB = 0;
+                }
                 if (a.shadow16 != nullptr && cut16 != -__builtin_inff() && nB > 0) {
                     // ---- second screen: the bf16 image of every survivor (half the bytes of its fp32 row) under the
                     // bf16 bound (~5x tighter than the int8 one): t16 + E16 < exact k-th best -> cannot reach the top-k.
@@ -339,40 +383,20 @@ __device__ __forceinline__ void prune_body(const PruneArgs& a, char* smem) {
                 }
             if (lane == 0) {
                 if (!a.thr_only) a.st.best_n[q] = n_keep;
-                a.st.cnt[q] = 0;
+                a.st.cnt[q] = carried;  // (the next chunk's appends go behind the carried survivors)
+                a.st.carry[q] = carried;
                 if (n_keep >= a.k) {
                     const uint64_t wk = K2[a.k - 1];
                     if (!a.thr_only) {  // (the exact path's threshold speaks for KEPT rows)
                         a.st.thr_key[q] = wk;
                         a.st.thr_row[q] = R2[a.k - 1];
                     }
-                    if (wk != kKeyNaN && !(a.st.status[q] & kStIrregular)) {
-                        if (a.metric == 0) {
-                            const float th = float_below((float)((1.0 - key_to_dist(wk)) - (double)E));
-                            a.st.thr[q] = th;
-                        } else {
-                            // a row can only beat dot_k > 0 if its cosine is at least dot_k / (|q| cmax)
-                            const double dk = -key_to_dist(wk);
-                            const double den = (double)sqrtf(nq) * (double)a.cmax;
-                            if (dk > 0.0 && den > 0.0 && den < 1e300) {
-                                const float th = float_below((float)(dk / den * (1.0 - 4e-6) - (double)E));
-                                a.st.thr[q] = th;
-                            }
-                        }
-                    }
+                    if (wk != kKeyNaN && !(a.st.status[q] & kStIrregular))
+                        a.st.thr[q] = screen_threshold(a.metric, key_to_dist(wk), E, nq);
                 }
             }
             return;
         }
-    }
-    if (!a.exact && a.metric != 0) {
-        // inner product is screened by the one-wave form only; what it skipped (k > ~500, > 1024 candidates) is
-        // recomputed by the exact scan
-        if (tid == 0) {
-            a.st.status[q] |= kStOverflow;
-            a.st.cnt[q] = 0;
-        }
-        return;
     }
     if (!a.exact) {
         // ---- phase 1: order the new candidates by their screen value, best first.  NaN = "no bound" sorts first;
@@ -439,9 +463,12 @@ __device__ __forceinline__ void prune_body(const PruneArgs& a, char* smem) {
             bitonic_asc_key_row(SK, SR, np1);
             n_base = min(a.k, n1);
             float cut = -__builtin_inff();
-            if (n1 >= a.k && a.metric == 0) {
+            if (n1 >= a.k) {
                 const uint64_t wk = SK[a.k - 1];
-                if (wk != kKeyNaN) cut = (float)(1.0 - key_to_dist(wk)) - E * 1.001f - 2e-6f;
+                if (wk != kKeyNaN) {
+                    const float ku = unit_sim(a.metric, key_to_dist(wk), inv_qn);
+                    cut = ku - fabsf(ku) * (a.metric == 0 ? 0.0f : 4e-6f) - E * 1.001f - 2e-6f * a.cscale;
+                }
             }
             if (tid == 0) s_cnt = nA;
             __syncthreads();
@@ -494,10 +521,8 @@ __device__ __forceinline__ void prune_body(const PruneArgs& a, char* smem) {
             const uint64_t wk = SK[a.k - 1];
             a.st.thr_key[q] = wk;
             a.st.thr_row[q] = SR[a.k - 1];
-            if (a.metric == 0 && wk != kKeyNaN && !(a.st.status[q] & kStIrregular)) {
-                const float th = float_below((float)((1.0 - key_to_dist(wk)) - (double)E));
-                a.st.thr[q] = th;
-            }
+            if (!a.exact && wk != kKeyNaN && !(a.st.status[q] & kStIrregular))
+                a.st.thr[q] = screen_threshold(a.metric, key_to_dist(wk), E, nq);
         }
     }
 }

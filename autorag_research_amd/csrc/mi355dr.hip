@@ -105,6 +105,7 @@ int ensure_qstate(mi355dr_index* idx) {
     HIPCHECK(idx, hipMalloc(&idx->st.sc, B * sizeof(float)));
     HIPCHECK(idx, hipMalloc(&idx->st.kq, B * sizeof(float)));
     HIPCHECK(idx, hipMalloc(&idx->st.qhat8, B * idx->dpad8));
+    HIPCHECK(idx, hipMalloc(&idx->st.carry, B * sizeof(int)));
     HIPCHECK(idx, hipMalloc(&idx->qdev, B * idx->dim * sizeof(float)));
     HIPCHECK(idx, hipMalloc(&idx->cand_row, B * kCandCap * sizeof(int32_t)));
     HIPCHECK(idx, hipMalloc(&idx->cand_val, B * kCandCap * sizeof(float)));
@@ -207,10 +208,11 @@ inline bool use_i8(const mi355dr_index* idx) {
 }
 
 int launch_prune(mi355dr_index* idx, hipStream_t s, int nblocks, const int* qlist, int k, int exact, bool thr_only = false,
-                 bool one_wave_only = false) {
+                 bool one_wave_only = false, bool defer_b = false) {
     PruneArgs pa{};
     pa.thr_only = thr_only ? 1 : 0;
     pa.one_wave_only = one_wave_only ? 1 : 0;
+    pa.defer_b = defer_b && idx->defer_round_b ? 1 : 0;
     pa.rows = idx->rows;
     pa.nrm2 = idx->nrm2;
     pa.q = idx->qdev;
@@ -225,7 +227,7 @@ int launch_prune(mi355dr_index* idx, hipStream_t s, int nblocks, const int* qlis
     pa.metric = idx->metric;
     pa.exact = exact;
     pa.flag8 = use_i8(idx) ? idx->flag8 : nullptr;
-    pa.cmax = idx->cmax;
+    pa.cscale = idx->metric == MI355DR_METRIC_IP ? idx->cmax : 1.0f;
     // int8 screen, cosine: candidates that survive the exact cut are screened once more on their bf16 shadow rows
     // (half the bytes of an fp32 row, a bound ~5x tighter) before the exact re-score
     pa.shadow16 = (use_i8(idx) && idx->metric == 0 && !exact && idx->prefilter16) ? idx->shadow : nullptr;
@@ -249,7 +251,7 @@ int launch_prune(mi355dr_index* idx, hipStream_t s, int nblocks, const int* qlis
 int launch_prep(mi355dr_index* idx, hipStream_t s, int B, int Bpad, int metric, int cnt0 = 0) {
     hipLaunchKernelGGL(k_prep_queries, dim3(Bpad), dim3(64), (size_t)idx->dim * sizeof(float), s, idx->qdev, B, idx->dim,
                        idx->dpad, metric, idx->st, idx->dpad8, use_i8(idx) ? 1 : 0, idx->bf16_ec, idx->status_or_dev,
-                       idx->prune_skip, cnt0);
+                       idx->prune_skip, cnt0, idx->metric == MI355DR_METRIC_IP ? idx->cmax : 1.0f);
     idx->prune_parity = 0;
     HIPCHECK(idx, hipGetLastError());
     return MI355DR_OK;
@@ -333,7 +335,8 @@ int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t 
 //    launches (~80 us) where the ladder 1 024 -> 4 096 -> 16 384 took six (~290 us), at every shard size.
 //  * The chunk ends are PLANNED: n = the fewest steps of ratio <= 1 + growth from the starter's sample (or the emit-all first
 //    chunk) to the end, then one uniform ratio (N / S)^(1/n) -- no short last chunk with a prune of its own.
-//  * No general-form companion behind the one-wave prune while k is small: what it cannot hold is flagged and re-screened.
+//  * (Option prune_companion = 0: no general-form launch behind the one-wave prune, what it cannot hold is flagged and
+//    re-screened -- measured slower: see index.h.)
 constexpr int kStarterKMax = 32;          // the starter's round A re-scores max(32, 2k) <= 64 rows: one batch of the one-wave form
 constexpr int64_t kStarterRows = 16384;   // sample size (256 slabs); a corpus must hold at least 4 samples
 struct PassPlan {
@@ -385,14 +388,13 @@ PassPlan plan_pass(const mi355dr_index* idx, int B, int k, double growth) {
 inline int starter_count(const PassPlan& p) { return (int)((p.sample + kSlabRows - 1) / kSlabRows); }
 
 PassPlan make_plan(const mi355dr_index* idx, int B, int k) {
-    double growth = std::max(0.25, idx->chunk_growth_set ? std::min((double)idx->chunk_growth, growth_budget(idx, k, use_i8(idx)))
-                                                         : growth_budget(idx, k, use_i8(idx)));
-    growth = std::min(growth, 8.0);
+    // (measured round 3, N = 10 M, k = 10: a ratio of 4 per step -- 5 chunks -- 7.43 ms, the budget's 4.8 -- 4 chunks -- 7.54)
+    double growth = std::max(0.25, std::min((double)idx->chunk_growth, growth_budget(idx, k, use_i8(idx))));
     // small query blocks: a pass is one stream over the shadow rows plus one latency-bound re-score launch per chunk, and an
     // append costs nothing -- fewer, larger chunks (the k-dependent budget alone bounds the growth: x7 per step at k = 10)
     if (B <= 64 && idx->retry_level == 0 && idx->chunk_growth_set == 0)
         growth = std::max(growth, std::min(8.0, growth_budget(idx, k, use_i8(idx)) * kSmallBlockBudget));
-    if (idx->retry_level == 1) growth = std::max(0.25, std::min(growth, 3.0) * 0.5);
+    if (idx->retry_level == 1) growth = std::max(0.25, growth * 0.5);
     if (idx->retry_level >= 2) growth = 0.25;  // (every chunk then holds <= 20 % of the rows: a dense neighbourhood is split up)
     return plan_pass(idx, B, k, growth);
 }
@@ -449,7 +451,9 @@ int run_screen(mi355dr_index* idx, hipStream_t s, int B, int k, const PassPlan& 
             HIPCHECK(idx, hipGetLastError());
             side_done = true;
         }
-        CHECK(launch_prune(idx, s, B, nullptr, k, /*exact=*/0, false, lean));
+        // every prune but the pass's last one carries its survivors over instead of re-scoring them (k_prune: defer_b)
+        const bool last = end >= idx->n && (side_n == 0 || side_done);
+        CHECK(launch_prune(idx, s, B, nullptr, k, /*exact=*/0, false, lean, !last));
         done = end;
     }
     if (side_n > 0 && !side_done) {
@@ -467,6 +471,7 @@ __global__ void k_reset_queries(QueryState st, const int* qlist, int nq) {
     if (i >= nq) return;
     const int q = qlist[i];
     st.cnt[q] = 0;
+    st.carry[q] = 0;
     st.best_n[q] = 0;
     st.thr_key[q] = kKeyNaN;
     st.thr_row[q] = 0x7FFFFFFF;
@@ -776,7 +781,7 @@ void mi355dr_destroy(mi355dr_index* idx) {
     void* ptrs[] = {idx->retry_q[2], idx->retry_dist[2], idx->retry_rows[2], idx->retry_map[2],
                     idx->n2max_dev, idx->bf16_res2_dev, idx->retry_q[0], idx->retry_dist[0], idx->retry_rows[0], idx->retry_map[0], idx->retry_q[1],
                     idx->retry_dist[1], idx->retry_rows[1], idx->retry_map[1], idx->shadow8, idx->flag8, idx->grp8, idx->irr8_rows, idx->irr8_count, idx->st.E, idx->st.E16, idx->st.sc, idx->st.kq,
-                    idx->st.qhat8,
+                    idx->st.qhat8, idx->st.carry,
                     idx->rows, idx->shadow, idx->nrm2, idx->irr_rows, idx->irr_count, idx->st.qn, idx->st.qhat,
                     idx->st.thr, idx->st.cnt, idx->st.best_n, idx->st.best_key, idx->st.best_row, idx->st.thr_key,
                     idx->st.thr_row, idx->st.status, idx->qdev, idx->cand_row, idx->cand_val, idx->qlist_dev,
@@ -830,7 +835,8 @@ static int add_rows_impl(mi355dr_index* idx, const float* rows, int64_t n, hipMe
                            idx->dim, idx->nrm2, idx->n2max_dev);
         HIPCHECK(idx, hipGetLastError());
         hipLaunchKernelGGL(k_build_shadow, dim3((unsigned)m), dim3(256), 0, s, idx->rows, idx->nrm2, first, m, idx->dim,
-                           idx->dpad, idx->shadow, idx->irr_rows, idx->irr_count, idx->bf16_res2_dev);
+                           idx->dpad, idx->shadow, idx->irr_rows, idx->irr_count, idx->bf16_res2_dev,
+                           idx->metric == MI355DR_METRIC_IP ? 1 : 0);
         HIPCHECK(idx, hipGetLastError());
     }
     {   // int8 shadow: whole groups of 32 rows, from the (possibly partly filled) group the first new row falls into
@@ -839,7 +845,7 @@ static int add_rows_impl(mi355dr_index* idx, const float* rows, int64_t n, hipMe
             const int64_t m = std::min(kBuildSlice, g_hi - g0);
             hipLaunchKernelGGL(k_build_shadow8, dim3((unsigned)m), dim3(256), 0, s, idx->rows, idx->nrm2, g0, idx->n + n,
                                idx->n, idx->dim, idx->dpad8, idx->shadow8, idx->flag8, idx->grp8, idx->irr8_rows,
-                               idx->irr8_count);
+                               idx->irr8_count, idx->metric == MI355DR_METRIC_IP ? 1 : 0);
             HIPCHECK(idx, hipGetLastError());
         }
     }
@@ -849,10 +855,11 @@ static int add_rows_impl(mi355dr_index* idx, const float* rows, int64_t n, hipMe
     float res2 = 0.0f;
     HIPCHECK(idx, hipMemcpyAsync(&res2, idx->bf16_res2_dev, sizeof(float), hipMemcpyDeviceToHost, s));
     HIPCHECK(idx, hipStreamSynchronize(s));
-    idx->bf16_ec = std::min(std::sqrt(res2) * 1.001f, 0.00390625f * 1.0001f);  // (a-priori cap: 2^-8 |c_hat|)
     float n2max = 0.0f;
     HIPCHECK(idx, hipMemcpy(&n2max, idx->n2max_dev, sizeof(float), hipMemcpyDeviceToHost));
     idx->cmax = std::sqrt(n2max) * 1.000001f;
+    // (a-priori cap: 2^-8 |c_hat|; inner product: the shadow holds the rows themselves, residuals in their units)
+    idx->bf16_ec = std::min(std::sqrt(res2) * 1.001f, 0.00390625f * 1.0001f * (idx->metric == MI355DR_METRIC_IP ? idx->cmax : 1.0f));
     idx->irr_n = irr;
     idx->irr8_n = irr8;
     idx->n += n;
@@ -1033,6 +1040,8 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
         idx->starter = value != 0;
     } else if (k == "prune_companion") {
         idx->prune_companion = value != 0;
+    } else if (k == "defer_round_b") {
+        idx->defer_round_b = value != 0;
     } else if (k == "chunk_growth") {
         if (value < 1) return fail(idx, MI355DR_E_INVALID, "chunk_growth must be >= 1");
         idx->chunk_growth = value;

@@ -74,6 +74,7 @@ def parse_args():
     ap.add_argument("--metric", choices=["cosine", "ip"], default="cosine", help="cosine (headline) or inner product")
     ap.add_argument("--small-chunk", type=int, default=None, help="override small_chunk_rows (developer sweep)")
     ap.add_argument("--starter", type=int, default=None, help="0/1: pass schedule with / without the sampled threshold estimator (A/B)")
+    ap.add_argument("--defer-b", type=int, default=None, help="0/1: prunes before the last carry their survivors over instead of re-scoring them (A/B)")
     ap.add_argument("--prune-companion", type=int, default=None, help="0/1: general-form prune launch behind every one-wave prune (A/B)")
     ap.add_argument("--layout", default="rows",
                     help="ranks as (row shards R) x (query groups Q): 'rows' (default) = world x 1: the corpus row-sharded over "
@@ -529,6 +530,8 @@ def main() -> None:
         idx.set_option("starter", args.starter)
     if args.prune_companion is not None:
         idx.set_option("prune_companion", args.prune_companion)
+    if args.defer_b is not None:
+        idx.set_option("defer_round_b", args.defer_b)
     aniso = synth.Anisotropic(torch, d, device) if args.data == "anisotropic" else None
 
     def gen_chunk(c: int, rows: int):
@@ -769,6 +772,7 @@ def main() -> None:
             "candidates_per_query_per_step": round(cand / max(args.steps * B, 1), 1),
             "rescored_per_query_per_step": round(resc / max(args.steps * B, 1), 1),
             "fallback_queries": fallback,
+            "retry_queries": idx.stat("retry_queries"),
             "loose_rows": idx.stat("loose_rows"),
             "hbm_bytes_resident": idx.stat("hbm_bytes_resident"),
         },

@@ -74,6 +74,42 @@ def test_screen_values_match_bf16_emulation(pkg, d, B):
             assert (np.abs(t - cos) <= Eq[:, None]).all()
 
 
+@pytest.mark.parametrize("screen", ["bf16", "i8"])
+@pytest.mark.parametrize("d,B,spread", [(768, 130, 0.02), (128, 17, 3.0), (5, 40, 0.5)])
+def test_inner_product_screen_estimates_dot_over_query_norm(pkg, screen, d, B, spread):
+    """inner-product metric (round 3): the shadows hold the rows THEMSELVES, the screen value estimates <q_hat, c> = dot / |q|
+    and exact dot / |q| <= value + E with E in the rows' units (scaled by the largest row norm) -- row norms spread by 2 %
+    (the C2 stand-in), by e^+-3, and low-dimensional aligned data; rows appended in two batches with a growing largest norm."""
+    rng = np.random.default_rng(1000 + d)
+    n = 1536
+    C = rng.standard_normal((n, d)).astype(np.float32)
+    if d == 5:
+        C = C[rng.integers(0, 8, size=n)] + (0.01 * rng.standard_normal((n, d))).astype(np.float32)
+    C /= np.linalg.norm(C, axis=1, keepdims=True)
+    C *= np.exp(spread * rng.uniform(-1, 1, size=(n, 1))).astype(np.float32)
+    C[900:] *= 1.7   # the second batch raises the largest norm
+    Q = (C[rng.integers(0, n, size=B)] + 0.05 * rng.standard_normal((B, d)).astype(np.float32)) * 3.0
+    with pkg.Mi355Index(d, "ip") as idx:
+        idx.set_option("screen_dtype", screen)
+        idx.add(C[:900])
+        idx.add(C[900:])
+        E = idx.debug_screen_bound(Q).astype(np.float64)
+        cmax = float(np.linalg.norm(C.astype(np.float64), axis=1).max())
+        assert (E > 0).all() and (E < 0.05 * cmax).all()
+        qh = Q.astype(np.float64) / np.linalg.norm(Q.astype(np.float64), axis=1, keepdims=True)
+        for row0, cnt in [(0, 1536), (512, 300)]:
+            t = idx.debug_screen_dense(Q, row0, cnt).astype(np.float64)
+            ref = qh @ C[row0:row0 + cnt].astype(np.float64).T
+            seen = ~np.isnan(t).all(axis=0)   # (a row with an outlier component stays out of the int8 shadow: "loose")
+            assert seen.sum() >= cnt - 2 and not np.isnan(t[:, seen]).any()
+            t, ref = t[:, seen], ref[:, seen]
+            if screen == "bf16":
+                assert (np.abs(t - ref) <= E[:, None]).all()
+            else:  # int8: the value already carries the pair's share of the bound: ref <= t + E, and t is not far above
+                assert (ref <= t + E[:, None]).all()
+                assert (t - ref <= 0.06 * cmax).all()
+
+
 @pytest.mark.parametrize("d", [2, 5, 16])
 def test_bf16_bound_holds_on_low_dimensional_aligned_data(pkg, d):
     """worst case of the bf16 bound: few dimensions, query and rows almost parallel, so the per-operand rounding errors

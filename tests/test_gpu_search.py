@@ -113,6 +113,34 @@ def test_inner_product_metric(pkg, oracle):
         _check(idx, oracle, C, Q, 10, metric="ip")
 
 
+@pytest.mark.parametrize("screen", SCREENS + ["auto"])
+def test_inner_product_screens_without_row_norms_in_the_threshold(pkg, oracle, screen):
+    """round 3: the inner-product shadows hold the rows themselves, so the threshold is dot_k / |q| - E whatever the norms and
+    whatever the SIGN of the k-th best dot (round 2 needed a positive one and the largest row norm): norms spread over a
+    decade, a block of rows whose dots are all negative, k up to the general prune's range, 300 queries -- the oracle's
+    ids and distances bit for bit, nobody on the exact-scan path."""
+    rng = np.random.default_rng(5)
+    n, d = 50_000, 128
+    C = rng.standard_normal((n, d)).astype(np.float32)
+    C *= np.exp(rng.uniform(-1.2, 1.2, size=(n, 1))).astype(np.float32)
+    Q = rng.standard_normal((300, d)).astype(np.float32)
+    Cneg = (-np.abs(C[:6000]) - 0.1).astype(np.float32)   # every dot with a non-negative query is negative
+    Qpos = np.abs(Q[:40])
+    for k in (10, 100, 600):
+        with pkg.Mi355Index(d, "ip") as idx:
+            idx.set_option("screen_dtype", screen)
+            idx.add(C)
+            idx.reset_stats()
+            _check(idx, oracle, C, Q, k, metric="ip")
+            assert idx.stat("fallback_queries") == 0
+    with pkg.Mi355Index(d, "ip") as idx:
+        idx.set_option("screen_dtype", screen)
+        idx.add(Cneg)
+        idx.reset_stats()
+        dist, _ = _check(idx, oracle, Cneg, Qpos, 10, metric="ip")
+        assert (dist > 0).all() and idx.stat("fallback_queries") == 0   # distance = -dot
+
+
 def test_near_ties_stress(pkg, oracle):
     """many rows within a few ulp of each other: ranking must still equal the oracle's bit for bit."""
     rng = np.random.default_rng(99)
@@ -184,16 +212,18 @@ def test_starter_pass_equals_ladder_pass(pkg, oracle, screen, n, d, B, k):
     C[7] = 0.0                              # zero row (irregular) in the sample
     C[9, 3] = 40.0 * np.abs(C[9]).max()     # outlier component: loose row for the int8 shadow
     res = []
-    for starter in (1, 0):
+    for starter, defer, companion in ((1, 1, 1), (0, 1, 1), (1, 0, 1), (1, 1, 0)):
         with pkg.Mi355Index(d) as idx:
             idx.set_option("screen_dtype", screen)
             idx.set_option("starter", starter)
+            idx.set_option("defer_round_b", defer)  # survivors of a prune's cut carried to the next prune / re-scored at once
+            idx.set_option("prune_companion", companion)  # 0: what the one-wave prune cannot hold is re-screened
             idx.add(C)
             idx.reset_stats()
             res.append(_check(idx, oracle, C, Q, k))
             assert idx.stat("starters") == starter * idx.stat("passes")
             assert idx.stat("fallback_queries") == 0
-    assert np.array_equal(res[0][1], res[1][1])
+    assert all(np.array_equal(res[0][1], r[1]) for r in res[1:])
 
 
 @pytest.mark.parametrize("k,expect_dtype", [(10, 2), (24, 2), (26, 1), (100, 1), (400, 1)])

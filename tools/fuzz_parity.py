@@ -70,6 +70,8 @@ def check_single(rng, case):
         opts["starter"] = 0
     if rng.random() < 0.15:
         opts["prune_companion"] = 1
+    if rng.random() < 0.15:
+        opts["defer_round_b"] = 0
     row_offset = int(rng.choice([0, 0, 12345, 2**33]))
     desc = f"single n={n} d={d} B={B} k={k} mode={mode} metric={metric} opts={opts} row_offset={row_offset}"
     import hashlib
