@@ -119,7 +119,18 @@ struct MsArgs {
     int q_col0[4];          // first column of each query (multiple of 32)
     int q_len[4];           // real token count of each query
     int clamp0;             // 1: every query token contributes max(0, max_j <q_i, d_j>)  (ColBERT reranker, rerankers/colbert.py:79)
+    // a query with more vectors than one launch stages (ms_cols_for(dpad) <= 128 columns) is scored in TILES of its vectors:
+    // the launch of tile t starts every item's sum from the value tile t-1 left (same layout as `dist`; may be `dist` itself),
+    // so the fp32 sum still runs over the query's vectors in order -- bit for bit the one-launch chain
+    const float* dist_in;
 };
+
+// query-token columns one launch of k_maxsim stages: whole 32-column blocks, at most kMsCols, inside the 160 KiB of LDS
+// (d = 128: 128 columns; d = 768, the hidden size the ColBERT reranker scores with: 32)
+inline int ms_cols_for(int dpad) {
+    const int c = (int)((size_t)160 * 1024 / ((size_t)(dpad + 4) * sizeof(float))) / 32 * 32;
+    return c < kMsCols ? c : kMsCols;
+}
 
 // Column order inside every group of 8 dims, for BOTH stored token rows and the staged query rows:
 // position j holds original column kPerm[j] = {0,4,2,6,1,5,3,7}[j].  A lane of the lower half (k-slot 0 of the
@@ -171,6 +182,7 @@ __global__ __launch_bounds__(kMsThreads, 2) void k_maxsim(MsArgs a) {
         const int y = blockIdx.y;
         a.doc_list += (int64_t)y * a.list_stride;
         a.dist += (int64_t)y * a.list_stride;
+        if (a.dist_in) a.dist_in += (int64_t)y * a.list_stride;
         a.n_items_dev += 2 * y;
         int c0 = a.q_col0[0], ln = a.q_len[0];
 #pragma unroll
@@ -246,7 +258,7 @@ __global__ __launch_bounds__(kMsThreads, 2) void k_maxsim(MsArgs a) {
     }
     // per query: distance = sum over its tokens (in order) of -(max dot); empty docs are skipped by the select
     for (int qi = 0; qi < a.nq_launch; ++qi) {
-        float accd = 0.0f;
+        float accd = a.dist_in ? a.dist_in[(int64_t)qi * a.n_items + item] : 0.0f;  // (wave-uniform address)
         for (int j = 0; j < a.q_len[qi]; ++j) {
             const int c = a.q_col0[qi] + j;
             float v = 0.0f;
@@ -966,14 +978,14 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
     for (int b = 0; b < B; ++b) {
         const int nq = q_offsets[b + 1] - q_offsets[b];
         if (nq < 0) return fail(idx, MI355DR_E_INVALID, "q_offsets must be non-decreasing");
-        if (nq > kMsCols) return fail(idx, MI355DR_E_UNSUPPORTED, "more than 128 query vectors per query");
     }
     HIPCHECK(idx, hipSetDevice(idx->device));
     hipStream_t s = idx->stream;
     const int dp = m->dpad, d = idx->dim, nkk = m->nkk;
-    const size_t lds = (size_t)kMsCols * (dp + 4) * sizeof(float);
+    const int cols = ms_cols_for(dp);  // query vectors one launch stages; longer queries are scored in tiles (exact kernel)
+    if (cols < 32) return fail(idx, MI355DR_E_UNSUPPORTED, "dim too large for the MaxSim kernel's LDS budget (dim <= 1272)");
+    const size_t lds = (size_t)cols * (dp + 4) * sizeof(float);
     const size_t lds16 = (size_t)4 * nkk * 64 * sizeof(uint4);
-    if (lds > 160 * 1024) return fail(idx, MI355DR_E_UNSUPPORTED, "dim too large for the MaxSim kernel's LDS budget");
     // scratch
     if (!m->qtok) {
         HIPCHECK(idx, hipMalloc(&m->qtok, (size_t)kMsCols * dp * sizeof(float)));
@@ -1070,7 +1082,7 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
         while (bb < B && g.nql < 4) {
             const int nq = q_offsets[bb + 1] - q_offsets[bb];
             const int need = (int)round_up(std::max(nq, 1), 32);
-            if (g.col + need > kMsCols) break;
+            if (g.col + need > cols) break;  // (a query longer than `cols` never fits: the caller scores it in tiles)
             g.q_col0[g.nql] = g.col;
             g.q_len[g.nql] = nq;
             double norm_sum = 0.0, res_sum = 0.0;
@@ -1127,6 +1139,40 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
         a.doc_list = nullptr;
         a.n_items_dev = nullptr;
         a.dpad = dp;
+        if (q_offsets[b + 1] - q_offsets[b] > cols) {
+            // ---- a query with more vectors than one launch stages (VectorChord's `@#` has no such limit: base.py:518-524):
+            // the exact kernel over every doc, one launch per tile of <= cols query vectors, each continuing the per-doc sums
+            const int nq = q_offsets[b + 1] - q_offsets[b];
+            for (int t0 = 0; t0 < nq; t0 += cols) {
+                const int tl = std::min(cols, nq - t0);
+                if (t0 > 0) HIPCHECK(idx, hipStreamSynchronize(s));  // (the previous tile's launch has read the staging image)
+                std::fill(qimg.begin(), qimg.end(), 0.0f);
+                for (int j = 0; j < tl; ++j) {
+                    const float* sv = qtok + (int64_t)(q_offsets[b] + t0 + j) * d;
+                    float* dst = &qimg[(size_t)j * dp];
+                    for (int c = 0; c < dp; ++c) {
+                        const int oc = ms_perm(c);
+                        dst[c] = oc < d ? sv[oc] : 0.0f;
+                    }
+                }
+                HIPCHECK(idx, hipMemcpyAsync(m->qtok, qimg.data(), (size_t)cols * dp * sizeof(float), hipMemcpyHostToDevice, s));
+                MsArgs f = a;
+                f.nq_launch = 1;
+                f.q_col0[0] = 0;
+                f.q_len[0] = tl;
+                f.dist_in = t0 > 0 ? m->dist : nullptr;
+                hipLaunchKernelGGL(k_maxsim, dim3(grid_all), dim3(kMsThreads), lds, s, f);
+                HIPCHECK(idx, hipGetLastError());
+            }
+            idx->s_ms_fallbacks++;
+            int cur = 0;
+            CHECK(ms_topk(idx, m, s, m->dist, m->n_docs, k, seg, nullptr, nullptr, &cur));
+            CHECK(ms_emit_result(idx, m, s, cur, k, out_dist + (int64_t)b * k, out_rows + (int64_t)b * k));
+            HIPCHECK(idx, hipStreamSynchronize(s));
+            pre_first = -1;
+            ++b;
+            continue;
+        }
         const bool pre = pre_first == b;  // this group was screened together with the previous one
         std::fill(qimg.begin(), qimg.end(), 0.0f);
         if (!pre) std::fill(qf16.begin(), qf16.end(), (uint16_t)0);
@@ -1334,69 +1380,75 @@ static int maxsim_subset_impl(mi355dr_index* idx, const float* qtok, const int32
     for (int64_t i = 0; i < (int64_t)B * m_ids; ++i) out_dist[i] = NAN;
     MultiVecStore* m = idx->mv;
     if (B == 0 || m_ids == 0 || !m || m->n_docs == 0) return MI355DR_OK;
-    for (int b = 0; b < B; ++b) {
-        const int nq = q_offsets[b + 1] - q_offsets[b];
-        if (nq < 0) return fail(idx, MI355DR_E_INVALID, "q_offsets must be non-decreasing");
-        if (nq > kMsCols) return fail(idx, MI355DR_E_UNSUPPORTED, "more than 128 query vectors per query");
-    }
+    for (int b = 0; b < B; ++b)
+        if (q_offsets[b + 1] - q_offsets[b] < 0) return fail(idx, MI355DR_E_INVALID, "q_offsets must be non-decreasing");
     HIPCHECK(idx, hipSetDevice(idx->device));
     hipStream_t s = idx->stream;
     const int dp = m->dpad, d = idx->dim;
-    const size_t lds = (size_t)kMsCols * (dp + 4) * sizeof(float);
-    if (lds > 160 * 1024) return fail(idx, MI355DR_E_UNSUPPORTED, "dim too large for the MaxSim kernel's LDS budget");
+    const int cols = ms_cols_for(dp);  // query vectors per launch; a longer query is scored in tiles (MsArgs::dist_in)
+    if (cols < 32) return fail(idx, MI355DR_E_UNSUPPORTED, "dim too large for the MaxSim kernel's LDS budget (dim <= 1272)");
+    const size_t lds = (size_t)cols * (dp + 4) * sizeof(float);
     HIPCHECK(idx, hipFuncSetAttribute((const void*)k_maxsim, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    // per call scratch (candidate lists are small: a few hundred docs per query)
-    int32_t* list_dev = nullptr;
-    float* dist_dev = nullptr;
-    float* q_dev = nullptr;
+    // per call scratch (candidate lists are small: a few hundred docs per query), released on every exit
+    struct Scratch {
+        int32_t* list = nullptr;
+        float* dist = nullptr;
+        float* q = nullptr;
+        ~Scratch() {
+            if (list) (void)hipFree(list);
+            if (dist) (void)hipFree(dist);
+            if (q) (void)hipFree(q);
+        }
+    } sc;
     std::vector<int32_t> list((size_t)B * m_ids);
     for (int64_t i = 0; i < (int64_t)B * m_ids; ++i) {
         const int64_t v = doc_ids[i] - idx->row_offset;  // ids are global rows, like the search results
         list[i] = (v >= 0 && v < m->n_docs) ? (int32_t)v : -1;
     }
-    HIPCHECK(idx, hipMalloc(&list_dev, list.size() * sizeof(int32_t)));
-    HIPCHECK(idx, hipMalloc(&dist_dev, list.size() * sizeof(float)));
-    HIPCHECK(idx, hipMalloc(&q_dev, (size_t)kMsCols * dp * sizeof(float)));
-    HIPCHECK(idx, hipMemcpyAsync(list_dev, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    std::vector<float> qimg((size_t)kMsCols * dp);
+    HIPCHECK(idx, hipMalloc(&sc.list, list.size() * sizeof(int32_t)));
+    HIPCHECK(idx, hipMalloc(&sc.dist, list.size() * sizeof(float)));
+    HIPCHECK(idx, hipMalloc(&sc.q, (size_t)cols * dp * sizeof(float)));
+    HIPCHECK(idx, hipMemcpyAsync(sc.list, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    std::vector<float> qimg((size_t)cols * dp);
     for (int b = 0; b < B; ++b) {
         const int nq = q_offsets[b + 1] - q_offsets[b];
         if (nq == 0) continue;  // reference heaven.py:251-252: no query vectors -> every score 0 (host side)
-        std::fill(qimg.begin(), qimg.end(), 0.0f);
-        for (int j = 0; j < nq; ++j) {
-            float* dst = &qimg[(size_t)j * dp];
-            const float* sv = qtok + (int64_t)(q_offsets[b] + j) * d;
-            for (int c = 0; c < dp; ++c) {
-                const int oc = ms_perm(c);
-                dst[c] = oc < d ? sv[oc] : 0.0f;
+        for (int t0 = 0; t0 < nq; t0 += cols) {  // tiles of the query's vectors: each launch continues the per-doc sums
+            const int tl = std::min(cols, nq - t0);
+            std::fill(qimg.begin(), qimg.end(), 0.0f);
+            for (int j = 0; j < tl; ++j) {
+                float* dst = &qimg[(size_t)j * dp];
+                const float* sv = qtok + (int64_t)(q_offsets[b] + t0 + j) * d;
+                for (int c = 0; c < dp; ++c) {
+                    const int oc = ms_perm(c);
+                    dst[c] = oc < d ? sv[oc] : 0.0f;
+                }
             }
+            // the staging buffer is reused: the previous launch must have consumed it (stream order + pageable copy)
+            HIPCHECK(idx, hipMemcpyAsync(sc.q, qimg.data(), qimg.size() * sizeof(float), hipMemcpyHostToDevice, s));
+            HIPCHECK(idx, hipStreamSynchronize(s));
+            MsArgs a{};
+            a.tok = m->tok;
+            a.blk_off = m->blk_off;
+            a.qtok = sc.q;
+            a.dist = sc.dist + (int64_t)b * m_ids;
+            a.dist_in = t0 > 0 ? a.dist : nullptr;
+            a.doc_list = sc.list + (int64_t)b * m_ids;
+            a.n_items = m_ids;
+            a.n_docs = m->n_docs;
+            a.dpad = dp;
+            a.nq_launch = 1;
+            a.q_col0[0] = 0;
+            a.q_len[0] = tl;
+            a.clamp0 = clamp0;
+            hipLaunchKernelGGL(k_maxsim, dim3((unsigned)std::min<int64_t>((m_ids + 3) / 4, kMsListGrid)), dim3(kMsThreads),
+                               lds, s, a);
+            HIPCHECK(idx, hipGetLastError());
         }
-        // the staging buffer is reused: the previous launch must have consumed it (stream order + pageable copy)
-        HIPCHECK(idx, hipMemcpyAsync(q_dev, qimg.data(), qimg.size() * sizeof(float), hipMemcpyHostToDevice, s));
-        HIPCHECK(idx, hipStreamSynchronize(s));
-        MsArgs a{};
-        a.tok = m->tok;
-        a.blk_off = m->blk_off;
-        a.qtok = q_dev;
-        a.dist = dist_dev + (int64_t)b * m_ids;
-        a.doc_list = list_dev + (int64_t)b * m_ids;
-        a.n_items = m_ids;
-        a.n_docs = m->n_docs;
-        a.dpad = dp;
-        a.nq_launch = 1;
-        a.q_col0[0] = 0;
-        a.q_len[0] = nq;
-        a.clamp0 = clamp0;
-        hipLaunchKernelGGL(k_maxsim, dim3((unsigned)std::min<int64_t>((m_ids + 3) / 4, kMsListGrid)), dim3(kMsThreads), lds,
-                           s, a);
-        HIPCHECK(idx, hipGetLastError());
-        HIPCHECK(idx, hipMemcpyAsync(out_dist + (int64_t)b * m_ids, dist_dev + (int64_t)b * m_ids, m_ids * sizeof(float),
+        HIPCHECK(idx, hipMemcpyAsync(out_dist + (int64_t)b * m_ids, sc.dist + (int64_t)b * m_ids, m_ids * sizeof(float),
                                      hipMemcpyDeviceToHost, s));
     }
     HIPCHECK(idx, hipStreamSynchronize(s));
-    (void)hipFree(list_dev);
-    (void)hipFree(dist_dev);
-    (void)hipFree(q_dev);
     return MI355DR_OK;
 }
 

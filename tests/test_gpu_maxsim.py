@@ -48,6 +48,35 @@ def _check(idx, oracle, tok, off, qtok, qoff, k):
     idx.set_option("maxsim_screen", 1)
 
 
+@pytest.mark.parametrize("d,n_docs,tmax,qlens,k", [
+    (128, 800, 60, [300, 32, 129, 257], 10),   # queries with more than 128 vectors next to ordinary ones
+    (768, 120, 40, [20, 70, 33], 5),           # d = 768: one launch stages 32 query vectors, everything longer runs in tiles
+    (1000, 40, 12, [40], 3),                   # dim 1000 (one launch: 32 vectors of 1004 floats)
+])
+def test_long_queries_and_wide_vectors_run_in_tiles(pkg, oracle, d, n_docs, tmax, qlens, k):
+    """round 3: VectorChord's `@#` takes any number of query vectors (reference base.py:518-524) and any dimension; the kernel
+    stages min(128, what 160 KiB of LDS hold) query vectors per launch and scores a longer query in TILES, each launch
+    continuing the per-document fp32 sums of the one before it -- the oracle's one chain over the query's vectors, bit for
+    bit, in the full search and in the candidate-subset form (HEAVEN stage 2 / reranker)."""
+    rng = np.random.default_rng(d + n_docs)
+    tok, off = _ragged(rng, n_docs, d, 1, tmax)
+    qtok, qoff = _queries(rng, qlens, d)
+    with pkg.Mi355Index(d) as idx:
+        idx.add_multivec(tok, off)
+        _check(idx, oracle, tok, off, qtok, qoff, k)
+        # subset form: every query against a list of docs (some ids not in the store) == the oracle's full distances
+        ids = rng.integers(-2, n_docs + 2, size=(len(qlens), 17)).astype(np.int64)
+        got = idx.maxsim_subset(qtok, qoff, ids)
+        fd, fr = oracle.maxsim_topk(tok, off, qtok, qoff, n_docs)   # every doc's distance
+        for b in range(len(qlens)):
+            want = {int(r): x for r, x in zip(fr[b], fd[b])}
+            for j, i in enumerate(ids[b]):
+                if 0 <= i < n_docs:
+                    assert got[b, j].view(np.uint32) == np.float32(want[int(i)]).view(np.uint32)
+                else:
+                    assert np.isnan(got[b, j])
+
+
 def test_golden_inputs(pkg, oracle):
     g = np.load(GOLDEN / "scores_golden.npz")
     tok, off, qtok, qoff = g["ms_tok"], g["ms_offsets"], g["ms_qtok"], g["ms_qoff"]

@@ -67,6 +67,26 @@ def test_gpu_scores_match_the_reference(native_built, oracle, c):
 
 
 @pytest.mark.gpu
+def test_gpu_reranker_at_the_reference_models_shape(native_built, oracle):
+    """colbert-ir/colbertv2.0 scored the reference's way (rerankers/colbert.py:41-84: AutoModel.last_hidden_state, hidden
+    size 768, max_length 512): 768-dimensional token vectors and a query of more than 128 valid tokens -- both outside what
+    one launch of the MaxSim kernel stages, both served in tiles since round 3 -- against the `_maxsim_score` restatement."""
+    from autorag_research_amd.rerank import colbert_maxsim_scores
+
+    rng = np.random.default_rng(12)
+    d, lq, n_docs, ld = 768, 200, 9, 90
+    q = rng.standard_normal((lq, d)).astype(np.float32) / np.sqrt(d)
+    qm = np.ones((lq,), np.int64)
+    qm[170:] = 0                                  # padded tail
+    docs = rng.standard_normal((n_docs, ld, d)).astype(np.float32) / np.sqrt(d)
+    dm = (np.arange(ld)[None, :] < rng.integers(0, ld + 1, size=(n_docs, 1))).astype(np.int64)
+    dm[3] = 0                                     # a document without a valid token scores 0
+    got = colbert_maxsim_scores(q, qm, docs, dm)
+    want = oracle.colbert_rerank_scores(q, qm, docs, dm)
+    assert np.allclose(got, want, rtol=0, atol=2e-6) and got[3] == 0.0
+
+
+@pytest.mark.gpu
 def test_device_built_store_equals_host_built_store(native_built):
     """mi355dr_add_multivec_device (kernel-built padded store, bf16 fragments, bound quantities) vs mi355dr_add_multivec:
     the screened MaxSim search and the exact subset scoring return identical bits, appended in two batches."""
