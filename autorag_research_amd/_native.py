@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "mi355dr_create", "mi355dr_destroy", "mi355dr_last_error", "mi355dr_version", "mi355dr_reserve",
     "mi355dr_add_rows", "mi355dr_add_rows_device", "mi355dr_size", "mi355dr_dim", "mi355dr_get_rows",
     "mi355dr_search", "mi355dr_search_device", "mi355dr_search_device_async", "mi355dr_search_wait", "mi355dr_add_multivec", "mi355dr_size_multivec",
-    "mi355dr_search_maxsim", "mi355dr_maxsim_subset", "mi355dr_maxsim_subset_ex", "mi355dr_add_multivec_device", "mi355dr_gqr_refine", "mi355dr_gqr_refine_maxsim",
+    "mi355dr_search_maxsim", "mi355dr_search_maxsim_device", "mi355dr_maxsim_subset", "mi355dr_maxsim_subset_ex", "mi355dr_add_multivec_device", "mi355dr_gqr_refine", "mi355dr_gqr_refine_maxsim",
     "mi355dr_gqr_refine_scores", "mi355dr_merge_topk_device", "mi355dr_pack_topk_device",
     "mi355dr_merge_topk_packed_device", "mi355dr_comm_unique_id", "mi355dr_comm_init", "mi355dr_comm_world",
     "mi355dr_search_sharded_device", "mi355dr_set_option", "mi355dr_get_stat",
@@ -114,6 +114,8 @@ def load() -> ctypes.CDLL:
     L.mi355dr_size_multivec.argtypes = [vp]
     L.mi355dr_search_maxsim.restype = c_int
     L.mi355dr_search_maxsim.argtypes = [vp, f32p, i32p, c_int, c_int, f32p, i64p]
+    L.mi355dr_search_maxsim_device.restype = c_int
+    L.mi355dr_search_maxsim_device.argtypes = [vp, vp, i32p, c_int, c_int, vp, vp, vp]
     L.mi355dr_maxsim_subset.restype = c_int
     L.mi355dr_maxsim_subset.argtypes = [vp, f32p, i32p, c_int, i64p, c_int, f32p]
     L.mi355dr_maxsim_subset_ex.restype = c_int

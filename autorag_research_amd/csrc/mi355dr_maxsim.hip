@@ -951,7 +951,14 @@ int ms_topk(mi355dr_index* idx, MultiVecStore* m, hipStream_t s, const float* di
     return MI355DR_OK;
 }
 
-int ms_emit_result(mi355dr_index* idx, MultiVecStore* m, hipStream_t s, int cur, int k, float* out_dist, int64_t* out_rows) {
+int ms_emit_result(mi355dr_index* idx, MultiVecStore* m, hipStream_t s, int cur, int k, float* out_dist, int64_t* out_rows,
+                   bool out_dev) {
+    if (out_dev) {  // straight into the caller's device buffers
+        hipLaunchKernelGGL(k_ms_write_out, dim3((k + 255) / 256), dim3(256), 0, s, m->pk[cur], m->pr[cur], k, idx->row_offset,
+                           out_dist, out_rows);
+        HIPCHECK(idx, hipGetLastError());
+        return MI355DR_OK;
+    }
     hipLaunchKernelGGL(k_ms_write_out, dim3((k + 255) / 256), dim3(256), 0, s, m->pk[cur], m->pr[cur], k, idx->row_offset,
                        m->out_d, m->out_r);
     HIPCHECK(idx, hipGetLastError());
@@ -960,18 +967,34 @@ int ms_emit_result(mi355dr_index* idx, MultiVecStore* m, hipStream_t s, int cur,
     return MI355DR_OK;
 }
 
+__global__ void k_ms_fill_empty(float* d, int64_t* r, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        d[i] = __uint_as_float(0x7FC00000u);
+        r[i] = -1;
+    }
+}
+
 }  // namespace
 
-int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* q_offsets, int B, int k,
-                          float* out_dist, int64_t* out_rows) {
-    if (!idx) return fail(nullptr, MI355DR_E_INVALID, "null index");
-    std::lock_guard<std::mutex> g(idx->mu);
-    if (B < 0 || k <= 0 || !q_offsets || (B > 0 && (!out_dist || !out_rows)))
-        return fail(idx, MI355DR_E_INVALID, "bad maxsim arguments");
+// qtok: HOST [sum_nq, dim]; outputs on the host (out_dev = false) or in device memory of the index's GPU (out_dev = true:
+// written by kernels / device copies on the index's stream, complete on return)
+static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32_t* q_offsets, int B, int k, float* out_dist,
+                              int64_t* out_rows, bool out_dev) {
     if (k > kKMax) return fail(idx, MI355DR_E_UNSUPPORTED, "k exceeds 1024");
-    for (int64_t i = 0; i < (int64_t)B * k; ++i) {
-        out_dist[i] = NAN;
-        out_rows[i] = -1;
+    if (out_dev) {
+        if (B > 0) {
+            HIPCHECK(idx, hipSetDevice(idx->device));
+            const int64_t n = (int64_t)B * k;
+            hipLaunchKernelGGL(k_ms_fill_empty, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, idx->stream, out_dist, out_rows, n);
+            HIPCHECK(idx, hipGetLastError());
+            HIPCHECK(idx, hipStreamSynchronize(idx->stream));
+        }
+    } else {
+        for (int64_t i = 0; i < (int64_t)B * k; ++i) {
+            out_dist[i] = NAN;
+            out_rows[i] = -1;
+        }
     }
     MultiVecStore* m = idx->mv;
     if (B == 0 || !m || m->n_docs == 0) return MI355DR_OK;
@@ -1167,7 +1190,7 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
             idx->s_ms_fallbacks++;
             int cur = 0;
             CHECK(ms_topk(idx, m, s, m->dist, m->n_docs, k, seg, nullptr, nullptr, &cur));
-            CHECK(ms_emit_result(idx, m, s, cur, k, out_dist + (int64_t)b * k, out_rows + (int64_t)b * k));
+            CHECK(ms_emit_result(idx, m, s, cur, k, out_dist + (int64_t)b * k, out_rows + (int64_t)b * k, out_dev));
             HIPCHECK(idx, hipStreamSynchronize(s));
             pre_first = -1;
             ++b;
@@ -1302,8 +1325,15 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
                 handled[qi] = true;
                 idx->s_ms_screened++;
                 idx->s_ms_candidates += m->cand_ctl_host[2 * qi];
-                memcpy(out_dist + (int64_t)(first + qi) * k, &hd[(size_t)qi * k], k * sizeof(float));
-                memcpy(out_rows + (int64_t)(first + qi) * k, &hr[(size_t)qi * k], k * sizeof(int64_t));
+                if (out_dev) {
+                    HIPCHECK(idx, hipMemcpyAsync(out_dist + (int64_t)(first + qi) * k, m->out_d + (size_t)qi * k, k * sizeof(float),
+                                                 hipMemcpyDeviceToDevice, s));
+                    HIPCHECK(idx, hipMemcpyAsync(out_rows + (int64_t)(first + qi) * k, m->out_r + (size_t)qi * k,
+                                                 k * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+                } else {
+                    memcpy(out_dist + (int64_t)(first + qi) * k, &hd[(size_t)qi * k], k * sizeof(float));
+                    memcpy(out_rows + (int64_t)(first + qi) * k, &hr[(size_t)qi * k], k * sizeof(int64_t));
+                }
             }
         }
         for (int qi = 0; qi < nql; ++qi) {
@@ -1343,7 +1373,7 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
                                    dim3(kMsThreads), lds, s, c);
                 HIPCHECK(idx, hipGetLastError());
                 CHECK(ms_topk(idx, m, s, m->cand_dist, n_cand_max, k, seg, m->cand_list, m->cand_ctl, &cur));
-                CHECK(ms_emit_result(idx, m, s, cur, k, od, orow));
+                CHECK(ms_emit_result(idx, m, s, cur, k, od, orow, out_dev));
                 HIPCHECK(idx, hipMemcpyAsync(m->cand_ctl_host, m->cand_ctl, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
                 HIPCHECK(idx, hipStreamSynchronize(s));
                 if (m->cand_ctl_host[1] == 0) {
@@ -1363,12 +1393,46 @@ int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* 
             if (!done) {
                 const float* dist_q = screen ? m->dist : m->dist + (int64_t)qi * m->n_docs;
                 CHECK(ms_topk(idx, m, s, dist_q, m->n_docs, k, seg, nullptr, nullptr, &cur));
-                CHECK(ms_emit_result(idx, m, s, cur, k, od, orow));
+                CHECK(ms_emit_result(idx, m, s, cur, k, od, orow, out_dev));
                 HIPCHECK(idx, hipStreamSynchronize(s));
             }
         }
     }
+    HIPCHECK(idx, hipStreamSynchronize(s));  // (device outputs: the last copies)
     return MI355DR_OK;
+}
+
+int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* q_offsets, int B, int k,
+                          float* out_dist, int64_t* out_rows) {
+    if (!idx) return fail(nullptr, MI355DR_E_INVALID, "null index");
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (B < 0 || k <= 0 || !q_offsets || (B > 0 && (!out_dist || !out_rows)))
+        return fail(idx, MI355DR_E_INVALID, "bad maxsim arguments");
+    return search_maxsim_impl(idx, qtok, q_offsets, B, k, out_dist, out_rows, false);
+}
+
+int mi355dr_search_maxsim_device(mi355dr_index* idx, const float* qtok_dev, const int32_t* q_offsets, int B, int k,
+                                 float* out_dist_dev, int64_t* out_rows_dev, void* stream) {
+    if (!idx) return fail(nullptr, MI355DR_E_INVALID, "null index");
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (B < 0 || k <= 0 || !q_offsets || (B > 0 && (!out_dist_dev || !out_rows_dev)))
+        return fail(idx, MI355DR_E_INVALID, "bad maxsim arguments");
+    if (B == 0) return MI355DR_OK;
+    for (int b = 0; b < B; ++b)
+        if (q_offsets[b + 1] < q_offsets[b]) return fail(idx, MI355DR_E_INVALID, "q_offsets must be non-decreasing");
+    const int64_t n_tok = q_offsets[B] - q_offsets[0];
+    if (n_tok > 0 && !qtok_dev) return fail(idx, MI355DR_E_INVALID, "null query vectors");
+    HIPCHECK(idx, hipSetDevice(idx->device));
+    // The query side of a pass is tiny (8 queries x 32 vectors x 128 dims = 128 KiB) and its bound is evaluated in double on
+    // the host: the vectors come down once (ordered behind the caller's stream), the k results of every query never leave HBM.
+    if (stream) HIPCHECK(idx, hipStreamSynchronize((hipStream_t)stream));
+    std::vector<float> qh((size_t)std::max<int64_t>(n_tok, 1) * idx->dim);
+    if (n_tok > 0)
+        HIPCHECK(idx, hipMemcpy(qh.data(), qtok_dev + (int64_t)q_offsets[0] * idx->dim, (size_t)n_tok * idx->dim * sizeof(float),
+                                hipMemcpyDeviceToHost));
+    std::vector<int32_t> off(B + 1);
+    for (int b = 0; b <= B; ++b) off[b] = q_offsets[b] - q_offsets[0];
+    return search_maxsim_impl(idx, qh.data(), off.data(), B, k, out_dist_dev, out_rows_dev, true);
 }
 
 static int maxsim_subset_impl(mi355dr_index* idx, const float* qtok, const int32_t* q_offsets, int B, const int64_t* doc_ids,

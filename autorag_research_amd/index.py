@@ -194,6 +194,16 @@ class Mi355Index:
                                                        ptr(dist, ctypes.c_float), ptr(rows, ctypes.c_int64)))
         return dist, rows
 
+    def search_maxsim_device(self, qtok_ptr: int, q_offsets, k: int, out_dist_ptr: int, out_rows_ptr: int,
+                             stream: int | None = None) -> None:
+        """MaxSim top-k with the query vectors ([sum_nq, dim] fp32 at `qtok_ptr`) and the results (fp32 [B,k] at
+        `out_dist_ptr`, int64 [B,k] at `out_rows_ptr`) in device memory; `q_offsets` is a host array [B+1]."""
+        q_offsets = np.ascontiguousarray(q_offsets, dtype=np.int32)
+        check(self._h, self._lib.mi355dr_search_maxsim_device(
+            self._h, ctypes.c_void_p(int(qtok_ptr)), ptr(q_offsets, ctypes.c_int32), q_offsets.shape[0] - 1, int(k),
+            ctypes.c_void_p(int(out_dist_ptr)), ctypes.c_void_p(int(out_rows_ptr)),
+            ctypes.c_void_p(int(stream) if stream else None)))
+
     def maxsim_subset(self, qtok, q_offsets, doc_ids, clamp0: bool = False) -> np.ndarray:
         """Exact MaxSim distance of each query to its own list of docs: doc_ids [B, m] -> distances [B, m] (NaN = skipped).
         `clamp0`: every query vector contributes max(0, max_j <q_i, d_j>) (the ColBERT reranker's MaxSim)."""

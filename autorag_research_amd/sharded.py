@@ -178,26 +178,48 @@ class ShardedSearcher:
         nbmax = min(block, B)
         packed = [torch.empty((2 * nbmax * k,), dtype=torch.int64, device=dev) for _ in range(2)]
         gathered = [torch.empty((self.world * 2 * nbmax * k,), dtype=torch.int64, device=dev) for _ in range(2)]
-        compute = torch.cuda.current_stream(dev)
+        # the searches run on an explicit NON-default stream: its handle is never 0, so the library uses this very stream
+        # (a null handle means "the index's own stream", which torch events would not see)
+        compute = torch.cuda.Stream(dev)
         comm = torch.cuda.Stream(dev)
+        compute.wait_stream(torch.cuda.current_stream(dev))  # the upload of the queries
         done = [None, None]
-        for i, b0 in enumerate(range(0, B, block)):
-            nb, buf = min(block, B - b0), i & 1
-            if done[buf] is not None:
-                compute.wait_event(done[buf])  # the gather that read this packed block two blocks ago
+        use_async = hasattr(self.index, "search_device_async")
+
+        def finish(p):
+            """block complete on the host (the library re-did the rare flagged queries) -> gather + merge on the second stream"""
+            ticket, buf, b0, nb = p
+            if ticket is not None:
+                self.index.search_wait(ticket)
             pk = packed[buf][: 2 * nb * k]
-            self.index.search_device(qd[b0:b0 + nb].data_ptr(), nb, k, pk.data_ptr(), pk[nb * k:].data_ptr(),
-                                     compute.cuda_stream)
-            ready = torch.cuda.Event()
-            ready.record(compute)
             with torch.cuda.stream(comm):
-                comm.wait_event(ready)
+                if ticket is None:
+                    comm.wait_stream(compute)
                 ga = gathered[buf][: self.world * 2 * nb * k]
                 dist.all_gather_into_tensor(ga, pk, group=self.group)
                 self.index.merge_topk_packed_device(ga.data_ptr(), self.world, nb, k, out_d[b0:b0 + nb].data_ptr(),
                                                     out_r[b0:b0 + nb].data_ptr(), comm.cuda_stream)
                 done[buf] = torch.cuda.Event()
                 done[buf].record(comm)
+
+        pend = None
+        for i, b0 in enumerate(range(0, B, block)):
+            nb, buf = min(block, B - b0), i & 1
+            if done[buf] is not None:
+                compute.wait_event(done[buf])  # the gather that read this packed block two blocks ago
+            pk = packed[buf][: 2 * nb * k]
+            args = (qd[b0:b0 + nb].data_ptr(), nb, k, pk.data_ptr(), pk[nb * k:].data_ptr(), compute.cuda_stream)
+            if use_async:   # block i is on the stream before the host waits for block i - 1
+                t = self.index.search_device_async(*args)
+                if pend is not None:
+                    finish(pend)
+                    self.overlapped_blocks += 1
+                pend = (t, buf, b0, nb)
+            else:
+                self.index.search_device(*args)
+                finish((None, buf, b0, nb))
+        if pend is not None:
+            finish(pend)
         comm.synchronize()
         return out_d.cpu().numpy(), out_r.cpu().numpy()
 
@@ -241,28 +263,39 @@ class ShardedSearcher:
 
     def search_maxsim(self, qtok, q_offsets, k: int) -> tuple[np.ndarray, np.ndarray]:
         """Every rank passes the same queries; every rank gets the same global [B,k] (fp32 distance, doc) result."""
-        dist_l, rows_l = self.index.search_maxsim(qtok, q_offsets, k)
-        if self.world == 1:
-            return dist_l, rows_l
+        if self.world == 1 and not self.force_pipeline:
+            return self.index.search_maxsim(qtok, q_offsets, k)
         import torch
 
         on_gpu = self.backend == "nccl"
-        dev = torch.device("cuda", self.device) if on_gpu else torch.device("cpu")
-        B = dist_l.shape[0]
-        # fp32 -> float8 is exact and order-preserving, so the float8 merge applies unchanged
-        d64 = np.ascontiguousarray(dist_l.astype(np.float64))
-        packed = torch.from_numpy(np.stack([d64.view(np.int64), rows_l])).to(dev)
-        gathered = torch.empty((self.world, 2, B, k), dtype=torch.int64, device=dev)
-        self._dist.all_gather_into_tensor(gathered.view(-1), packed.view(-1), group=self.group)
-        if on_gpu and hasattr(self.index, "merge_topk_packed_device"):
-            # the world*k -> k merge stays on the device (k_merge_topk, same total order); the MaxSim entry point of
-            # the library returns host arrays, so only the [B,k] lists make the round trip
+        if on_gpu and hasattr(self.index, "search_maxsim_device"):
+            # nccl: the shard's lists stay in HBM from the MaxSim kernels to the merge -- mi355dr_search_maxsim_device writes
+            # them to device buffers, fp32 -> float8 (exact, order-preserving) and the packing are device ops, one
+            # all-gather, k_merge_topk
+            dev = torch.device("cuda", self.device)
+            q_offsets = np.ascontiguousarray(q_offsets, dtype=np.int32)
+            B = q_offsets.shape[0] - 1
+            qd = torch.from_numpy(np.ascontiguousarray(qtok, dtype=np.float32)).to(dev)
+            d32 = torch.empty((B, k), dtype=torch.float32, device=dev)
+            packed = torch.empty((2, B, k), dtype=torch.int64, device=dev)
+            cur = torch.cuda.current_stream(dev)
+            self.index.search_maxsim_device(qd.data_ptr(), q_offsets, k, d32.data_ptr(), packed[1].data_ptr(), cur.cuda_stream)
+            packed[0].view(torch.float64).copy_(d32)
+            gathered = torch.empty((self.world, 2, B, k), dtype=torch.int64, device=dev)
+            self._dist.all_gather_into_tensor(gathered.view(-1), packed.view(-1), group=self.group)
             out_d = torch.empty((B, k), dtype=torch.float64, device=dev)
             out_r = torch.empty((B, k), dtype=torch.int64, device=dev)
             self.index.merge_topk_packed_device(gathered.data_ptr(), self.world, B, k, out_d.data_ptr(), out_r.data_ptr(),
-                                                torch.cuda.current_stream(dev).cuda_stream)
+                                                cur.cuda_stream)
             return out_d.cpu().numpy().astype(np.float32), out_r.cpu().numpy()
-        g = gathered.cpu().numpy()
+        dist_l, rows_l = self.index.search_maxsim(qtok, q_offsets, k)
+        B = dist_l.shape[0]
+        # fp32 -> float8 is exact and order-preserving, so the float8 merge applies unchanged
+        d64 = np.ascontiguousarray(dist_l.astype(np.float64))
+        packed = torch.from_numpy(np.stack([d64.view(np.int64), rows_l]))
+        gathered = torch.empty((self.world, 2, B, k), dtype=torch.int64)
+        self._dist.all_gather_into_tensor(gathered.view(-1), packed.view(-1), group=self.group)
+        g = gathered.numpy()
         out_d, out_r = merge_topk_host(np.ascontiguousarray(g[:, 0]).view(np.float64), np.ascontiguousarray(g[:, 1]), k)
         return out_d.astype(np.float32), out_r
 

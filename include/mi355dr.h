@@ -120,6 +120,14 @@ int64_t mi355dr_size_multivec(const mi355dr_index* idx);
 /* qtok: host [sum_nq, dim], q_offsets: [B+1].  out_dist: [B,k] fp32 (= -sum_i max_j <q_i,d_j>). */
 int mi355dr_search_maxsim(mi355dr_index* idx, const float* qtok, const int32_t* q_offsets, int B, int k,
                           float* out_dist, int64_t* out_rows);
+/* The same with the query vectors and the results in DEVICE memory of the index's GPU (an encoder's output tensor in, the
+ * packed block of a row-sharded search out: BaseVectorRepository.maxsim_search behind a multi-GPU caller,
+ * orm/repository/base.py:487-535).  qtok_dev: device [sum_nq, dim]; q_offsets: HOST [B+1]; out_dist_dev [B,k] fp32 and
+ * out_rows_dev [B,k] int64 on the device, complete on return.  `stream`: the stream that produced qtok_dev (waited for
+ * before the vectors are read; NULL: none).  The query side of a pass is small (a few hundred KiB) and its screen bound is
+ * evaluated in double on the host, so the vectors are read back once; the results never leave HBM. */
+int mi355dr_search_maxsim_device(mi355dr_index* idx, const float* qtok_dev, const int32_t* q_offsets, int B, int k,
+                                 float* out_dist_dev, int64_t* out_rows_dev, void* stream);
 
 /* exact MaxSim distance of every query to an explicit list of docs (candidate re-scoring: HEAVEN stage 2,
  * autorag_research/pipelines/retrieval/heaven.py:244-266 `_score_candidates`, score = -distance / n_q; GQR pools,

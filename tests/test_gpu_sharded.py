@@ -57,7 +57,35 @@ s.force_pipeline = True
 s.add_local(C, 1000)
 d2, r2 = s.search(Q, k, block=256)   # 3 blocks: gathers of blocks 0 and 1 overlap the searches of blocks 1 and 2
 assert np.array_equal(r2, rr) and np.array_equal(d2.view(np.uint64), rd.view(np.uint64))
+assert s.overlapped_blocks == 2   # blocks 1 and 2 were on the stream before blocks 0 and 1 were waited for
 s.close()
+
+# (3) MaxSim with the query vectors and the results in device memory (mi355dr_search_maxsim_device), alone and behind
+# ShardedSearcher's nccl path (lists packed, gathered and merged without leaving the device)
+dm = 128
+lens = rng.integers(1, 90, size=900)
+tok = rng.standard_normal((int(lens.sum()), dm)).astype(np.float32)
+tok /= np.linalg.norm(tok, axis=1, keepdims=True)
+off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+qlens = [32, 24, 7, 200, 32, 32, 32, 32, 32]          # one query longer than a launch stages; > 8 queries = two passes
+qtok = rng.standard_normal((sum(qlens), dm)).astype(np.float32)
+qoff = np.concatenate([[0], np.cumsum(qlens)]).astype(np.int32)
+mv = pkg.Mi355Index(dm)
+mv.set_option("row_offset", 500)
+mv.add_multivec(tok, off)
+hd, hr = mv.search_maxsim(qtok, qoff, 7)
+qt_d = torch.from_numpy(qtok).cuda()
+dd = torch.empty((len(qlens), 7), dtype=torch.float32, device="cuda")
+dr = torch.empty((len(qlens), 7), dtype=torch.int64, device="cuda")
+mv.search_maxsim_device(qt_d.data_ptr(), qoff, 7, dd.data_ptr(), dr.data_ptr(), torch.cuda.current_stream().cuda_stream)
+assert np.array_equal(dr.cpu().numpy(), hr) and np.array_equal(dd.cpu().numpy().view(np.uint32), hd.view(np.uint32))
+mv.close()
+sm = ShardedSearcher(dm, "cosine", device=0)
+sm.force_pipeline = True
+sm.add_local_multivec(tok, off, 500)
+sd, sr = sm.search_maxsim(qtok, qoff, 7)
+assert np.array_equal(sr, hr) and np.array_equal(sd.view(np.uint32), hd.view(np.uint32))
+sm.close()
 dist.destroy_process_group()
 print("SHARDED_OK")
 """
