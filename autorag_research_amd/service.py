@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import asyncio
 import logging
+import os
 from collections.abc import Awaitable, Callable
 from typing import Any, Literal
 
@@ -30,6 +31,37 @@ logger = logging.getLogger("AutoRAG-Research")
 RetrievalFunc = Callable[[int | str, int], Awaitable[list[dict[str, Any]]]]
 
 
+class _World:
+    """The process group a pipeline runs in when it is launched one process per GPU (`torchrun --nproc-per-node N`, or any
+    launcher that initialises torch.distributed before the Executor constructs its pipelines): every rank constructs the same
+    pipeline over the same database; the corpus is ROW-SHARDED over the ranks (multi-vector tables by cumulative token
+    count), every page of `run()` is answered by all ranks together -- local top-k, one all-gather over RCCL / xGMI, merge --
+    and rank 0 alone reads the page's query ids and writes the results (reference caller: executor.py:383-463 ->
+    pipelines/retrieval/base.py:156-199 -> retrieval_pipeline.py:184-307)."""
+
+    def __init__(self, dist: Any):
+        self.dist = dist
+        self.rank, self.size = dist.get_rank(), dist.get_world_size()
+
+    @classmethod
+    def detect(cls) -> "_World | None":
+        if os.environ.get("MI355DR_DISTRIBUTED", "1") == "0":
+            return None
+        try:
+            import torch.distributed as dist  # noqa: PLC0415
+        except ImportError:  # pragma: no cover
+            return None
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() < 2:
+            return None
+        return cls(dist)
+
+    def from_root(self, make: Callable[[], Any]) -> Any:
+        """`make()` on rank 0, its (picklable) value on every rank."""
+        box = [make() if self.rank == 0 else None]
+        self.dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+
 class _UnitIndex:
     """GPU index of one table (chunk / image_chunk): row <-> primary-key mapping + the native handle."""
 
@@ -40,6 +72,40 @@ class _UnitIndex:
         self.single_rows: np.ndarray | None = None  # index row -> table position (NULL embeddings skipped)
         self.multi_rows: np.ndarray | None = None
         self.device = device
+        self.single_sharded: Any | None = None      # ShardedSearcher over this rank's rows (a _World is active)
+        self.multi_sharded: Any | None = None
+
+    def ensure_single_sharded(self, world: "_World") -> Any:
+        """This rank's contiguous share of the NOT NULL rows behind a ShardedSearcher (global row ids = positions in the
+        table's not-null order, the same ids the unsharded index uses)."""
+        if self.single_sharded is None:
+            from .sharded import ShardedSearcher, shard_bounds  # noqa: PLC0415
+
+            emb = self.table.embedding
+            if emb is None:
+                raise ValueError("table has no single-vector embeddings")
+            not_null = ~np.isnan(emb).all(axis=1)
+            self.single_rows = np.nonzero(not_null)[0]
+            lo, hi = shard_bounds(int(self.single_rows.shape[0]), world.size, world.rank)
+            s = ShardedSearcher(emb.shape[1], "cosine", self.device, index_factory=Mi355Index)
+            s.add_local(emb[self.single_rows[lo:hi]], lo)
+            self.single_sharded = s
+        return self.single_sharded
+
+    def ensure_multi_sharded(self, world: "_World") -> Any:
+        """Multi-vector table: docs cut by cumulative TOKEN count (the MaxSim pass streams token rows: SURVEY 8(e))."""
+        if self.multi_sharded is None:
+            from .sharded import ShardedSearcher, shard_bounds_by_tokens  # noqa: PLC0415
+
+            tok, off = self.table.mv_tokens, self.table.mv_offsets
+            if tok is None or off is None:
+                raise ValueError("table has no multi-vector embeddings")
+            lo, hi = shard_bounds_by_tokens(off, world.size, world.rank)
+            s = ShardedSearcher(tok.shape[1], "cosine", self.device, index_factory=Mi355Index)
+            s.add_local_multivec(tok[off[lo]:off[hi]], off[lo:hi + 1] - off[lo], lo)
+            self.multi_sharded = s
+            self.multi_rows = np.arange(off.shape[0] - 1)
+        return self.multi_sharded
 
     def ensure_single(self) -> Mi355Index:
         if self.single is None:
@@ -63,10 +129,10 @@ class _UnitIndex:
         return self.multi
 
     def close(self) -> None:
-        for ix in (self.single, self.multi):
+        for ix in (self.single, self.multi, self.single_sharded, self.multi_sharded):
             if ix is not None:
                 ix.close()
-        self.single = self.multi = None
+        self.single = self.multi = self.single_sharded = self.multi_sharded = None
 
 
 def _is_store(obj: Any) -> bool:
@@ -86,6 +152,10 @@ class Mi355RetrievalService:
     def __init__(self, session_factory: Callable[[], Any], schema: Any | None = None, device: int = 0):
         self.session_factory = session_factory
         self._schema = schema
+        # one process per GPU under torch.distributed: this rank's GPU, row-sharded units, rank 0 reads ids / writes results
+        self._world = _World.detect()
+        if self._world is not None and "LOCAL_RANK" in os.environ:
+            device = int(os.environ["LOCAL_RANK"])
         self._device = device
         self._units: dict[str, _UnitIndex] = {}
         self._uow_store: UowStore | None = None
@@ -108,6 +178,8 @@ class Mi355RetrievalService:
 
     def delete_pipeline_results(self, pipeline_id) -> int:
         """Reference RetrievalPipelineService.delete_pipeline_results (:359-372): the Executor's health-check cleanup."""
+        if self._world is not None:
+            return self._world.from_root(lambda: self._store().delete_pipeline_results(pipeline_id))
         return self._store().delete_pipeline_results(pipeline_id)
 
     def _unit(self, unit: str) -> _UnitIndex:
@@ -125,6 +197,8 @@ class Mi355RetrievalService:
             self._scratch = None
 
     def get_or_create_pipeline(self, name: str, config: dict[str, Any]) -> tuple[int, bool]:
+        if self._world is not None:  # one row in the pipeline table, created by rank 0
+            return tuple(self._world.from_root(lambda: tuple(self._store().get_or_create_pipeline(name, config))))
         return self._store().get_or_create_pipeline(name, config)
 
     def find_query_by_text(self, query_text: str):
@@ -177,8 +251,10 @@ class Mi355RetrievalService:
 
     def _single_block(self, Q: np.ndarray, top_k: int, unit: str) -> list[list[dict]]:
         u = self._unit(unit)
-        ix = u.ensure_single()
-        dist, rows = ix.search(Q, top_k)
+        if self._world is not None:  # every rank: local top-k of its rows, all-gather, merge -> the same global lists
+            dist, rows = u.ensure_single_sharded(self._world).search(Q, top_k)
+        else:
+            dist, rows = u.ensure_single().search(Q, top_k)
         # reference: score = 1 - distance (retrieval_pipeline.py:522-524) in Python float arithmetic = IEEE double
         return self._results_from_block(u.table, u.single_rows, rows, 1.0 - dist, unit == "chunk")
 
@@ -189,8 +265,9 @@ class Mi355RetrievalService:
 
     def maxsim_search_by_embeddings(self, query_vectors: list, top_k: int, unit: str = "chunk") -> list[list[dict]]:
         u = self._unit(unit)
-        ix = u.ensure_multi()
-        mats = [np.asarray(qv, dtype=np.float32).reshape(-1, ix.dim) for qv in query_vectors]
+        ix = u.ensure_multi_sharded(self._world) if self._world is not None else u.ensure_multi()
+        dim = u.table.mv_tokens.shape[1]
+        mats = [np.asarray(qv, dtype=np.float32).reshape(-1, dim) for qv in query_vectors]
         lens = [m.shape[0] for m in mats]
         live = [i for i, n in enumerate(lens) if n > 0]
         out: list[list[dict]] = [[] for _ in mats]  # reference: `if not query_vectors: return []`
@@ -309,7 +386,8 @@ class Mi355RetrievalService:
         """
         store = self._store()
         result_id_key = "image_chunk_id" if unit == "image_chunk" else "chunk_id"
-        configured = store.pipeline_config(pipeline_id).get("retrieval_unit", "chunk")
+        read_unit = lambda: store.pipeline_config(pipeline_id).get("retrieval_unit", "chunk")  # noqa: E731
+        configured = self._world.from_root(read_unit) if self._world is not None else read_unit()
         if configured == "mixed":
             raise ValueError(f"Pipeline {pipeline_id!r} is configured for mixed results, which cannot be persisted directly.")
         if configured != unit:
@@ -339,18 +417,29 @@ class Mi355RetrievalService:
 
             return list(await asyncio.gather(*[guarded(q) for q in qids]))
 
+        world = self._world
+        writer = world is None or world.rank == 0  # one process per GPU: rank 0 reads the page's ids and persists
+        if world is not None:
+            max_concurrency = 1  # the per-query fallback is a sequence of collective searches: the same order on every rank
+
+        def next_page(eff: int, offset: int):
+            """(number of queries on the page, ids still to answer) -- (0, []) at the end."""
+            queries = store.get_all_queries(limit=eff, offset=offset)
+            if not queries:
+                return 0, []
+            ids = [q.id for q in queries]
+            done = store.completed_query_ids(unit, pipeline_id, ids)
+            return len(queries), [q for q in ids if q not in done]
+
         total_queries = total_results = offset = 0
         failed: list = []
         while True:
             if query_limit is not None and total_queries >= query_limit:
                 break
             eff = min(batch_size, query_limit - total_queries) if query_limit is not None else batch_size
-            queries = store.get_all_queries(limit=eff, offset=offset)
-            if not queries:
+            n_page, qids = world.from_root(lambda: next_page(eff, offset)) if world is not None else next_page(eff, offset)
+            if n_page == 0:
                 break
-            qids = [q.id for q in queries]
-            done = store.completed_query_ids(unit, pipeline_id, qids)
-            qids = [q for q in qids if q not in done]
             if not qids:
                 offset += batch_size
                 continue
@@ -368,7 +457,10 @@ class Mi355RetrievalService:
             else:
                 results = asyncio.run(page(qids))
             insert_page = getattr(store, "insert_page", None)
-            if callable(insert_page):
+            if not writer:  # (the same lists on every rank: count what rank 0 stores)
+                failed.extend(q for q, r in zip(qids, results, strict=True) if r is None)
+                total_results += sum(len(r) for r in results if r is not None)
+            elif callable(insert_page):
                 # a store that takes a page as it is (ranked lists per query): skips flattening it into one dict per
                 # result row only to regroup them by query again
                 failed.extend(q for q, r in zip(qids, results, strict=True) if r is None)
@@ -379,7 +471,7 @@ class Mi355RetrievalService:
                     store.bulk_insert(unit, rows)
                     total_results += len(rows)
             total_queries += len([r for r in results if r is not None])
-            offset += len(queries)
+            offset += n_page
             logger.info(f"Processed {total_queries} queries, stored {total_results} results")
         if failed:
             logger.warning(f"Failed to process {len(failed)} queries after retries: {failed}")

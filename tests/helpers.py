@@ -44,6 +44,9 @@ class OracleIndex:
         self._tok = np.ascontiguousarray(vecs, dtype=np.float32)
         self._off = np.ascontiguousarray(offsets, dtype=np.int64)
 
+    def n_docs(self):
+        return 0 if self._off is None else self._off.shape[0] - 1
+
     def search_maxsim(self, qtok, q_offsets, k):
         d, r = self._o.maxsim_topk(self._tok, self._off, qtok, q_offsets, k)
         return d, np.where(r >= 0, r + self.row_offset, r)
