@@ -119,6 +119,9 @@ struct mi355dr_index {
     int64_t s_big_launches = 0, s_big_ns = 0, s_big_rows = 0;  // the k_screen256 share of the three above
     int64_t s_retry_queries = 0;  // queries whose candidate list overflowed and that were re-screened with the bf16 bound
     int64_t s_ms_screened = 0, s_ms_candidates = 0, s_ms_fallbacks = 0;  // MaxSim: queries screened, docs re-scored, full re-runs
+    // option "profile": HIP-event time of the MaxSim screen launches (k_maxsim16*) and of the exact launches on candidate lists
+    int64_t s_ms_screen_ns = 0, s_ms_screen_launches = 0, s_ms_exact_ns = 0, s_ms_exact_launches = 0;
+    hipEvent_t ms_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<mi355::EventPair> ev_pool, ev_pending;
     hipEvent_t t0 = nullptr, t1 = nullptr;
 

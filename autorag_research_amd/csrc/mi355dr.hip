@@ -799,6 +799,8 @@ void mi355dr_destroy(mi355dr_index* idx) {
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
     }
+    for (hipEvent_t e : idx->ms_ev)
+        if (e) (void)hipEventDestroy(e);
     if (idx->t0) (void)hipEventDestroy(idx->t0);
     if (idx->t1) (void)hipEventDestroy(idx->t1);
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
@@ -1096,6 +1098,10 @@ int mi355dr_get_stat(mi355dr_index* idx, const char* key, int64_t* out) {
     else if (k == "maxsim_screened") *out = idx->s_ms_screened;
     else if (k == "maxsim_candidates") *out = idx->s_ms_candidates;
     else if (k == "maxsim_fallbacks") *out = idx->s_ms_fallbacks;
+    else if (k == "maxsim_screen_ns") *out = idx->s_ms_screen_ns;
+    else if (k == "maxsim_screen_launches") *out = idx->s_ms_screen_launches;
+    else if (k == "maxsim_exact_ns") *out = idx->s_ms_exact_ns;
+    else if (k == "maxsim_exact_launches") *out = idx->s_ms_exact_launches;
     else if (k == "irregular_rows") *out = idx->irr_n;
     else if (k == "loose_rows") *out = idx->irr8_n;
     else if (k == "screen_dtype_active") *out = use_i8(idx) ? MI355DR_SCREEN_I8 : MI355DR_SCREEN_BF16;
@@ -1112,6 +1118,7 @@ int mi355dr_reset_stats(mi355dr_index* idx) {
     idx->s_screen_launches = idx->s_screen_ns = idx->s_screen_rows = idx->s_fallback_queries = idx->s_chunks =
         idx->s_passes = idx->s_big_launches = idx->s_big_ns = idx->s_big_rows = idx->s_starters = 0;
     idx->s_ms_screened = idx->s_ms_candidates = idx->s_ms_fallbacks = idx->s_retry_queries = 0;
+    idx->s_ms_screen_ns = idx->s_ms_screen_launches = idx->s_ms_exact_ns = idx->s_ms_exact_launches = 0;
     if (idx->stat_dev) {
         HIPCHECK(idx, hipSetDevice(idx->device));
         HIPCHECK(idx, hipMemset(idx->stat_dev, 0, 2 * kQBlockMax * sizeof(unsigned long long)));

@@ -1149,6 +1149,7 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
         return g;
     };
     int b = 0;
+    bool ms_screen_timed = false;  // option "profile": a screen launch is bracketed by ms_ev[0..1] and not read yet
     int pre_first = -1;  // first query of the group whose screen distances already sit in rows 4..7 of dist16
     while (b < B) {
         HIPCHECK(idx, hipStreamSynchronize(s));  // the staging buffers are free again
@@ -1250,6 +1251,11 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
             }
             HIPCHECK(idx, hipMemcpyAsync(m->qfrag, qf16.data(), (size_t)std::max(ncb_launch, 4) * nkk * 64 * 8 * sizeof(uint16_t),
                                          hipMemcpyHostToDevice, s));
+            if (idx->profile) {
+                for (auto& e : idx->ms_ev)
+                    if (!e) HIPCHECK(idx, hipEventCreate(&e));
+                HIPCHECK(idx, hipEventRecord(idx->ms_ev[0], s));
+            }
             if (nkk == 8) {  // dims <= 128: the compile-time-unrolled form, only as many column blocks as the pass has
                 const size_t l16 = (size_t)ncb_launch * 8 * 64 * sizeof(uint4);
                 switch (ncb_launch) {
@@ -1266,6 +1272,10 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
                 hipLaunchKernelGGL(k_maxsim16, dim3(grid_all), dim3(kMsThreads), lds16, s, sa);
             }
             HIPCHECK(idx, hipGetLastError());
+            if (idx->profile) {
+                HIPCHECK(idx, hipEventRecord(idx->ms_ev[1], s));
+                ms_screen_timed = true;
+            }
         } else {
             pre_first = -1;
             hipLaunchKernelGGL(k_maxsim, dim3(grid_all), dim3(kMsThreads), lds, s, a);
@@ -1306,9 +1316,11 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
             c.n_items = n_cand_max;
             c.n_items_dev = m->cand_ctl;
             c.list_stride = kMsCandCap;
+            if (idx->profile) HIPCHECK(idx, hipEventRecord(idx->ms_ev[2], s));
             hipLaunchKernelGGL(k_maxsim, dim3((unsigned)std::min<int64_t>((n_cand_max + 3) / 4, kMsListGrid), nql),
                                dim3(kMsThreads), lds, s, c);
             HIPCHECK(idx, hipGetLastError());
+            if (idx->profile) HIPCHECK(idx, hipEventRecord(idx->ms_ev[3], s));
             hipLaunchKernelGGL(k_ms_final, dim3(1, nql), dim3(256), (size_t)kMsCandCap * 12, s, m->cand_dist, m->cand_list,
                                m->cand_ctl, kMsCandCap, k, idx->row_offset, m->out_d, m->out_r);
             HIPCHECK(idx, hipGetLastError());
@@ -1316,6 +1328,18 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
             HIPCHECK(idx, hipMemcpyAsync(hr, m->out_r, (size_t)nql * k * sizeof(int64_t), hipMemcpyDeviceToHost, s));
             HIPCHECK(idx, hipMemcpyAsync(m->cand_ctl_host, m->cand_ctl, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
             HIPCHECK(idx, hipStreamSynchronize(s));
+            if (idx->profile) {
+                float ms = 0.f;
+                if (ms_screen_timed && hipEventElapsedTime(&ms, idx->ms_ev[0], idx->ms_ev[1]) == hipSuccess) {
+                    idx->s_ms_screen_ns += (int64_t)(ms * 1e6);
+                    idx->s_ms_screen_launches++;
+                }
+                ms_screen_timed = false;
+                if (hipEventElapsedTime(&ms, idx->ms_ev[2], idx->ms_ev[3]) == hipSuccess) {
+                    idx->s_ms_exact_ns += (int64_t)(ms * 1e6);
+                    idx->s_ms_exact_launches++;
+                }
+            }
             for (int qi = 0; qi < nql; ++qi) {
                 if (a.q_len[qi] == 0) {
                     handled[qi] = true;

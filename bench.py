@@ -226,26 +226,50 @@ def run_maxsim(args, n_docs: int, tokens: str, nq: int, steps: int, warmup: int,
 
     for i in range(warmup):
         step(i)
+    idx.reset_stats()
+    idx.set_option("profile", 1)   # HIP events around the screen launch (k_maxsim16*) and the exact launch on the candidates
     t0 = time.perf_counter()
     for i in range(steps):
         res = step(warmup + i)
     el = time.perf_counter() - t0
+    idx.set_option("profile", 0)
     assert (np.diff(res[0], axis=1) >= 0).all()
     blocks = int(((lens + 31) // 32).sum())
-    alg_bytes = float(lens.sum()) * d * 4 * steps                # fp32 token rows read once per 8-query pass
-    streamed = float(blocks) * 32 * d * 2 * steps                # bf16 fragment store the screen streams
-    flops = 2.0 * (qblock * nq) * blocks * 32 * d * steps        # what the screen issues (32-row padded docs)
+    alg_bytes = float(lens.sum()) * d * 4                        # fp32 token rows read once per 8-query pass
+    streamed = float(blocks) * 32 * d * 2                        # bf16 fragment store the screen streams, per pass
+    flops = 2.0 * (qblock * nq) * blocks * 32 * d                # what the screen issues per pass (32-row padded docs)
     screened, cands, fb = idx.stat("maxsim_screened"), idx.stat("maxsim_candidates"), idx.stat("maxsim_fallbacks")
+    scr_n, scr_ns = idx.stat("maxsim_screen_launches"), idx.stat("maxsim_screen_ns")
+    ex_n, ex_ns = idx.stat("maxsim_exact_launches"), idx.stat("maxsim_exact_ns")
+    scr_s = scr_ns * 1e-9 / max(scr_n, 1)                        # average duration of one screen launch (= one pass)
+    # HBM traffic of the screen kernel from the committed PMC pass of this shape (tools/r3_maxsim_pmc.sh): bytes per streamed byte
+    traffic, traffic_src = None, None
+    tfile = ROOT / "profiles" / f"r03_maxsim_traffic_{tokens}.json"
+    if tfile.exists():
+        tj = json.loads(tfile.read_text())
+        traffic = round(tj["hbm_read_bytes_per_streamed_byte"] * streamed)
+        traffic_src = (f"REPLAYED, not measured in this run: {tj['hbm_read_bytes_per_streamed_byte']:.3f} HBM bytes per byte of bf16 "
+                       f"fragment store from profiles/{tfile.name} (rocprofv3 --pmc FETCH_SIZE pass, gfx950-corrected) x this store")
     out = {
         "workload": f"MaxSim top-{k}: {n_docs} docs, {int(lens.sum())} doc vectors ({'U{32..180}' if tokens == 'text' else '1030'}"
-                    f"/doc), d=128, {qblock} queries x {nq} vectors per step; store built on the device in {t_build:.2f} s",
+                    f"/doc), d=128, {qblock} queries x {nq} vectors per step, {steps * qblock} queries timed; store built on the "
+                    f"device in {t_build:.2f} s",
         "queries_per_s": round(steps * qblock / el, 2), "ms_per_step": round(el * 1e3 / steps, 3), "steps": steps,
         "includes": "H2D of the query block, D2H of results",
-        "roofline": {"bound": "hbm", "kernel": "k_maxsim16", "achieved": round(alg_bytes / el / 1e9, 1), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(alg_bytes / el / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                     "note": "algorithmic fp32 token bytes over WALL-CLOCK per step (screen + select + exact re-score of the "
-                             "candidates + copies); the screen streams the bf16 copy",
-                     "streamed_GBps": round(streamed / el / 1e9, 1), "screen_tflops": round(flops / el / 1e12, 2)},
+        "roofline": {"bound": "hbm", "kernel": "k_maxsim16_d128<8>", "achieved": round(alg_bytes / scr_s / 1e9, 1) if scr_n else None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(alg_bytes / scr_s / 1e9 / HBM_PEAK_GBS, 4) if scr_n else None,
+                     "traffic": traffic, "traffic_unit": f"HBM read bytes per launch, vs algorithmic {round(alg_bytes)} (fp32 token rows) "
+                                                         f"and {round(streamed)} streamed (bf16 copy)", "traffic_source": traffic_src,
+                     "launches": scr_n, "avg_launch_ms": round(scr_s * 1e3, 4),
+                     "note": "algorithmic fp32 token bytes per pass over the screen kernel's average launch (HIP events on the "
+                             "launch stream, library option `profile`); one launch screens the 8 queries of a step",
+                     "streamed_GBps": round(streamed / scr_s / 1e9, 1) if scr_n else None,
+                     "screen_tflops": round(flops / scr_s / 1e12, 2) if scr_n else None,
+                     "exact_rescore_ms_per_step": round(ex_ns * 1e-6 / max(steps, 1), 4), "exact_launches": ex_n,
+                     "wall_clock_view": {"algorithmic_GBps": round(alg_bytes * steps / el / 1e9, 1),
+                                         "streamed_GBps": round(streamed * steps / el / 1e9, 1),
+                                         "frac": round(alg_bytes * steps / el / 1e9 / HBM_PEAK_GBS, 4)}},
         "queries_screened": screened, "candidates_per_query": round(cands / max(screened, 1), 1),
         "exact_full_scan_fallbacks": fb,
     }
@@ -861,9 +885,11 @@ def main() -> None:
 
     if rank == 0 and world == 1 and not args.no_extras and args.data == "gaussian":
         # (3) the multi-vector half of the path (configs C4 / C5) at SURVEY 8(d) sizes, as secondary figures of the same run
+        # SURVEY 8(d) sizes: 1 M text docs (~106 M vectors: 54 GB fp32 + 27 GB bf16 copy) and 100 k pages (103 M vectors),
+        # 1000 queries each (125 steps of 8)
         result["maxsim"] = {
-            "colbert_like": run_maxsim(args, 100_000, "text", 32, 25, 3, 0 if args.no_cpu_baseline else 1500),
-            "colpali_like": run_maxsim(args, 20_000, "page", 24, 15, 3, 0),
+            "colbert_like": run_maxsim(args, 1_000_000, "text", 32, 125, 3, 0 if args.no_cpu_baseline else 1500),
+            "colpali_like": run_maxsim(args, 100_000, "page", 24, 125, 3, 0),
         }
 
     # ---- CPU baseline (rank 0, N=1 run only): the oracle on a bounded sample of the same workload
