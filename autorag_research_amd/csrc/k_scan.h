@@ -28,10 +28,12 @@ struct ScanArgs {
     int64_t row0, row1;   // chunk
 };
 
-// per wave: a 64-row x 64-column piece of the corpus rows and the matching 32-query x 64-column piece of the queries
+// per wave: a 64-row x 64-column piece of the corpus rows; per WORKGROUP: the matching 32-query x 64-column piece of the
+// queries (round 3: one copy for the four waves instead of one each -- 77 KiB instead of 103 per workgroup, so TWO workgroups
+// fit a CU and every SIMD holds two waves: one walks its LDS hand-off while the other one's MFMAs run)
 constexpr int kScanQTileFloats = 32 * kStageLd;
 __host__ __device__ inline size_t scan_lds_bytes(int /*d*/, int /*nq*/) {
-    return (size_t)4 * (kStageFloats + kScanQTileFloats) * sizeof(float);
+    return (size_t)(4 * kStageFloats + kScanQTileFloats) * sizeof(float);
 }
 
 typedef float scan_f32x16 __attribute__((ext_vector_type(16)));
@@ -44,16 +46,18 @@ typedef float scan_f32x16 __attribute__((ext_vector_type(16)));
 // feeds k+h, then k+2+h.  Zero padding (columns >= d, idle rows, queries >= nq) adds fma(0, 0, acc) = acc: exact.
 // At 32 queries per pass the MFMA time of a piece equals its HBM time (16 B/clk/CU): the first form of this kernel (one
 // VALU chain per lane, 8 queries, operands fetched one scalar LDS read per fma, no prefetch) ran at ~1 TB/s.
-__global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
+__global__ __launch_bounds__(kScanThreads, 2) void k_scan(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* tile = (float*)smem + wave * (kStageFloats + kScanQTileFloats);
-    float* qtile = tile + kStageFloats;
+    float* tile = (float*)smem + wave * kStageFloats;
+    float* qtile = (float*)smem + 4 * kStageFloats;  // shared by the four waves
     const int64_t wrow0 = a.row0 + (int64_t)blockIdx.x * kScanThreads + wave * kWave;
-    if (wrow0 >= a.row1) return;  // wave-uniform (no block-level barrier below)
+    // (a wave past the end of the chunk keeps walking with idle slots: the query piece is handed over at block barriers)
     const int64_t myrow = wrow0 + lane;
     const float* rp = myrow < a.row1 ? a.rows + myrow * (int64_t)a.d : nullptr;
     const int lq = lane & 31;
+    // the query piece of a K step is loaded ONCE per workgroup: wave w brings rows 8w .. 8w+7 of the 32 (its lanes' slots
+    // 8w + (lane >> 4) ... are the StageRows groups g = 2w, 2w + 1)
     const float* qp = (lane < 32 && lq < a.nq) ? a.q + (int64_t)a.qlist[lq] * a.d : nullptr;  // lanes 32..63: idle slots
     const int d = a.d;
     const bool vec = (d & 3) == 0;
@@ -64,8 +68,13 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[rb][r] = 0.0f;
 
+    // this wave's quarter of the query piece: groups g = 2 wave, 2 wave + 1 (query rows 8 wave .. 8 wave + 7)
+    struct QPiece {
+        float4 v[2];
+    };
     StageRows sr, sq;
-    StagePiece p0, p1, q0, q1;
+    StagePiece p0, p1;
+    QPiece q0, q1;
     // idle slots read a live lane's row (their products are never looked at): pieces inside the rows need no per-load
     // predicate (dev_common.h, stage_rows_init_dense)
     bool dense = false;
@@ -73,15 +82,23 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
         if (dense && k0 + kStageCols <= d) stage_issue_dense(p, r, k0, lane);  // wave-uniform
         else stage_issue(p, r, k0, d, lane);
     };
+    auto issue_q = [&](QPiece& p, const StageRows& r, int k0) __attribute__((always_inline)) {
+        const int c4 = (lane & 15) * 4;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float* src = wave == 0 ? r.r[u] : wave == 1 ? r.r[2 + u] : wave == 2 ? r.r[4 + u] : r.r[6 + u];
+            p.v[u] = (src != nullptr && k0 + c4 < d) ? load_gmem_f4(src + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
     if (vec) {
         const bool dr = stage_rows_init_dense(sr, rp, lane);
         const bool dq = stage_rows_init_dense(sq, qp, lane);
         dense = dr && dq;
         issue(p0, sr, 0);
-        issue(q0, sq, 0);
+        issue_q(q0, sq, 0);
         if (kStageCols < d) {
             issue(p1, sr, kStageCols);
-            issue(q1, sq, kStageCols);
+            issue_q(q1, sq, kStageCols);
         }
     }
     const int h = lane >> 5;
@@ -102,28 +119,30 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
     };
     // the query tile holds 32 rows: the committing helper writes rows 4g + (lane>>4), g = 0..15 -> rows 32..63 of a
     // 64-row image; qtile only has 32, so the query piece is committed by hand (g = 0..7)
-    auto commit_q = [&](const StagePiece& p) {
+    auto commit_q = [&](const QPiece& p) {  // rows 4 g + (lane >> 4), g = 2 wave + u
         const int sub = lane >> 4, c4 = (lane & 15) * 4;
 #pragma unroll
-        for (int g = 0; g < 8; ++g) *(float4*)(qtile + (g * 4 + sub) * kStageLd + c4) = p.v[g];
+        for (int u = 0; u < 2; ++u) *(float4*)(qtile + ((2 * wave + u) * 4 + sub) * kStageLd + c4) = p.v[u];
     };
     if (vec) {
         for (int k0 = 0; k0 < d; k0 += 2 * kStageCols) {
-            stage_commit(tile, p0, lane);  // (wave_sync before and after)
+            stage_commit(tile, p0, lane);  // (wave_sync before and after: this wave's rows)
+            __syncthreads();               // every wave is done reading the previous query piece
             commit_q(q0);
-            wave_sync();
+            __syncthreads();               // the query piece is complete
             if (k0 + 2 * kStageCols < d) {
                 issue(p0, sr, k0 + 2 * kStageCols);
-                issue(q0, sq, k0 + 2 * kStageCols);
+                issue_q(q0, sq, k0 + 2 * kStageCols);
             }
             mfma_piece();
             if (k0 + kStageCols < d) {
                 stage_commit(tile, p1, lane);
+                __syncthreads();
                 commit_q(q1);
-                wave_sync();
+                __syncthreads();
                 if (k0 + 3 * kStageCols < d) {
                     issue(p1, sr, k0 + 3 * kStageCols);
-                    issue(q1, sq, k0 + 3 * kStageCols);
+                    issue_q(q1, sq, k0 + 3 * kStageCols);
                 }
                 mfma_piece();
             }
@@ -131,19 +150,19 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
     } else {  // rows not 16-B aligned: scalar staging, no prefetch (rare dims)
         for (int k0 = 0; k0 < d; k0 += kStageCols) {
             stage_rows(tile, rp, k0, d, lane);
-            wave_sync();
-            for (int s = 0; s < 32; ++s) {  // query rows, one scalar column per lane
+            __syncthreads();
+            for (int s = wave * 8; s < wave * 8 + 8; ++s) {  // query rows, one scalar column per lane; 8 rows per wave
                 const int qi = s < a.nq ? a.qlist[s] : -1;
                 const int k = k0 + lane;
                 qtile[s * kStageLd + lane] = (qi >= 0 && k < d) ? a.q[(int64_t)qi * d + k] : 0.0f;
             }
-            wave_sync();
+            __syncthreads();
             mfma_piece();
         }
     }
 
     // ---- epilogue.  C/D layout: column (query) = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) within each block of 32
-    if (lq >= a.nq) return;
+    if (lq >= a.nq || wrow0 >= a.row1) return;
     const int q = a.qlist[lq];
     const uint64_t tk = a.st.thr_key[q];
     const int32_t tr = a.st.thr_row[q];

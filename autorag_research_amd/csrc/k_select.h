@@ -132,6 +132,9 @@ __device__ __forceinline__ void prune_body(const PruneArgs& a, char* smem) {
     const int raw_cnt = a.st.cnt[q];
     const int n_best = a.st.best_n[q];
     if (raw_cnt == 0) return;  // nothing new; kept list and thresholds stay as they are
+    // exact keys (scan path) only need the total-order sort: the four-wave form does it ~4x faster than one wave would, and
+    // is launched right behind this one for every listed query
+    if (a.exact && SORT < kPruneBigSort) return;
     auto leave_for_general = [&]() {  // one-wave form: hand the query over
         if (a.one_wave_only) {
             if (tid == 0) {

@@ -538,7 +538,10 @@ int run_scan(mi355dr_index* idx, hipStream_t s, const std::vector<int>& qs, int 
                 }
             }
             done = end;
-            chunk = std::max<int64_t>(chunk, done * idx->chunk_growth);
+            // exact keys: a chunk only appends the rows that enter the running top-k (k ln(ratio) of them on unordered data),
+            // so the ladder can be steep -- 3 launches and prunes for 2 M rows instead of 7 (an adversarial order overflows
+            // the list and takes the buffer-sized re-run above)
+            chunk = std::max<int64_t>(chunk, done * (idx->chunk_growth_set ? idx->chunk_growth : 31));
         }
     }
     idx->s_fallback_queries += nq_all;
