@@ -724,6 +724,15 @@ int mi355dr_add_multivec(mi355dr_index* idx, const float* vecs, const int64_t* o
     }
     MultiVecStore* m = idx->mv;
     if (m->n_docs + n_docs >= ((int64_t)1 << 31)) return fail(idx, MI355DR_E_UNSUPPORTED, "too many docs");
+    // the block-offset table grows while the images are built; a failure below (reservation, copies) takes it back
+    struct Rollback {
+        std::vector<int64_t>& v;
+        size_t n;
+        bool keep = false;
+        ~Rollback() {
+            if (!keep) v.resize(n);
+        }
+    } rollback{m->blk_off_host, m->blk_off_host.size()};
     // padded host image of the new docs: whole 32-row blocks, tail = copies of the last token, dim zero-padded
     int64_t new_blocks = 0;
     for (int64_t i = 0; i < n_docs; ++i) new_blocks += (offsets[i + 1] - offsets[i] + kMsBlkRows - 1) / kMsBlkRows;
@@ -789,6 +798,7 @@ int mi355dr_add_multivec(mi355dr_index* idx, const float* vecs, const int64_t* o
                                 hipMemcpyHostToDevice));
     HIPCHECK(idx, hipMemcpy(m->blk_off, m->blk_off_host.data(), m->blk_off_host.size() * sizeof(int64_t),
                             hipMemcpyHostToDevice));
+    rollback.keep = true;
     m->n_blocks += new_blocks;
     m->n_docs += n_docs;
     return MI355DR_OK;
@@ -874,6 +884,10 @@ int mi355dr_add_multivec_device(mi355dr_index* idx, const float* vecs_dev, const
     if (m->n_docs + n_docs >= ((int64_t)1 << 31)) return fail(idx, MI355DR_E_UNSUPPORTED, "too many docs");
     std::vector<int64_t> tok0(n_docs), T(n_docs), blk0(n_docs);
     std::vector<int32_t> blk_doc;
+    // the new docs' block offsets are built on the side and appended to the store's table only after everything below
+    // succeeded: a failed reservation / copy / kernel leaves the table as it was (n_docs and n_blocks are untouched too)
+    std::vector<int64_t> new_off;
+    new_off.reserve((size_t)n_docs);
     int64_t new_blocks = 0;
     for (int64_t i = 0; i < n_docs; ++i) {
         tok0[i] = offsets[i];
@@ -882,45 +896,57 @@ int mi355dr_add_multivec_device(mi355dr_index* idx, const float* vecs_dev, const
         const int64_t nb = (T[i] + kMsBlkRows - 1) / kMsBlkRows;
         for (int64_t b = 0; b < nb; ++b) blk_doc.push_back((int32_t)i);
         new_blocks += nb;
-        m->blk_off_host.push_back(m->n_blocks + new_blocks);
+        new_off.push_back(m->n_blocks + new_blocks);
     }
     CHECK(ms_reserve(idx, m, m->n_blocks + new_blocks, m->n_docs + n_docs));
+    double v[3] = {0.0, 0.0, 0.0};
+    int nf = 0;
     if (new_blocks > 0) {
-        int64_t *tok0_d = nullptr, *T_d = nullptr, *blk0_d = nullptr;
-        int32_t* blk_doc_d = nullptr;
-        unsigned long long* stats_d = nullptr;
-        int* nf_d = nullptr;
-        HIPCHECK(idx, hipMalloc(&tok0_d, n_docs * sizeof(int64_t)));
-        HIPCHECK(idx, hipMalloc(&T_d, n_docs * sizeof(int64_t)));
-        HIPCHECK(idx, hipMalloc(&blk0_d, n_docs * sizeof(int64_t)));
-        HIPCHECK(idx, hipMalloc(&blk_doc_d, blk_doc.size() * sizeof(int32_t)));
-        HIPCHECK(idx, hipMalloc(&stats_d, 3 * sizeof(unsigned long long)));
-        HIPCHECK(idx, hipMalloc(&nf_d, sizeof(int)));
+        struct Scratch {  // released on every exit
+            int64_t *tok0 = nullptr, *T = nullptr, *blk0 = nullptr;
+            int32_t* blk_doc = nullptr;
+            unsigned long long* stats = nullptr;
+            int* nf = nullptr;
+            ~Scratch() {
+                for (void* p : {(void*)tok0, (void*)T, (void*)blk0, (void*)blk_doc, (void*)stats, (void*)nf})
+                    if (p) (void)hipFree(p);
+            }
+        } sc;
+        HIPCHECK(idx, hipMalloc(&sc.tok0, n_docs * sizeof(int64_t)));
+        HIPCHECK(idx, hipMalloc(&sc.T, n_docs * sizeof(int64_t)));
+        HIPCHECK(idx, hipMalloc(&sc.blk0, n_docs * sizeof(int64_t)));
+        HIPCHECK(idx, hipMalloc(&sc.blk_doc, blk_doc.size() * sizeof(int32_t)));
+        HIPCHECK(idx, hipMalloc(&sc.stats, 3 * sizeof(unsigned long long)));
+        HIPCHECK(idx, hipMalloc(&sc.nf, sizeof(int)));
         hipStream_t s = idx->stream;
-        HIPCHECK(idx, hipMemcpyAsync(tok0_d, tok0.data(), n_docs * sizeof(int64_t), hipMemcpyHostToDevice, s));
-        HIPCHECK(idx, hipMemcpyAsync(T_d, T.data(), n_docs * sizeof(int64_t), hipMemcpyHostToDevice, s));
-        HIPCHECK(idx, hipMemcpyAsync(blk0_d, blk0.data(), n_docs * sizeof(int64_t), hipMemcpyHostToDevice, s));
-        HIPCHECK(idx, hipMemcpyAsync(blk_doc_d, blk_doc.data(), blk_doc.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-        HIPCHECK(idx, hipMemsetAsync(stats_d, 0, 3 * sizeof(unsigned long long), s));
-        HIPCHECK(idx, hipMemsetAsync(nf_d, 0, sizeof(int), s));
-        hipLaunchKernelGGL(k_ms_build, dim3((unsigned)new_blocks), dim3(64), 0, s, vecs_dev, tok0_d, T_d, blk_doc_d, blk0_d, idx->dim,
-                           m->dpad, m->nkk, m->n_blocks, m->tok, (uint16_t*)m->tok16, stats_d, nf_d);
+        HIPCHECK(idx, hipMemcpyAsync(sc.tok0, tok0.data(), n_docs * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        HIPCHECK(idx, hipMemcpyAsync(sc.T, T.data(), n_docs * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        HIPCHECK(idx, hipMemcpyAsync(sc.blk0, blk0.data(), n_docs * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        HIPCHECK(idx, hipMemcpyAsync(sc.blk_doc, blk_doc.data(), blk_doc.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        HIPCHECK(idx, hipMemsetAsync(sc.stats, 0, 3 * sizeof(unsigned long long), s));
+        HIPCHECK(idx, hipMemsetAsync(sc.nf, 0, sizeof(int), s));
+        hipLaunchKernelGGL(k_ms_build, dim3((unsigned)new_blocks), dim3(64), 0, s, vecs_dev, sc.tok0, sc.T, sc.blk_doc, sc.blk0,
+                           idx->dim, m->dpad, m->nkk, m->n_blocks, m->tok, (uint16_t*)m->tok16, sc.stats, sc.nf);
         HIPCHECK(idx, hipGetLastError());
         unsigned long long st[3] = {0, 0, 0};
-        int nf = 0;
-        HIPCHECK(idx, hipMemcpyAsync(st, stats_d, sizeof(st), hipMemcpyDeviceToHost, s));
-        HIPCHECK(idx, hipMemcpyAsync(&nf, nf_d, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHECK(idx, hipMemcpyAsync(st, sc.stats, sizeof(st), hipMemcpyDeviceToHost, s));
+        HIPCHECK(idx, hipMemcpyAsync(&nf, sc.nf, sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHECK(idx, hipStreamSynchronize(s));
-        double v[3];
         memcpy(v, st, sizeof(v));
-        m->tok_norm_max = std::max(m->tok_norm_max, v[0]);
-        m->tok16_norm_max = std::max(m->tok16_norm_max, v[1]);
-        m->tok_res_max = std::max(m->tok_res_max, v[2]);
-        if (nf) m->finite = false;
-        for (void* p : {(void*)tok0_d, (void*)T_d, (void*)blk0_d, (void*)blk_doc_d, (void*)stats_d, (void*)nf_d}) (void)hipFree(p);
     }
-    HIPCHECK(idx, hipMemcpy(m->blk_off, m->blk_off_host.data(), m->blk_off_host.size() * sizeof(int64_t),
-                            hipMemcpyHostToDevice));
+    // the device copy of the table first (the host vector is its source of truth): append, upload, roll back on failure
+    const size_t old_size = m->blk_off_host.size();
+    m->blk_off_host.insert(m->blk_off_host.end(), new_off.begin(), new_off.end());
+    const hipError_t ce = hipMemcpy(m->blk_off, m->blk_off_host.data(), m->blk_off_host.size() * sizeof(int64_t),
+                                    hipMemcpyHostToDevice);
+    if (ce != hipSuccess) {
+        m->blk_off_host.resize(old_size);
+        HIPCHECK(idx, ce);
+    }
+    m->tok_norm_max = std::max(m->tok_norm_max, v[0]);
+    m->tok16_norm_max = std::max(m->tok16_norm_max, v[1]);
+    m->tok_res_max = std::max(m->tok_res_max, v[2]);
+    if (nf) m->finite = false;
     m->n_blocks += new_blocks;
     m->n_docs += n_docs;
     return MI355DR_OK;

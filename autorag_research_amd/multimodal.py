@@ -103,16 +103,23 @@ class Mi355ColPaliEmbeddings(_EngineBacked, MultiVectorMultiModalEmbedding):
     SUPPORTED_MODEL_TYPES = list(COL_MODEL_REGISTRY.keys())
 
     def __init__(self, model_name: str = "vidore/colpali-v1.3", model_type: str = "pali", device: str = "cpu",
-                 torch_dtype: Any = "bfloat16", model: Any | None = None, processor: Any | None = None, batch_size: int = 8):
+                 torch_dtype: Any = "bfloat16", model: Any | None = None, processor: Any | None = None, batch_size: int = 8,
+                 drop_padding: bool = False):
         self._setup(COL_MODEL_REGISTRY, "ColPaliEmbeddings", model_name, model_type, device, torch_dtype, model, processor,
                     batch_size)
+        # The reference keeps EVERY row the model returns for an item of a batch, the padded positions included
+        # (`[emb.cpu().tolist() for emb in embeddings]`, colpali.py:218-245; colpali_engine zeroes them, so a stored doc then
+        # carries zero vectors and every query vector's max over it is at least 0).  False (default) = exactly that;
+        # True = only the attended positions (ragged, fewer rows to stream; scores differ where all real dots are negative).
+        self.drop_padding = drop_padding
 
     # ---- the model's output as ragged device tensors -------------------------------------------------------------
     def _ragged(self, out, inputs):
-        """[n, T, d] (+ optional attention_mask) -> (flat fp32 [sum_T, d], host offsets [n+1]); padding rows dropped."""
+        """[n, T, d] (+ optional attention_mask) -> (flat fp32 [sum_T, d], host offsets [n+1]); with `drop_padding` the rows
+        of masked positions are left out."""
         torch = self._torch
         h = out.float()
-        mask = inputs.get("attention_mask")
+        mask = inputs.get("attention_mask") if getattr(self, "drop_padding", False) else None
         if mask is not None and tuple(mask.shape) == tuple(h.shape[:2]):
             keep = mask.bool()
             lens = keep.sum(dim=1).cpu().numpy().astype(np.int64)
@@ -312,7 +319,11 @@ def make_random_col_model(dim: int = 128, patch: int = 14, image_size: int = 448
                     h = (h * m[..., None].to(h.dtype)).sum(1) / m.sum(1, keepdim=True).clamp(min=1).to(h.dtype)
                 else:
                     h = h.mean(1)
-            return torch.nn.functional.normalize(h.float(), dim=-1)
+                return torch.nn.functional.normalize(h.float(), dim=-1)
+            h = torch.nn.functional.normalize(h.float(), dim=-1)
+            if m is not None:  # colpali_engine's Col* heads zero the padded positions (`proj * attention_mask.unsqueeze(-1)`)
+                h = h * m[..., None].to(h.dtype)
+            return h
 
     return _M()
 

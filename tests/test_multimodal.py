@@ -38,8 +38,14 @@ def test_colpali_interface_and_shapes(col):
     assert np.allclose(asyncio.run(col.aembed_image(imgs[1])), many[1], atol=1e-6)
     q = col.embed_query("what is on the page")
     assert len(q) == 5 and len(q[0]) == 128 and col.embed_text("what is on the page") == q
+    # batches of 2: like the reference (`[emb.cpu().tolist() for emb in embeddings]`, colpali.py:218), every row the model
+    # returns for an item is kept -- the padded positions of the shorter item of a batch as zero vectors
     docs = col.embed_documents(["a b c", "d", ""])
-    assert [len(x) for x in docs] == [3, 1, 1] and col.embed_documents([]) == [] and col.embed_images([]) == []
+    assert [len(x) for x in docs] == [3, 3, 1] and col.embed_documents([]) == [] and col.embed_images([]) == []
+    assert np.allclose(docs[1][1:], 0.0) and abs(np.linalg.norm(docs[1][0]) - 1.0) < 1e-5
+    col.drop_padding = True      # the ragged form: attended positions only
+    assert [len(x) for x in col.embed_documents(["a b c", "d", ""])] == [3, 1, 1]
+    col.drop_padding = False
     assert col.embed_images_batch(imgs) == many or np.allclose(col.embed_images_batch(imgs)[2], many[2], atol=1e-6)
     # PNG bytes and a file path go through load_image like the reference's ImageType
     from PIL import Image
