@@ -571,7 +571,8 @@ __global__ __launch_bounds__(256) void k_merge_topk(const double* __restrict__ d
                                                      int B, int k, double* out_dist, int64_t* out_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint64_t* SK = (uint64_t*)smem;
-    int32_t* SI = (int32_t*)(smem + (size_t)kSortMax * 8);  // index into the gathered lists (row may exceed int32)
+    const int np_ = next_pow2(world * k);
+    int32_t* SI = (int32_t*)(smem + (size_t)np_ * 8);  // index into the gathered lists (row may exceed int32)
     const int q = blockIdx.x;
     const int n = world * k;
     const int np = next_pow2(n);

@@ -99,7 +99,8 @@ int ensure_qstate(mi355dr_index* idx) {
     HIPCHECK(idx, hipMalloc(&idx->st.best_row, B * kKMax * sizeof(int32_t)));
     HIPCHECK(idx, hipMalloc(&idx->st.thr_key, B * sizeof(uint64_t)));
     HIPCHECK(idx, hipMalloc(&idx->st.thr_row, B * sizeof(int32_t)));
-    HIPCHECK(idx, hipMalloc(&idx->st.status, B * sizeof(int)));
+    HIPCHECK(idx, hipMalloc(&idx->st.status, (B + 1) * sizeof(int)));  // [B]: the block's OR-ed status word
+    idx->status_or_dev = idx->st.status + B;
     HIPCHECK(idx, hipMalloc(&idx->st.E, B * sizeof(float)));
     HIPCHECK(idx, hipMalloc(&idx->st.E16, B * sizeof(float)));
     HIPCHECK(idx, hipMalloc(&idx->st.sc, B * sizeof(float)));
@@ -110,7 +111,6 @@ int ensure_qstate(mi355dr_index* idx) {
     HIPCHECK(idx, hipMalloc(&idx->cand_row, B * kCandCap * sizeof(int32_t)));
     HIPCHECK(idx, hipMalloc(&idx->cand_val, B * kCandCap * sizeof(float)));
     HIPCHECK(idx, hipMalloc(&idx->qlist_dev, 2 * B * sizeof(int)));  // second half: overflow re-runs
-    HIPCHECK(idx, hipMalloc(&idx->status_or_dev, sizeof(int)));
     HIPCHECK(idx, hipHostMalloc(&idx->status_host, (B + 1) * sizeof(int)));
     HIPCHECK(idx, hipMalloc(&idx->out_dist_dev, B * kKMax * sizeof(double)));
     HIPCHECK(idx, hipMalloc(&idx->out_rows_dev, B * kKMax * sizeof(int64_t)));
@@ -609,8 +609,8 @@ int enqueue_block(mi355dr_index* idx, hipStream_t s, const float* q_dev, int B, 
     hipLaunchKernelGGL(k_finalize, dim3(B), dim3(64), 0, s, idx->st, k, idx->row_offset, out_dist_dev, out_rows_dev,
                        idx->status_or_dev);
     HIPCHECK(idx, hipGetLastError());
-    HIPCHECK(idx, hipMemcpyAsync(p.status_host, idx->st.status, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHECK(idx, hipMemcpyAsync(p.status_host + kQBlockMax, idx->status_or_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+    // (one copy: the per-query words and, behind them, their OR)
+    HIPCHECK(idx, hipMemcpyAsync(p.status_host, idx->st.status, (size_t)(kQBlockMax + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHECK(idx, hipEventRecord(p.done, s));
     p.active = true;
     p.stream = s;
@@ -712,6 +712,15 @@ int search_block(mi355dr_index* idx, hipStream_t s, const float* q_dev, int B, i
     return complete_block(idx, p);
 }
 
+// k_merge_topk sorts next_pow2(world * k) entries: LDS and threads by need (80 entries at 8 ranks x k = 10 -- a 256-thread
+// workgroup with 48 KiB of LDS per query kept the merge from slipping in beside other work)
+inline size_t merge_lds(int world, int k) {
+    size_t np = 1;
+    while (np < (size_t)world * k) np <<= 1;
+    return np * 12;
+}
+inline int merge_threads(int world, int k) { return (int64_t)world * k <= 128 ? 64 : 256; }
+
 int check_search_args(mi355dr_index* idx, const void* q, int B, int k, const void* od, const void* orow) {
     if (!idx) return fail(nullptr, MI355DR_E_INVALID, "null index");
     if (B < 0 || k <= 0) return fail(idx, MI355DR_E_INVALID, "B must be >= 0 and k > 0");
@@ -788,7 +797,7 @@ void mi355dr_destroy(mi355dr_index* idx) {
                     idx->rows, idx->shadow, idx->nrm2, idx->irr_rows, idx->irr_count, idx->st.qn, idx->st.qhat,
                     idx->st.thr, idx->st.cnt, idx->st.best_n, idx->st.best_key, idx->st.best_row, idx->st.thr_key,
                     idx->st.thr_row, idx->st.status, idx->qdev, idx->cand_row, idx->cand_val, idx->qlist_dev,
-                    idx->status_or_dev, idx->out_dist_dev, idx->out_rows_dev, idx->stat_dev, idx->prune_skip};
+                    idx->out_dist_dev, idx->out_rows_dev, idx->stat_dev, idx->prune_skip};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     multivec_destroy(idx);
@@ -978,7 +987,7 @@ int mi355dr_merge_topk_device(mi355dr_index* idx, const double* dist_all_dev, co
     HIPCHECK(idx, hipSetDevice(idx->device));
     CHECK(ensure_qstate(idx));
     hipStream_t s = stream ? (hipStream_t)stream : idx->stream;
-    hipLaunchKernelGGL(k_merge_topk, dim3(B), dim3(256), (size_t)kSortMax * 12, s, dist_all_dev, rows_all_dev,
+    hipLaunchKernelGGL(k_merge_topk, dim3(B), dim3(merge_threads(world, k)), merge_lds(world, k), s, dist_all_dev, rows_all_dev,
                        (int64_t)B * k, world, B, k, out_dist_dev, out_rows_dev);
     HIPCHECK(idx, hipGetLastError());
     return MI355DR_OK;  // asynchronous on `s`
@@ -1010,7 +1019,7 @@ int mi355dr_merge_topk_packed_device(mi355dr_index* idx, const int64_t* packed_a
     CHECK(ensure_qstate(idx));
     hipStream_t s = stream ? (hipStream_t)stream : idx->stream;
     const int64_t plane = (int64_t)B * k;
-    hipLaunchKernelGGL(k_merge_topk, dim3(B), dim3(256), (size_t)kSortMax * 12, s, (const double*)packed_all_dev,
+    hipLaunchKernelGGL(k_merge_topk, dim3(B), dim3(merge_threads(world, k)), merge_lds(world, k), s, (const double*)packed_all_dev,
                        packed_all_dev + plane, 2 * plane, world, B, k, out_dist_dev, out_rows_dev);
     HIPCHECK(idx, hipGetLastError());
     return MI355DR_OK;  // asynchronous on `s`

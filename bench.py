@@ -717,7 +717,7 @@ def main() -> None:
     # inside the timed region): bytes per screened row x rows per launch.  See tools/collect_traffic.sh.
     traffic = None
     traffic_src = None
-    for tname in (("r02_traffic_i8.json", "r01_traffic_i8.json") if i8 else ("r02_traffic.json", "r01_traffic.json")):
+    for tname in (("r03_traffic_i8.json", "r02_traffic_i8.json", "r01_traffic_i8.json") if i8 else ("r02_traffic.json", "r01_traffic.json")):
         tfile = ROOT / "profiles" / tname
         if tfile.exists() and B > 128 and d == 768 and launches:
             per_row = json.loads(tfile.read_text())["hbm_read_bytes_per_screened_row"]
