@@ -191,7 +191,7 @@ __global__ __launch_bounds__(kMsThreads, 2) void k_maxsim(MsArgs a) {
                 c0 = a.q_col0[i];
                 ln = a.q_len[i];
             }
-        a.qtok += (int64_t)c0 * a.dpad;  // this query's columns become column block 0.. (c0 is a multiple of 32)
+        a.qtok += (int64_t)c0 * a.dpad;  // this query's columns become columns 0.. of the staged image (any c0)
         a.q_col0[0] = 0;
         a.q_len[0] = ln;
         a.nq_launch = 1;
@@ -363,12 +363,12 @@ __global__ __launch_bounds__(kMsThreads, 2) void k_maxsim16(Ms16Args a) {
             }
         }
         for (int qi = 0; qi < a.nq_launch; ++qi) {  // (masked butterfly sum over the query's column blocks: see k_maxsim16_d128)
-            const int cb0 = a.q_col0[qi] >> 5, len = a.q_len[qi];
+            const int c0 = a.q_col0[qi], len = a.q_len[qi];  // (queries are packed column after column: any first column)
             float part = 0.0f;
 #pragma unroll
             for (int cbi = 0; cbi < 4; ++cbi) {
-                const int j = (cbi - cb0) * 32 + (lane & 31);
-                if (cbi >= cb0 && j < len) part += run[cbi];
+                const int j = cbi * 32 + (lane & 31) - c0;  // this lane's column of block cbi as a token index of query qi
+                if (j >= 0 && j < len) part += run[cbi];
             }
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) part += __shfl_xor(part, o, kWave);
@@ -458,17 +458,19 @@ __global__ __launch_bounds__(kMsThreads, 2) void k_maxsim16_d128(Ms16Args a) {
         }
 #pragma unroll
         for (int c = 0; c < NCB; ++c) run[c] = fmaxf(run[c], __shfl_xor(run[c], 32, kWave));
-        // per query: the sum of its columns' maxima.  A query owns whole column blocks (its columns start at a multiple of 32),
-        // so this is a masked sum over the 32 lanes of its blocks: 5 butterfly steps instead of one shuffle per query token
-        // (the serial form -- 128 dependent shuffles per document -- was most of this kernel's time on 3-block documents).
+        // per query: the sum of its columns' maxima -- a masked sum over the lanes of the column blocks its columns fall
+        // into: 5 butterfly steps instead of one shuffle per query token (the serial form -- 128 dependent shuffles per
+        // document -- was most of this kernel's time on 3-block documents).  Round 3: the queries of a pass are packed column
+        // after column (eight 24-vector queries = 6 column blocks, not 8 padded ones: a quarter less MFMA and LDS work per token
+        // block), so a query may start anywhere and span a block boundary.
         // The order of the fp32 additions differs from the exact kernel's; the screen's bound covers any order (e_acc).
         for (int qi = 0; qi < a.nq_launch; ++qi) {
-            const int cb0 = a.q_col0[qi] >> 5, len = a.q_len[qi];
+            const int c0 = a.q_col0[qi], len = a.q_len[qi];
             float part = 0.0f;
 #pragma unroll
             for (int cbi = 0; cbi < NCB; ++cbi) {
-                const int j = (cbi - cb0) * 32 + (lane & 31);  // this lane's column of block cbi as a token index of query qi
-                if (cbi >= cb0 && j < len) part += run[cbi];
+                const int j = cbi * 32 + (lane & 31) - c0;  // this lane's column of block cbi as a token index of query qi
+                if (j >= 0 && j < len) part += run[cbi];
             }
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) part += __shfl_xor(part, o, kWave);
@@ -1037,7 +1039,10 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
     const size_t lds16 = (size_t)4 * nkk * 64 * sizeof(uint4);
     // scratch
     if (!m->qtok) {
-        HIPCHECK(idx, hipMalloc(&m->qtok, (size_t)kMsCols * dp * sizeof(float)));
+        // (+ 32 columns of slack: with tightly packed queries the list form of k_maxsim stages whole 32-column blocks from a
+        // query's FIRST column on, which may run past column 127; those columns' results are never read)
+        HIPCHECK(idx, hipMalloc(&m->qtok, (size_t)(kMsCols + 32) * dp * sizeof(float)));
+        HIPCHECK(idx, hipMemsetAsync(m->qtok, 0, (size_t)(kMsCols + 32) * dp * sizeof(float), s));
         HIPCHECK(idx, hipMalloc(&m->qfrag, 2 * lds16));
         HIPCHECK(idx, hipMalloc(&m->out_d, 4 * kKMax * sizeof(float)));
         HIPCHECK(idx, hipMalloc(&m->out_r, 4 * kKMax * sizeof(int64_t)));
@@ -1130,7 +1135,7 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
         int bb = b0;
         while (bb < B && g.nql < 4) {
             const int nq = q_offsets[bb + 1] - q_offsets[bb];
-            const int need = (int)round_up(std::max(nq, 1), 32);
+            const int need = std::max(nq, 1);  // (columns are packed tightly: no padding of a query to whole 32-column blocks)
             if (g.col + need > cols) break;  // (a query longer than `cols` never fits: the caller scores it in tiles)
             g.q_col0[g.nql] = g.col;
             g.q_len[g.nql] = nq;
@@ -1262,17 +1267,18 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
             // The screen is HBM-bound on the token stream: the NEXT group (<= 4 more queries) rides the same pass in column blocks
             // 4..7 and rows 4..7 of dist16 (dims <= 128, the single-launch selection path); its turn then starts at the selection.
             if (nkk == 8 && k <= kMsFastK && b < B) {
-                const Group H = pack(b, kMsCols, false);
+                const Group H = pack(b, col, false);  // its columns follow this group's directly
                 if (H.nql > 0 && H.finite) {
                     for (int qi = 0; qi < 4; ++qi) {
-                        sa.q_col0[4 + qi] = kMsCols + H.q_col0[qi];
+                        sa.q_col0[4 + qi] = col + H.q_col0[qi];
                         sa.q_len[4 + qi] = H.q_len[qi];
                     }
                     sa.nq_launch = 4 + H.nql;  // (rows nql..3: zero-length queries, their rows are never read)
-                    ncb_launch = 4 + (H.col + 31) / 32;
+                    ncb_launch = (col + H.col + 31) / 32;
                     pre_first = b;
-                } else {  // (the fragments pack() may have written for H are not used: clear them)
-                    std::fill(qf16.begin() + (size_t)4 * nkk * 64 * 8, qf16.end(), (uint16_t)0);
+                } else {  // (the fragments pack() may have written for H are not used: rebuild this group's alone)
+                    std::fill(qf16.begin(), qf16.end(), (uint16_t)0);
+                    (void)pack(first, 0, false);
                 }
             }
             HIPCHECK(idx, hipMemcpyAsync(m->qfrag, qf16.data(), (size_t)std::max(ncb_launch, 4) * nkk * 64 * 8 * sizeof(uint16_t),

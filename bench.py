@@ -265,6 +265,9 @@ def run_maxsim(args, n_docs: int, tokens: str, nq: int, steps: int, warmup: int,
                      "note": "algorithmic fp32 token bytes per pass over the screen kernel's average launch (HIP events on the "
                              "launch stream, library option `profile`); one launch screens the 8 queries of a step",
                      "streamed_GBps": round(streamed / scr_s / 1e9, 1) if scr_n else None,
+                     "streamed_frac": round(streamed / scr_s / 1e9 / HBM_PEAK_GBS, 4) if scr_n else None,
+                     "frac_note": "`frac` is on ALGORITHMIC fp32 token bytes (SURVEY 8d); the kernel streams a bf16 copy, half of "
+                                  "them, so `frac` can exceed 1 -- `streamed_frac` is the HBM-bandwidth fraction the kernel itself reaches",
                      "screen_tflops": round(flops / scr_s / 1e12, 2) if scr_n else None,
                      "exact_rescore_ms_per_step": round(ex_ns * 1e-6 / max(steps, 1), 4), "exact_launches": ex_n,
                      "wall_clock_view": {"algorithmic_GBps": round(alg_bytes * steps / el / 1e9, 1),
