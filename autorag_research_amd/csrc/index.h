@@ -105,6 +105,7 @@ struct mi355dr_index {
     // queries per block exceed the 1024 entries in some chunk, and their re-screen pass costs 0.25 ms per block (0.85 ms with
     // carried survivors in the lists), against 20 us of companion launches
     int prune_companion = 1;
+    int scan_dma = 1;         // exact scan: the LDS-DMA form (k_scan32) when dim % 32 == 0 (option "scan_dma", A/B and tests)
     int defer_round_b = 1;    // k_prune before the pass's last one carries the survivors of its cut over instead of re-scoring them
     int chunk0_set = 0;       // the first chunk's size was set by the caller: emit-all ladder, no starter
     int64_t chunk0_rows = 1024;

@@ -185,6 +185,119 @@ __global__ __launch_bounds__(kScanThreads, 2) void k_scan(ScanArgs a) {
         }
 }
 
+// ---- round 3: the same scan with LDS-DMA staging (dims that are a multiple of 32: every 128-byte piece of a row is whole)
+// What bounded k_scan above: two 64-column pieces of 64 rows live in 128 VGPRs per wave, every piece walks a ds_write phase
+// behind a wave-level hand-off, and at 256 VGPRs the allocator spills.  Here a piece is 32 columns (128 B of every row):
+// a wave's 64 rows x 128 B = 8 KiB arrive by eight global_load_lds_dwordx4 (8 rows x 128 B each, full lines, the screens'
+// lane-linear image with the XOR swizzle on the source chunk), the 32-query piece (4 KiB) by one such instruction per wave;
+// double-buffered in LDS (2 x (4 x 8 + 4) KiB = 72 KiB per workgroup: two workgroups per CU), ONE block barrier per piece.
+// No register pieces, no ds_write, fragments read back as 16-byte chunks (k .. k+3 of a row; the wave half picks k + h, then
+// k + 2 + h).  Same MFMA chain, same epilogue: bit-identical to k_scan.
+typedef __bf16 scan_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float scan_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kScan32PieceCols = 32;
+constexpr int kScan32RowTile = 64 * 128;    // one wave's rows of a piece: 8 KiB
+constexpr int kScan32QTile = 32 * 128;      // the query piece: 4 KiB
+constexpr int kScan32Stage = 4 * kScan32RowTile + kScan32QTile;  // 36 KiB
+constexpr int kScan32Lds = 2 * kScan32Stage;                       // 72 KiB
+
+__device__ __forceinline__ void scan_glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+// 16-byte chunk c of row r of a 128-byte-pitch image lives in slot c ^ ((r >> 1) & 7)
+__device__ __forceinline__ scan_f32x4 scan_frag(const char* tile, int row, int chunk) {
+    // (typed bf16x8 on purpose: with a plain float4 / uint4 type the waitcnt insertion assumes the read may alias the LDS-DMA in
+    // flight and puts s_waitcnt vmcnt(0) in front of it -- see the NOTE in k_screen.h)
+    return __builtin_bit_cast(scan_f32x4, *(const scan_bf16x8*)(tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)));
+}
+
+__global__ __launch_bounds__(kScanThreads, 2) void k_scan32(ScanArgs a, int64_t n_rows_valid) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t wrow0 = a.row0 + (int64_t)blockIdx.x * kScanThreads + wave * kWave;
+    const int d = a.d, npieces = d / kScan32PieceCols;
+    const int64_t row_bytes = (int64_t)d * 4;
+    // ---- DMA sources.  Rows: instruction g (0..7) brings local rows 8 g + (lane >> 3), lane & 7 = the LDS slot, whose source
+    // chunk is slot ^ ((row >> 1) & 7).  Rows past the end of the index read its last row (their results are never looked at).
+    const char* srcA[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const int r = 8 * g + (lane >> 3);
+        const int64_t row = min(wrow0 + r, n_rows_valid - 1);
+        srcA[g] = (const char*)a.rows + row * row_bytes + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+    }
+    // Queries: wave w brings query slots 8 w + (lane >> 3); slots >= nq read query slot 0 (their columns are never looked at)
+    const char* srcQ;
+    {
+        const int r = 8 * wave + (lane >> 3);
+        const int qi = a.qlist[r < a.nq ? r : 0];
+        srcQ = (const char*)a.q + (int64_t)qi * row_bytes + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+    }
+    auto stage = [&](int piece, int buf) __attribute__((always_inline)) {
+        char* base = smem + buf * kScan32Stage;
+        const int64_t koff = (int64_t)piece * 128;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) scan_glds16(srcA[g] + koff, base + wave * kScan32RowTile + g * 1024);
+        scan_glds16(srcQ + koff, base + 4 * kScan32RowTile + wave * 1024);
+    };
+    scan_f32x16 acc[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rb][r] = 0.0f;
+    const int h = lane >> 5, lq = lane & 31;
+    stage(0, 0);
+    for (int p = 0; p < npieces; ++p) {
+        const int buf = p & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's parts of piece p have landed
+        __syncthreads();                                   // ... everybody's; and everybody is done reading the other buffer
+        if (p + 1 < npieces) stage(p + 1, buf ^ 1);
+        const char* ta = smem + buf * kScan32Stage + wave * kScan32RowTile;
+        const char* tq = smem + buf * kScan32Stage + 4 * kScan32RowTile;
+        // all 24 fragments of the piece are requested up front (96 VGPRs; the kernel has room: no register pieces), so the
+        // 32 MFMAs of the piece run without an LDS round trip between them
+        scan_f32x4 fa0[8], fa1[8], fb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            fa0[u] = scan_frag(ta, lq, u);
+            fa1[u] = scan_frag(ta, 32 + lq, u);
+            fb[u] = scan_frag(tq, lq, u);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {  // 4 columns per step: K pairs (4u, 4u+1) and (4u+2, 4u+3)
+            const scan_f32x4 a0 = fa0[u], a1 = fa1[u], b = fb[u];
+            const float bx = h ? b.y : b.x, bz = h ? b.w : b.z;
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a0.y : a0.x, bx, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a1.y : a1.x, bx, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a0.w : a0.z, bz, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a1.w : a1.z, bz, acc[1], 0, 0, 0);
+        }
+    }
+    // ---- epilogue (as k_scan).  C/D layout: column (query) = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) per block of 32
+    if (lq >= a.nq || wrow0 >= a.row1) return;
+    const int q = a.qlist[lq];
+    const uint64_t tk = a.st.thr_key[q];
+    const int32_t tr = a.st.thr_row[q];
+    const float qn = a.st.qn[q];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = wrow0 + 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row >= a.row1) continue;
+            const float dot = acc[rb][r];
+            const uint64_t key = dist_to_key(distance_from(a.metric, dot, qn, a.nrm2[row]));
+            if (key < tk || (key == tk && (int32_t)row < tr)) {
+                const int slot = atomicAdd(&a.st.cnt[q], 1);
+                if (slot < a.cap) {
+                    a.cand_row[(int64_t)q * a.cap + slot] = (int32_t)row;
+                    a.cand_val[(int64_t)q * a.cap + slot] = dot;
+                }
+            }
+        }
+}
+
 // debug / test hook: exact dot + distance for explicit (query,row) pairs through the same staged chain.
 // grid: ceil(n_pairs/64) blocks of 64 threads.  The query row is staged like a corpus row.
 __global__ __launch_bounds__(64) void k_rescore_pairs(const float* __restrict__ rows, const float* __restrict__ nrm2,

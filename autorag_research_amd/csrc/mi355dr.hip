@@ -132,6 +132,7 @@ int ensure_qstate(mi355dr_index* idx) {
         HIPCHECK(idx, hipFuncSetAttribute((const void*)k_scan, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)scan_lds_bytes(idx->dim, per)));
     }
+    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_scan32, hipFuncAttributeMaxDynamicSharedMemorySize, kScan32Lds));
     HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreenLds));
     HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreenLds));
     {
@@ -495,7 +496,10 @@ int scan_range(mi355dr_index* idx, hipStream_t s, int off, int nq, int k, int64_
     sa.row0 = r0;
     sa.row1 = r1;
     const int64_t grid = (r1 - r0 + kScanThreads - 1) / kScanThreads;
-    hipLaunchKernelGGL(k_scan, dim3((unsigned)grid), dim3(kScanThreads), scan_lds_bytes(idx->dim, nq), s, sa);
+    if (idx->dim % kScan32PieceCols == 0 && idx->scan_dma)  // rows are whole 128-byte pieces: the LDS-DMA form
+        hipLaunchKernelGGL(k_scan32, dim3((unsigned)grid), dim3(kScanThreads), kScan32Lds, s, sa, idx->n);
+    else
+        hipLaunchKernelGGL(k_scan, dim3((unsigned)grid), dim3(kScanThreads), scan_lds_bytes(idx->dim, nq), s, sa);
     HIPCHECK(idx, hipGetLastError());
     return launch_prune(idx, s, nq, idx->qlist_dev + off, k, /*exact=*/1);
 }
@@ -539,9 +543,9 @@ int run_scan(mi355dr_index* idx, hipStream_t s, const std::vector<int>& qs, int 
             }
             done = end;
             // exact keys: a chunk only appends the rows that enter the running top-k (k ln(ratio) of them on unordered data),
-            // so the ladder can be steep -- 3 launches and prunes for 2 M rows instead of 7 (an adversarial order overflows
+            // so the ladder can be steep (x64) -- 3 launches and prunes for 2 M rows instead of 7 (an adversarial order overflows
             // the list and takes the buffer-sized re-run above)
-            chunk = std::max<int64_t>(chunk, done * (idx->chunk_growth_set ? idx->chunk_growth : 31));
+            chunk = std::max<int64_t>(chunk, done * (idx->chunk_growth_set ? idx->chunk_growth : 63));
         }
     }
     idx->s_fallback_queries += nq_all;
@@ -1054,6 +1058,8 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
         idx->starter = value != 0;
     } else if (k == "prune_companion") {
         idx->prune_companion = value != 0;
+    } else if (k == "scan_dma") {
+        idx->scan_dma = value != 0;
     } else if (k == "defer_round_b") {
         idx->defer_round_b = value != 0;
     } else if (k == "chunk_growth") {
