@@ -942,6 +942,45 @@ def main() -> None:
         rd_, rr_ = res[0].cpu().numpy(), res[1].cpu().numpy()
         assert (np.diff(rd_, axis=1) >= 0).all(), "distances not ascending"
         assert rr_.min() >= 0 and rr_.max() < n_total
+    if use_dist and (world > 1 or args.force_dist) and not args.no_extras:
+        try:  # (a secondary check must not take the headline line down with it; every rank takes the same path)
+            # (4) the sharded answer against ONE GPU's: rank 0 builds the whole corpus next to its shard (54 GB at N = 10 M) and
+            # answers block 0 of the pool alone; every rank's merged lists must equal it bit for bit
+            chk = torch.empty((2, B, k), device=device, dtype=torch.int64)
+            idx.search_device(qpool[0].data_ptr(), B, k, packed[0].data_ptr(), packed[1].data_ptr(), stream)
+            dist.all_gather_into_tensor(packed_all.view(-1), packed.view(-1), group=row_group)
+            idx.merge_topk_packed_device(packed_all.data_ptr(), gworld, B, k, chk[0].data_ptr(), chk[1].data_ptr(), stream)
+            torch.cuda.synchronize()
+            one = torch.zeros((2, B, k), device=device, dtype=torch.int64)
+            built = torch.zeros((1,), device=device, dtype=torch.int64)
+            if rank == 0:
+              try:  # (rank 0 alone builds: whatever happens here, it still joins the collectives below)
+                with pkg.Mi355Index(d, args.metric, device=local_rank) as whole:
+                    whole.reserve(n_total)
+                    whole.set_option("screen_dtype", args.screen)
+                    for c in range(n_chunks):
+                        rows = min(CHUNK_ROWS, n_total - c * CHUNK_ROWS)
+                        x = gen_chunk(c, rows)
+                        sel = (p_pos_t >= c * CHUNK_ROWS) & (p_pos_t < c * CHUNK_ROWS + rows)
+                        if bool(sel.any()):
+                            x[p_pos_t[sel] - c * CHUNK_ROWS] = p_vec[sel]
+                        torch.cuda.synchronize()
+                        whole.add_device(x.data_ptr(), rows)
+                        del x
+                    whole.search_device(qpool[0].data_ptr(), B, k, one[0].data_ptr(), one[1].data_ptr(), stream)
+                    torch.cuda.synchronize()
+                    built += 1
+              except Exception as e:  # noqa: BLE001
+                result["extra"]["identical_to_one_gpu_error"] = f"{type(e).__name__}: {e}"
+            dist.broadcast(one, src=0)
+            dist.broadcast(built, src=0)
+            same = torch.tensor([1.0 if bool(torch.equal(one, chk)) else 0.0], device=device, dtype=torch.float64)
+            dist.all_reduce(same, op=dist.ReduceOp.MIN)
+            if rank == 0:
+                result["extra"]["identical_to_one_gpu"] = bool(same.item() == 1.0) if int(built.item()) == 1 else None
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                result["extra"]["identical_to_one_gpu"] = f"error: {type(e).__name__}: {e}"
     want_leg = args.row_sharded_leg and (R != world or world == 1)
     ref_block = None
     if want_leg:
