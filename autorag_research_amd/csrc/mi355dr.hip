@@ -1046,6 +1046,8 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
         idx->i8_demoted = false;  // (setting the option again re-arms AUTO)
     } else if (k == "maxsim_screen") {
         idx->maxsim_screen = value != 0;
+    } else if (k == "maxsim_persistent") {
+        idx->maxsim_persistent = value != 0;
     } else if (k == "row_offset") {
         idx->row_offset = value;
     } else if (k == "profile") {

@@ -199,6 +199,8 @@ def run_maxsim(args, n_docs: int, tokens: str, nq: int, steps: int, warmup: int,
     rng = np.random.default_rng(777)
     lens = rng.integers(32, 181, size=n_docs) if tokens == "text" else np.full((n_docs,), 1030, dtype=np.int64)
     idx = pkg.Mi355Index(d, "cosine", device=dev.index)
+    if os.environ.get("MI355DR_MAXSIM_PERSISTENT") is not None:   # developer A/B
+        idx.set_option("maxsim_persistent", int(os.environ["MI355DR_MAXSIM_PERSISTENT"]))
     g = torch.Generator(device=dev)
     g.manual_seed(777)
     t_build = time.perf_counter()
