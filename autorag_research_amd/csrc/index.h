@@ -1,5 +1,6 @@
 // index.h -- the opaque handle behind mi355dr_index and the host-side error helpers (internal).
 #pragma once
+#include <climits>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -80,7 +81,8 @@ struct mi355dr_index {
     int path = 0;  // MI355DR_PATH_AUTO
     int screen_dtype = 0;  // MI355DR_SCREEN_AUTO
     int retry_level = 0;   // > 0 while overflowed queries are re-screened: bf16 bound, slower chunk growth
-    bool i8_demoted = false;  // AUTO saw the int8 bound overflow on this corpus' score distribution: bf16 from now on
+    int i8_demoted_k = INT_MAX;  // AUTO saw the int8 bound overflow on this corpus' score distribution at this k: bf16 from there up
+    double i8_min_budget = 0.25;  // AUTO keeps the int8 screen while growth_budget(k, int8) stays above this (k <= 133)
     // buffers of the sub-block a search at retry level L re-screens (one set per level: the nested call owns the next)
     float* retry_q[3] = {nullptr, nullptr, nullptr};      // [kQBlockMax, dim] queries being re-screened / re-scanned
     double* retry_dist[3] = {nullptr, nullptr, nullptr};  // [kQBlockMax, kKMax]

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void k_scan(ScanArgs a) {
     struct QPiece {
         float4 v[2];
     };
-    StageRows sr, sq;
+    StageRows sr;
     StagePiece p0, p1;
     QPiece q0, q1;
     // idle slots read a live lane's row (their products are never looked at): pieces inside the rows need no per-load
@@ -82,23 +82,30 @@ __global__ __launch_bounds__(kScanThreads, 2) void k_scan(ScanArgs a) {
         if (dense && k0 + kStageCols <= d) stage_issue_dense(p, r, k0, lane);  // wave-uniform
         else stage_issue(p, r, k0, d, lane);
     };
-    auto issue_q = [&](QPiece& p, const StageRows& r, int k0) __attribute__((always_inline)) {
+    int qoff[2] = {-1, -1};  // this wave's two query rows as float offsets from a.q (picked once: holding all eight pointers spills)
+    auto issue_q = [&](QPiece& p, int k0) __attribute__((always_inline)) {
         const int c4 = (lane & 15) * 4;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const float* src = wave == 0 ? r.r[u] : wave == 1 ? r.r[2 + u] : wave == 2 ? r.r[4 + u] : r.r[6 + u];
-            p.v[u] = (src != nullptr && k0 + c4 < d) ? load_gmem_f4(src + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int u = 0; u < 2; ++u)
+            p.v[u] = (qoff[u] >= 0 && k0 + c4 < d) ? load_gmem_f4(a.q + qoff[u] + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     if (vec) {
         const bool dr = stage_rows_init_dense(sr, rp, lane);
-        const bool dq = stage_rows_init_dense(sq, qp, lane);
-        dense = dr && dq;
+        {
+            StageRows sq;
+            const bool dq = stage_rows_init_dense(sq, qp, lane);
+            dense = dr && dq;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float* src = wave == 0 ? sq.r[u] : wave == 1 ? sq.r[2 + u] : wave == 2 ? sq.r[4 + u] : sq.r[6 + u];
+                qoff[u] = src != nullptr ? (int)(src - a.q) : -1;  // (query blocks are far below 2^31 floats)
+            }
+        }
         issue(p0, sr, 0);
-        issue_q(q0, sq, 0);
+        issue_q(q0, 0);
         if (kStageCols < d) {
             issue(p1, sr, kStageCols);
-            issue_q(q1, sq, kStageCols);
+            issue_q(q1, kStageCols);
         }
     }
     const int h = lane >> 5;
@@ -132,7 +139,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void k_scan(ScanArgs a) {
             __syncthreads();               // the query piece is complete
             if (k0 + 2 * kStageCols < d) {
                 issue(p0, sr, k0 + 2 * kStageCols);
-                issue_q(q0, sq, k0 + 2 * kStageCols);
+                issue_q(q0, k0 + 2 * kStageCols);
             }
             mfma_piece();
             if (k0 + kStageCols < d) {
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void k_scan(ScanArgs a) {
                 __syncthreads();
                 if (k0 + 3 * kStageCols < d) {
                     issue(p1, sr, k0 + 3 * kStageCols);
-                    issue_q(q1, sq, k0 + 3 * kStageCols);
+                    issue_q(q1, k0 + 3 * kStageCols);
                 }
                 mfma_piece();
             }

@@ -198,14 +198,17 @@ inline double growth_budget(const mi355dr_index* idx, int k, bool i8) {
     return 0.6 * std::min(room, idx->cap) / ((double)k * (i8 ? kInflationI8 : kInflationBf16));
 }
 
-// which screen the search in progress uses: int8 needs the cosine metric, a corpus that quantised within the limit, and
-// (in AUTO) a k small enough that its wider bound still allows chunks to grow (k <= 24); larger k keeps bf16
+// which screen the search in progress uses: int8 needs a corpus that quantised within the limit and (in AUTO) a k small
+// enough that its wider bound still allows chunks to grow (k <= 133 at the default budget line); larger k keeps bf16
 inline bool i8_available(const mi355dr_index* idx) { return idx->irr8_n <= kIrrCap; }
 inline bool use_i8(const mi355dr_index* idx) {
     if (idx->retry_level > 0) return false;  // re-screening overflowed queries: the ~3x tighter bf16 bound
     if (idx->screen_dtype == MI355DR_SCREEN_I8) return true;
-    return idx->screen_dtype == MI355DR_SCREEN_AUTO && i8_available(idx) && !idx->i8_demoted &&
-           growth_budget(idx, idx->k_now, true) >= 1.5;
+    // (measured round 3, N = 10 M, 1024 queries: int8 7.4 / 8.0 / 9.5 / 11.7 / 12.7 ms at k = 10 / 32 / 64 / 100 / 128 against
+    // 13-14.4 ms for bf16, whose kernel alone is 11 ms; 22 against 16 at k = 200, where the int8 chunks hardly grow any more:
+    // the cross-over is near k = 160, budget 0.2; round 2 drew the line at k = 24, budget 1.5)
+    return idx->screen_dtype == MI355DR_SCREEN_AUTO && i8_available(idx) && idx->k_now < idx->i8_demoted_k &&
+           growth_budget(idx, idx->k_now, true) >= idx->i8_min_budget;
 }
 
 int launch_prune(mi355dr_index* idx, hipStream_t s, int nblocks, const int* qlist, int k, int exact, bool thr_only = false,
@@ -682,7 +685,7 @@ int complete_block(mi355dr_index* idx, Pending& p) {
     }
     if (n_retry > 0) {
         idx->s_retry_queries += n_retry;
-        if (p.was_i8 && idx->screen_dtype == MI355DR_SCREEN_AUTO && n_retry * 20 > B) idx->i8_demoted = true;
+        if (p.was_i8 && idx->screen_dtype == MI355DR_SCREEN_AUTO && n_retry * 20 > B) idx->i8_demoted_k = std::min(idx->i8_demoted_k, k);
         idx->retry_level = level + 1;
         rc = search_block(idx, s, idx->retry_q[level] + (size_t)n_todo * idx->dim, n_retry, k,
                           idx->retry_dist[level] + (size_t)n_todo * k, idx->retry_rows[level] + (size_t)n_todo * k);
@@ -1043,7 +1046,10 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
     } else if (k == "screen_dtype") {
         if (value < 0 || value > 2) return fail(idx, MI355DR_E_INVALID, "screen_dtype must be 0,1,2");
         idx->screen_dtype = (int)value;
-        idx->i8_demoted = false;  // (setting the option again re-arms AUTO)
+        idx->i8_demoted_k = INT_MAX;  // (setting the option again re-arms AUTO)
+    } else if (k == "i8_min_budget_x100") {
+        if (value < 1 || value > 1000) return fail(idx, MI355DR_E_INVALID, "i8_min_budget_x100 must be in 1..1000");
+        idx->i8_min_budget = (double)value / 100.0;
     } else if (k == "maxsim_screen") {
         idx->maxsim_screen = value != 0;
     } else if (k == "maxsim_persistent") {
@@ -1114,7 +1120,8 @@ int mi355dr_get_stat(mi355dr_index* idx, const char* key, int64_t* out) {
     else if (k == "passes") *out = idx->s_passes;
     else if (k == "starters") *out = idx->s_starters;
     else if (k == "retry_queries") *out = idx->s_retry_queries;
-    else if (k == "i8_demoted") *out = idx->i8_demoted ? 1 : 0;
+    else if (k == "i8_demoted") *out = idx->i8_demoted_k != INT_MAX ? 1 : 0;
+    else if (k == "i8_demoted_k") *out = idx->i8_demoted_k == INT_MAX ? 0 : idx->i8_demoted_k;
     else if (k == "maxsim_screened") *out = idx->s_ms_screened;
     else if (k == "maxsim_candidates") *out = idx->s_ms_candidates;
     else if (k == "maxsim_fallbacks") *out = idx->s_ms_fallbacks;

@@ -473,6 +473,9 @@ __global__ __launch_bounds__(kMsThreads, 2) void k_maxsim16_d128(Ms16Args a) {
             float part = 0.0f;
 #pragma unroll
             for (int cbi = 0; cbi < NCB; ++cbi) {
+                // (wave-uniform skip of the blocks the query does not touch: a 32-token query touches one or two of the eight,
+                // and on 3-block text documents this epilogue is a fifth of the kernel)
+                if (cbi * 32 + 31 < c0 || cbi * 32 >= c0 + len) continue;
                 const int j = cbi * 32 + (lane & 31) - c0;  // this lane's column of block cbi as a token index of query qi
                 if (j >= 0 && j < len) part += run[cbi];
             }

@@ -226,10 +226,11 @@ def test_starter_pass_equals_ladder_pass(pkg, oracle, screen, n, d, B, k):
     assert all(np.array_equal(res[0][1], r[1]) for r in res[1:])
 
 
-@pytest.mark.parametrize("k,expect_dtype", [(10, 2), (24, 2), (26, 1), (100, 1), (400, 1)])
+@pytest.mark.parametrize("k,expect_dtype", [(10, 2), (24, 2), (26, 2), (100, 2), (133, 2), (140, 1), (400, 1)])
 def test_schedule_adapts_to_k(pkg, oracle, k, expect_dtype):
-    """the wider int8 bound keeps ~16x k candidates per chunk, the bf16 bound ~3x: AUTO keeps int8 for small k only and
-    the chunk growth shrinks with k, so no query overflows its candidate list (which would cost an exact re-scan)"""
+    """the wider int8 bound keeps ~16x k candidates per chunk, the bf16 bound ~3x: AUTO keeps int8 while its chunks can still
+    grow (k <= 133: it wins up to k ~ 160 at the headline corpus) and the chunk growth shrinks with k, so no query overflows
+    its candidate list (which would cost an exact re-scan)"""
     rng = np.random.default_rng(1000 + k)
     n, d, B = 150_000, 128, 300
     C = rng.standard_normal((n, d)).astype(np.float32)
