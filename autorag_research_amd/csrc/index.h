@@ -95,7 +95,7 @@ struct mi355dr_index {
     int64_t seq_next = 0, seq_done = 0;
     int k_now = 10;        // k of the search in progress (the screen element type and the chunk growth depend on it)
     int maxsim_persistent = 0;  // MaxSim screen (dims <= 128): persistent workgroups walking the docs in rounds.  A/B on one box
-                                // (tools/r3_job8.sh, 1 M text docs / 100 k pages): text +-0, pages 4 % SLOWER -- off
+                                // (interleaved A/B through this option, 1 M text docs / 100 k pages): text +-0, pages 4 % SLOWER -- off
     int maxsim_screen = 1; // 1: bf16 MFMA screen + exact re-score of the candidates, 0: exact kernel over every doc
     int64_t row_offset = 0;
     int round_a = 0;      // k_prune: rows re-scored before the cut is known (0 = max(32, 2k)); tuning option "round_a"
