@@ -94,6 +94,7 @@ struct mi355dr_index {
     mi355::Pending sub_pend[4];
     int64_t seq_next = 0, seq_done = 0;
     int k_now = 10;        // k of the search in progress (the screen element type and the chunk growth depend on it)
+    int maxsim_coop = -1;       // exact MaxSim on candidate lists: one workgroup per candidate (1), one wave (0), by document length (-1)
     int maxsim_persistent = 0;  // MaxSim screen (dims <= 128): persistent workgroups walking the docs in rounds.  A/B on one box
                                 // (interleaved A/B through this option, 1 M text docs / 100 k pages): text +-0, pages 4 % SLOWER -- off
     int maxsim_screen = 1; // 1: bf16 MFMA screen + exact re-score of the candidates, 0: exact kernel over every doc

@@ -1052,6 +1052,9 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
         idx->i8_min_budget = (double)value / 100.0;
     } else if (k == "maxsim_screen") {
         idx->maxsim_screen = value != 0;
+    } else if (k == "maxsim_coop") {
+        if (value < -1 || value > 1) return fail(idx, MI355DR_E_INVALID, "maxsim_coop must be -1 (by document length), 0 or 1");
+        idx->maxsim_coop = (int)value;
     } else if (k == "maxsim_persistent") {
         idx->maxsim_persistent = value != 0;
     } else if (k == "row_offset") {

@@ -39,6 +39,7 @@ constexpr int kMsThreads = 256;     // 4 waves
 constexpr int kMsDocsPerWave = 4;   // docs a wave walks per workgroup (amortises staging the query block in LDS)
 constexpr int kSegSort = kSortMax;  // select: largest segment (entries sorted per workgroup)
 constexpr int kMsListGrid = 256;    // workgroups of a doc-list launch of k_maxsim (4 waves each stride over the list)
+constexpr int kMsRedBytes = 4 * 4 * 32 * 4;  // k_maxsim, cooperative list mode: [wave][column block][column] maxima
 constexpr int kMsCandCap = 8192;    // docs the screen may hand to the exact kernel per query (more: exact full scan)
 
 struct MultiVecStore {
@@ -123,12 +124,19 @@ struct MsArgs {
     // the launch of tile t starts every item's sum from the value tile t-1 left (same layout as `dist`; may be `dist` itself),
     // so the fp32 sum still runs over the query's vectors in order -- bit for bit the one-launch chain
     const float* dist_in;
+    // list mode, long documents (ColPali pages: 33 blocks): the four waves of a workgroup share ONE item -- wave w multiplies
+    // blocks w, w + 4, ... -- and their per-column maxima meet in LDS (byte offset red_off of the dynamic segment, 2 KiB) before
+    // wave 0 adds them up in token order.  A maximum does not depend on the order: the same bits as one wave per item.  With a
+    // whole page per wave a 570-candidate list kept 570 of the chip's 1024 SIMDs busy for 33 blocks each, two deep where two
+    // workgroups shared a CU: 0.5 ms per launch against 0.13 ms of fp32 MFMA work.
+    int coop;
+    int red_off;
 };
 
 // query-token columns one launch of k_maxsim stages: whole 32-column blocks, at most kMsCols, inside the 160 KiB of LDS
 // (d = 128: 128 columns; d = 768, the hidden size the ColBERT reranker scores with: 32)
 inline int ms_cols_for(int dpad) {
-    const int c = (int)((size_t)160 * 1024 / ((size_t)(dpad + 4) * sizeof(float))) / 32 * 32;
+    const int c = (int)(((size_t)160 * 1024 - kMsRedBytes) / ((size_t)(dpad + 4) * sizeof(float))) / 32 * 32;
     return c < kMsCols ? c : kMsCols;
 }
 
@@ -197,7 +205,9 @@ __global__ __launch_bounds__(kMsThreads, 2) void k_maxsim(MsArgs a) {
         a.nq_launch = 1;
     }
     const int64_t n_items = a.n_items_dev ? min((int64_t)*a.n_items_dev, a.n_items) : a.n_items;
-    if ((int64_t)blockIdx.x * 4 >= n_items) return;  // nothing for this workgroup: skip staging the query block
+    const bool coop = a.coop != 0;
+    if ((int64_t)blockIdx.x * (coop ? 1 : 4) >= n_items) return;  // nothing for this workgroup: skip staging the query block
+    float* red = (float*)(smem + a.red_off);
     int ncb = 0;   // column blocks in use
     for (int qi = 0; qi < a.nq_launch; ++qi) ncb = max(ncb, (a.q_col0[qi] + a.q_len[qi] + 31) / 32);
     for (int i = tid; i < ncb * 32 * (a.dpad / 4); i += kMsThreads) {
@@ -211,27 +221,29 @@ __global__ __launch_bounds__(kMsThreads, 2) void k_maxsim(MsArgs a) {
     // (with a doc list the grid is small and fixed -- the real list length is only known on the device -- and the
     // waves stride over the list until it ends)
     for (int dw = 0; a.doc_list || dw < kMsDocsPerWave; ++dw) {
-    const int64_t item = ((int64_t)dw * gridDim.x + blockIdx.x) * 4 + wave;
-    if (item >= n_items) break;
+    const int64_t item = coop ? (int64_t)dw * gridDim.x + blockIdx.x : ((int64_t)dw * gridDim.x + blockIdx.x) * 4 + wave;
+    if (item >= n_items) break;  // (cooperative: the same item in all four waves -- every branch on it is workgroup-uniform)
     const int64_t doc = a.doc_list ? (int64_t)a.doc_list[item] : item;
     if (doc < 0 || doc >= a.n_docs) {  // (subset scoring) not a stored doc
-        if (lane == 0)
+        if (lane == 0 && (!coop || wave == 0))
             for (int qi = 0; qi < a.nq_launch; ++qi) a.dist[(int64_t)qi * a.n_items + item] = __uint_as_float(0x7FC00000u);
         continue;
     }
     const int64_t b0 = a.blk_off[doc], b1 = a.blk_off[doc + 1];
+    const int bfirst = coop ? wave : 0, bstep = coop ? 4 : 1;  // this wave's blocks of the document: b0 + bfirst + bstep * i
+    const int64_t nb_w = b1 - b0 > bfirst ? (b1 - b0 - bfirst + bstep - 1) / bstep : 0;
     float run[4];  // running max per column block (this lane's column)
 #pragma unroll
     for (int c = 0; c < 4; ++c) run[c] = -__builtin_inff();
 
-    const int64_t npieces = (b1 - b0) * nchunk;
+    const int64_t npieces = nb_w * nchunk;
     f32x16 acc[4];
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
     float4 pa[16], pb[16];
-    auto row_of = [&](int64_t p) { return a.tok + ((b0 + p / nchunk) * kMsBlkRows + col) * (int64_t)a.dpad + 4 * half; };
+    auto row_of = [&](int64_t p) { return a.tok + ((b0 + bfirst + bstep * (p / nchunk)) * kMsBlkRows + col) * (int64_t)a.dpad + 4 * half; };
     auto finish_block = [&]() {  // block max per column: 16 rows in this lane, the other 16 in lane^32
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
@@ -255,6 +267,26 @@ __global__ __launch_bounds__(kMsThreads, 2) void k_maxsim(MsArgs a) {
             ms_compute_piece(acc, pb, qs, ld, ncb, col, half, (int)((p + 1) % nchunk), a.dpad);
             if ((p + 2) % nchunk == 0) finish_block();
         }
+    }
+    if (coop) {  // the four waves' column maxima -> wave 0
+        if (lane < 32) {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+                if (cb < ncb) red[(wave * 4 + cb) * 32 + lane] = run[cb];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                if (cb >= ncb) break;
+                float m = red[cb * 32 + col];
+#pragma unroll
+                for (int w = 1; w < 4; ++w) m = fmaxf(m, red[(w * 4 + cb) * 32 + col]);
+                run[cb] = m;
+            }
+        }
+        __syncthreads();  // (red is rewritten by the next item)
+        if (wave != 0) continue;
     }
     // per query: distance = sum over its tokens (in order) of -(max dot); empty docs are skipped by the select
     for (int qi = 0; qi < a.nq_launch; ++qi) {
@@ -1061,7 +1093,7 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
         HIPCHECK(idx, hipHostMalloc(&m->cand_ctl_host, 8 * sizeof(int)));
         HIPCHECK(idx, hipFuncSetAttribute((const void*)k_ms_final, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           kMsCandCap * 12));
-        HIPCHECK(idx, hipFuncSetAttribute((const void*)k_maxsim, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHECK(idx, hipFuncSetAttribute((const void*)k_maxsim, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + kMsRedBytes)));
         if (lds16 <= 160 * 1024)
             HIPCHECK(idx, hipFuncSetAttribute((const void*)k_maxsim16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
         HIPCHECK(idx, hipFuncSetAttribute((const void*)k_maxsim16_d128<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 8192));
@@ -1362,9 +1394,13 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
             c.n_items = n_cand_max;
             c.n_items_dev = m->cand_ctl;
             c.list_stride = kMsCandCap;
+            // long documents (>= 8 blocks on average: pages): one workgroup per candidate, its four waves share the blocks
+            const bool coop = idx->maxsim_coop < 0 ? m->n_blocks >= 8 * m->n_docs : idx->maxsim_coop != 0;
+            c.coop = coop ? 1 : 0;
+            c.red_off = (int)lds;
             if (idx->profile) HIPCHECK(idx, hipEventRecord(idx->ms_ev[2], s));
-            hipLaunchKernelGGL(k_maxsim, dim3((unsigned)std::min<int64_t>((n_cand_max + 3) / 4, kMsListGrid), nql),
-                               dim3(kMsThreads), lds, s, c);
+            hipLaunchKernelGGL(k_maxsim, dim3((unsigned)std::min<int64_t>(coop ? n_cand_max : (n_cand_max + 3) / 4, kMsListGrid), nql),
+                               dim3(kMsThreads), lds + kMsRedBytes, s, c);
             HIPCHECK(idx, hipGetLastError());
             if (idx->profile) HIPCHECK(idx, hipEventRecord(idx->ms_ev[3], s));
             hipLaunchKernelGGL(k_ms_final, dim3(1, nql), dim3(256), (size_t)kMsCandCap * 12, s, m->cand_dist, m->cand_list,
@@ -1522,7 +1558,7 @@ static int maxsim_subset_impl(mi355dr_index* idx, const float* qtok, const int32
     const int cols = ms_cols_for(dp);  // query vectors per launch; a longer query is scored in tiles (MsArgs::dist_in)
     if (cols < 32) return fail(idx, MI355DR_E_UNSUPPORTED, "dim too large for the MaxSim kernel's LDS budget (dim <= 1272)");
     const size_t lds = (size_t)cols * (dp + 4) * sizeof(float);
-    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_maxsim, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_maxsim, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + kMsRedBytes)));
     // per call scratch (candidate lists are small: a few hundred docs per query), released on every exit
     struct Scratch {
         int32_t* list = nullptr;

@@ -198,11 +198,19 @@ int mi355dr_search_sharded_device(mi355dr_index* idx, const float* queries_dev, 
  *          over every doc + exact re-score of the candidates [default], 0: exact kernel over every doc; same results),
  *          "screen_stream" (1 [default]: query blocks of at most 64 are screened by the streaming kernel -- resident query
  *          block, ring of row stages --, 0: by the tile kernel; same results).
+ *          Round 3, all with identical results (A/B switches of the pass schedule): "starter" (1 [default]: sampled threshold
+ *          estimator instead of the three smallest chunks, k <= 32), "defer_round_b" (1 [default]: prunes before the last one
+ *          carry their survivors over instead of re-scoring them), "prune_companion" (1 [default]: general-form prune launch
+ *          behind every one-wave prune), "scan_dma" (1 [default]: k_scan32, LDS-DMA staging, for dims that are a multiple
+ *          of 32), "maxsim_persistent" (0 [default]), "maxsim_coop" (exact MaxSim on candidate lists: -1 [default] one workgroup per
+ *          candidate for stores of long documents, 0 one wave, 1 always one workgroup), "i8_min_budget_x100" (AUTO keeps the int8 screen while the chunk-growth
+ *          budget at this k is at least value / 100; default 25 = k <= 133).
  * stats:   "screen_launches", "screen_ns" (profile=1), "screen_rows" (all screen launches) and their k_screen256 share
  *          "screen256_launches", "screen256_ns", "screen256_rows"; "candidates", "rescored",
  *          "fallback_queries" (queries recomputed by the exact scan), "retry_queries" (queries whose candidate list
  *          overflowed and that were re-screened with the bf16 bound and slower chunk growth first), "i8_demoted" (AUTO
- *          gave up the int8 screen for this index after > 5 % of a block overflowed), "chunks", "passes", "irregular_rows", "loose_rows" (rows outside the int8 shadow,
+ *          gave up the int8 screen for this index after > 5 % of a block overflowed -- from "i8_demoted_k", the k of that
+ *          block, upwards; smaller k keep int8), "starters", "chunks", "passes", "irregular_rows", "loose_rows" (rows outside the int8 shadow,
  *          irregular ones included), "screen_dtype_active" (MI355DR_SCREEN_BF16 / _I8: what AUTO resolves to now),
  *          "maxsim_screened" (queries served by the MaxSim screen), "maxsim_candidates" (docs re-scored exactly for them),
  *          "maxsim_fallbacks" (queries re-run by the exact full scan),

@@ -107,6 +107,31 @@ def test_maxsim_matches_oracle(pkg, oracle, d, n_docs, tmin, tmax, qlens, k):
         _check(idx, oracle, tok, off, qtok, qoff, k)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("tmin,tmax,qlens", [
+    (200, 420, [24, 20, 33, 7]),      # 7..14 blocks per doc: the four waves get uneven shares, two column blocks
+    (1, 70, [24, 128, 5]),            # short docs forced through the cooperative form: waves without a block, empty docs
+    (1030, 1030, [24, 24, 24, 24, 24, 24, 24, 24]),   # pages, two groups of four queries
+])
+def test_candidate_lists_scored_by_one_workgroup_per_candidate(pkg, oracle, tmin, tmax, qlens):
+    """the exact kernel on the screen's candidate lists, cooperative form (option maxsim_coop: the four waves of a workgroup
+    share one candidate's blocks, column maxima meet in LDS): the same bits as one wave per candidate and as the oracle"""
+    rng = np.random.default_rng(tmax * 7 + len(qlens))
+    d, n_docs, k = 128, 90 if tmax > 500 else 400, 10
+    tok, off = _ragged(rng, n_docs, d, tmin if tmin > 1 else 0, tmax)
+    qtok, qoff = _queries(rng, qlens, d)
+    with pkg.Mi355Index(d) as idx:
+        idx.add_multivec(tok, off)
+        got = {}
+        for coop in (1, 0, -1):
+            idx.set_option("maxsim_coop", coop)
+            idx.reset_stats()
+            _check(idx, oracle, tok, off, qtok, qoff, k)
+            assert idx.stat("maxsim_screened") > 0
+            got[coop] = idx.search_maxsim(qtok, qoff, k)
+        assert np.array_equal(got[1][1], got[0][1]) and np.array_equal(got[1][0].view(np.uint32), got[0][0].view(np.uint32))
+
+
 def test_empty_docs_appends_and_unnormalised(pkg, oracle):
     rng = np.random.default_rng(77)
     d = 64

@@ -193,6 +193,7 @@ def check_maxsim(rng, case):
         return desc + " (no tokens: skipped)"
     with pkg.Mi355Index(d) as idx:
         idx.set_option("maxsim_screen", screen)
+        idx.set_option("maxsim_coop", int(rng.integers(-1, 2)))
         idx.add_multivec(tok, off)
         dist, rows = idx.search_maxsim(qtok, qoff, k)
         stats = {s: idx.stat(s) for s in ("maxsim_screened", "maxsim_fallbacks")}
