@@ -230,7 +230,9 @@ int launch_prune(mi355dr_index* idx, hipStream_t s, int nblocks, const int* qlis
     pa.k = k;
     pa.metric = idx->metric;
     pa.exact = exact;
-    pa.flag8 = use_i8(idx) ? idx->flag8 : nullptr;
+    // (flags exist only for loose rows, and every loose row is counted: a corpus without any -- the usual case -- spares each
+    // candidate the dependent flag8[row] load, one memory round trip of the prune's latency chain)
+    pa.flag8 = (use_i8(idx) && idx->irr8_n > 0) ? idx->flag8 : nullptr;
     pa.cscale = idx->metric == MI355DR_METRIC_IP ? idx->cmax : 1.0f;
     // int8 screen, cosine: candidates that survive the exact cut are screened once more on their bf16 shadow rows
     // (half the bytes of an fp32 row, a bound ~5x tighter) before the exact re-score

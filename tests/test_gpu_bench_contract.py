@@ -1,0 +1,56 @@
+"""GPU: `bench.py` keeps the driver's contract -- ONE JSON line, last on stdout, with the keys the driver reads, the
+`roofline` and `cpu_baseline` objects, and the bench's own parity verdicts true -- on a corpus small enough to run inside the
+suite (the driver runs the full-size line itself).  A second run takes the distributed code path with a world of one
+(process group on RCCL, packed all-gather + merge inside the timed loop, the sharded answer compared with one GPU's)."""
+
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parent.parent
+TOP_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def _bench(*args, env=None):
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], cwd=ROOT, env=e, capture_output=True, text=True,
+                       timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    return json.loads(lines[-1])  # the JSON line is the LAST line of stdout
+
+
+def test_default_shape_line_on_a_small_corpus(native_built):
+    d = _bench("--rows", "500000", "--steps", "4", "--warmup", "1", "--cpu-sample-rows", "250000", "--cpu-sample-queries", "1024")
+    assert TOP_KEYS <= set(d), TOP_KEYS - set(d)
+    assert d["metric"] == "queries/sec" and d["unit"] == "queries/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and d["dtype"] == "f32" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["config"]["queries_per_step"] / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] > 0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r and r["launches"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
+    assert c["parity_on_sample"] is True                      # the GPU lists equal the oracle's on the sample, bit for bit
+    x = d["extra"]
+    assert x["fallback_queries"] == 0 and x["pcie_inclusive"]["queries_per_s"] < d["value"] * 1.05
+    assert d["ndcg_at_10"]["sample_check"]["identical"] is True   # planted answers: GPU ids / nDCG == the oracle's on the sample
+
+
+def test_distributed_code_path_with_a_world_of_one(native_built):
+    d = _bench("--rows", "500000", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--force-dist",
+               env={"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29541", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
+    assert d["n_gpus"] == 1 and d["config"]["layout"]["row_shards"] == 1
+    assert d["extra"]["identical_to_one_gpu"] is True         # all-gather + merge of one shard == the plain search
