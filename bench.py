@@ -258,7 +258,7 @@ def run_maxsim(args, n_docs: int, tokens: str, nq: int, steps: int, warmup: int,
                     f"device in {t_build:.2f} s",
         "queries_per_s": round(steps * qblock / el, 2), "ms_per_step": round(el * 1e3 / steps, 3), "steps": steps,
         "includes": "H2D of the query block, D2H of results",
-        "roofline": {"bound": "hbm", "kernel": "k_maxsim16_d128<8>", "achieved": round(alg_bytes / scr_s / 1e9, 1) if scr_n else None,
+        "roofline": {"bound": "hbm", "kernel": f"k_maxsim16_d128<{(qblock * nq + 31) // 32}>", "achieved": round(alg_bytes / scr_s / 1e9, 1) if scr_n else None,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(alg_bytes / scr_s / 1e9 / HBM_PEAK_GBS, 4) if scr_n else None,
                      "traffic": traffic, "traffic_unit": f"HBM read bytes per launch, vs algorithmic {round(alg_bytes)} (fp32 token rows) "
@@ -297,6 +297,48 @@ def run_maxsim(args, n_docs: int, tokens: str, nq: int, steps: int, warmup: int,
     return out
 
 
+def pmc_fetch_subrun(bench_args: list, kernel_substr: str, timeout_s: int = 420):
+    """HBM read bytes per launch of the dominant kernel, MEASURED in this run: the same workload re-run for 3 steps under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` (counters in a pass of their own, kernel trace only: MI355X_MICROARCH.md's HBM
+    recipe; FETCH_SIZE is in KiB and counts the 128-B requests of a wide stream as 64 B on gfx950: x 1024 x 2).
+    Returns (bytes per launch, launches profiled, note) or (None, 0, why not).  Never raises."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if os.environ.get("MI355DR_BENCH_PMC", "1") == "0":
+        return None, 0, "disabled (MI355DR_BENCH_PMC=0)"
+    if any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ):
+        return None, 0, "this process is itself running under a profiler"
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, 0, "rocprofv3 not found"
+    out = tempfile.mkdtemp(prefix="mi355dr_pmc_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp", MI355DR_BENCH_PMC="0")
+        for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+            env.pop(var, None)
+        cmd = [exe, "--kernel-trace", "--pmc", "FETCH_SIZE", "-f", "csv", "-d", out, "-o", "fetch", "--", sys.executable,
+               str(ROOT / "bench.py"), *[str(a) for a in bench_args], "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+               "--no-extras"]
+        p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+        vals = []
+        for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
+            with open(f) as fh:
+                for r in csv.DictReader(fh):
+                    if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
+                        vals.append(float(r["Counter_Value"]))
+        if not vals:
+            return None, 0, f"no {kernel_substr} launches in the counter file (rc {p.returncode}): {p.stderr[-200:]!r}"
+        return sum(vals) / len(vals) * 1024 * 2, len(vals), "ok"
+    except Exception as e:  # noqa: BLE001 - a secondary figure must not take the line down
+        return None, 0, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 def main_maxsim(args) -> None:
     """Secondary workload as the whole bench line: `python bench.py --workload maxsim [--docs N] [--tokens text|page]`."""
     r = run_maxsim(args, args.docs, args.tokens, 32 if args.tokens == "text" else 24, args.steps, args.warmup,
@@ -308,6 +350,16 @@ def main_maxsim(args) -> None:
            "extra": {kk: r[kk] for kk in ("queries_screened", "candidates_per_query", "exact_full_scan_fallbacks")}}
     if "cpu_baseline" in r:
         out["cpu_baseline"] = r["cpu_baseline"]
+    if not args.no_extras:
+        per_launch, n_prof, note = pmc_fetch_subrun(["--workload", "maxsim", "--tokens", args.tokens, "--docs", args.docs],
+                                                    "k_maxsim16")
+        if per_launch is not None:
+            out["roofline"]["traffic"] = round(per_launch)
+            out["roofline"]["traffic_source"] = (
+                f"MEASURED in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE sub-run of this workload (3 steps, {n_prof} screen "
+                "launches; KiB x 1024 x 2: the gfx950 correction of MI355X_MICROARCH.md), mean per launch")
+        else:
+            out["roofline"]["traffic_source"] = (out["roofline"].get("traffic_source") or "") + f" [live PMC sub-run: {note}]"
     print(json.dumps(out))
 
 
@@ -1028,6 +1080,21 @@ def main() -> None:
             result["extra"]["replicated"] = leg
     if have_pg:
         dist.destroy_process_group()
+    if rank == 0 and world == 1 and not args.no_extras and B > 128:
+        # (every index of this process is closed by now: the sub-run builds its own copy of the corpus)
+        sub = ["--rows", n_total, "--dim", d, "--block", B, "--k", k, "--metric", args.metric, "--data", args.data,
+               "--screen", args.screen]
+        per_launch, n_prof, note = pmc_fetch_subrun(sub, "k_screen256c")
+        rl = result["roofline"]
+        if per_launch is not None:
+            rl["traffic_replayed"] = rl.get("traffic")
+            rl["traffic"] = round(per_launch)
+            rl["traffic_source"] = (
+                f"MEASURED in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE sub-run of this workload (3 steps, {n_prof} "
+                "k_screen256c launches; KiB x 1024 x 2: the gfx950 correction of MI355X_MICROARCH.md), mean per launch -- the "
+                "launches of a pass differ in size exactly as in the timed region")
+        else:
+            rl["traffic_source"] = (rl.get("traffic_source") or "") + f" [live PMC sub-run: {note}]"
     if rank == 0:
         # RCCL writes its version banner through C stdio; on a pipe that buffer would be flushed at exit, AFTER the
         # result.  Flush it now so that the JSON line is the last line of rank 0's output.

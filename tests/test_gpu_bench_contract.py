@@ -41,6 +41,9 @@ def test_default_shape_line_on_a_small_corpus(native_built):
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] > 0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r and r["launches"] > 0
+    if r["traffic_source"].startswith("MEASURED"):            # (rocprofv3 present: the PMC sub-run of this same workload)
+        rows_per_launch = d["config"]["rows_total"] / (r["launches"] / d["steps"])
+        assert 0.9 * 768 * rows_per_launch < r["traffic"] < 1.3 * 768 * rows_per_launch   # the int8 shadow, read about once
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
     assert c["parity_on_sample"] is True                      # the GPU lists equal the oracle's on the sample, bit for bit

@@ -8,9 +8,9 @@ for shape in text page; do
   ARGS="--workload maxsim --tokens $shape --docs $docs --steps 12 --warmup 2 --no-cpu-baseline"
   python bench.py $ARGS --steps 125 > $OUT/line_$shape.json 2> $OUT/line_$shape.err; cut -c1-900 $OUT/line_$shape.json
   rm -rf $OUT/st_$shape $OUT/pmc_$shape
-  rocprofv3 --kernel-trace --stats -f csv -d $OUT/st_$shape -o ms -- python bench.py $ARGS > $OUT/st_$shape.log 2>&1
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $OUT/pmc_$shape -o fetch -- python bench.py $ARGS > $OUT/pmc_${shape}_fetch.log 2>&1
-  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -f csv -d $OUT/pmc_$shape -o sq -- python bench.py $ARGS > $OUT/pmc_${shape}_sq.log 2>&1
+  MI355DR_BENCH_PMC=0 rocprofv3 --kernel-trace --stats -f csv -d $OUT/st_$shape -o ms -- python bench.py $ARGS > $OUT/st_$shape.log 2>&1
+  MI355DR_BENCH_PMC=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $OUT/pmc_$shape -o fetch -- python bench.py $ARGS > $OUT/pmc_${shape}_fetch.log 2>&1
+  MI355DR_BENCH_PMC=0 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -f csv -d $OUT/pmc_$shape -o sq -- python bench.py $ARGS > $OUT/pmc_${shape}_sq.log 2>&1
   python - "$OUT" "$shape" "$docs" <<'PY'
 import collections, csv, glob, json, sys
 out_dir, shape, docs = sys.argv[1], sys.argv[2], int(sys.argv[3])

@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 ROWS=${ROWS:-1250000}
-rm -rf gpurun_out/tl; rocprofv3 --kernel-trace -f csv -d gpurun_out/tl -- python bench.py --rows $ROWS --steps ${STEPS:-3} --warmup 2 --no-cpu-baseline ${BENCH_ARGS:-} > gpurun_out/tl.log 2>&1
+rm -rf gpurun_out/tl; MI355DR_BENCH_PMC=0 rocprofv3 --kernel-trace -f csv -d gpurun_out/tl -- python bench.py --rows $ROWS --steps ${STEPS:-3} --warmup 2 --no-cpu-baseline ${BENCH_ARGS:-} > gpurun_out/tl.log 2>&1
 tail -1 gpurun_out/tl.log
 python - <<'PY'
 import csv,glob
