@@ -297,7 +297,7 @@ def run_maxsim(args, n_docs: int, tokens: str, nq: int, steps: int, warmup: int,
     return out
 
 
-def pmc_fetch_subrun(bench_args: list, kernel_substr: str, timeout_s: int = 420):
+def pmc_fetch_subrun(bench_args: list, kernel_substr: str, timeout_s: int = 240):
     """HBM read bytes per launch of the dominant kernel, MEASURED in this run: the same workload re-run for 3 steps under
     `rocprofv3 --kernel-trace --pmc FETCH_SIZE` (counters in a pass of their own, kernel trace only: MI355X_MICROARCH.md's HBM
     recipe; FETCH_SIZE is in KiB and counts the 128-B requests of a wide stream as 64 B on gfx950: x 1024 x 2).
