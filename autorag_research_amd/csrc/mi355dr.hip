@@ -687,7 +687,11 @@ int complete_block(mi355dr_index* idx, Pending& p) {
     }
     if (n_retry > 0) {
         idx->s_retry_queries += n_retry;
-        if (p.was_i8 && idx->screen_dtype == MI355DR_SCREEN_AUTO && n_retry * 20 > B) idx->i8_demoted_k = std::min(idx->i8_demoted_k, k);
+        // AUTO gives the int8 screen up (from this k upwards) when more than 1 % of a block overflowed under its bound: the
+        // re-screen is a bf16 pass of its own, and lists that overflow are lists that cost -- at d = 2048 (the int8 bound is
+        // absolute, ~0.0175, the spread of the scores shrinks like 1 / sqrt(d)) 1.5 % of the queries overflowed and the pass
+        // took 17.1 ms against 12.9 on bf16; at d = 768 nothing overflows.  (Round 2: 5 %.)
+        if (p.was_i8 && idx->screen_dtype == MI355DR_SCREEN_AUTO && n_retry * 100 > B) idx->i8_demoted_k = std::min(idx->i8_demoted_k, k);
         idx->retry_level = level + 1;
         rc = search_block(idx, s, idx->retry_q[level] + (size_t)n_todo * idx->dim, n_retry, k,
                           idx->retry_dist[level] + (size_t)n_todo * k, idx->retry_rows[level] + (size_t)n_todo * k);

@@ -209,7 +209,7 @@ int mi355dr_search_sharded_device(mi355dr_index* idx, const float* queries_dev, 
  *          "screen256_launches", "screen256_ns", "screen256_rows"; "candidates", "rescored",
  *          "fallback_queries" (queries recomputed by the exact scan), "retry_queries" (queries whose candidate list
  *          overflowed and that were re-screened with the bf16 bound and slower chunk growth first), "i8_demoted" (AUTO
- *          gave up the int8 screen for this index after > 5 % of a block overflowed -- from "i8_demoted_k", the k of that
+ *          gave up the int8 screen for this index after > 1 % of a block overflowed -- from "i8_demoted_k", the k of that
  *          block, upwards; smaller k keep int8), "starters", "chunks", "passes", "irregular_rows", "loose_rows" (rows outside the int8 shadow,
  *          irregular ones included), "screen_dtype_active" (MI355DR_SCREEN_BF16 / _I8: what AUTO resolves to now),
  *          "maxsim_screened" (queries served by the MaxSim screen), "maxsim_candidates" (docs re-scored exactly for them),

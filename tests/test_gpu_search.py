@@ -44,6 +44,31 @@ def test_search_matches_oracle(pkg, oracle, path, n, d, B, k):
         _check(idx, oracle, C, Q, k)
 
 
+@pytest.mark.parametrize("path", ["scan", "screen:bf16", "screen:i8", "auto"])
+@pytest.mark.parametrize("metric", ["cosine", "ip"])
+@pytest.mark.parametrize("n,d,B,k", [(9000, 1024, 40, 10), (6000, 1536, 300, 10), (5000, 2048, 1, 10), (4000, 3072, 130, 20),
+                                     (3000, 4096, 64, 10), (3000, 1500, 17, 5)])
+def test_wide_embeddings(pkg, oracle, path, metric, n, d, B, k):
+    """embedding sizes above the headline's 768 (e5-large 1024, OpenAI 1536 / 3072, 2048 / 4096-wide encoders, and one that is
+    not a multiple of 32): the reference's `VECTOR(dim)` column takes any `embedding_dim` (orm/schema_factory.py:31)"""
+    rng = np.random.default_rng(n + d + B)
+    C = rng.standard_normal((n, d)).astype(np.float32)
+    C /= np.linalg.norm(C, axis=1, keepdims=True)
+    if metric == "ip":
+        C *= rng.uniform(0.5, 2.0, size=(n, 1)).astype(np.float32)
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    with pkg.Mi355Index(d, metric) as idx:
+        if ":" in path:
+            path, screen = path.split(":")
+            idx.set_option("screen_dtype", screen)
+        idx.set_option("path", path)
+        idx.add(C)
+        rd, rr = oracle.topk_search(C, Q, k, metric=metric)
+        dist, rows = idx.search(Q, k)
+        assert np.array_equal(rows, rr)
+        assert np.array_equal(dist.view(np.uint64), rd.view(np.uint64))
+
+
 def test_k_larger_than_n_and_empty(pkg, oracle):
     rng = np.random.default_rng(5)
     C = rng.standard_normal((6, 32)).astype(np.float32)
@@ -269,7 +294,7 @@ def test_overflow_is_rescreened_before_the_exact_scan(pkg, oracle):
         idx.reset_stats()
         _check(idx, oracle, C, Q, k)
         assert idx.stat("retry_queries") >= 8 and idx.stat("fallback_queries") == 0
-        assert idx.stat("i8_demoted") == 1 and idx.stat("screen_dtype_active") == 1   # 8 of 64 > 5 %
+        assert idx.stat("i8_demoted") == 1 and idx.stat("screen_dtype_active") == 1   # 8 of 64 > 1 %
         idx.reset_stats()
         _check(idx, oracle, C, Q, k)                                                   # now bf16 from the start
         assert idx.stat("retry_queries") == 0 and idx.stat("fallback_queries") == 0
