@@ -81,6 +81,8 @@ struct mi355dr_index {
     int path = 0;  // MI355DR_PATH_AUTO
     int screen_dtype = 0;  // MI355DR_SCREEN_AUTO
     int retry_level = 0;   // > 0 while overflowed queries are re-screened: bf16 bound, slower chunk growth
+    int i8_backoff = 0, i8_probation = 0;  // demotion is not for ever: after i8_probation more blocks at such a k AUTO tries int8 again;
+                                           // the wait doubles (16 ... 4096 blocks) every time that try overflows again
     int i8_demoted_k = INT_MAX;  // AUTO saw the int8 bound overflow on this corpus' score distribution at this k: bf16 from there up
     double i8_min_budget = 0.25;  // AUTO keeps the int8 screen while growth_budget(k, int8) stays above this (k <= 133)
     // buffers of the sub-block a search at retry level L re-screens (one set per level: the nested call owns the next)

@@ -592,6 +592,9 @@ int enqueue_block(mi355dr_index* idx, hipStream_t s, const float* q_dev, int B, 
     CHECK(ensure_qstate(idx));
     CHECK(pending_alloc(idx, p));
     idx->k_now = k;
+    // a demoted int8 screen (AUTO) is on probation: first attempts at a demoted k count it down, then int8 gets another try
+    if (idx->retry_level == 0 && idx->screen_dtype == MI355DR_SCREEN_AUTO && k >= idx->i8_demoted_k && --idx->i8_probation <= 0)
+        idx->i8_demoted_k = INT_MAX;
     const int Bpad = (int)round_up(B, screen_tile(B));
     if (idx->screen_dtype == MI355DR_SCREEN_I8 && !i8_available(idx) && idx->path != MI355DR_PATH_SCAN)
         return fail(idx, MI355DR_E_UNSUPPORTED, "int8 screen unavailable: too many rows outside the residual limit");
@@ -691,7 +694,14 @@ int complete_block(mi355dr_index* idx, Pending& p) {
         // re-screen is a bf16 pass of its own, and lists that overflow are lists that cost -- at d = 2048 (the int8 bound is
         // absolute, ~0.0175, the spread of the scores shrinks like 1 / sqrt(d)) 1.5 % of the queries overflowed and the pass
         // took 17.1 ms against 12.9 on bf16; at d = 768 nothing overflows.  (Round 2: 5 %.)
-        if (p.was_i8 && idx->screen_dtype == MI355DR_SCREEN_AUTO && n_retry * 100 > B) idx->i8_demoted_k = std::min(idx->i8_demoted_k, k);
+        // Not for ever -- a burst of queries into one dense neighbourhood must not cost a Gaussian-like corpus its int8 screen
+        // (7.4 against 12.8 ms per block at the headline size): after 16 more blocks at such a k int8 gets another try, and the
+        // wait doubles (up to 4096 blocks) whenever that try overflows again.
+        if (p.was_i8 && idx->screen_dtype == MI355DR_SCREEN_AUTO && n_retry * 100 > B) {
+            idx->i8_demoted_k = std::min(idx->i8_demoted_k, k);
+            idx->i8_backoff = idx->i8_backoff == 0 ? 16 : std::min(idx->i8_backoff * 2, 4096);
+            idx->i8_probation = idx->i8_backoff;
+        }
         idx->retry_level = level + 1;
         rc = search_block(idx, s, idx->retry_q[level] + (size_t)n_todo * idx->dim, n_retry, k,
                           idx->retry_dist[level] + (size_t)n_todo * k, idx->retry_rows[level] + (size_t)n_todo * k);
@@ -1053,6 +1063,7 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
         if (value < 0 || value > 2) return fail(idx, MI355DR_E_INVALID, "screen_dtype must be 0,1,2");
         idx->screen_dtype = (int)value;
         idx->i8_demoted_k = INT_MAX;  // (setting the option again re-arms AUTO)
+        idx->i8_backoff = idx->i8_probation = 0;
     } else if (k == "i8_min_budget_x100") {
         if (value < 1 || value > 1000) return fail(idx, MI355DR_E_INVALID, "i8_min_budget_x100 must be in 1..1000");
         idx->i8_min_budget = (double)value / 100.0;

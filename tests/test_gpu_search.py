@@ -298,7 +298,16 @@ def test_overflow_is_rescreened_before_the_exact_scan(pkg, oracle):
         idx.reset_stats()
         _check(idx, oracle, C, Q, k)                                                   # now bf16 from the start
         assert idx.stat("retry_queries") == 0 and idx.stat("fallback_queries") == 0
-        idx.set_option("screen_dtype", "auto")                                         # re-arms AUTO
+        # demotion is a probation, not a verdict: 16 more blocks at such a k, then int8 gets another try (and, overflowing
+        # again, waits 32)
+        q_easy = rng.standard_normal((8, d)).astype(np.float32)
+        for _ in range(15):
+            idx.search(q_easy, k)
+        assert idx.stat("screen_dtype_active") == 2 and idx.stat("i8_demoted") == 0
+        idx.reset_stats()
+        _check(idx, oracle, C, Q, k)
+        assert idx.stat("retry_queries") >= 8 and idx.stat("i8_demoted") == 1
+        idx.set_option("screen_dtype", "auto")                                         # re-arms AUTO at once
         assert idx.stat("screen_dtype_active") == 2
     # a denser neighbourhood (6000 rows within 0.005): re-screening (bf16 at half the growth, then -- if that list
     # overflows too -- in chunks of <= 20 % of the rows, which splits the neighbourhood up) still avoids the exact scan
