@@ -297,6 +297,51 @@ def run_maxsim(args, n_docs: int, tokens: str, nq: int, steps: int, warmup: int,
     return out
 
 
+def power_probe(run_n_steps, s_per_step: float, seconds: float = 2.0) -> dict:
+    """Socket power and shader clock WHILE the steps run: `rocm-smi --showpower --showclocks` polled from a thread next to
+    ~`seconds` of back-to-back steps.  Medians over the samples taken after the first 0.4 s (the governor's ramp)."""
+    import re
+    import shutil
+    import statistics
+    import subprocess
+    import threading
+
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return {"error": "rocm-smi not found"}
+    samples, stop = [], threading.Event()
+
+    def poll():
+        t0 = time.perf_counter()
+        while not stop.is_set():
+            try:
+                out = subprocess.run([exe, "--showpower", "--showclocks", "--showmaxpower"], capture_output=True, text=True,
+                                     timeout=5).stdout
+            except Exception:  # noqa: BLE001
+                break
+            pw = re.search(r"GPU\[0\].*Socket Graphics Package Power \(W\): ([0-9.]+)", out)
+            ck = re.search(r"GPU\[0\].*sclk clock level: \S+ \((\d+)Mhz\)", out)
+            cap = re.search(r"GPU\[0\].*Max Graphics Package Power \(W\): ([0-9.]+)", out)
+            if pw and ck:
+                samples.append((time.perf_counter() - t0, float(pw.group(1)), int(ck.group(1)), float(cap.group(1)) if cap else None))
+
+    th = threading.Thread(target=poll, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    n = max(20, int(seconds / max(s_per_step, 1e-4)))
+    run_n_steps(n)
+    dt = time.perf_counter() - t0
+    stop.set()
+    th.join(timeout=6)
+    used = [x for x in samples if 0.4 <= x[0] <= dt] or samples
+    if not used:
+        return {"error": "no rocm-smi sample landed inside the burst", "burst_s": round(dt, 2)}
+    return {"socket_power_W_median": statistics.median(x[1] for x in used), "sclk_MHz_median": statistics.median(x[2] for x in used),
+            "power_cap_W": next((x[3] for x in used if x[3]), None), "sclk_max_MHz": 2400, "samples": len(used),
+            "burst": f"{n} steps in {dt:.2f} s ({dt / n * 1e3:.3f} ms per step)",
+            "note": "rocm-smi polled next to back-to-back steps of this workload; NOT part of the timed region"}
+
+
 def pmc_fetch_subrun(bench_args: list, kernel_substr: str, timeout_s: int = 240):
     """HBM read bytes per launch of the dominant kernel, MEASURED in this run: the same workload re-run for 3 steps under
     `rocprofv3 --kernel-trace --pmc FETCH_SIZE` (counters in a pass of their own, kernel trace only: MI355X_MICROARCH.md's HBM
@@ -904,6 +949,13 @@ def main() -> None:
                                     "note": f"planted-answer block (SURVEY 8d): 1-3 relevant rows per query, sigma in "
                                             f"{{0.3,0.6,1,5,7}} ({hard:.0%} of them hard: cos ~0.2/0.14); group-nDCG as the "
                                             "reference computes it (BEIR = one OR-group, hotpotqa = AND-chain)"}
+    if rank == 0 and world == 1 and not args.no_extras and B > 128:
+        # (1b) what the chip draws and clocks at under this workload: ~2 s of the same steps with rocm-smi sampled next to them
+        # (the screen kernels run AT the socket power cap, which -- not the schedule -- sets their clock)
+        try:
+            result["extra"]["power_probe"] = power_probe(lambda n: (run_steps(0, n), torch.cuda.synchronize()), elapsed / args.steps)
+        except Exception as e:  # noqa: BLE001 - a secondary figure must not take the line down
+            result["extra"]["power_probe"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_extras:
         # (2) PCIe-inclusive rate: the host entry point (H2D of the query block, D2H of [B,k]) instead of device buffers
         qh = [qpool[i % n_pool].cpu().numpy() for i in range(3)]
