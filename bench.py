@@ -183,7 +183,7 @@ def cpu_shape_baselines(Cs: np.ndarray, Qs: np.ndarray, k: int, metric: str, n_t
     return out
 
 
-def run_maxsim(args, n_docs: int, tokens: str, nq: int, steps: int, warmup: int, cpu_sample_docs: int = 0) -> dict:
+def run_maxsim(args, n_docs: int, tokens: str, nq: int, steps: int, warmup: int, cpu_sample_docs: int = 0, probe: bool = False) -> dict:
     """MaxSim top-k (VectorChord `@#`) on a synthetic multi-vector store built ON THE DEVICE (token vectors generated in
     HBM, handed to the index by pointer: mi355dr_add_multivec_device).  `tokens` = "text" (ColBERT-like: U{32..180} vectors
     per doc) or "page" (ColPali-like: 1030 patch vectors per doc); d = 128, unit-norm vectors, seed 777.
@@ -236,6 +236,12 @@ def run_maxsim(args, n_docs: int, tokens: str, nq: int, steps: int, warmup: int,
     el = time.perf_counter() - t0
     idx.set_option("profile", 0)
     assert (np.diff(res[0], axis=1) >= 0).all()
+    probe_out = None
+    if probe:  # socket power / shader clock next to ~2 s of the same steps (not timed)
+        try:
+            probe_out = power_probe(lambda n: [step(i % (warmup + steps)) for i in range(n)], el / steps)
+        except Exception as e:  # noqa: BLE001
+            probe_out = {"error": f"{type(e).__name__}: {e}"}
     blocks = int(((lens + 31) // 32).sum())
     alg_bytes = float(lens.sum()) * d * 4                        # fp32 token rows read once per 8-query pass
     streamed = float(blocks) * 32 * d * 2                        # bf16 fragment store the screen streams, per pass
@@ -293,6 +299,8 @@ def run_maxsim(args, n_docs: int, tokens: str, nq: int, steps: int, warmup: int,
                                "kind": "port", "sample": f"oracle MaxSim on the first {S} docs x {qblock} queries, scaled "
                                                          f"linearly to {n_docs} docs; {tc:.1f} s of CPU work",
                                "parity_on_sample": bool(np.array_equal(gr, rr) and np.array_equal(gd, rd))}
+    if probe_out is not None:
+        out["power_probe"] = probe_out
     idx.close()
     return out
 
@@ -387,12 +395,13 @@ def pmc_fetch_subrun(bench_args: list, kernel_substr: str, timeout_s: int = 240)
 def main_maxsim(args) -> None:
     """Secondary workload as the whole bench line: `python bench.py --workload maxsim [--docs N] [--tokens text|page]`."""
     r = run_maxsim(args, args.docs, args.tokens, 32 if args.tokens == "text" else 24, args.steps, args.warmup,
-                   0 if args.no_cpu_baseline else 2000)
+                   0 if args.no_cpu_baseline else 2000, probe=not args.no_extras)
     out = {"metric": "queries/sec", "value": r["queries_per_s"], "unit": "queries/s", "n_gpus": 1, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": r["workload"], "includes": r["includes"]}, "roofline": r["roofline"],
-           "extra": {kk: r[kk] for kk in ("queries_screened", "candidates_per_query", "exact_full_scan_fallbacks")}}
+           "extra": {kk: r[kk] for kk in ("queries_screened", "candidates_per_query", "exact_full_scan_fallbacks", "power_probe")
+                     if kk in r}}
     if "cpu_baseline" in r:
         out["cpu_baseline"] = r["cpu_baseline"]
     if not args.no_extras:
