@@ -567,6 +567,36 @@ def block_size_table(idx, torch, qpool, d: int, k: int, n_rows: int, device) -> 
     return out
 
 
+def other_k_line(idx, torch, qpool, B: int, k2: int, n_rows: int, device) -> dict:
+    """BASELINE.json quotes k in {10, 100}: the same corpus pass at the other k as a secondary figure (device buffers,
+    steps pipelined like the timed region)."""
+    stream = torch.cuda.current_stream().cuda_stream
+    out2 = [torch.empty((2, B, k2), device=device, dtype=torch.int64) for _ in range(2)]
+    n_pool = qpool.shape[0]
+
+    def run(first, count):
+        pend = None
+        for i in range(first, first + count):
+            o = out2[i & 1]
+            t = idx.search_device_async(qpool[i % n_pool].data_ptr(), B, k2, o[0].data_ptr(), o[1].data_ptr(), stream)
+            if pend is not None:
+                idx.search_wait(pend)
+            pend = t
+        idx.search_wait(pend)
+
+    run(0, 3)
+    torch.cuda.synchronize()
+    idx.reset_stats()
+    n = 10
+    t = time.perf_counter()
+    run(3, n)
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t) / n
+    return {"k": k2, "ms_per_step": round(t * 1e3, 3), "queries_per_s": round(B / t, 1),
+            "screen": "int8" if idx.stat("screen_dtype_active") == 2 else "bf16", "retry_queries": idx.stat("retry_queries"),
+            "fallback_queries": idx.stat("fallback_queries"), "rows": n_rows}
+
+
 def small_corpus_line(args, torch, pkg, qpool, device, local_rank, n_rows: int) -> dict:
     """SURVEY 8(d)'s second corpus size (N = 1 M) as a secondary figure of the same run: same generator, same 1024-query blocks."""
     d, B, k = args.dim, args.block, args.k
@@ -998,6 +1028,7 @@ def main() -> None:
     if rank == 0 and world == 1 and not args.no_extras:
         # (2c) SURVEY 8(d): the HBM-bound regime (1 / 32 / 128 queries per call) and the second corpus size
         result["extra"]["block_sizes"] = block_size_table(idx, torch, qpool, d, k, n_total, device)
+        result["extra"]["other_k"] = other_k_line(idx, torch, qpool, B, 10 if k == 100 else 100, n_total, device)
         if args.data == "gaussian" and n_total > 1_000_000:
             result["extra"]["n_1m"] = small_corpus_line(args, torch, pkg, qpool, device, local_rank, 1_000_000)
 

@@ -49,6 +49,7 @@ def test_default_shape_line_on_a_small_corpus(native_built):
     assert c["parity_on_sample"] is True                      # the GPU lists equal the oracle's on the sample, bit for bit
     x = d["extra"]
     assert x["fallback_queries"] == 0 and x["pcie_inclusive"]["queries_per_s"] < d["value"] * 1.05
+    assert x["other_k"]["k"] == 100 and x["other_k"]["fallback_queries"] == 0 and x["other_k"]["queries_per_s"] > 0
     assert "power_probe" in x and ("socket_power_W_median" in x["power_probe"] or "error" in x["power_probe"])
     assert d["ndcg_at_10"]["sample_check"]["identical"] is True   # planted answers: GPU ids / nDCG == the oracle's on the sample
 
