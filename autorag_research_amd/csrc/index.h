@@ -136,8 +136,12 @@ struct mi355dr_index {
     // RCCL communicator of a row-sharded index (mi355dr_comm.hip)
     void* comm = nullptr;
     int comm_rank = 0, comm_world = 0;
-    int64_t* comm_packed = nullptr;      // [2, kQBlockMax, k] this rank's packed block
-    int64_t* comm_packed_all = nullptr;  // [world, 2, kQBlockMax, k]
+    // two of each: block i's all-gather + merge run on comm_stream under block i + 1's search (mi355dr_search_sharded_device)
+    int64_t* comm_packed[2] = {nullptr, nullptr};      // [2, kQBlockMax, k] this rank's packed block
+    int64_t* comm_packed_all[2] = {nullptr, nullptr};  // [world, 2, kQBlockMax, k]
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t comm_done[2] = {nullptr, nullptr};      // gather + merge of the block that used buffer b have been enqueued / finished
+    bool comm_done_armed[2] = {false, false};
     size_t comm_cap = 0;
 
     // multi-vector store (MaxSim), owned by mi355dr_maxsim.hip

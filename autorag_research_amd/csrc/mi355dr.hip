@@ -355,8 +355,16 @@ PassPlan plan_pass(const mi355dr_index* idx, int B, int k, double growth) {
     const int64_t n = idx->n;
     const int tile = screen_tile(B);
     int64_t seen = 0;  // rows whose k-th best the first planned chunk's threshold comes from
-    if (idx->starter && k <= kStarterKMax && idx->retry_level == 0 && idx->chunk0_set == 0 && n >= 4 * 1024) {
-        p.sample = std::min<int64_t>(kStarterRows, n / 4) / kTileM * kTileM;
+    // the starter leaves one candidate per 64-row slab of its sample in every query's list: the list must hold them
+    // (option cand_cap goes down to 16: with fewer slots than slabs every list would start past its end and the whole block
+    // would be flagged for a re-screen), and the sample must offer at least k of them, else its prune publishes no threshold
+    // and the first regular chunk would run at thr = -inf WITHOUT the emit-all epilogue -- correct, pathologically slow
+    // (4096 <= n < 8192 with k in 17..32).  Either way: the emit-all ladder.
+    const int64_t starter_rows = std::min<int64_t>(kStarterRows, n / 4) / kTileM * kTileM;
+    const int64_t starter_slabs = (starter_rows + kSlabRows - 1) / kSlabRows;
+    if (idx->starter && k <= kStarterKMax && idx->retry_level == 0 && idx->chunk0_set == 0 && n >= 4 * 1024 &&
+        starter_slabs <= idx->cap && starter_slabs >= k) {
+        p.sample = starter_rows;
         seen = p.sample;
     } else {
         const int64_t c0 = std::min<int64_t>(n, round_up(std::max<int64_t>(tile, std::min<int64_t>(idx->chunk0_rows, idx->cap)), tile));

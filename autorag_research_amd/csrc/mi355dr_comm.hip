@@ -22,6 +22,7 @@ typedef int (*fn_comm_init_rank)(void** comm, int nranks, NcclUniqueId id, int r
 typedef int (*fn_comm_destroy)(void* comm);
 typedef int (*fn_all_gather)(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t s);
 typedef const char* (*fn_get_error_string)(int);
+typedef int (*fn_comm_count)(const void* comm, int* count);
 constexpr int kNcclInt64 = 4;
 
 struct RcclApi {
@@ -31,6 +32,7 @@ struct RcclApi {
     fn_comm_destroy comm_destroy = nullptr;
     fn_all_gather all_gather = nullptr;
     fn_get_error_string error_string = nullptr;
+    fn_comm_count comm_count = nullptr;
     std::string why;
 };
 
@@ -54,6 +56,7 @@ RcclApi& rccl() {
         api.comm_destroy = (fn_comm_destroy)dlsym(api.handle, "ncclCommDestroy");
         api.all_gather = (fn_all_gather)dlsym(api.handle, "ncclAllGather");
         api.error_string = (fn_get_error_string)dlsym(api.handle, "ncclGetErrorString");
+        api.comm_count = (fn_comm_count)dlsym(api.handle, "ncclCommCount");
         if (!api.get_unique_id || !api.comm_init_rank || !api.comm_destroy || !api.all_gather) api.why = "librccl lacks an entry point";
     });
     return api;
@@ -73,9 +76,16 @@ void comm_destroy(mi355dr_index* idx) {
         if (r.comm_destroy) (void)r.comm_destroy(idx->comm);
         idx->comm = nullptr;
     }
-    if (idx->comm_packed) (void)hipFree(idx->comm_packed);
-    if (idx->comm_packed_all) (void)hipFree(idx->comm_packed_all);
-    idx->comm_packed = idx->comm_packed_all = nullptr;
+    for (int i = 0; i < 2; ++i) {
+        if (idx->comm_packed[i]) (void)hipFree(idx->comm_packed[i]);
+        if (idx->comm_packed_all[i]) (void)hipFree(idx->comm_packed_all[i]);
+        idx->comm_packed[i] = idx->comm_packed_all[i] = nullptr;
+        if (idx->comm_done[i]) (void)hipEventDestroy(idx->comm_done[i]);
+        idx->comm_done[i] = nullptr;
+        idx->comm_done_armed[i] = false;
+    }
+    if (idx->comm_stream) (void)hipStreamDestroy(idx->comm_stream);
+    idx->comm_stream = nullptr;
     idx->comm_cap = 0;
 }
 }  // namespace mi355
@@ -115,6 +125,24 @@ int mi355dr_comm_init(mi355dr_index* idx, int rank, int world, const void* nccl_
 
 int mi355dr_comm_world(const mi355dr_index* idx) { return idx && idx->comm ? idx->comm_world : 0; }
 
+int mi355dr_comm_count(mi355dr_index* idx, int* out) {
+    if (!idx || !out) return mi355::fail(idx, MI355DR_E_INVALID, "null argument");
+    *out = 0;
+    if (!idx->comm) return MI355DR_OK;
+    RcclApi& r = rccl();
+    if (!r.comm_count) return mi355::fail(idx, MI355DR_E_UNSUPPORTED, "librccl lacks ncclCommCount");
+    int n = 0;
+    const int rc = r.comm_count(idx->comm, &n);
+    if (rc != 0) return nccl_fail(idx, "ncclCommCount", rc);
+    *out = n;
+    return MI355DR_OK;
+}
+
+// Two packed blocks, two gathered blocks, a second stream: block i + 1 is put on the caller's stream BEFORE the host waits for
+// block i (mi355dr_search_device_async / _wait), and block i's all-gather + merge run on the index's communication stream under
+// block i + 1's search.  A block's packed buffer is reused two blocks later: the search that writes it waits (on the stream) for
+// the gather that read it.  On return the caller's stream has been made to wait for the last merges, so the outputs are ordered
+// behind `stream` exactly as with the serial form.
 int mi355dr_search_sharded_device(mi355dr_index* idx, const float* queries_dev, int B, int k, double* out_dist_dev,
                                   int64_t* out_rows_dev, void* stream) {
     if (!idx) return mi355::fail(nullptr, MI355DR_E_INVALID, "null index");
@@ -122,35 +150,71 @@ int mi355dr_search_sharded_device(mi355dr_index* idx, const float* queries_dev, 
     if (B < 0 || k <= 0 || k > mi355::kKMax) return mi355::fail(idx, MI355DR_E_INVALID, "bad B / k");
     if ((int64_t)idx->comm_world * k > mi355::kSortMax) return mi355::fail(idx, MI355DR_E_UNSUPPORTED, "world*k exceeds 4096");
     if (B == 0) return MI355DR_OK;
+    if (!queries_dev || !out_dist_dev || !out_rows_dev) return mi355::fail(idx, MI355DR_E_INVALID, "null buffer");
     RcclApi& r = rccl();
     HIPCHECK(idx, hipSetDevice(idx->device));
     hipStream_t s = stream ? (hipStream_t)stream : idx->stream;
     const int world = idx->comm_world;
-    {   // staging: one packed [2, nb, k] int64 block per rank (plane 0 = float8 distance bits, plane 1 = global rows)
+    {   // staging: per buffer one packed [2, nb, k] int64 block per rank (plane 0 = float8 distance bits, plane 1 = global rows)
         std::lock_guard<std::mutex> g(idx->mu);
         const size_t need = (size_t)2 * mi355::kQBlockMax * k;
         if (idx->comm_cap < need) {
-            if (idx->comm_packed) (void)hipFree(idx->comm_packed);
-            if (idx->comm_packed_all) (void)hipFree(idx->comm_packed_all);
-            idx->comm_packed = idx->comm_packed_all = nullptr;
+            HIPCHECK(idx, hipDeviceSynchronize());  // (a previous call's gathers may still read the old buffers)
+            for (int i = 0; i < 2; ++i) {
+                if (idx->comm_packed[i]) (void)hipFree(idx->comm_packed[i]);
+                if (idx->comm_packed_all[i]) (void)hipFree(idx->comm_packed_all[i]);
+                idx->comm_packed[i] = idx->comm_packed_all[i] = nullptr;
+                idx->comm_done_armed[i] = false;
+            }
             idx->comm_cap = 0;
-            HIPCHECK(idx, hipMalloc(&idx->comm_packed, need * sizeof(int64_t)));
-            HIPCHECK(idx, hipMalloc(&idx->comm_packed_all, need * sizeof(int64_t) * world));
+            for (int i = 0; i < 2; ++i) {
+                HIPCHECK(idx, hipMalloc(&idx->comm_packed[i], need * sizeof(int64_t)));
+                HIPCHECK(idx, hipMalloc(&idx->comm_packed_all[i], need * sizeof(int64_t) * world));
+            }
             idx->comm_cap = need;
         }
+        if (!idx->comm_stream) HIPCHECK(idx, hipStreamCreateWithFlags(&idx->comm_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i)
+            if (!idx->comm_done[i]) HIPCHECK(idx, hipEventCreateWithFlags(&idx->comm_done[i], hipEventDisableTiming));
     }
-    for (int b0 = 0; b0 < B; b0 += mi355::kQBlockMax) {
-        const int nb = std::min(mi355::kQBlockMax, B - b0);
-        const size_t plane = (size_t)nb * k;
-        // the shard's list goes straight into the packed block (the float8 plane is written as doubles)
-        CHECK(mi355dr_search_device(idx, queries_dev + (int64_t)b0 * idx->dim, nb, k, (double*)idx->comm_packed,
-                                    idx->comm_packed + plane, s));
-        const int rc = r.all_gather(idx->comm_packed, idx->comm_packed_all, 2 * plane, kNcclInt64, idx->comm, s);
+    struct InFlight {
+        int64_t ticket = -1;
+        int buf = 0, b0 = 0, nb = 0;
+    } pend;
+    auto finish = [&](const InFlight& p) -> int {
+        // complete on the host (the library re-does the rare flagged queries here): the packed block is final and visible
+        CHECK(mi355dr_search_wait(idx, p.ticket));
+        const size_t plane = (size_t)p.nb * k;
+        const int rc = r.all_gather(idx->comm_packed[p.buf], idx->comm_packed_all[p.buf], 2 * plane, kNcclInt64, idx->comm,
+                                    idx->comm_stream);
         if (rc != 0) return nccl_fail(idx, "ncclAllGather", rc);
-        CHECK(mi355dr_merge_topk_packed_device(idx, idx->comm_packed_all, world, nb, k, out_dist_dev + (int64_t)b0 * k,
-                                               out_rows_dev + (int64_t)b0 * k, s));
+        CHECK(mi355dr_merge_topk_packed_device(idx, idx->comm_packed_all[p.buf], world, p.nb, k, out_dist_dev + (int64_t)p.b0 * k,
+                                               out_rows_dev + (int64_t)p.b0 * k, idx->comm_stream));
+        HIPCHECK(idx, hipEventRecord(idx->comm_done[p.buf], idx->comm_stream));
+        idx->comm_done_armed[p.buf] = true;
+        return MI355DR_OK;
+    };
+    int i = 0;
+    for (int b0 = 0; b0 < B; b0 += mi355::kQBlockMax, ++i) {
+        const int nb = std::min(mi355::kQBlockMax, B - b0), buf = i & 1;
+        const size_t plane = (size_t)nb * k;
+        // the gather that read this packed block two blocks (or one call) ago
+        if (idx->comm_done_armed[buf]) HIPCHECK(idx, hipStreamWaitEvent(s, idx->comm_done[buf], 0));
+        InFlight cur;
+        cur.buf = buf;
+        cur.b0 = b0;
+        cur.nb = nb;
+        // the shard's list goes straight into the packed block (the float8 plane is written as doubles)
+        CHECK(mi355dr_search_device_async(idx, queries_dev + (int64_t)b0 * idx->dim, nb, k, (double*)idx->comm_packed[buf],
+                                          idx->comm_packed[buf] + plane, s, &cur.ticket));
+        if (pend.ticket >= 0) CHECK(finish(pend));
+        pend = cur;
     }
-    return MI355DR_OK;  // asynchronous on `s` after the last block's search
+    if (pend.ticket >= 0) CHECK(finish(pend));
+    // outputs ordered behind the caller's stream
+    for (int b = 0; b < 2; ++b)
+        if (idx->comm_done_armed[b]) HIPCHECK(idx, hipStreamWaitEvent(s, idx->comm_done[b], 0));
+    return MI355DR_OK;  // asynchronous on `s`: the last merges run on the communication stream, `s` waits for them
 }
 
 }  // extern "C"

@@ -139,7 +139,7 @@ class Mi355HEAVENRetrievalPipeline(Mi355BaseRetrievalPipeline):
                 "stage1_weight": self.stage1_weight, "default_key_token_ratio": self.default_key_token_ratio}
 
     def _stored_query(self, query_id) -> tuple[str, Any, Any]:
-        q = self._service._store().get_query(query_id)
+        q = self._service.get_queries([query_id])[0]
         if q is None:
             raise ValueError(f"Query {query_id} not found")  # noqa: TRY003
         if q.embedding is None:

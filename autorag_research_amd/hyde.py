@@ -92,7 +92,7 @@ class Mi355HyDERetrievalPipeline(Mi355BaseRetrievalPipeline):
         return self._extract_response_content(response)
 
     def _query_text(self, query_id) -> str:
-        q = self._service._store().get_query(query_id)
+        q = self._service.get_queries([query_id])[0]
         if q is None:
             raise ValueError(f"Query {query_id} not found")  # noqa: TRY003  (fetch_query_texts, retrieval_pipeline.py:552-571)
         return q.contents

@@ -151,6 +151,12 @@ class Mi355Index:
     def comm_world(self) -> int:
         return int(self._lib.mi355dr_comm_world(self._h))
 
+    def comm_count(self) -> int:
+        """Ranks RCCL itself reports for this index's communicator (ncclCommCount); 0 before comm_init."""
+        n = ctypes.c_int(0)
+        check(self._h, self._lib.mi355dr_comm_count(self._h, ctypes.byref(n)))
+        return int(n.value)
+
     def search_sharded_device(self, q_ptr: int, B: int, k: int, out_dist_ptr: int, out_rows_ptr: int,
                               stream: int | None = None) -> None:
         """Local search + ONE ncclAllGather + merge, on device buffers (every rank: same queries in, same result out)."""

@@ -125,9 +125,7 @@ class _VectorSearchMixin:
         """One GPU block for the whole page; a query that cannot be scored (missing row / embedding) fails alone."""
         unit = self.retrieval_unit or "chunk"
         ok, bad = [], set()
-        store = self._service._store()
-        for qid in query_ids:
-            q = store.get_query(qid)
+        for qid, q in zip(query_ids, self._service.get_queries(list(query_ids)), strict=True):
             has = q is not None and ((q.embeddings is not None) if self.search_mode == "multi" else (q.embedding is not None))
             if has:
                 ok.append(qid)
@@ -182,7 +180,8 @@ class Mi355VectorSearchRetrievalPipeline(_VectorSearchMixin, Mi355BaseRetrievalP
     async def _retrieve_by_text(self, query_text: str, top_k: int) -> list[dict[str, Any]]:
         if self._embedding_model is None:
             raise EmbeddingError
-        query_embedding = await self._embedding_model.aembed_query(query_text)
+        # (one process per GPU: rank 0 embeds, every rank searches the same vector)
+        query_embedding = await self._service.on_root(lambda: self._embedding_model.aembed_query(query_text))
         return self._service.vector_search_by_embedding(query_embedding, top_k)
 
 
@@ -224,9 +223,9 @@ class Mi355ImageVectorSearchRetrievalPipeline(_VectorSearchMixin, Mi355BaseRetri
         if self._embedding_model is None:
             raise EmbeddingError
         if self.search_mode == "multi":
-            query_vectors = await self._embedding_model.aembed_query(query_text)
+            query_vectors = await self._service.on_root(lambda: self._embedding_model.aembed_query(query_text))
             return self._service.maxsim_search_by_embeddings([query_vectors], top_k, unit="image_chunk")[0]
-        query_vector = await self._embedding_model.aembed_query(query_text)
+        query_vector = await self._service.on_root(lambda: self._embedding_model.aembed_query(query_text))
         return self._service.vector_search_by_embedding(query_vector, top_k, unit="image_chunk")
 
 

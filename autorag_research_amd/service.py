@@ -56,10 +56,76 @@ class _World:
         return cls(dist)
 
     def from_root(self, make: Callable[[], Any]) -> Any:
-        """`make()` on rank 0, its (picklable) value on every rank."""
-        box = [make() if self.rank == 0 else None]
+        """`make()` on rank 0, its (picklable) value on every rank.  An exception raised by `make()` on rank 0 travels the
+        same way and is re-raised on EVERY rank: rank 0 always reaches the broadcast, so the other ranks never block on a
+        collective that rank 0 left through an exception (a database error in `get_or_create_pipeline` / `next_page`)."""
+        box: list[Any] = [None]
+        if self.rank == 0:
+            try:
+                box[0] = (True, make())
+            except Exception as e:  # noqa: BLE001 - re-raised below, on every rank
+                box[0] = (False, self._portable(e))
         self.dist.broadcast_object_list(box, src=0)
-        return box[0]
+        ok, value = box[0]
+        if not ok:
+            raise value
+        return value
+
+    @staticmethod
+    def _portable(e: Exception) -> Exception:
+        """The exception itself when it pickles (ValueError, KeyError ... the ones the reference's callers test for), else a
+        RuntimeError carrying its text."""
+        import pickle  # noqa: PLC0415
+
+        try:
+            pickle.loads(pickle.dumps(e))
+        except Exception:  # noqa: BLE001
+            return RuntimeError(f"{type(e).__name__}: {e}")
+        return e
+
+    def agree(self, ok: bool) -> bool:
+        """True iff `ok` on every rank: ranks settle the outcome of a rank-local step BEFORE any of them branches into a
+        different sequence of collectives (block answer vs per-query fallback vs retry)."""
+        flags: list[Any] = [None] * self.size
+        self.dist.all_gather_object(flags, bool(ok))
+        return all(flags)
+
+    def same_everywhere(self, what: str, digest: str) -> None:
+        """Fail loudly, on every rank, when the ranks did not compute the same `digest` (the exported table's key order:
+        global row ids are positions in that order, so two ranks that saw different orders would silently map each other's
+        rows to the wrong primary keys)."""
+        seen: list[Any] = [None] * self.size
+        self.dist.all_gather_object(seen, digest)
+        if any(d != seen[0] for d in seen):
+            raise RuntimeError(f"{what}: the ranks exported different tables ({len(set(seen))} distinct digests over "
+                               f"{self.size} ranks) -- the table changed during the export or the keys are not totally "
+                               "ordered; refusing to search with inconsistent global row ids")
+
+    def bind_device(self, device: int) -> None:
+        """nccl collectives and broadcast_object_list run on torch's CURRENT device: make it this rank's GPU (a launcher
+        that did not call torch.cuda.set_device would run every rank's collectives on cuda:0 -- a duplicate-GPU error or a
+        hang).  No-op on the gloo backend."""
+        if self.dist.get_backend() != "nccl":
+            return
+        import torch  # noqa: PLC0415
+
+        torch.cuda.set_device(device)
+
+
+def _table_digest(table: ChunkTable) -> str:
+    """Key order + NULL pattern of an exported table (what global row ids depend on)."""
+    import hashlib  # noqa: PLC0415
+
+    h = hashlib.sha256()
+    h.update(repr(len(table.ids)).encode())
+    for pk in table.ids:
+        h.update(repr(pk).encode())
+        h.update(b"\x00")
+    if table.embedding is not None:
+        h.update(np.ascontiguousarray(np.isnan(table.embedding).all(axis=1)).tobytes())
+    if table.mv_offsets is not None:
+        h.update(np.ascontiguousarray(table.mv_offsets, dtype=np.int64).tobytes())
+    return h.hexdigest()
 
 
 class _UnitIndex:
@@ -157,6 +223,8 @@ class Mi355RetrievalService:
         if self._world is not None and "LOCAL_RANK" in os.environ:
             device = int(os.environ["LOCAL_RANK"])
         self._device = device
+        if self._world is not None:
+            self._world.bind_device(device)
         self._units: dict[str, _UnitIndex] = {}
         self._uow_store: UowStore | None = None
         probe = session_factory()
@@ -185,8 +253,37 @@ class Mi355RetrievalService:
     def _unit(self, unit: str) -> _UnitIndex:
         if unit not in self._units:
             store = self._store()
-            self._units[unit] = _UnitIndex(store.image_chunks if unit == "image_chunk" else store.chunks, self._device)
+            table = store.image_chunks if unit == "image_chunk" else store.chunks
+            if self._world is not None:
+                # every rank exported the table by itself: global row ids are positions in the export order, so the ranks
+                # must have seen the SAME keys in the SAME order with the same NULL pattern before any of them shards it
+                self._world.same_everywhere(f"table {unit!r}", _table_digest(table))
+            self._units[unit] = _UnitIndex(table, self._device)
         return self._units[unit]
+
+    def get_queries(self, query_ids: list) -> list:
+        """The stored query rows (None = no such query).  One process per GPU: rank 0 reads them and every rank gets the same
+        rows -- a transient database error then happens once, on rank 0, and reaches every rank as the same exception instead
+        of sending one rank down the retry path while the others wait in the block's collective."""
+        read = lambda: [self._store().get_query(q) for q in query_ids]  # noqa: E731
+        return self._world.from_root(read) if self._world is not None else read()
+
+    async def on_root(self, make: Callable[[], Awaitable[Any]]) -> Any:
+        """`await make()` -- under a _World on rank 0 only, its value (or its exception) on every rank: an embedding-model
+        call in `_retrieve_by_text` is a rank-local step that may fail or differ between ranks."""
+        if self._world is None:
+            return await make()
+        box: list[Any] = [None]
+        if self._world.rank == 0:
+            try:
+                box[0] = (True, await make())
+            except Exception as e:  # noqa: BLE001
+                box[0] = (False, _World._portable(e))
+        self._world.dist.broadcast_object_list(box, src=0)
+        ok, value = box[0]
+        if not ok:
+            raise value
+        return value
 
     def close(self) -> None:
         for u in self._units.values():
@@ -202,6 +299,8 @@ class Mi355RetrievalService:
         return self._store().get_or_create_pipeline(name, config)
 
     def find_query_by_text(self, query_text: str):
+        if self._world is not None:
+            return self._world.from_root(lambda: self._store().find_query_by_text(query_text))
         return self._store().find_query_by_text(query_text)
 
     def _make_retrieval_result(self, table: ChunkTable, pos: int, score: float, with_content: bool) -> dict[str, Any]:
@@ -211,10 +310,8 @@ class Mi355RetrievalService:
     def vector_search(self, query_ids: list[int | str], top_k: int = 10,
                       search_mode: Literal["single", "multi"] = "single", unit: str = "chunk") -> list[list[dict]]:
         """Top-k for every query id, scored as one block.  Raises ValueError exactly like the reference."""
-        store = self._store()
         queries = []
-        for qid in query_ids:
-            q = store.get_query(qid)
+        for qid, q in zip(query_ids, self.get_queries(list(query_ids)), strict=True):
             if q is None:
                 raise ValueError(f"Query {qid} not found")  # noqa: TRY003
             if search_mode == "multi":
@@ -307,12 +404,12 @@ class Mi355RetrievalService:
     # ---- Guided Query Refinement support (reference retrieval_pipeline.py:573-641 + gqr_hybrid.py:306-362) ----
     def get_query_embedding(self, query_id) -> np.ndarray | None:
         """Stored single-vector query embedding as float64, None when the query or its embedding is missing (:573-587)."""
-        q = self._store().get_query(query_id)
+        q = self.get_queries([query_id])[0]
         return None if q is None or q.embedding is None else np.asarray(q.embedding, dtype=np.float64)
 
     def get_query_multi_embedding(self, query_id) -> np.ndarray | None:
         """Stored multi-vector query embedding [n_q, d] float64, or None (:589-603)."""
-        q = self._store().get_query(query_id)
+        q = self.get_queries([query_id])[0]
         return None if q is None or q.embeddings is None else np.asarray(q.embeddings, dtype=np.float64)
 
     def _gqr_handle(self) -> Mi355Index:
@@ -394,18 +491,26 @@ class Mi355RetrievalService:
             raise ValueError(f"Pipeline {pipeline_id!r} is configured for {configured} results; "
                              f"refusing to persist {unit} results into the same pipeline identity.")
 
+        world = self._world
+
         async def one(qid) -> list[dict] | None:
             assert retrieval_func is not None
             delay = retry_delay
             for attempt in range(max(1, max_retries)):
+                res, err = None, None
                 try:
-                    return await retrieval_func(qid, top_k)
-                except Exception:  # noqa: BLE001
-                    if attempt + 1 >= max(1, max_retries):
-                        logger.exception(f"Retrieval failed for query {qid} after {max_retries} attempts")
-                        return None
-                    await asyncio.sleep(min(max(delay, retry_delay), 60))
-                    delay *= 2
+                    res = await retrieval_func(qid, top_k)
+                except Exception as e:  # noqa: BLE001
+                    err = e
+                # one process per GPU: an attempt counts only if it succeeded on EVERY rank -- all ranks then retry (or give
+                # the query up) together, and their sequences of collective searches stay aligned
+                if (err is None) if world is None else world.agree(err is None):
+                    return res
+                if attempt + 1 >= max(1, max_retries):
+                    logger.error(f"Retrieval failed for query {qid} after {max_retries} attempts", exc_info=err)
+                    return None
+                await asyncio.sleep(min(max(delay, retry_delay), 60))
+                delay *= 2
             return None
 
         async def page(qids) -> list[list[dict] | None]:
@@ -417,7 +522,6 @@ class Mi355RetrievalService:
 
             return list(await asyncio.gather(*[guarded(q) for q in qids]))
 
-        world = self._world
         writer = world is None or world.rank == 0  # one process per GPU: rank 0 reads the page's ids and persists
         if world is not None:
             max_concurrency = 1  # the per-query fallback is a sequence of collective searches: the same order on every rank
@@ -444,15 +548,20 @@ class Mi355RetrievalService:
                 offset += batch_size
                 continue
             if block_func is not None:
+                results, block_err = None, None
                 try:
                     results = block_func(qids, top_k)
-                except Exception:  # noqa: BLE001
+                except Exception as e:  # noqa: BLE001
+                    block_err = e
+                # (one process per GPU: the page is answered as a block only if every rank's block succeeded)
+                if not ((block_err is None) if world is None else world.agree(block_err is None)):
                     # one bad query (missing / malformed embedding, too many query vectors for a block, an embedding-batch
                     # error) must not abort the run: the page falls back to the reference's per-query path, where retries,
                     # backoff and `failed_queries` apply to that query alone (retrieval_pipeline.py:222-236)
-                    logger.exception(f"block retrieval failed for a page of {len(qids)} queries; retrying it query by query")
+                    logger.error(f"block retrieval failed for a page of {len(qids)} queries; retrying it query by query",
+                                 exc_info=block_err)
                     if retrieval_func is None:
-                        raise
+                        raise block_err if block_err is not None else RuntimeError("block retrieval failed on another rank")
                     results = asyncio.run(page(qids))
             else:
                 results = asyncio.run(page(qids))

@@ -261,6 +261,18 @@ class UowStore:
         if len(set(ids)) != len(ids):
             raise RuntimeError(f"{repo_name}: the export returned {len(ids) - len(set(ids))} duplicate primary keys "
                                "(unordered paging over a table that changed?)")
+        # Rows in PRIMARY-KEY order whatever the statements returned: index row ids (and, one process per GPU, every rank's
+        # global row ids) are positions in this order.  The reference's ImageChunkRepository has no `get_all_ids`, so that
+        # table still pages with an unordered `get_all(limit, offset)`; N ranks scanning it at once is exactly what
+        # PostgreSQL's synchronize_seqscans reorders.  (Ties between equal distances fall to the smaller key -- the
+        # reference leaves that order to the database.)  service._unit() compares a digest of the result across ranks.
+        try:
+            order = sorted(range(len(ids)), key=ids.__getitem__)
+        except TypeError as e:  # mixed key types cannot be ordered: no deterministic export exists
+            raise RuntimeError(f"{repo_name}: primary keys of mixed types cannot be ordered") from e
+        if order != list(range(len(ids))):
+            ids, contents = [ids[i] for i in order], [contents[i] for i in order]
+            single, multi = [single[i] for i in order], [multi[i] for i in order]
         t = ChunkTable(ids=ids, contents=contents)
         d1 = next((v.shape[0] for v in single if v is not None), 0)
         if d1:

@@ -343,10 +343,10 @@ def power_probe(run_n_steps, s_per_step: float, seconds: float = 2.0) -> dict:
     th.join(timeout=6)
     used = [x for x in samples if 0.4 <= x[0] <= dt] or samples
     if not used:
-        return {"error": "no rocm-smi sample landed inside the burst", "burst_s": round(dt, 2)}
+        return {"error": "no rocm-smi sample landed inside the burst", "burst_s": round(dt, 4), "burst_steps": n}
     return {"socket_power_W_median": statistics.median(x[1] for x in used), "sclk_MHz_median": statistics.median(x[2] for x in used),
             "power_cap_W": next((x[3] for x in used if x[3]), None), "sclk_max_MHz": 2400, "samples": len(used),
-            "burst": f"{n} steps in {dt:.2f} s ({dt / n * 1e3:.3f} ms per step)",
+            "burst": f"{n} steps in {dt:.2f} s ({dt / n * 1e3:.3f} ms per step)", "burst_s": round(dt, 4), "burst_steps": n,
             "note": "rocm-smi polled next to back-to-back steps of this workload; NOT part of the timed region"}
 
 
@@ -763,7 +763,15 @@ def main() -> None:
             uid = [pkg.Mi355Index.comm_unique_id() if rank == first else None]
             dist.broadcast_object_list(uid, src=first, group=row_group)
             idx.comm_init(layout.shard, gworld, uid[0])
-    stream = torch.cuda.current_stream().cuda_stream
+    # Every search of this process runs on an EXPLICIT non-default stream, made torch's current stream from here on: the
+    # default stream's handle is 0, which the library reads as "use the index's own stream" -- a stream torch events do not
+    # see, so `wait_event(gather_done[buf])` below would order the wrong stream and step i + 2's search could overwrite
+    # packed2[buf] while step i's all-gather still reads it.  (sharded.py takes the same precaution.)
+    search_stream = torch.cuda.Stream(device)
+    search_stream.wait_stream(torch.cuda.current_stream())
+    torch.cuda.set_stream(search_stream)
+    stream = search_stream.cuda_stream
+    assert stream != 0, "the search stream must not be the null stream"
 
     def q_of(i: int):
         return qpool[(i * QG + layout.group) % n_pool]   # every query group serves its own block of the pool
@@ -926,6 +934,11 @@ def main() -> None:
             "layout": {"row_shards": R, "query_groups": QG, "rule": args.layout},
             "parallelism": f"{layout.describe()}" + ((" + one packed RCCL all-gather of the per-shard top-k + k_merge_topk per step, inside the timed loop (" + ("library RCCL communicator" if args.comm == "lib"
                             else "torch.distributed, on a second stream under the next step's search") + ")") if use_dist else ""),
+            "collective": ({"transport": "library RCCL communicator (ncclAllGather)" if args.comm == "lib"
+                            else "torch.distributed backend nccl (= RCCL)",
+                            "ranks_in_all_gather": int(dist.get_world_size(row_group)),
+                            "rccl_comm_count": idx.comm_count() if args.comm == "lib" else None,
+                            "search_stream_handle_nonzero": bool(stream != 0)} if use_dist else None),
             "stepping": "blocking call per step" if args.sync_steps else "async: block i+1 enqueued before the wait for block i (mi355dr_search_device_async)",
             "arithmetic": ("int8" if i8 else "bf16") + " MFMA screen over a normalised shadow corpus (rigorous "
                           "per-query error bound), exact fp32 chain re-score, float8 distance (results bit-exact vs "
@@ -992,7 +1005,17 @@ def main() -> None:
         # (1b) what the chip draws and clocks at under this workload: ~2 s of the same steps with rocm-smi sampled next to them
         # (the screen kernels run AT the socket power cap, which -- not the schedule -- sets their clock)
         try:
-            result["extra"]["power_probe"] = power_probe(lambda n: (run_steps(0, n), torch.cuda.synchronize()), elapsed / args.steps)
+            pp = power_probe(lambda n: (run_steps(0, n), torch.cuda.synchronize()), elapsed / args.steps)
+            result["extra"]["power_probe"] = pp
+            if "burst_s" in pp and "burst_steps" in pp:
+                # the timed region above is a fraction of a second; this is the same loop held for >= 2 s (the governor settles
+                # at the socket power cap after ~0.4 s): the rate a long-running job sees
+                result["extra"]["sustained"] = {
+                    "seconds": pp["burst_s"], "steps": pp["burst_steps"],
+                    "ms_per_step": round(pp["burst_s"] * 1e3 / pp["burst_steps"], 3),
+                    "queries_per_s": round(pp["burst_steps"] * B * QG / pp["burst_s"], 1),
+                    "socket_power_W_median": pp.get("socket_power_W_median"), "sclk_MHz_median": pp.get("sclk_MHz_median"),
+                    "note": "back-to-back steps of the timed loop for >= 2 s, synchronised at both ends; NOT `value`"}
         except Exception as e:  # noqa: BLE001 - a secondary figure must not take the line down
             result["extra"]["power_probe"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_extras:
@@ -1004,9 +1027,14 @@ def main() -> None:
         for i in range(5):
             idx.search(qh[i % 3], k)
         t1 = (time.perf_counter() - t1) / 5
+        # "end-to-end QPS includes H2D of the query block and D2H of [B,k]" -- a top-level sibling of `value`
+        # (`value` itself keeps inputs resident in HBM: the task's bench contract)
+        result["value_pcie_inclusive"] = {
+            "value": round(B / t1, 1), "unit": "queries/s", "ms_per_step": round(t1 * 1e3, 3),
+            "note": "mi355dr_search: pageable host queries in (H2D of the query block), float8 distances + int64 rows "
+                    "out (D2H of [B,k]), one blocking call per step; corpus upload excluded"}
         result["extra"]["pcie_inclusive"] = {"ms_per_step": round(t1 * 1e3, 3), "queries_per_s": round(B / t1, 1),
-                                             "note": "mi355dr_search: pageable host queries in (H2D), float8 distances + "
-                                                     "int64 rows out (D2H), one blocking call per step; NOT `value`"}
+                                             "note": "same figure as the top-level value_pcie_inclusive (kept for older readers)"}
 
     if rank == 0 and world == 1 and not args.no_extras:
         # (2b) the reference's own call shape: ONE query per call (pipelines/retrieval/vector_search.py:157-169), through the

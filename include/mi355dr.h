@@ -186,8 +186,13 @@ int mi355dr_merge_topk_packed_device(mi355dr_index* idx, const int64_t* packed_a
 int mi355dr_comm_unique_id(void* out_128_bytes, size_t len);
 int mi355dr_comm_init(mi355dr_index* idx, int rank, int world, const void* nccl_unique_id, size_t id_len);
 int mi355dr_comm_world(const mi355dr_index* idx);  /* 0 before mi355dr_comm_init */
-/* device buffers in / out like mi355dr_search_device; every rank passes the same queries and receives the same result;
- * asynchronous on `stream` (NULL = the index's own stream) after the last block's local search */
+/* the rank count RCCL itself reports for the communicator (ncclCommCount): what a caller logs to show that the collective
+ * really spans N ranks; 0 before mi355dr_comm_init */
+int mi355dr_comm_count(mi355dr_index* idx, int* out);
+/* device buffers in / out like mi355dr_search_device; every rank passes the same queries and receives the same result.
+ * Blocks of 1024 queries are software-pipelined: block i + 1 is searched while block i's all-gather + merge run on the
+ * index's communication stream (two packed / gathered buffers).  Asynchronous on `stream` (NULL = the index's own stream):
+ * on return `stream` has been made to wait for the last merge. */
 int mi355dr_search_sharded_device(mi355dr_index* idx, const float* queries_dev, int B, int k, double* out_dist_dev,
                                   int64_t* out_rows_dev, void* stream);
 

@@ -49,6 +49,13 @@ def test_default_shape_line_on_a_small_corpus(native_built):
     assert c["parity_on_sample"] is True                      # the GPU lists equal the oracle's on the sample, bit for bit
     x = d["extra"]
     assert x["fallback_queries"] == 0 and x["pcie_inclusive"]["queries_per_s"] < d["value"] * 1.05
+    # the PCIe-inclusive rate is a top-level sibling of `value`; the >= 2 s sustained figure sits next to the burst
+    v = d["value_pcie_inclusive"]
+    assert v["unit"] == "queries/s" and 0 < v["value"] < d["value"] * 1.05 and v["ms_per_step"] > 0
+    if "error" not in x["power_probe"]:
+        su = x["sustained"]
+        assert su["seconds"] >= 1.5 and su["steps"] >= 20 and su["ms_per_step"] > 0
+        assert abs(su["queries_per_s"] - su["steps"] * d["config"]["queries_per_step"] / su["seconds"]) <= 1e-3 * su["queries_per_s"]
     assert x["other_k"]["k"] == 100 and x["other_k"]["fallback_queries"] == 0 and x["other_k"]["queries_per_s"] > 0
     assert "power_probe" in x and ("socket_power_W_median" in x["power_probe"] or "error" in x["power_probe"])
     assert d["ndcg_at_10"]["sample_check"]["identical"] is True   # planted answers: GPU ids / nDCG == the oracle's on the sample
@@ -59,3 +66,16 @@ def test_distributed_code_path_with_a_world_of_one(native_built):
                env={"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29541", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
     assert d["n_gpus"] == 1 and d["config"]["layout"]["row_shards"] == 1
     assert d["extra"]["identical_to_one_gpu"] is True         # all-gather + merge of one shard == the plain search
+    # the searches run on an explicit non-default stream (a null handle would make the library use its own stream, which the
+    # `wait_event(gather_done)` that protects the double-buffered packed blocks does not order), and the line says how many
+    # ranks the collective spans
+    c = d["config"]["collective"]
+    assert c["search_stream_handle_nonzero"] is True and c["ranks_in_all_gather"] == 1
+
+
+def test_distributed_code_path_through_the_library_communicator(native_built):
+    d = _bench("--rows", "500000", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--force-dist", "--comm", "lib",
+               env={"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29542", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
+    c = d["config"]["collective"]
+    assert c["rccl_comm_count"] == 1 and c["ranks_in_all_gather"] == 1   # ncclCommCount, asked of RCCL itself
+    assert d["extra"]["identical_to_one_gpu"] is True

@@ -41,13 +41,31 @@ idx.set_option("row_offset", 1000)
 idx.add(C)
 assert idx.comm_world() == 0
 idx.comm_init(0, 1, pkg.Mi355Index.comm_unique_id())
-assert idx.comm_world() == 1
+assert idx.comm_world() == 1 and idx.comm_count() == 1   # (comm_count: ncclCommCount, RCCL's own answer)
 qd = torch.from_numpy(Q).cuda()
 od = torch.empty((B, k), dtype=torch.float64, device="cuda")
 orow = torch.empty((B, k), dtype=torch.int64, device="cuda")
 idx.search_sharded_device(qd.data_ptr(), B, k, od.data_ptr(), orow.data_ptr(), torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize()
 assert np.array_equal(orow.cpu().numpy(), rr) and np.array_equal(od.cpu().numpy().view(np.uint64), rd.view(np.uint64))
+# more than one block per call: block i + 1 is searched while block i's all-gather + merge run on the communication stream
+# (two packed buffers), on an explicit non-default stream, twice in a row (the second call reuses the buffers)
+Q3 = rng.standard_normal((2500, d)).astype(np.float32)
+with pkg.Mi355Index(d) as ref3:
+    ref3.set_option("row_offset", 1000)
+    ref3.add(C)
+    rd3, rr3 = ref3.search(Q3, k)
+q3 = torch.from_numpy(Q3).cuda()
+o3d = torch.empty((2500, k), dtype=torch.float64, device="cuda")
+o3r = torch.empty((2500, k), dtype=torch.int64, device="cuda")
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+for _ in range(2):
+    o3d.zero_(); o3r.zero_()
+    side.wait_stream(torch.cuda.current_stream())
+    idx.search_sharded_device(q3.data_ptr(), 2500, k, o3d.data_ptr(), o3r.data_ptr(), side.cuda_stream)
+    side.synchronize()   # `side` was made to wait for the last merges
+    assert np.array_equal(o3r.cpu().numpy(), rr3) and np.array_equal(o3d.cpu().numpy().view(np.uint64), rd3.view(np.uint64))
 idx.close()
 
 # (2) ShardedSearcher over torch.distributed (nccl = RCCL), pipelined blocks

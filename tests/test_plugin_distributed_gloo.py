@@ -110,3 +110,104 @@ def test_pipeline_run_row_sharded_over_two_ranks(tmp_path, oracle):
     got = r0["image_rows"]["q2"]
     assert [c for c, _ in got] == [e["doc_id"] for e in exp]
     assert np.allclose([s for _, s in got], [e["score"] for e in exp], rtol=0, atol=1e-6)
+
+
+def _fault_worker(rank: int, world: int, port: int, out_dir: str):
+    """Rank-local faults under a _World: every rank must leave through the same door."""
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+
+    import autorag_research_amd.service as svc
+    from helpers import OracleIndex, build_golden_stores
+    from autorag_research_amd.pipelines import Mi355VectorSearchPipelineConfig
+
+    svc.Mi355Index = OracleIndex
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = {}
+    cfg = Mi355VectorSearchPipelineConfig(name="faults", search_mode="single", top_k=4, batch_size=4, retry_delay=0.0)
+
+    def make(store, name="faults"):
+        return cfg.get_pipeline_class()(session_factory=lambda: store, name=name, schema=None, **cfg.get_pipeline_kwargs())
+
+    def golden_store():
+        store, _ = build_golden_stores()
+        del store.queries["q_noemb"]
+        store.query_order.remove("q_noemb")
+        return store
+
+    # (1) rank 0's database call fails inside from_root: the SAME exception on every rank, nobody left in the broadcast
+    store = golden_store()
+    if rank == 0:
+        def boom(name, config):
+            raise KeyError("pipeline table is gone")
+        store.get_or_create_pipeline = boom
+    try:
+        make(store)
+        out["from_root"] = "no error"
+    except KeyError as e:
+        out["from_root"] = f"KeyError:{e.args[0]}"
+    # (2) the ranks exported the table in different orders: refused on every rank before anything is sharded
+    store = golden_store()
+    if rank == 1:
+        t = store.chunks
+        t.ids[0], t.ids[1] = t.ids[1], t.ids[0]
+    p = make(store, "order")
+    try:
+        p._service._unit("chunk")
+        out["digest"] = "no error"
+    except RuntimeError as e:
+        out["digest"] = "refused" if "different tables" in str(e) else str(e)
+    p.close()
+    # (3) + (4) rank 1 alone fails AFTER its block / its first per-query attempt: both ranks fall back / retry together
+    store = golden_store()
+    p = make(store, "flaky")
+    calls = {"block": 0, "one": 0}
+    real_block, real_one = p._retrieve_block, p._retrieve_by_id
+
+    def flaky_block(qids, k):
+        res = real_block(qids, k)
+        calls["block"] += 1
+        if rank == 1 and calls["block"] == 1:
+            raise MemoryError("host conversion of the page failed on this rank")
+        return res
+
+    async def flaky_one(qid, k):
+        res = await real_one(qid, k)
+        calls["one"] += 1
+        if rank == 1 and calls["one"] == 1:
+            raise MemoryError("first attempt failed on this rank")
+        return res
+
+    p._retrieve_block, p._retrieve_by_id = flaky_block, flaky_one
+    out["run"] = p.run(**cfg.get_run_kwargs())
+    out["calls"] = calls
+    out["rows"] = sorted(((q, c, s) for (pid, q), lst in store.chunk_results.items() for c, s in lst),
+                         key=lambda t: (str(t[0]), -t[2], str(t[1])))
+    p.close()
+    with open(os.path.join(out_dir, f"f{rank}.json"), "w") as f:
+        json.dump(out, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank_local_faults_do_not_split_the_ranks(tmp_path, oracle):
+    import torch.multiprocessing as mp
+
+    from helpers import GOLDEN
+
+    world, port = 2, _free_port()
+    mp.spawn(_fault_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (json.loads((tmp_path / f"f{r}.json").read_text()) for r in range(world))
+    gold_exec = json.loads((GOLDEN / "executor_golden.json").read_text())["store_factory"]
+    for r in (r0, r1):
+        assert r["from_root"] == "KeyError:pipeline table is gone"
+        assert r["digest"] == "refused"
+        assert r["run"]["total_queries"] == 6 and r["run"]["failed_queries"] == []
+        # page 1: the block failed on rank 1 -> both ranks answered its 4 queries one by one, the first of them twice
+        # (rank 1's first attempt failed); page 2 went through as a block on both
+        assert r["calls"] == {"block": 2, "one": 5}
+    assert r1["rows"] == []
+    assert [[q, c] for q, c, _ in r0["rows"]] == [[q, c] for q, c, _ in gold_exec["persisted"]]
