@@ -6,8 +6,11 @@ Mirrors, name for name:
   BiPaliEmbeddings    autorag_research/embeddings/bipali.py:53-250    SingleVectorMultiModalEmbedding: one vector per input
 The reference loads `colpali_engine` Col* / Bi* classes by `model_type` and moves every embedding through Python lists
 (`embeddings[0].cpu().tolist()`); these wrappers do the same when `colpali_engine` is importable, and take a ready
-`model` + `processor` pair otherwise (no checkpoint or colpali_engine offline: tests use the random-init stand-ins below,
-which reproduce the SHAPES -- 1030 patch vectors of 128 dims per page for the `pali` family).
+`model` + `processor` pair otherwise -- a colpali_engine module, or transformers' own `ColPaliForRetrieval` /
+`ColQwen2ForRetrieval` (their output object's `.embeddings` is unwrapped).  No checkpoint is reachable offline:
+tests/test_hf_models.py runs transformers' ColPaliForRetrieval from a small random config through these wrappers (and the
+`colpali_engine` loading branch through a module of that name that serves the same class); the random-init stand-ins below
+reproduce the full-size SHAPES -- 1030 patch vectors of 128 dims per page for the `pali` family.
 
 What is new: `encode_images_to_device` / `encode_texts_to_device` return the model's output as ONE ragged device tensor
 ([sum_T, d] fp32 + host offsets) and `index_images_on_device` hands it to the MaxSim store by pointer
@@ -89,6 +92,10 @@ class _EngineBacked:
         inputs = {k: (v.to(self.device) if hasattr(v, "to") else v) for k, v in inputs.items()}
         with torch.no_grad():
             out = self._model(**inputs)
+        # colpali_engine's Col* / Bi* modules return the embedding tensor itself (what the reference indexes with `[0]`,
+        # colpali.py:130-133); transformers' own ColPaliForRetrieval / ColQwen2ForRetrieval return an output object that
+        # carries it as `.embeddings`
+        out = getattr(out, "embeddings", out)
         return out, inputs
 
     def _text_inputs(self, texts: list[str], query: bool):
