@@ -173,6 +173,16 @@ class _UnitIndex:
             self.multi_rows = np.arange(off.shape[0] - 1)
         return self.multi_sharded
 
+    def single_positions(self) -> np.ndarray:
+        """index row -> table position for the single-vector column (`WHERE embedding IS NOT NULL` order), without building
+        an index (one process per GPU: no rank holds the whole table on its GPU)."""
+        if self.single_rows is None:
+            emb = self.table.embedding
+            if emb is None:
+                raise ValueError("table has no single-vector embeddings")
+            self.single_rows = np.nonzero(~np.isnan(emb).all(axis=1))[0]
+        return self.single_rows
+
     def ensure_single(self) -> Mi355Index:
         if self.single is None:
             emb = self.table.embedding
@@ -395,8 +405,9 @@ class Mi355RetrievalService:
         q = np.asarray(query_vectors, dtype=np.float32)
         if q.size == 0:
             return {pk: 0.0 for pk, _ in known}
-        ix = u.ensure_multi()
-        q = q.reshape(-1, ix.dim)
+        # one process per GPU: the token-sharded store -- every rank scores the candidates it owns, one all-gather of [1, m] fp32
+        ix = u.ensure_multi_sharded(self._world) if self._world is not None else u.ensure_multi()
+        q = q.reshape(-1, u.table.mv_tokens.shape[1])
         rows = np.array([[p for _, p in known]], dtype=np.int64)
         dist = ix.maxsim_subset(q, np.array([0, q.shape[0]], dtype=np.int32), rows)[0]
         return {pk: -float(dv) / q.shape[0] for (pk, _), dv in zip(known, dist) if dv == dv}
@@ -427,7 +438,10 @@ class Mi355RetrievalService:
         u = self._unit("chunk")
         if u.table.embedding is None:
             return None
-        u.ensure_single()
+        if self._world is not None:
+            u.single_positions()   # (the mapping only: the rows themselves are staged per page, see gqr_refine_single)
+        else:
+            u.ensure_single()
         inv = getattr(u, "_row_of_pos", None)
         if inv is None:
             inv = u._row_of_pos = {int(p): r for r, p in enumerate(u.single_rows)}
@@ -441,7 +455,8 @@ class Mi355RetrievalService:
         off = u.table.mv_offsets
         if off is None:
             return None
-        u.ensure_multi()
+        if self._world is None:
+            u.ensure_multi()
         if getattr(u, "_pos_of_id", None) is None:
             u._pos_of_id = {pk: i for i, pk in enumerate(u.table.ids)}
         pos = [u._pos_of_id.get(pk, -1) for pk in doc_ids]
@@ -449,12 +464,43 @@ class Mi355RetrievalService:
             return None
         return np.asarray(pos, dtype=np.int64)
 
+    # The refinement is a loop of n_steps (25) dependent steps over a pool of a few dozen candidates per query: under a
+    # _World it is NOT spread over the ranks (a collective per step for a few KB of work).  The pools' vectors -- a page's
+    # worth: kilobytes to a few MB -- are staged from the exported table into a scratch store on every rank and refined there,
+    # identically on every rank; no rank ever holds the whole table on its GPU for it (reference gqr_hybrid.py:366-406
+    # fetches the same vectors out of PostgreSQL per query).
+    @staticmethod
+    def _compact_pools(pools: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+        """[B,P] rows (-1 padded) -> (the distinct rows, ascending; the same pools in positions of that list)."""
+        pools = np.asarray(pools, dtype=np.int64)
+        live = pools >= 0
+        uniq, inv = np.unique(pools[live], return_inverse=True)
+        local = np.full(pools.shape, -1, dtype=np.int64)
+        local[live] = inv
+        return uniq, local
+
     def gqr_refine_single(self, queries: np.ndarray, pools: np.ndarray, comp: np.ndarray, **prm) -> np.ndarray:
-        return self._unit("chunk").ensure_single().gqr_refine(queries, pools, comp, **prm)
+        u = self._unit("chunk")
+        if self._world is None:
+            return u.ensure_single().gqr_refine(queries, pools, comp, **prm)
+        uniq, local = self._compact_pools(pools)
+        emb = u.table.embedding[u.single_positions()[uniq]]
+        with Mi355Index(emb.shape[1], "cosine", self._device) as scratch:
+            scratch.add(emb)
+            return scratch.gqr_refine(queries, local, comp, **prm)
 
     def gqr_refine_multi(self, qtok: np.ndarray, q_offsets: np.ndarray, pools: np.ndarray, comp: np.ndarray,
                          **prm) -> np.ndarray:
-        return self._unit("chunk").ensure_multi().gqr_refine_maxsim(qtok, q_offsets, pools, comp, **prm)
+        u = self._unit("chunk")
+        if self._world is None:
+            return u.ensure_multi().gqr_refine_maxsim(qtok, q_offsets, pools, comp, **prm)
+        uniq, local = self._compact_pools(pools)   # (multi-vector rows are table positions)
+        tok, off = u.table.mv_tokens, u.table.mv_offsets
+        lens = off[uniq + 1] - off[uniq]
+        sub = np.concatenate([tok[off[p]:off[p + 1]] for p in uniq], axis=0) if len(uniq) else tok[:0]
+        with Mi355Index(tok.shape[1], "cosine", self._device) as scratch:
+            scratch.add_multivec(sub, np.concatenate([[0], np.cumsum(lens)]).astype(np.int64))
+            return scratch.gqr_refine_maxsim(qtok, q_offsets, local, comp, **prm)
 
     def gqr_refine_scores(self, primary: np.ndarray, counts: np.ndarray, comp: np.ndarray, **prm) -> np.ndarray:
         return self._gqr_handle().gqr_refine_scores(primary, counts, comp, **prm)

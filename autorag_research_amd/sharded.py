@@ -302,6 +302,31 @@ class ShardedSearcher:
         out_d, out_r = merge_topk_host(np.ascontiguousarray(g[:, 0]).view(np.float64), np.ascontiguousarray(g[:, 1]), k)
         return out_d.astype(np.float32), out_r
 
+    def maxsim_subset(self, qtok, q_offsets, doc_ids, clamp0: bool = False) -> np.ndarray:
+        """Late-interaction distance of EXPLICIT candidates (global doc ids, [B,m]) over a token-sharded store: every rank
+        scores the candidates it owns (mi355dr_maxsim_subset leaves NaN for ids outside its shard), ONE all-gather of the
+        [B,m] fp32 block, and the owner's value wins.  Every rank passes the same arguments and gets the same [B,m] result --
+        bit for bit what one store holding every doc returns (a candidate is scored by exactly one rank, with the same kernel).
+        Callers: HEAVEN stage 2 (reference heaven.py:244-266), the ColBERT reranker form with `clamp0`."""
+        ids = np.ascontiguousarray(doc_ids, dtype=np.int64)
+        if ids.ndim == 1:
+            ids = ids[None, :]
+        kw = {"clamp0": True} if clamp0 else {}
+        local = np.ascontiguousarray(self.index.maxsim_subset(qtok, q_offsets, ids, **kw), dtype=np.float32)
+        if self.world == 1 and not self.force_pipeline:
+            return local
+        import torch
+
+        dev = torch.device("cuda", self.device) if self.backend == "nccl" else torch.device("cpu")
+        mine = torch.from_numpy(local).to(dev)
+        gathered = torch.empty((self.world,) + tuple(mine.shape), dtype=torch.float32, device=dev)
+        self._dist.all_gather_into_tensor(gathered.view(-1), mine.reshape(-1), group=self.group)
+        g = gathered.cpu().numpy()
+        out = g[0].copy()
+        for r in range(1, self.world):   # NaN = "not mine" (or a genuinely undefined score, which then stays NaN)
+            out = np.where(np.isnan(out), g[r], out)
+        return out
+
     def close(self) -> None:
         self.index.close()
 

@@ -67,7 +67,7 @@ class OracleIndex:
         n_docs = self._off.shape[0] - 1
         for b in range(ids.shape[0]):
             qb = q[q_offsets[b]:q_offsets[b + 1]]
-            for j, i in enumerate(ids[b]):
+            for j, i in enumerate(ids[b] - self.row_offset):   # ids are GLOBAL rows, like the search results (mi355dr.h)
                 if 0 <= i < n_docs and self._off[i + 1] > self._off[i] and qb.shape[0]:
                     doc = self._tok[self._off[i]:self._off[i + 1]]
                     if clamp0:  # ColBERT reranker form: every query token contributes max(0, max_j <q_i, d_j>)

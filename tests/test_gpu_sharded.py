@@ -103,6 +103,17 @@ sm.force_pipeline = True
 sm.add_local_multivec(tok, off, 500)
 sd, sr = sm.search_maxsim(qtok, qoff, 7)
 assert np.array_equal(sr, hr) and np.array_equal(sd.view(np.uint32), hd.view(np.uint32))
+# explicit candidates over the sharded store (HEAVEN stage 2 behind a _World): owned ids scored, foreign ids NaN, one all-gather
+cand = np.array([[500, 501, 1399, 499, 1400, 777], [900, 500, 1398, 5, 600, 601]], dtype=np.int64)   # 499 / 1400 / 5: not in this shard
+sub_q, sub_off = qtok[: qlens[0] + qlens[1]], qoff[:3]
+mv2 = pkg.Mi355Index(dm)
+mv2.set_option("row_offset", 500)
+mv2.add_multivec(tok, off)
+want = mv2.maxsim_subset(sub_q, sub_off, cand)
+mv2.close()
+got = sm.maxsim_subset(sub_q, sub_off, cand)
+assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(got).sum() == 3
+assert np.array_equal(got[~np.isnan(got)].view(np.uint32), want[~np.isnan(want)].view(np.uint32))
 sm.close()
 dist.destroy_process_group()
 print("SHARDED_OK")

@@ -211,3 +211,99 @@ def test_rank_local_faults_do_not_split_the_ranks(tmp_path, oracle):
         assert r["calls"] == {"block": 2, "one": 5}
     assert r1["rows"] == []
     assert [[q, c] for q, c, _ in r0["rows"]] == [[q, c] for q, c, _ in gold_exec["persisted"]]
+
+
+def _fake_tagger(tokens):
+    """(the deterministic POS stand-in tests/golden/make_golden.py patched into the reference: nltk is not installed)"""
+    return [(t, "NN" if len(t) % 2 == 0 else "VB") for t in tokens]
+
+
+def _rescore_worker(rank: int, world: int, port: int, out_dir: str):
+    """The candidate re-scorers behind a _World: HEAVEN stage 2 = `maxsim_subset` over the TOKEN-SHARDED
+    store (every rank scores the candidates it owns, one all-gather of [1, m] fp32, the owner's value wins); GQR = the pools'
+    vectors staged into a scratch store per page.  No rank builds a whole-table index."""
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import asyncio
+
+    import torch.distributed as dist
+
+    import autorag_research_amd.service as svc
+    from helpers import OracleIndex, build_golden_stores, check_gqr_flow, load_service_golden
+    from autorag_research_amd.heaven import Mi355HEAVENPipelineConfig, Mi355HEAVENRetrievalPipeline
+    from autorag_research_amd.pipelines import Mi355VectorSearchRetrievalPipeline
+
+    svc.Mi355Index = OracleIndex
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    store, _ = build_golden_stores()
+    gold = load_service_golden()
+    out = {}
+    cfg = Mi355HEAVENPipelineConfig(name="heaven", **gold["heaven_config"])
+    p = Mi355HEAVENRetrievalPipeline(lambda: store, "heaven", pos_tagger=_fake_tagger,
+                                     **{k: v for k, v in cfg.get_pipeline_kwargs().items() if "model" not in k})
+    out["heaven"] = {qid: asyncio.run(p._retrieve_by_id(qid, gold["top_k"])) for qid in gold["heaven"]}
+    u = p._service._unit("image_chunk")
+    out["heaven_whole_table_indices"] = int(u.single is not None) + int(u.multi is not None)
+    out["heaven_shard_docs"] = u.multi_sharded.index.n_docs()
+    out["heaven_shard_rows"] = len(u.single_sharded.index)
+    p.close()
+    # GQR: every golden case (embedding, multi-vector, forced-single and score-space branches), per query and as one block
+    services = []
+
+    def make_primary(mode):
+        c = Mi355VectorSearchRetrievalPipeline(lambda: store, f"vs_{mode}", search_mode=mode)
+        services.append(c._service)
+        return c
+
+    import autorag_research_amd.gqr as gqr_mod
+
+    made = []
+    real_init = gqr_mod.Mi355GQRHybridRetrievalPipeline.__init__
+
+    def spy_init(self, *a, **kw):
+        real_init(self, *a, **kw)
+        made.append(self._service)
+
+    gqr_mod.Mi355GQRHybridRetrievalPipeline.__init__ = spy_init
+    # (units are closed with their pipeline: count whole-table indices at close time)
+    whole = {"n": 0}
+    real_close = svc._UnitIndex.close
+
+    def spy_close(self):
+        whole["n"] += int(self.single is not None) + int(self.multi is not None)
+        real_close(self)
+
+    svc._UnitIndex.close = spy_close
+    check_gqr_flow(store, make_primary, atol=1e-9)
+    for s in services:
+        s.close()
+    out["gqr_services"] = len(made)
+    out["gqr_whole_table_indices"] = whole["n"]
+    with open(os.path.join(out_dir, f"s{rank}.json"), "w") as f:
+        json.dump(out, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_candidate_rescorers_run_on_the_sharded_stores(tmp_path, oracle):
+    import torch.multiprocessing as mp
+
+    from helpers import build_golden_stores, load_service_golden
+
+    world, port = 2, _free_port()
+    mp.spawn(_rescore_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (json.loads((tmp_path / f"s{r}.json").read_text()) for r in range(world))
+    gold = load_service_golden()
+    store, _ = build_golden_stores()
+    n_docs = len(store.image_chunks.ids)
+    # each rank holds about half of the tokens / rows and no rank holds a whole-table index
+    assert r0["heaven_shard_docs"] + r1["heaven_shard_docs"] == n_docs and 0 < r0["heaven_shard_docs"] < n_docs
+    assert 0 < r0["heaven_shard_rows"] < n_docs
+    for r in (r0, r1):
+        assert r["heaven_whole_table_indices"] == 0 and r["gqr_whole_table_indices"] == 0 and r["gqr_services"] > 0
+        for qid, exp in gold["heaven"].items():     # the reference's _retrieve_by_id dicts, on every rank
+            got = r["heaven"][qid]
+            assert [x["doc_id"] for x in got] == [e["doc_id"] for e in exp]
+            assert np.allclose([x["score"] for x in got], [e["score"] for e in exp], rtol=0, atol=1e-6)
