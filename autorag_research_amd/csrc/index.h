@@ -99,6 +99,9 @@ struct mi355dr_index {
     int maxsim_coop = -1;       // exact MaxSim on candidate lists: one workgroup per candidate (1), one wave (0), by document length (-1)
     int maxsim_persistent = 0;  // MaxSim screen (dims <= 128): persistent workgroups walking the docs in rounds.  A/B on one box
                                 // (interleaved A/B through this option, 1 M text docs / 100 k pages): text +-0, pages 4 % SLOWER -- off
+    int maxsim_wg = 1;  // MaxSim screen, 9..16 column blocks: the workgroup-cooperative form (k_maxsim_wg.h); 0: one wave per document
+                        // with the query fragments in LDS (k_maxsim16_d128<NCB, 8>) -- option "maxsim_wg", A/B and tests
+    int maxsim_pass_groups = 4;  // groups of <= 4 queries one pass of the MaxSim screen serves (1 .. 4; option "maxsim_pass_groups", A/B and tests)
     int maxsim_screen = 1; // 1: bf16 MFMA screen + exact re-score of the candidates, 0: exact kernel over every doc
     int64_t row_offset = 0;
     int round_a = 0;      // k_prune: rows re-scored before the cut is known (0 = max(32, 2k)); tuning option "round_a"
@@ -129,6 +132,7 @@ struct mi355dr_index {
     int64_t s_ms_screened = 0, s_ms_candidates = 0, s_ms_fallbacks = 0;  // MaxSim: queries screened, docs re-scored, full re-runs
     // option "profile": HIP-event time of the MaxSim screen launches (k_maxsim16*) and of the exact launches on candidate lists
     int64_t s_ms_screen_ns = 0, s_ms_screen_launches = 0, s_ms_exact_ns = 0, s_ms_exact_launches = 0;
+    int64_t s_ms_screen_cols = 0;  // query-vector columns (whole blocks of 32) the screen launches multiplied every token by
     hipEvent_t ms_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<mi355::EventPair> ev_pool, ev_pending;
     hipEvent_t t0 = nullptr, t1 = nullptr;

@@ -1,0 +1,237 @@
+// k_maxsim_wg.h -- the MaxSim bf16 screen for 9..16 column blocks of query vectors per pass (up to 16 queries x 32 vectors),
+// dims <= 128: ONE workgroup of 8 waves walks a contiguous range of documents as ONE stream of 32-token blocks; the waves
+// split the query COLUMNS, not the documents.
+//
+// Why a second form (round 4).  k_maxsim16_d128 gives every wave its own documents: the wave pulls its token fragments
+// HBM -> VGPR and multiplies them with every column block, reading each query fragment from LDS -- one ds_read_b128 per MFMA --
+// and pays the per-document epilogue (16 masked butterflies at 16 queries) alone.  At 16 queries per pass the pass is no
+// longer bound by the token stream but by the matrix pipe at the socket power cap (bench: 16 queries per pass ran no faster per
+// query than 8), so what is left to shave is everything around the MFMAs:
+//   * the query fragments of a wave's OWN column blocks (w and w + 8: at most two) stay in REGISTERS for the whole launch;
+//   * the token blocks go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction = one k-group fragment
+//     of a block, which the fragment-ordered bf16 copy stores contiguously), once per WORKGROUP: a ring of 7 stages of two
+//     blocks, six stages = 96 KiB per CU in flight, counted vmcnt waits, one barrier per stage placed between the MFMA bursts
+//     of a stage's two blocks; every wave reads a block's 8 fragments from LDS once and uses each for its one or two column
+//     blocks: 0.5 .. 1 LDS read per MFMA instead of 1, no token fragment ever crosses a VGPR on its way in;
+//   * the per-document epilogue is shared: the waves' per-column maxima meet in 2 KiB of LDS, wave w then sums the columns of
+//     queries w and w + 8 (one masked butterfly each instead of sixteen).
+// Column blocks w and w + 8 sit on the same wave, waves w and w + 4 on the same SIMD: 12 column blocks (sixteen 24-vector
+// queries) are 3 per SIMD, 16 are 4 per SIMD -- balanced.
+// The per-document sums add the column maxima in another order than k_maxsim16_d128 and the exact kernel do; the screen's
+// bound covers any order (search_maxsim_impl: e_acc).  Bit-exactness of the RESULTS is the exact re-score's business, as before.
+#pragma once
+#include "k_screen256_common.h"
+
+namespace mi355 {
+
+constexpr int kMwStages = 7;                 // ring stages
+constexpr int kMwStageBytes = 2 * 8192;      // two 32-token blocks of 128 dims bf16, fragment order [kk][lane][8]
+constexpr int kMwColmaxOff = kMwStages * kMwStageBytes;
+constexpr int kMwLds = kMwColmaxOff + 2 * 512 * (int)sizeof(float);  // + two parities of 512 column maxima
+static_assert(kMwLds <= 160 * 1024, "LDS per workgroup");
+
+template <int NCB>
+__global__ __launch_bounds__(512, 2) void k_maxsim16_wg(Ms16Args a, int64_t n_blocks) {
+    static_assert(NCB >= 9 && NCB <= 16, "this form serves 9..16 column blocks");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cb0 = wave, cb1 = wave + 8;
+    const bool two = cb1 < NCB;
+    float* const colmax = (float*)(smem + kMwColmaxOff);
+
+    // ---- this wave's query fragments: registers for the whole launch
+    ms_bf16x8 qf0[8], qf1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        qf0[i] = __builtin_bit_cast(ms_bf16x8, a.qfrag[(cb0 * 8 + i) * 64 + lane]);
+        qf1[i] = two ? __builtin_bit_cast(ms_bf16x8, a.qfrag[(cb1 * 8 + i) * 64 + lane]) : qf0[i];
+    }
+    // The fragments are "used" here, before any LDS-DMA is in flight: left to their first use, the compiler's s_waitcnt vmcnt(0)
+    // for these loads sits inside the block loop and drains the ring once per block (tests/test_build_pipeline.py pins the loop).
+    typedef int mw_i32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        asm volatile("" ::"v"(__builtin_bit_cast(mw_i32x4, qf0[i])));
+        asm volatile("" ::"v"(__builtin_bit_cast(mw_i32x4, qf1[i])));
+    }
+
+    // Block offsets are read through the SCALAR cache (constant address space: nothing in this launch writes them, and the
+    // index is made wave-uniform by hand): as vector loads their s_waitcnt vmcnt(0) -- one per document -- drained the
+    // LDS-DMA ring, and a text document is two stages long.
+    typedef const __attribute__((address_space(4))) int64_t c_i64;
+    c_i64* const boff = (c_i64*)(const int64_t*)a.blk_off;
+    auto uni = [](int64_t x) -> int64_t {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uint64_t)x);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((uint64_t)x >> 32));
+        return (int64_t)(((uint64_t)hi << 32) | lo);
+    };
+    // ---- this workgroup's documents: a contiguous range holding ~1/gridDim of the token blocks
+    auto first_doc_at = [&](int64_t t) -> int64_t {  // first doc whose first block is >= t (wave-uniform binary search)
+        int64_t lo = 0, hi = a.n_docs;               // blk_off[n_docs] = n_blocks >= t
+        while (lo < hi) {
+            const int64_t mid = uni((lo + hi) >> 1);
+            if (boff[mid] >= t) hi = mid;
+            else lo = mid + 1;
+        }
+        return uni(lo);
+    };
+    const int64_t g = blockIdx.x, G = gridDim.x;
+    const int64_t d0 = first_doc_at(n_blocks * g / G);
+    const int64_t d1 = g + 1 == G ? a.n_docs : first_doc_at(n_blocks * (g + 1) / G);
+    if (d0 >= d1) return;  // (workgroup-uniform)
+    const int64_t b_begin = boff[d0], b_end = boff[d1];
+    const int64_t n_my = b_end - b_begin;
+    const int64_t b_last = n_my > 0 ? b_end - 1 : 0;
+    const int64_t n_stages = (n_my + 1) >> 1;
+
+    const float kNaN = __uint_as_float(0x7FC00000u);
+    // queries whose sums this wave writes: wave and wave + 8
+    const int qa = wave, qb = wave + 8;
+    auto write_doc = [&](int64_t doc, float va, float vb) {
+        if (lane == 0) {
+            if (qa < a.nq_launch) a.dist[(int64_t)qa * a.n_docs + doc] = va;
+            if (qb < a.nq_launch) a.dist[(int64_t)qb * a.n_docs + doc] = vb;
+        }
+    };
+
+    // ---- document cursor: cur = the doc the stream is in, end_cur = its end block, end_next = the next doc's (one ahead)
+    int64_t cur = d0;
+    int64_t end_cur = boff[cur + 1];
+    int64_t end_next = cur + 2 <= a.n_docs ? boff[cur + 2] : end_cur;
+    int64_t pos = b_begin;  // next block of the stream to be multiplied
+    auto advance_doc = [&]() {  // to the next doc; empty docs on the way get NaN (the select skips them)
+        for (;;) {
+            cur = uni(cur + 1);
+            if (cur >= d1) return;
+            const int64_t prev_end = end_cur;
+            end_cur = end_next;
+            end_next = cur + 2 <= a.n_docs ? boff[cur + 2] : end_cur;
+            if (end_cur != prev_end) return;
+            write_doc(cur, kNaN, kNaN);
+        }
+    };
+    while (cur < d1 && end_cur == pos) {  // leading empty docs
+        write_doc(cur, kNaN, kNaN);
+        cur = uni(cur + 1);
+        if (cur >= d1) break;
+        end_cur = end_next;
+        end_next = cur + 2 <= a.n_docs ? boff[cur + 2] : end_cur;
+    }
+    if (n_my == 0) return;
+
+    float run0 = -__builtin_inff(), run1 = -__builtin_inff();
+    int par = 0;
+    auto finish_doc = [&]() {
+        // the two halves of the wave hold different token rows of the same query column
+        const float r0 = fmaxf(run0, __shfl_xor(run0, 32, kWave));
+        const float r1 = fmaxf(run1, __shfl_xor(run1, 32, kWave));
+        float* cm = colmax + par * 512;
+        if (lane < 32) {
+            cm[cb0 * 32 + lane] = r0;
+            if (two) cm[cb1 * 32 + lane] = r1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        MI355_BARRIER();
+        float out[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int qi = wave + 8 * s;
+            float part = 0.0f;
+            if (qi < a.nq_launch) {  // wave-uniform
+                const int c0 = a.q_col0[qi], len = a.q_len[qi];
+                if (lane < len) part += cm[c0 + lane];
+                if (lane + 64 < len) part += cm[c0 + 64 + lane];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, kWave);
+            }
+            out[s] = -part;
+        }
+        write_doc(cur, out[0], out[1]);
+        par ^= 1;  // (the buffer is rewritten two documents later: a barrier of the next document's epilogue lies between)
+        run0 = run1 = -__builtin_inff();
+    };
+
+    // ---- staging: wave w moves k-group fragment w of every block (1 KiB per instruction); past the range: the last block again
+    const char* const tokbase = (const char*)a.tok16;
+    const unsigned voff = (unsigned)lane * 16u;
+    int64_t s_issue = 0;  // next stage to stage
+    int slot_issue = 0;
+    auto issue_stage = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int64_t bi = b_begin + 2 * s_issue + u;
+            if (bi > b_last) bi = b_last;
+            glds16_saddr(tokbase + ((bi * 8 + wave) << 10), voff,
+                         lds_addr(smem + slot_issue * kMwStageBytes + u * 8192 + wave * 1024));
+        }
+        ++s_issue;
+        if (++slot_issue == kMwStages) slot_issue = 0;
+    };
+#pragma unroll 1
+    for (int s = 0; s < kMwStages; ++s) issue_stage();
+
+    ms_bf16x8 tfA[8], tfB[8];
+    auto read_block = [&](ms_bf16x8(&tf)[8], int slot, int u) {
+        const char* p = smem + slot * kMwStageBytes + u * 8192 + lane * 16;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) tf[kk] = __builtin_bit_cast(ms_bf16x8, *(const uint4*)(p + kk * 1024));
+    };
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto mul_block = [&](const ms_bf16x8(&tf)[8]) {
+        f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[0], qf0[0], zero, 0, 0, 0);
+#pragma unroll
+        for (int i = 1; i < 8; ++i) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[i], qf0[i], acc0, 0, 0, 0);
+        if (two) {  // wave-uniform
+            f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[0], qf1[0], zero, 0, 0, 0);
+#pragma unroll
+            for (int i = 1; i < 8; ++i) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[i], qf1[i], acc1, 0, 0, 0);
+            float m1 = acc1[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m1 = fmaxf(m1, acc1[r]);
+            run1 = fmaxf(run1, m1);
+        }
+        float m0 = acc0[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) m0 = fmaxf(m0, acc0[r]);
+        run0 = fmaxf(run0, m0);
+    };
+    auto after_block = [&]() {  // one block of the stream has been multiplied
+        ++pos;
+        if (pos == end_cur) {  // workgroup-uniform: the document is complete
+            finish_doc();
+            advance_doc();
+        }
+    };
+
+    // stage 0 has landed (this wave's pieces: the 2 (kMwStages - 1) youngest may still fly) and is visible
+    static_assert(kMwStages == 7, "the counted waits below are 2 * (kMwStages - 1) and 2 * (kMwStages - 2)");
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    MI355_BARRIER();
+    int slot = 0;
+    read_block(tfA, 0, 0);
+    read_block(tfB, 0, 1);
+    for (int64_t s = 0; s < n_stages; ++s) {
+        // ---- block A of stage s
+        mul_block(tfA);
+        after_block();
+        // ---- hand-over: this wave's pieces of stage s + 1 have landed, its last fragments of stage s are in registers
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        MI355_BARRIER();  // ... everybody's have, and everybody is done reading stage s: its slot is refilled with stage s + 7
+        issue_stage();
+        const int slot_n = slot + 1 == kMwStages ? 0 : slot + 1;
+        read_block(tfA, slot_n, 0);  // block A of stage s + 1: lands under block B's MFMAs
+        // ---- block B of stage s (the range may end on block A)
+        if (pos < b_end) {  // workgroup-uniform
+            mul_block(tfB);
+            after_block();
+        }
+        read_block(tfB, slot_n, 1);  // block B of stage s + 1: lands under its block A's MFMAs
+        slot = slot_n;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the dummy stages must land before the LDS is freed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+}  // namespace mi355

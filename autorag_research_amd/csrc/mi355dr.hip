@@ -1082,6 +1082,11 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
         idx->maxsim_coop = (int)value;
     } else if (k == "maxsim_persistent") {
         idx->maxsim_persistent = value != 0;
+    } else if (k == "maxsim_wg") {
+        idx->maxsim_wg = value != 0;
+    } else if (k == "maxsim_pass_groups") {
+        if (value < 1 || value > 4) return fail(idx, MI355DR_E_INVALID, "maxsim_pass_groups must be in 1..4");
+        idx->maxsim_pass_groups = (int)value;
     } else if (k == "row_offset") {
         idx->row_offset = value;
     } else if (k == "profile") {
@@ -1157,6 +1162,7 @@ int mi355dr_get_stat(mi355dr_index* idx, const char* key, int64_t* out) {
     else if (k == "maxsim_screen_launches") *out = idx->s_ms_screen_launches;
     else if (k == "maxsim_exact_ns") *out = idx->s_ms_exact_ns;
     else if (k == "maxsim_exact_launches") *out = idx->s_ms_exact_launches;
+    else if (k == "maxsim_screen_cols") *out = idx->s_ms_screen_cols;
     else if (k == "irregular_rows") *out = idx->irr_n;
     else if (k == "loose_rows") *out = idx->irr8_n;
     else if (k == "screen_dtype_active") *out = use_i8(idx) ? MI355DR_SCREEN_I8 : MI355DR_SCREEN_BF16;
@@ -1173,7 +1179,7 @@ int mi355dr_reset_stats(mi355dr_index* idx) {
     idx->s_screen_launches = idx->s_screen_ns = idx->s_screen_rows = idx->s_fallback_queries = idx->s_chunks =
         idx->s_passes = idx->s_big_launches = idx->s_big_ns = idx->s_big_rows = idx->s_starters = 0;
     idx->s_ms_screened = idx->s_ms_candidates = idx->s_ms_fallbacks = idx->s_retry_queries = 0;
-    idx->s_ms_screen_ns = idx->s_ms_screen_launches = idx->s_ms_exact_ns = idx->s_ms_exact_launches = 0;
+    idx->s_ms_screen_ns = idx->s_ms_screen_launches = idx->s_ms_exact_ns = idx->s_ms_exact_launches = idx->s_ms_screen_cols = 0;
     if (idx->stat_dev) {
         HIPCHECK(idx, hipSetDevice(idx->device));
         HIPCHECK(idx, hipMemset(idx->stat_dev, 0, 2 * kQBlockMax * sizeof(unsigned long long)));

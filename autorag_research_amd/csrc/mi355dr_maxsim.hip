@@ -25,6 +25,9 @@
 //   (Dmax = largest token norm in the store) and |T - S| <= E = (eps + 2 n_q 2^-24) Dmax sum_i |q_i| for the
 //   per-doc sums.  k docs have T >= x_k (k-th best screen score) hence S >= x_k - E; any doc of the exact top-k
 //   (ties included) has S >= that, hence T >= x_k - 2E: the candidate set.
+#include <array>
+#include <utility>
+
 #include "index.h"
 
 using namespace mi355;
@@ -41,6 +44,12 @@ constexpr int kSegSort = kSortMax;  // select: largest segment (entries sorted p
 constexpr int kMsListGrid = 256;    // workgroups of a doc-list launch of k_maxsim (4 waves each stride over the list)
 constexpr int kMsRedBytes = 4 * 4 * 32 * 4;  // k_maxsim, cooperative list mode: [wave][column block][column] maxima
 constexpr int kMsCandCap = 8192;    // docs the screen may hand to the exact kernel per query (more: exact full scan)
+// One pass of the bf16 screen over the token store serves up to kMsPassGroups groups of <= 4 queries (dims <= 128): the pass is
+// bound by the HBM stream of the fragment copy up to ~8 column blocks and by the matrix pipe beyond, so every further query
+// that rides a pass costs MFMA time only -- 16 queries x 32 vectors = 16 column blocks = 128 KiB of query fragments in LDS.
+constexpr int kMsPassGroups = 4;
+constexpr int kMsPassQueries = 4 * kMsPassGroups;
+constexpr int kMsPassBlocks = 4 * kMsPassGroups;  // column blocks of 32 query vectors
 
 struct MultiVecStore {
     int64_t n_docs = 0;
@@ -56,8 +65,8 @@ struct MultiVecStore {
     double tok16_norm_max = 0.0;   // largest norm of a bf16-rounded token
     double tok_res_max = 0.0;      // largest residual norm |d - bf16(d)| of a token
     bool finite = true;            // every stored value is finite (else: no screen)
-    uint4* qfrag = nullptr;        // [8 * nkk * 64] query fragments of one screen launch (two groups of <= 4 queries)
-    float* dist16 = nullptr;       // [8, cap_docs] screen distances (rows 4..7: the group screened ahead)
+    uint4* qfrag = nullptr;        // [kMsPassBlocks * nkk * 64] query fragments of one screen launch (up to four groups of <= 4 queries)
+    float* dist16 = nullptr;       // [kMsPassQueries, cap_docs] screen distances (rows 4 g ..: the groups screened ahead)
     int32_t* cand_list = nullptr;  // [kMsCandCap]
     float* cand_dist = nullptr;    // [kMsCandCap]
     int* cand_ctl = nullptr;       // [2]: count, overflow flag
@@ -318,8 +327,8 @@ struct Ms16Args {
     int64_t n_docs;
     int nkk;
     int nq_launch;
-    int q_col0[8];          // (k_maxsim16_d128 serves two groups of <= 4 queries per launch: rows 0..3 and 4..7)
-    int q_len[8];
+    int q_col0[kMsPassQueries];  // (k_maxsim16_d128 serves up to FOUR groups of <= 4 queries per launch: rows 4 g .. 4 g + 3)
+    int q_len[kMsPassQueries];
 };
 
 __device__ __forceinline__ void ms16_load_piece(uint4 (&a)[8], const uint4* blk, int piece, int nkk, int lane) {
@@ -413,12 +422,15 @@ __global__ __launch_bounds__(kMsThreads, 2) void k_maxsim16(Ms16Args a) {
 // with the number of column blocks a template parameter: every loop is unrolled at compile time, the query fragments
 // stay in registers, LDS and global addresses are one base register + immediates, and the accumulator of a block
 // starts from the MFMA's inline-zero C operand instead of 16 v_mov. ----
-template <int NCB>
-__global__ __launch_bounds__(kMsThreads, 2) void k_maxsim16_d128(Ms16Args a) {
+// NW = waves per workgroup: 4 while two workgroups fit a CU (<= 8 column blocks = 64 KiB of query fragments each), 8 beyond
+// (one workgroup per CU by LDS: still two waves per SIMD).  A wave's documents do not depend on NW's siblings: no barrier
+// after the staging.
+template <int NCB, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void k_maxsim16_d128(Ms16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4* qs = (uint4*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < NCB * 8 * 64; i += kMsThreads) qs[i] = a.qfrag[i];
+    for (int i = tid; i < NCB * 8 * 64; i += NW * 64) qs[i] = a.qfrag[i];
     __syncthreads();
     const uint4* const ql = qs + lane;
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -428,11 +440,11 @@ __global__ __launch_bounds__(kMsThreads, 2) void k_maxsim16_d128(Ms16Args a) {
     // The grid may be smaller than the store (option maxsim_persistent): the workgroups then walk the documents in rounds of 4
     // docs per wave and stage the query fragments once.  Measured (round 3, interleaved on one box): no gain on 1 M text docs,
     // 4 % slower on 100 k pages -- the default grid is one round.
-    for (int64_t round = 0; round * ((int64_t)gridDim.x * 4 * kMsDocsPerWave) < a.n_docs; ++round) {
+    for (int64_t round = 0; round * ((int64_t)gridDim.x * NW * kMsDocsPerWave) < a.n_docs; ++round) {
     int64_t dq[kMsDocsPerWave], db0[kMsDocsPerWave], dnb[kMsDocsPerWave];
 #pragma unroll
     for (int dw = 0; dw < kMsDocsPerWave; ++dw) {
-        dq[dw] = ((round * kMsDocsPerWave + dw) * (int64_t)gridDim.x + blockIdx.x) * 4 + wave;
+        dq[dw] = ((round * kMsDocsPerWave + dw) * (int64_t)gridDim.x + blockIdx.x) * NW + wave;
         const bool live = dq[dw] < a.n_docs;
         db0[dw] = live ? a.blk_off[dq[dw]] : 0;
         dnb[dw] = live ? a.blk_off[dq[dw] + 1] - db0[dw] : 0;
@@ -445,14 +457,23 @@ __global__ __launch_bounds__(kMsThreads, 2) void k_maxsim16_d128(Ms16Args a) {
     };
     float run[NCB];
     auto block = [&](const uint4(&fr)[8]) {
+        // Up to 8 column blocks the compiler keeps as many query fragments in registers as fit (they are loop-invariant) and
+        // reads the rest per MFMA.  Beyond 8 that hoisting only costs: 16 blocks x 32 VGPRs cannot stay, and what it keeps anyway
+        // pushes the kernel into scratch (10 spilled VGPRs at 16 blocks).  There the base pointer is made opaque once per token
+        // block: every fragment is one ds_read_b128 in front of its MFMA, 128 B/clk per CU at the full matrix rate -- half of
+        // what the LDS delivers.
+        typedef const __attribute__((address_space(3))) uint4 lds_uint4;
+        unsigned qoff = (unsigned)(unsigned long)((const __attribute__((address_space(3))) char*)(const char*)ql);
+        if constexpr (NCB > 8) asm volatile("" : "+v"(qoff));  // (an LDS byte offset: the reads stay ds_read_b128, not FLAT)
+        lds_uint4* const qlb = (lds_uint4*)(unsigned long)qoff;
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ms_bf16x8, fr[0]),
-                                                                 __builtin_bit_cast(ms_bf16x8, ql[(cb * 8) * 64]), zero, 0, 0, 0);
+                                                                 __builtin_bit_cast(ms_bf16x8, qlb[(cb * 8) * 64]), zero, 0, 0, 0);
 #pragma unroll
             for (int i = 1; i < 8; ++i)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ms_bf16x8, fr[i]),
-                                                              __builtin_bit_cast(ms_bf16x8, ql[(cb * 8 + i) * 64]), acc, 0, 0, 0);
+                                                              __builtin_bit_cast(ms_bf16x8, qlb[(cb * 8 + i) * 64]), acc, 0, 0, 0);
             float m = acc[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
@@ -518,6 +539,10 @@ __global__ __launch_bounds__(kMsThreads, 2) void k_maxsim16_d128(Ms16Args a) {
     }
     }  // rounds
 }
+
+}  // namespace mi355
+#include "k_maxsim_wg.h"
+namespace mi355 {
 
 // fp32 -> sortable key (distance asc, NaN last)
 __device__ __forceinline__ uint64_t f32_to_key(float f) {
@@ -745,6 +770,61 @@ int ms_reserve(mi355dr_index* idx, MultiVecStore* m, int64_t want_blocks, int64_
     return MI355DR_OK;
 }
 
+}  // namespace
+
+// ---- k_maxsim16_d128<NCB, NW> by run-time NCB (1 .. kMsPassBlocks): NW = 4 up to 8 column blocks, 8 beyond ----
+namespace {
+typedef void (*Ms16Kernel)(mi355::Ms16Args);
+template <int NCB>
+constexpr Ms16Kernel ms16_kernel_of() {
+    if constexpr (NCB <= 8) return mi355::k_maxsim16_d128<NCB, 4>;
+    else return mi355::k_maxsim16_d128<NCB, 8>;
+}
+template <int... I>
+constexpr std::array<Ms16Kernel, sizeof...(I)> ms16_table(std::integer_sequence<int, I...>) {
+    return {ms16_kernel_of<I + 1>()...};
+}
+const std::array<Ms16Kernel, mi355::kMsPassBlocks> kMs16Kernels = ms16_table(std::make_integer_sequence<int, mi355::kMsPassBlocks>{});
+inline int ms16_waves(int ncb) { return ncb <= 8 ? 4 : 8; }
+
+// the workgroup-cooperative form (k_maxsim_wg.h) for 9 .. 16 column blocks
+typedef void (*Ms16WgKernel)(mi355::Ms16Args, int64_t);
+template <int... I>
+constexpr std::array<Ms16WgKernel, sizeof...(I)> ms16wg_table(std::integer_sequence<int, I...>) {
+    return {mi355::k_maxsim16_wg<I + 9>...};
+}
+const std::array<Ms16WgKernel, 8> kMs16WgKernels = ms16wg_table(std::make_integer_sequence<int, 8>{});
+
+int ms16_d128_prepare(mi355dr_index* idx) {
+    for (int ncb = 1; ncb <= mi355::kMsPassBlocks; ++ncb)
+        if (ncb * 8192 > 64 * 1024)
+            HIPCHECK(idx, hipFuncSetAttribute((const void*)kMs16Kernels[ncb - 1], hipFuncAttributeMaxDynamicSharedMemorySize, ncb * 8192));
+    for (auto kfn : kMs16WgKernels)
+        HIPCHECK(idx, hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, mi355::kMwLds));
+    return MI355DR_OK;
+}
+
+// one screen launch over every doc: each wave walks kMsDocsPerWave docs; `persistent`: only as many workgroups as are resident
+// at once, walking the docs in rounds (evened out: 100 k pages over 512 workgroups would be 12.2 rounds, a fifth of the chip
+// idle in the last one)
+int ms16_d128_launch(mi355dr_index* idx, hipStream_t s, int ncb, int64_t n_docs, int64_t n_blocks, bool persistent,
+                     const mi355::Ms16Args& sa) {
+    if (ncb >= 9 && idx->maxsim_wg) {
+        // one workgroup per CU, each a contiguous range of documents with ~1/256 of the token blocks (at least 32 blocks each)
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(256, (n_blocks + 31) / 32));
+        hipLaunchKernelGGL(kMs16WgKernels[ncb - 9], dim3(grid), dim3(512), (size_t)mi355::kMwLds, s, sa, n_blocks);
+        HIPCHECK(idx, hipGetLastError());
+        return MI355DR_OK;
+    }
+    const int nw = ms16_waves(ncb);
+    const unsigned grid_docs = (unsigned)((n_docs + (int64_t)nw * mi355::kMsDocsPerWave - 1) / ((int64_t)nw * mi355::kMsDocsPerWave));
+    const unsigned resident = ncb <= 10 && nw == 4 ? 512u : 256u;
+    const unsigned rounds = persistent ? (grid_docs + resident - 1) / resident : 1u;
+    const unsigned grid = std::max(1u, (grid_docs + rounds - 1) / std::max(rounds, 1u));
+    hipLaunchKernelGGL(kMs16Kernels[ncb - 1], dim3(grid), dim3(nw * 64), (size_t)ncb * 8 * 64 * sizeof(uint4), s, sa);
+    HIPCHECK(idx, hipGetLastError());
+    return MI355DR_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -1083,7 +1163,7 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
         // query's FIRST column on, which may run past column 127; those columns' results are never read)
         HIPCHECK(idx, hipMalloc(&m->qtok, (size_t)(kMsCols + 32) * dp * sizeof(float)));
         HIPCHECK(idx, hipMemsetAsync(m->qtok, 0, (size_t)(kMsCols + 32) * dp * sizeof(float), s));
-        HIPCHECK(idx, hipMalloc(&m->qfrag, 2 * lds16));
+        HIPCHECK(idx, hipMalloc(&m->qfrag, kMsPassGroups * lds16));
         HIPCHECK(idx, hipMalloc(&m->out_d, 4 * kKMax * sizeof(float)));
         HIPCHECK(idx, hipMalloc(&m->out_r, 4 * kKMax * sizeof(int64_t)));
         HIPCHECK(idx, hipMalloc(&m->cand_list, 4 * kMsCandCap * sizeof(int32_t)));
@@ -1096,10 +1176,7 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
         HIPCHECK(idx, hipFuncSetAttribute((const void*)k_maxsim, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + kMsRedBytes)));
         if (lds16 <= 160 * 1024)
             HIPCHECK(idx, hipFuncSetAttribute((const void*)k_maxsim16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
-        HIPCHECK(idx, hipFuncSetAttribute((const void*)k_maxsim16_d128<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 8192));
-        HIPCHECK(idx, hipFuncSetAttribute((const void*)k_maxsim16_d128<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 8192));
-        HIPCHECK(idx, hipFuncSetAttribute((const void*)k_maxsim16_d128<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 7 * 8192));
-        HIPCHECK(idx, hipFuncSetAttribute((const void*)k_maxsim16_d128<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192));
+        CHECK(ms16_d128_prepare(idx));
         HIPCHECK(idx, hipFuncSetAttribute((const void*)k_topk_segments, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           kSegSort * 12));
     }
@@ -1107,7 +1184,7 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
         if (m->dist) (void)hipFree(m->dist);
         if (m->dist16) (void)hipFree(m->dist16);
         HIPCHECK(idx, hipMalloc(&m->dist, (size_t)4 * m->cap_docs * sizeof(float)));
-        HIPCHECK(idx, hipMalloc(&m->dist16, (size_t)8 * m->cap_docs * sizeof(float)));
+        HIPCHECK(idx, hipMalloc(&m->dist16, (size_t)kMsPassQueries * m->cap_docs * sizeof(float)));
         for (int i = 0; i < 2; ++i) {
             if (m->sel[i]) (void)hipFree(m->sel[i]);
             HIPCHECK(idx, hipMalloc(&m->sel[i], (size_t)4 * ((m->cap_docs + kMsSelSeg - 1) / kMsSelSeg) * kMsFastK * sizeof(uint32_t)));
@@ -1134,7 +1211,7 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
     // bf16 round-to-nearest: unit roundoff 2^-8 per operand -> 2^-7 + 2^-16 per product
     const double eps = std::ldexp(1.0, -7) + std::ldexp(1.0, -15) + 3.0 * d * std::ldexp(1.0, -24);
     // pinned staging (pageable copies are synchronous and cost ~20 us each)
-    const size_t qimg_n = (size_t)kMsCols * dp, qf16_n = (size_t)8 * nkk * 64 * 8;
+    const size_t qimg_n = (size_t)kMsCols * dp, qf16_n = (size_t)kMsPassBlocks * nkk * 64 * 8;
     const size_t need_stage = qimg_n * 4 + qf16_n * 2 + 4 * kKMax * 12 + 64;
     if (m->stage_bytes < need_stage) {
         if (m->stage_host) (void)hipHostFree(m->stage_host);
@@ -1222,7 +1299,9 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
     };
     int b = 0;
     bool ms_screen_timed = false;  // option "profile": a screen launch is bracketed by ms_ev[0..1] and not read yet
-    int pre_first = -1;  // first query of the group whose screen distances already sit in rows 4..7 of dist16
+    // groups whose screen distances already sit in dist16 (screened together with an earlier group of the same pass):
+    // (first query of the group, slot = its row block 4 * slot .. 4 * slot + 3)
+    int pre_b[kMsPassGroups], pre_slot[kMsPassGroups], n_pre = 0;
     while (b < B) {
         HIPCHECK(idx, hipStreamSynchronize(s));  // the staging buffers are free again
         MsArgs a{};
@@ -1265,11 +1344,14 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
             CHECK(ms_topk(idx, m, s, m->dist, m->n_docs, k, seg, nullptr, nullptr, &cur));
             CHECK(ms_emit_result(idx, m, s, cur, k, out_dist + (int64_t)b * k, out_rows + (int64_t)b * k, out_dev));
             HIPCHECK(idx, hipStreamSynchronize(s));
-            pre_first = -1;
+            n_pre = 0;
             ++b;
             continue;
         }
-        const bool pre = pre_first == b;  // this group was screened together with the previous one
+        int slot = -1;  // > 0: this group was screened together with an earlier one (its distances: rows 4 * slot ..)
+        for (int i = 0; i < n_pre; ++i)
+            if (pre_b[i] == b) slot = pre_slot[i];
+        const bool pre = slot > 0;
         std::fill(qimg.begin(), qimg.end(), 0.0f);
         if (!pre) std::fill(qf16.begin(), qf16.end(), (uint16_t)0);
         const int first = b;
@@ -1288,10 +1370,9 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
         const bool screen = idx->maxsim_screen && m->finite && q_finite && lds16 <= 160 * 1024;
         float* dist16 = m->dist16;  // this group's screen distances: [4, n_docs]
         if (screen && pre) {
-            dist16 = m->dist16 + 4 * m->n_docs;
-            pre_first = -1;
+            dist16 = m->dist16 + (int64_t)4 * slot * m->n_docs;
         } else if (screen) {
-            pre_first = -1;
+            n_pre = 0;
             Ms16Args sa{};
             sa.tok16 = m->tok16;
             sa.blk_off = m->blk_off;
@@ -1305,22 +1386,38 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
                 sa.q_len[qi] = a.q_len[qi];
             }
             int ncb_launch = (col + 31) / 32;
-            // The screen is HBM-bound on the token stream: the NEXT group (<= 4 more queries) rides the same pass in column blocks
-            // 4..7 and rows 4..7 of dist16 (dims <= 128, the single-launch selection path); its turn then starts at the selection.
-            if (nkk == 8 && k <= kMsFastK && b < B) {
-                const Group H = pack(b, col, false);  // its columns follow this group's directly
-                if (H.nql > 0 && H.finite) {
-                    for (int qi = 0; qi < 4; ++qi) {
-                        sa.q_col0[4 + qi] = col + H.q_col0[qi];
-                        sa.q_len[4 + qi] = H.q_len[qi];
+            // The NEXT groups (<= 4 queries each, up to kMsPassGroups groups = 16 column blocks per pass) ride the same pass
+            // over the token stream: columns packed behind this group's, screen distances in rows 4 g .. 4 g + 3 of dist16
+            // (dims <= 128, the single-launch selection path); their turns then start at the selection.
+            if (nkk == 8 && k <= kMsFastK) {
+                int total_col = col, bn = b, accepted = 1;
+                while (accepted < kMsPassGroups && accepted < idx->maxsim_pass_groups && bn < B &&
+                       q_offsets[bn + 1] - q_offsets[bn] <= cols) {
+                    const Group H = pack(bn, total_col, false);  // its columns follow the previous group's directly
+                    if (H.nql == 0 || !H.finite) {
+                        // (the fragments pack() may have written for H are not used: rebuild the accepted groups alone)
+                        std::fill(qf16.begin(), qf16.end(), (uint16_t)0);
+                        int rb = first, rc = 0;
+                        for (int g2 = 0; g2 < accepted; ++g2) {
+                            const Group R = pack(rb, rc, false);
+                            rb = R.b_end;
+                            rc += R.col;
+                        }
+                        break;
                     }
-                    sa.nq_launch = 4 + H.nql;  // (rows nql..3: zero-length queries, their rows are never read)
-                    ncb_launch = (col + H.col + 31) / 32;
-                    pre_first = b;
-                } else {  // (the fragments pack() may have written for H are not used: rebuild this group's alone)
-                    std::fill(qf16.begin(), qf16.end(), (uint16_t)0);
-                    (void)pack(first, 0, false);
+                    for (int qi = 0; qi < 4; ++qi) {
+                        sa.q_col0[4 * accepted + qi] = total_col + H.q_col0[qi];
+                        sa.q_len[4 * accepted + qi] = H.q_len[qi];
+                    }
+                    sa.nq_launch = 4 * accepted + H.nql;  // (rows nql..3 of a group: zero-length queries, never read)
+                    pre_b[n_pre] = bn;
+                    pre_slot[n_pre] = accepted;
+                    ++n_pre;
+                    total_col += H.col;
+                    bn = H.b_end;
+                    ++accepted;
                 }
+                ncb_launch = (total_col + 31) / 32;
             }
             HIPCHECK(idx, hipMemcpyAsync(m->qfrag, qf16.data(), (size_t)std::max(ncb_launch, 4) * nkk * 64 * 8 * sizeof(uint16_t),
                                          hipMemcpyHostToDevice, s));
@@ -1330,24 +1427,11 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
                 HIPCHECK(idx, hipEventRecord(idx->ms_ev[0], s));
             }
             if (nkk == 8) {  // dims <= 128: the compile-time-unrolled form, only as many column blocks as the pass has
-                const size_t l16 = (size_t)ncb_launch * 8 * 64 * sizeof(uint4);
-                // persistent grid: as many workgroups as are resident at once (two per CU by LDS up to 8 column blocks)
-                // (evened out: every workgroup walks the same number of rounds -- 100 k pages over 512 workgroups would be
-                // 12.2 rounds, a fifth of the chip idle in the last one)
-                const unsigned rounds = idx->maxsim_persistent ? (grid_all_docs + 511u) / 512u : 1u;
-                const unsigned grid_all = std::max(1u, (grid_all_docs + rounds - 1) / std::max(rounds, 1u));
-                switch (ncb_launch) {
-                    case 1: hipLaunchKernelGGL(k_maxsim16_d128<1>, dim3(grid_all), dim3(kMsThreads), l16, s, sa); break;
-                    case 2: hipLaunchKernelGGL(k_maxsim16_d128<2>, dim3(grid_all), dim3(kMsThreads), l16, s, sa); break;
-                    case 3: hipLaunchKernelGGL(k_maxsim16_d128<3>, dim3(grid_all), dim3(kMsThreads), l16, s, sa); break;
-                    case 4: hipLaunchKernelGGL(k_maxsim16_d128<4>, dim3(grid_all), dim3(kMsThreads), l16, s, sa); break;
-                    case 5: hipLaunchKernelGGL(k_maxsim16_d128<5>, dim3(grid_all), dim3(kMsThreads), l16, s, sa); break;
-                    case 6: hipLaunchKernelGGL(k_maxsim16_d128<6>, dim3(grid_all), dim3(kMsThreads), l16, s, sa); break;
-                    case 7: hipLaunchKernelGGL(k_maxsim16_d128<7>, dim3(grid_all), dim3(kMsThreads), l16, s, sa); break;
-                    default: hipLaunchKernelGGL(k_maxsim16_d128<8>, dim3(grid_all), dim3(kMsThreads), l16, s, sa); break;
-                }
+                CHECK(ms16_d128_launch(idx, s, ncb_launch, m->n_docs, m->n_blocks, idx->maxsim_persistent != 0, sa));
+                idx->s_ms_screen_cols += 32 * (int64_t)ncb_launch;
             } else {
                 hipLaunchKernelGGL(k_maxsim16, dim3(grid_all), dim3(kMsThreads), lds16, s, sa);
+                idx->s_ms_screen_cols += 32 * (int64_t)((col + 31) / 32);
             }
             HIPCHECK(idx, hipGetLastError());
             if (idx->profile) {
@@ -1355,7 +1439,7 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
                 ms_screen_timed = true;
             }
         } else {
-            pre_first = -1;
+            n_pre = 0;
             hipLaunchKernelGGL(k_maxsim, dim3(grid_all), dim3(kMsThreads), lds, s, a);
             HIPCHECK(idx, hipGetLastError());
         }

@@ -63,6 +63,7 @@ def parse_args():
     ap.add_argument("--workload", choices=["single", "maxsim"], default="single",
                     help="single = headline cosine top-k (default); maxsim = multi-vector late interaction (SURVEY 8a row a2)")
     ap.add_argument("--docs", type=int, default=100_000, help="maxsim: documents (d=128)")
+    ap.add_argument("--maxsim-queries", type=int, default=16, help="maxsim: queries per step (one screen pass serves up to 16)")
     ap.add_argument("--tokens", choices=["text", "page"], default="text",
                     help="maxsim: 'text' = U{32..180} vectors per doc, 32-vector queries (ColBERT-like); 'page' = 1030 patch "
                          "vectors per doc, 24-vector queries (ColPali-like)")
@@ -187,14 +188,14 @@ def run_maxsim(args, n_docs: int, tokens: str, nq: int, steps: int, warmup: int,
     """MaxSim top-k (VectorChord `@#`) on a synthetic multi-vector store built ON THE DEVICE (token vectors generated in
     HBM, handed to the index by pointer: mi355dr_add_multivec_device).  `tokens` = "text" (ColBERT-like: U{32..180} vectors
     per doc) or "page" (ColPali-like: 1030 patch vectors per doc); d = 128, unit-norm vectors, seed 777.
-    A step = one call with 8 queries x `nq` query vectors against every document: ONE bf16 MFMA screen pass over the bf16
-    fragment copy (HBM-bound) serves both groups of 4, then per group the selection and the exact fp32 MFMA kernel on the
-    candidates; wall clock includes H2D of the queries and D2H of [8,k]."""
+    A step = one call with 16 queries x `nq` query vectors against every document: ONE bf16 MFMA screen pass over the bf16
+    fragment copy serves all four groups of 4 (round 4; 8 queries in rounds 2-3), then per group the selection and the exact
+    fp32 MFMA kernel on the candidates; wall clock includes H2D of the queries and D2H of [16,k]."""
     import torch
 
     import autorag_research_amd as pkg
 
-    d, qblock, k = 128, 8, args.k
+    d, qblock, k = 128, getattr(args, "maxsim_queries", 16), args.k
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     rng = np.random.default_rng(777)
     lens = rng.integers(32, 181, size=n_docs) if tokens == "text" else np.full((n_docs,), 1030, dtype=np.int64)
@@ -243,44 +244,46 @@ def run_maxsim(args, n_docs: int, tokens: str, nq: int, steps: int, warmup: int,
         except Exception as e:  # noqa: BLE001
             probe_out = {"error": f"{type(e).__name__}: {e}"}
     blocks = int(((lens + 31) // 32).sum())
-    alg_bytes = float(lens.sum()) * d * 4                        # fp32 token rows read once per 8-query pass
+    n_tok = float(lens.sum())
+    alg_bytes = n_tok * d * 4                                    # fp32 token rows read once per pass
     streamed = float(blocks) * 32 * d * 2                        # bf16 fragment store the screen streams, per pass
-    flops = 2.0 * (qblock * nq) * blocks * 32 * d                # what the screen issues per pass (32-row padded docs)
     screened, cands, fb = idx.stat("maxsim_screened"), idx.stat("maxsim_candidates"), idx.stat("maxsim_fallbacks")
     scr_n, scr_ns = idx.stat("maxsim_screen_launches"), idx.stat("maxsim_screen_ns")
     ex_n, ex_ns = idx.stat("maxsim_exact_launches"), idx.stat("maxsim_exact_ns")
+    cols_issued = idx.stat("maxsim_screen_cols") / max(scr_n, 1)  # query columns per launch, whole blocks of 32
     scr_s = scr_ns * 1e-9 / max(scr_n, 1)                        # average duration of one screen launch (= one pass)
-    # HBM traffic of the screen kernel from the committed PMC pass of this shape (tools/r3_maxsim_pmc.sh): bytes per streamed byte
-    traffic, traffic_src = None, None
-    tfile = ROOT / "profiles" / f"r03_maxsim_traffic_{tokens}.json"
-    if tfile.exists():
-        tj = json.loads(tfile.read_text())
-        traffic = round(tj["hbm_read_bytes_per_streamed_byte"] * streamed)
-        traffic_src = (f"REPLAYED, not measured in this run: {tj['hbm_read_bytes_per_streamed_byte']:.3f} HBM bytes per byte of bf16 "
-                       f"fragment store from profiles/{tfile.name} (rocprofv3 --pmc FETCH_SIZE pass, gfx950-corrected) x this store")
+    # MaxSim is compute-bound from one 32-vector query up -- "the MFMA roofline is the honest one here".
+    # Algorithmic flops of a pass = 2 * (query vectors of the pass) * (doc vectors) * d; the kernel issues the same on whole
+    # 32-row doc blocks and whole 32-column query blocks.
+    alg_flops = 2.0 * (qblock * nq) * n_tok * d
+    issued_flops = 2.0 * cols_issued * blocks * 32 * d
     out = {
         "workload": f"MaxSim top-{k}: {n_docs} docs, {int(lens.sum())} doc vectors ({'U{32..180}' if tokens == 'text' else '1030'}"
                     f"/doc), d=128, {qblock} queries x {nq} vectors per step, {steps * qblock} queries timed; store built on the "
                     f"device in {t_build:.2f} s",
         "queries_per_s": round(steps * qblock / el, 2), "ms_per_step": round(el * 1e3 / steps, 3), "steps": steps,
+        "queries_per_pass": qblock,
         "includes": "H2D of the query block, D2H of results",
-        "roofline": {"bound": "hbm", "kernel": f"k_maxsim16_d128<{(qblock * nq + 31) // 32}>", "achieved": round(alg_bytes / scr_s / 1e9, 1) if scr_n else None,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(alg_bytes / scr_s / 1e9 / HBM_PEAK_GBS, 4) if scr_n else None,
-                     "traffic": traffic, "traffic_unit": f"HBM read bytes per launch, vs algorithmic {round(alg_bytes)} (fp32 token rows) "
-                                                         f"and {round(streamed)} streamed (bf16 copy)", "traffic_source": traffic_src,
+        "roofline": {"bound": "mfma", "kernel": f"k_maxsim16_d128<{(qblock * nq + 31) // 32}>",
+                     "op": "bf16 flops (v_mfma_f32_32x32x16_bf16)",
+                     "achieved": round(alg_flops / scr_s / 1e12, 2) if scr_n else None,
+                     "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": round(alg_flops / scr_s / 1e12 / MFMA_BF16_PEAK_TF, 4) if scr_n else None,
+                     "issued_tflops": round(issued_flops / scr_s / 1e12, 2) if scr_n else None,
+                     "traffic": None,
+                     "traffic_unit": f"HBM read bytes per launch, vs {round(streamed)} streamed (the bf16 fragment copy) and "
+                                     f"algorithmic {round(alg_bytes)} (fp32 token rows, SURVEY 8d)", "traffic_source": None,
                      "launches": scr_n, "avg_launch_ms": round(scr_s * 1e3, 4),
-                     "note": "algorithmic fp32 token bytes per pass over the screen kernel's average launch (HIP events on the "
-                             "launch stream, library option `profile`); one launch screens the 8 queries of a step",
-                     "streamed_GBps": round(streamed / scr_s / 1e9, 1) if scr_n else None,
-                     "streamed_frac": round(streamed / scr_s / 1e9 / HBM_PEAK_GBS, 4) if scr_n else None,
-                     "frac_note": "`frac` is on ALGORITHMIC fp32 token bytes (SURVEY 8d); the kernel streams a bf16 copy, half of "
-                                  "them, so `frac` can exceed 1 -- `streamed_frac` is the HBM-bandwidth fraction the kernel itself reaches",
-                     "screen_tflops": round(flops / scr_s / 1e12, 2) if scr_n else None,
+                     "note": "algorithmic 2 * query vectors * doc vectors * d per pass over the screen kernel's average launch "
+                             f"(HIP events on the launch stream, library option `profile`); one launch screens the {qblock} "
+                             "queries of a step",
+                     "hbm_view": {"streamed_GBps": round(streamed / scr_s / 1e9, 1) if scr_n else None,
+                                  "streamed_frac": round(streamed / scr_s / 1e9 / HBM_PEAK_GBS, 4) if scr_n else None,
+                                  "algorithmic_GBps": round(alg_bytes / scr_s / 1e9, 1) if scr_n else None,
+                                  "note": "the pass as a stream: what the kernel reads (bf16 copy) and SURVEY 8(d)'s fp32 bytes "
+                                          "over the same launch; NOT the binding roof at 16 queries per pass"},
                      "exact_rescore_ms_per_step": round(ex_ns * 1e-6 / max(steps, 1), 4), "exact_launches": ex_n,
-                     "wall_clock_view": {"algorithmic_GBps": round(alg_bytes * steps / el / 1e9, 1),
-                                         "streamed_GBps": round(streamed * steps / el / 1e9, 1),
-                                         "frac": round(alg_bytes * steps / el / 1e9 / HBM_PEAK_GBS, 4)}},
+                     "wall_clock_tflops": round(alg_flops * steps / el / 1e12, 2)},
         "queries_screened": screened, "candidates_per_query": round(cands / max(screened, 1), 1),
         "exact_full_scan_fallbacks": fb,
     }
@@ -392,6 +395,19 @@ def pmc_fetch_subrun(bench_args: list, kernel_substr: str, timeout_s: int = 240)
         shutil.rmtree(out, ignore_errors=True)
 
 
+def maxsim_traffic(roof: dict, tokens: str, docs: int) -> None:
+    """Fill roofline.traffic of a MaxSim leg from a `rocprofv3 --kernel-trace --pmc FETCH_SIZE` sub-run of the same workload."""
+    per_launch, n_prof, note = pmc_fetch_subrun(["--workload", "maxsim", "--tokens", tokens, "--docs", docs], "k_maxsim16",
+                                                timeout_s=300)
+    if per_launch is not None:
+        roof["traffic"] = round(per_launch)
+        roof["traffic_source"] = (
+            f"MEASURED in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE sub-run of this workload (3 steps, {n_prof} screen "
+            "launches; KiB x 1024 x 2: the gfx950 correction of MI355X_MICROARCH.md), mean per launch")
+    else:
+        roof["traffic_source"] = f"not measured [live PMC sub-run: {note}]"
+
+
 def main_maxsim(args) -> None:
     """Secondary workload as the whole bench line: `python bench.py --workload maxsim [--docs N] [--tokens text|page]`."""
     r = run_maxsim(args, args.docs, args.tokens, 32 if args.tokens == "text" else 24, args.steps, args.warmup,
@@ -405,15 +421,7 @@ def main_maxsim(args) -> None:
     if "cpu_baseline" in r:
         out["cpu_baseline"] = r["cpu_baseline"]
     if not args.no_extras:
-        per_launch, n_prof, note = pmc_fetch_subrun(["--workload", "maxsim", "--tokens", args.tokens, "--docs", args.docs],
-                                                    "k_maxsim16")
-        if per_launch is not None:
-            out["roofline"]["traffic"] = round(per_launch)
-            out["roofline"]["traffic_source"] = (
-                f"MEASURED in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE sub-run of this workload (3 steps, {n_prof} screen "
-                "launches; KiB x 1024 x 2: the gfx950 correction of MI355X_MICROARCH.md), mean per launch")
-        else:
-            out["roofline"]["traffic_source"] = (out["roofline"].get("traffic_source") or "") + f" [live PMC sub-run: {note}]"
+        maxsim_traffic(out["roofline"], args.tokens, args.docs)
     print(json.dumps(out))
 
 
@@ -1064,9 +1072,10 @@ def main() -> None:
         # (3) the multi-vector half of the path (configs C4 / C5) at SURVEY 8(d) sizes, as secondary figures of the same run
         # SURVEY 8(d) sizes: 1 M text docs (~106 M vectors: 54 GB fp32 + 27 GB bf16 copy) and 100 k pages (103 M vectors),
         # 1000 queries each (125 steps of 8)
+        # (1000 queries each: 63 steps of 16)
         result["maxsim"] = {
-            "colbert_like": run_maxsim(args, 1_000_000, "text", 32, 125, 3, 0 if args.no_cpu_baseline else 1500),
-            "colpali_like": run_maxsim(args, 100_000, "page", 24, 125, 3, 0),
+            "colbert_like": run_maxsim(args, 1_000_000, "text", 32, 63, 3, 0 if args.no_cpu_baseline else 1500),
+            "colpali_like": run_maxsim(args, 100_000, "page", 24, 63, 3, 0),
         }
 
     # ---- CPU baseline (rank 0, N=1 run only): the oracle on a bounded sample of the same workload
@@ -1215,6 +1224,10 @@ def main() -> None:
                 "launches of a pass differ in size exactly as in the timed region")
         else:
             rl["traffic_source"] = (rl.get("traffic_source") or "") + f" [live PMC sub-run: {note}]"
+    if rank == 0 and world == 1 and not args.no_extras and "maxsim" in result:
+        # the MaxSim screens' HBM traffic, measured like the single-vector kernel's: a PMC sub-run of the same store + steps
+        for key, tokens, docs in (("colbert_like", "text", 1_000_000), ("colpali_like", "page", 100_000)):
+            maxsim_traffic(result["maxsim"][key]["roofline"], tokens, docs)
     if rank == 0:
         # RCCL writes its version banner through C stdio; on a pipe that buffer would be flushed at exit, AFTER the
         # result.  Flush it now so that the JSON line is the last line of rank 0's output.

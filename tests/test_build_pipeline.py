@@ -143,3 +143,40 @@ def test_screen_stream_ring_stays_in_flight(screen_asm, i8, nq):
     assert sum(o.startswith("global_load_lds_dwordx4") for o in body) == 4
     assert sum(o.startswith("ds_read_b128") for o in body) == 4 * (1 + nj)
     assert not any(_is_vm0(o) for o in body)
+
+
+@pytest.fixture(scope="module")
+def maxsim_asm_text(tmp_path_factory):
+    hipcc = Path("/opt/rocm/bin/hipcc")
+    if not hipcc.exists():
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("asm") / "mi355dr_maxsim.s"
+    cmd = [str(hipcc), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", f"-I{ROOT / 'include'}",
+           f"-I{CSRC}", str(CSRC / "mi355dr_maxsim.hip"), "-S", "--cuda-device-only", "-o", str(out)]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=900)
+    return out.read_text()
+
+
+@pytest.mark.parametrize("ncb", [12, 16])
+def test_maxsim_workgroup_screen_keeps_its_ring_in_flight(maxsim_asm_text, ncb):
+    """k_maxsim16_wg (round 4): the token blocks come through a ring of LDS-DMA stages shared by the workgroup's 8 waves.  Pinned on
+    the generated code: the query fragments live in registers (no ds_read feeds an MFMA's B operand -- 16 fragment reads per
+    stage, all of them token fragments), exactly one counted vector-memory wait inside the stage loop and NO full
+    `s_waitcnt vmcnt(0)` between the prologue's wait and the loop's last MFMA (a per-document vector load of the block offsets
+    -- or the query fragments left to their first use -- put one there and drained 96 KiB of stream per document), block
+    offsets through the scalar cache, no scratch."""
+    name = f"_ZN5mi35513k_maxsim16_wgILi{ncb}EEEvNS_8Ms16ArgsEl"
+    ops, desc = _whole_kernel(maxsim_asm_text, name)
+    assert ".amdhsa_private_segment_fixed_size 0" in desc and not any(o.startswith("scratch_") for o in ops)
+    w12 = [i for i, o in enumerate(ops) if o.startswith("s_waitcnt") and "vmcnt(12)" in o]
+    w10 = [i for i, o in enumerate(ops) if o.startswith("s_waitcnt") and "vmcnt(10)" in o]
+    assert len(w12) == 1 and len(w10) == 1 and w12[0] < w10[0]
+    mf = [i for i, o in enumerate(ops) if o.startswith("v_mfma_f32_32x32x16_bf16")]
+    assert len(mf) == 32   # block A and block B of a stage: 8 MFMAs for the wave's first column block + 8 for its second
+    loop = ops[w12[0] + 1:max(mf) + 1]
+    assert not any(_is_vm0(o) for o in loop), [o for o in loop if "vmcnt" in o]
+    assert sum(o.startswith("global_load_lds_dwordx4") for o in loop) == 2        # the stage seven ahead: two 1-KiB pieces per wave
+    assert not any(o.startswith(("global_load_dword", "flat_load")) for o in loop)  # (block offsets: s_load)
+    # token fragments only: 16 reads for stage 0 in front of the loop + 16 per stage inside it; the B operands never come from LDS
+    assert sum(o.startswith("ds_read_b128") for o in loop) == 32
+    assert any(o.startswith("s_load_dwordx2") for o in loop)

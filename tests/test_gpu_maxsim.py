@@ -271,3 +271,45 @@ def test_maxsim_subset_matches_oracle_and_heaven_golden(pkg, oracle):
             else:
                 exp = np.float32(oracle.maxsim_distance(tok[off[i]:off[i + 1]], q))
                 assert dist[b, j].view(np.uint32) == exp.view(np.uint32), (b, j)
+
+
+@pytest.mark.parametrize("tmin,tmax,n_docs", [(20, 150, 3000), (1030, 1030, 120)])
+def test_sixteen_queries_ride_one_screen_pass(pkg, oracle, tmin, tmax, n_docs):
+    """round 4: one pass of the bf16 screen over the token store serves up to FOUR groups of <= 4 queries (16 column blocks =
+    128 KiB of query fragments in LDS, 8 waves per workgroup beyond 8 blocks).  Every number of groups per pass must give the
+    oracle's lists bit for bit -- with ragged query lengths (a query may start anywhere in a column block and span blocks), a
+    zero-length query, a query longer than a launch stages (it takes the tile path and cuts the pass), a non-finite query (it
+    cuts the pass and takes the exact scan), duplicates of one query in different groups, and a pass that ends mid-group."""
+    rng = np.random.default_rng(41)
+    d = 128
+    tok, off = _ragged(rng, n_docs, d, tmin, tmax)
+    lens = [32, 24, 7, 32, 31, 1, 33, 32, 32, 32, 32, 32, 24, 24, 24, 24, 24, 24, 0, 32, 200, 32, 5, 32, 32, 17, 32, 32, 32, 9,
+            32, 32, 32, 32, 32, 32, 32]
+    qtok, qoff = _queries(rng, lens, d)
+    qtok[qoff[10]:qoff[11]] = qtok[qoff[3]:qoff[4]]            # the same 32-vector query in two groups of a pass
+    bad = qoff[26]
+    qtok[bad + 3, 5] = np.inf                                   # a non-finite query: the pass must not take its neighbours down
+    k = 10
+    rd, rr = oracle.maxsim_topk(tok, off, qtok, qoff, k)
+    with pkg.Mi355Index(d) as idx:
+        idx.add_multivec(tok, off)
+        for groups in (4, 1, 3, 2):
+            idx.set_option("maxsim_pass_groups", groups)
+            idx.reset_stats()
+            dist, rows = idx.search_maxsim(qtok, qoff, k)
+            live = np.asarray(lens) > 0   # (a query without vectors: the reference returns [] before any SQL, base.py:506-507)
+            assert (rows[~live] == -1).all() and np.isnan(dist[~live]).all()
+            assert np.array_equal(rows[live], rr[live]), groups
+            ok = ~np.isnan(rd) & live[:, None]
+            assert np.array_equal(np.isnan(dist[live]), np.isnan(rd[live])), groups
+            assert np.array_equal(dist[ok].view(np.uint32), rd[ok].view(np.uint32)), groups
+            if groups == 4:
+                # all but the empty one, the long one and the GROUP of the non-finite one (its three neighbours take the exact scan with it)
+                assert idx.stat("maxsim_screened") >= len(lens) - 6
+        with pytest.raises(pkg.NativeError):
+            idx.set_option("maxsim_pass_groups", 5)
+        # k above the fast path's 64: one group per pass, same answers
+        idx.set_option("maxsim_pass_groups", 4)
+        rd2, rr2 = oracle.maxsim_topk(tok, off, qtok[: qoff[9]], qoff[:10], 70)
+        d2, r2 = idx.search_maxsim(qtok[: qoff[9]], qoff[:10], 70)
+        assert np.array_equal(r2, rr2) and np.array_equal(d2.view(np.uint32), rd2.view(np.uint32))
