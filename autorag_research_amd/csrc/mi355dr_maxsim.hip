@@ -125,9 +125,9 @@ struct MsArgs {
                             //      n_items_dev pair (stride 2); the workgroup scores that query only
     int64_t n_docs;
     int dpad;
-    int nq_launch;          // queries in this launch (<= 4)
-    int q_col0[4];          // first column of each query (multiple of 32)
-    int q_len[4];           // real token count of each query
+    int nq_launch;          // queries in this launch (<= 4 scored together; list mode with list_stride: <= kMsPassQueries, one per grid.y)
+    int q_col0[kMsPassQueries];  // first column of each query in the staged image (any column)
+    int q_len[kMsPassQueries];   // real token count of each query
     int clamp0;             // 1: every query token contributes max(0, max_j <q_i, d_j>)  (ColBERT reranker, rerankers/colbert.py:79)
     // a query with more vectors than one launch stages (ms_cols_for(dpad) <= 128 columns) is scored in TILES of its vectors:
     // the launch of tile t starts every item's sum from the value tile t-1 left (same layout as `dist`; may be `dist` itself),
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(kMsThreads, 2) void k_maxsim(MsArgs a) {
         a.n_items_dev += 2 * y;
         int c0 = a.q_col0[0], ln = a.q_len[0];
 #pragma unroll
-        for (int i = 1; i < 4; ++i)
+        for (int i = 1; i < kMsPassQueries; ++i)
             if (i == y) {
                 c0 = a.q_col0[i];
                 ln = a.q_len[i];
@@ -1127,6 +1127,10 @@ __global__ void k_ms_fill_empty(float* d, int64_t* r, int64_t n) {
 
 // qtok: HOST [sum_nq, dim]; outputs on the host (out_dev = false) or in device memory of the index's GPU (out_dev = true:
 // written by kernels / device copies on the index's stream, complete on return)
+//
+// Round 4: a PASS = up to kMsPassGroups groups of <= 4 queries (dims <= 128, k <= kMsFastK): one screen launch for all of them,
+// then ONE selection / candidate / exact re-score / final sequence for all of them (grid.y = query of the pass) and one host
+// synchronisation -- rounds 2-3 ran that sequence (ten launches, three copies, one synchronisation) once per group of four.
 static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32_t* q_offsets, int B, int k, float* out_dist,
                               int64_t* out_rows, bool out_dev) {
     if (k > kKMax) return fail(idx, MI355DR_E_UNSUPPORTED, "k exceeds 1024");
@@ -1153,24 +1157,26 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
     HIPCHECK(idx, hipSetDevice(idx->device));
     hipStream_t s = idx->stream;
     const int dp = m->dpad, d = idx->dim, nkk = m->nkk;
-    const int cols = ms_cols_for(dp);  // query vectors one launch stages; longer queries are scored in tiles (exact kernel)
+    const int cols = ms_cols_for(dp);  // query vectors one launch of the EXACT kernel stages; longer queries are scored in tiles
     if (cols < 32) return fail(idx, MI355DR_E_UNSUPPORTED, "dim too large for the MaxSim kernel's LDS budget (dim <= 1272)");
     const size_t lds = (size_t)cols * (dp + 4) * sizeof(float);
     const size_t lds16 = (size_t)4 * nkk * 64 * sizeof(uint4);
+    // columns of the fp32 query image of a pass: every group's columns behind the previous group's (+ 32 columns of slack: the
+    // list form of k_maxsim stages whole 32-column blocks from a query's FIRST column on; those columns' results are never read)
+    constexpr int kImgCols = kMsPassBlocks * 32 + 32;
+    constexpr int kPQ = kMsPassQueries;
     // scratch
     if (!m->qtok) {
-        // (+ 32 columns of slack: with tightly packed queries the list form of k_maxsim stages whole 32-column blocks from a
-        // query's FIRST column on, which may run past column 127; those columns' results are never read)
-        HIPCHECK(idx, hipMalloc(&m->qtok, (size_t)(kMsCols + 32) * dp * sizeof(float)));
-        HIPCHECK(idx, hipMemsetAsync(m->qtok, 0, (size_t)(kMsCols + 32) * dp * sizeof(float), s));
+        HIPCHECK(idx, hipMalloc(&m->qtok, (size_t)kImgCols * dp * sizeof(float)));
+        HIPCHECK(idx, hipMemsetAsync(m->qtok, 0, (size_t)kImgCols * dp * sizeof(float), s));
         HIPCHECK(idx, hipMalloc(&m->qfrag, kMsPassGroups * lds16));
-        HIPCHECK(idx, hipMalloc(&m->out_d, 4 * kKMax * sizeof(float)));
-        HIPCHECK(idx, hipMalloc(&m->out_r, 4 * kKMax * sizeof(int64_t)));
-        HIPCHECK(idx, hipMalloc(&m->cand_list, 4 * kMsCandCap * sizeof(int32_t)));
-        HIPCHECK(idx, hipMalloc(&m->cand_dist, 4 * kMsCandCap * sizeof(float)));
-        HIPCHECK(idx, hipMalloc(&m->cand_ctl, 8 * sizeof(int)));
-        HIPCHECK(idx, hipMalloc(&m->two_e_dev, 4 * sizeof(float)));
-        HIPCHECK(idx, hipHostMalloc(&m->cand_ctl_host, 8 * sizeof(int)));
+        HIPCHECK(idx, hipMalloc(&m->out_d, (size_t)kPQ * kKMax * sizeof(float)));
+        HIPCHECK(idx, hipMalloc(&m->out_r, (size_t)kPQ * kKMax * sizeof(int64_t)));
+        HIPCHECK(idx, hipMalloc(&m->cand_list, (size_t)kPQ * kMsCandCap * sizeof(int32_t)));
+        HIPCHECK(idx, hipMalloc(&m->cand_dist, (size_t)kPQ * kMsCandCap * sizeof(float)));
+        HIPCHECK(idx, hipMalloc(&m->cand_ctl, 2 * kPQ * sizeof(int)));
+        HIPCHECK(idx, hipMalloc(&m->two_e_dev, kPQ * sizeof(float)));
+        HIPCHECK(idx, hipHostMalloc(&m->cand_ctl_host, 2 * kPQ * sizeof(int)));
         HIPCHECK(idx, hipFuncSetAttribute((const void*)k_ms_final, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           kMsCandCap * 12));
         HIPCHECK(idx, hipFuncSetAttribute((const void*)k_maxsim, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + kMsRedBytes)));
@@ -1184,10 +1190,10 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
         if (m->dist) (void)hipFree(m->dist);
         if (m->dist16) (void)hipFree(m->dist16);
         HIPCHECK(idx, hipMalloc(&m->dist, (size_t)4 * m->cap_docs * sizeof(float)));
-        HIPCHECK(idx, hipMalloc(&m->dist16, (size_t)kMsPassQueries * m->cap_docs * sizeof(float)));
+        HIPCHECK(idx, hipMalloc(&m->dist16, (size_t)kPQ * m->cap_docs * sizeof(float)));
         for (int i = 0; i < 2; ++i) {
             if (m->sel[i]) (void)hipFree(m->sel[i]);
-            HIPCHECK(idx, hipMalloc(&m->sel[i], (size_t)4 * ((m->cap_docs + kMsSelSeg - 1) / kMsSelSeg) * kMsFastK * sizeof(uint32_t)));
+            HIPCHECK(idx, hipMalloc(&m->sel[i], (size_t)kPQ * ((m->cap_docs + kMsSelSeg - 1) / kMsSelSeg) * kMsFastK * sizeof(uint32_t)));
         }
         m->dist_cap_docs = m->cap_docs;
     }
@@ -1206,49 +1212,31 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
         m->part_cap = nseg0 * kKMax;
     }
     const unsigned grid_all = (unsigned)((m->n_docs + 4 * kMsDocsPerWave - 1) / (4 * kMsDocsPerWave));
-    const unsigned grid_all_docs = grid_all;
     const int64_t n_cand_max = std::min<int64_t>(kMsCandCap, m->n_docs);
     // bf16 round-to-nearest: unit roundoff 2^-8 per operand -> 2^-7 + 2^-16 per product
     const double eps = std::ldexp(1.0, -7) + std::ldexp(1.0, -15) + 3.0 * d * std::ldexp(1.0, -24);
     // pinned staging (pageable copies are synchronous and cost ~20 us each)
-    const size_t qimg_n = (size_t)kMsCols * dp, qf16_n = (size_t)kMsPassBlocks * nkk * 64 * 8;
-    const size_t need_stage = qimg_n * 4 + qf16_n * 2 + 4 * kKMax * 12 + 64;
+    const size_t qimg_n = (size_t)kImgCols * dp, qf16_n = (size_t)kMsPassBlocks * nkk * 64 * 8;
+    const size_t need_stage = qimg_n * 4 + qf16_n * 2 + (size_t)kPQ * kKMax * 12 + 256;
     if (m->stage_bytes < need_stage) {
         if (m->stage_host) (void)hipHostFree(m->stage_host);
         HIPCHECK(idx, hipHostMalloc(&m->stage_host, need_stage));
         m->stage_bytes = need_stage;
     }
-    float* const qimg_p = (float*)m->stage_host;
-    uint16_t* const qf16_p = (uint16_t*)(m->stage_host + qimg_n * 4);
+    float* const qimg = (float*)m->stage_host;
+    uint16_t* const qf16 = (uint16_t*)(m->stage_host + qimg_n * 4);
     float* const hd = (float*)(m->stage_host + qimg_n * 4 + qf16_n * 2);
-    int64_t* const hr = (int64_t*)(hd + 4 * kKMax + 16);
-    struct Span {  // (keeps the vector-style accessors of the code below)
-        float* p;
-        size_t n;
-        float* begin() { return p; }
-        float* end() { return p + n; }
-        float* data() { return p; }
-        size_t size() const { return n; }
-        float& operator[](size_t i) { return p[i]; }
-    } qimg{qimg_p, qimg_n};
-    struct Span16 {
-        uint16_t* p;
-        size_t n;
-        uint16_t* begin() { return p; }
-        uint16_t* end() { return p + n; }
-        uint16_t* data() { return p; }
-        size_t size() const { return n; }
-        uint16_t& operator[](size_t i) { return p[i]; }
-    } qf16{qf16_p, qf16_n};
-    // one group = up to 4 queries whose 32-padded token counts fit 128 columns.  pack() writes the group's bf16 fragments at
-    // column base `fcol0` of qf16 (fcol0 < 0: none) and, with `img`, its fp32 image for the exact kernel into qimg.
+    int64_t* const hr = (int64_t*)(hd + (size_t)kPQ * kKMax + 16);
+    // one group = up to 4 queries whose token counts fit `cols` columns (packed tightly: a query may start anywhere in a
+    // column block).  pack() writes the group's bf16 fragments at column base `fcol0` of qf16 (fcol0 < 0: none) and its fp32
+    // image for the exact kernel at column base `icol0` of qimg (icol0 < 0: none).
     struct Group {
         int nql = 0, col = 0, b_end = 0;
         int q_col0[4] = {0, 0, 0, 0}, q_len[4] = {0, 0, 0, 0};
         double two_e[4] = {0, 0, 0, 0};
         bool finite = true;
     };
-    auto pack = [&](int b0, int fcol0, bool img) {
+    auto pack = [&](int b0, int fcol0, int icol0) {
         Group g;
         int bb = b0;
         while (bb < B && g.nql < 4) {
@@ -1260,8 +1248,8 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
             double norm_sum = 0.0, res_sum = 0.0;
             for (int j = 0; j < nq; ++j) {
                 const float* sv = qtok + (int64_t)(q_offsets[bb] + j) * d;
-                if (img) {
-                    float* dst = &qimg[(size_t)(g.col + j) * dp];
+                if (icol0 >= 0) {
+                    float* dst = &qimg[(size_t)(icol0 + g.col + j) * dp];
                     for (int c = 0; c < dp; ++c) {
                         const int oc = ms_perm(c);
                         dst[c] = oc < d ? sv[oc] : 0.0f;
@@ -1297,23 +1285,34 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
         g.b_end = bb;
         return g;
     };
+    MsArgs a0{};
+    a0.tok = m->tok;
+    a0.blk_off = m->blk_off;
+    a0.qtok = m->qtok;
+    a0.dist = m->dist;
+    a0.n_docs = m->n_docs;
+    a0.n_items = m->n_docs;
+    a0.doc_list = nullptr;
+    a0.n_items_dev = nullptr;
+    a0.dpad = dp;
+    // exact kernel over EVERY doc for one query whose image sits at column c0 of m->qtok -> m->dist row 0 -> top-k -> outputs
+    auto full_scan_query = [&](int c0, int len, float* od, int64_t* orow) -> int {
+        MsArgs f = a0;
+        f.qtok = m->qtok + (int64_t)c0 * dp;
+        f.nq_launch = 1;
+        f.q_col0[0] = 0;
+        f.q_len[0] = len;
+        hipLaunchKernelGGL(k_maxsim, dim3(grid_all), dim3(kMsThreads), lds, s, f);
+        HIPCHECK(idx, hipGetLastError());
+        int cur = 0;
+        CHECK(ms_topk(idx, m, s, m->dist, m->n_docs, k, seg, nullptr, nullptr, &cur));
+        CHECK(ms_emit_result(idx, m, s, cur, k, od, orow, out_dev));
+        HIPCHECK(idx, hipStreamSynchronize(s));
+        return MI355DR_OK;
+    };
     int b = 0;
-    bool ms_screen_timed = false;  // option "profile": a screen launch is bracketed by ms_ev[0..1] and not read yet
-    // groups whose screen distances already sit in dist16 (screened together with an earlier group of the same pass):
-    // (first query of the group, slot = its row block 4 * slot .. 4 * slot + 3)
-    int pre_b[kMsPassGroups], pre_slot[kMsPassGroups], n_pre = 0;
     while (b < B) {
         HIPCHECK(idx, hipStreamSynchronize(s));  // the staging buffers are free again
-        MsArgs a{};
-        a.tok = m->tok;
-        a.blk_off = m->blk_off;
-        a.qtok = m->qtok;
-        a.dist = m->dist;
-        a.n_docs = m->n_docs;
-        a.n_items = m->n_docs;
-        a.doc_list = nullptr;
-        a.n_items_dev = nullptr;
-        a.dpad = dp;
         if (q_offsets[b + 1] - q_offsets[b] > cols) {
             // ---- a query with more vectors than one launch stages (VectorChord's `@#` has no such limit: base.py:518-524):
             // the exact kernel over every doc, one launch per tile of <= cols query vectors, each continuing the per-doc sums
@@ -1321,7 +1320,7 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
             for (int t0 = 0; t0 < nq; t0 += cols) {
                 const int tl = std::min(cols, nq - t0);
                 if (t0 > 0) HIPCHECK(idx, hipStreamSynchronize(s));  // (the previous tile's launch has read the staging image)
-                std::fill(qimg.begin(), qimg.end(), 0.0f);
+                std::fill(qimg, qimg + (size_t)cols * dp, 0.0f);
                 for (int j = 0; j < tl; ++j) {
                     const float* sv = qtok + (int64_t)(q_offsets[b] + t0 + j) * d;
                     float* dst = &qimg[(size_t)j * dp];
@@ -1330,8 +1329,8 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
                         dst[c] = oc < d ? sv[oc] : 0.0f;
                     }
                 }
-                HIPCHECK(idx, hipMemcpyAsync(m->qtok, qimg.data(), (size_t)cols * dp * sizeof(float), hipMemcpyHostToDevice, s));
-                MsArgs f = a;
+                HIPCHECK(idx, hipMemcpyAsync(m->qtok, qimg, (size_t)cols * dp * sizeof(float), hipMemcpyHostToDevice, s));
+                MsArgs f = a0;
                 f.nq_launch = 1;
                 f.q_col0[0] = 0;
                 f.q_len[0] = tl;
@@ -1344,116 +1343,115 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
             CHECK(ms_topk(idx, m, s, m->dist, m->n_docs, k, seg, nullptr, nullptr, &cur));
             CHECK(ms_emit_result(idx, m, s, cur, k, out_dist + (int64_t)b * k, out_rows + (int64_t)b * k, out_dev));
             HIPCHECK(idx, hipStreamSynchronize(s));
-            n_pre = 0;
             ++b;
             continue;
         }
-        int slot = -1;  // > 0: this group was screened together with an earlier one (its distances: rows 4 * slot ..)
-        for (int i = 0; i < n_pre; ++i)
-            if (pre_b[i] == b) slot = pre_slot[i];
-        const bool pre = slot > 0;
-        std::fill(qimg.begin(), qimg.end(), 0.0f);
-        if (!pre) std::fill(qf16.begin(), qf16.end(), (uint16_t)0);
+        // ---- the groups of this pass
+        std::fill(qimg, qimg + qimg_n, 0.0f);
+        std::fill(qf16, qf16 + qf16_n, (uint16_t)0);
         const int first = b;
-        const Group G = pack(b, pre ? -1 : 0, true);
-        b = G.b_end;
-        const int nql = G.nql, col = G.col;
-        const bool q_finite = G.finite;
-        double two_e[4];
-        for (int qi = 0; qi < 4; ++qi) {
-            a.q_col0[qi] = G.q_col0[qi];
-            a.q_len[qi] = G.q_len[qi];
-            two_e[qi] = G.two_e[qi];
-        }
-        a.nq_launch = nql;
-        HIPCHECK(idx, hipMemcpyAsync(m->qtok, qimg.data(), qimg.size() * sizeof(float), hipMemcpyHostToDevice, s));
-        const bool screen = idx->maxsim_screen && m->finite && q_finite && lds16 <= 160 * 1024;
-        float* dist16 = m->dist16;  // this group's screen distances: [4, n_docs]
-        if (screen && pre) {
-            dist16 = m->dist16 + (int64_t)4 * slot * m->n_docs;
-        } else if (screen) {
-            n_pre = 0;
-            Ms16Args sa{};
-            sa.tok16 = m->tok16;
-            sa.blk_off = m->blk_off;
-            sa.qfrag = m->qfrag;
-            sa.dist = m->dist16;
-            sa.n_docs = m->n_docs;
-            sa.nkk = nkk;
-            sa.nq_launch = nql;
-            for (int qi = 0; qi < 4; ++qi) {
-                sa.q_col0[qi] = a.q_col0[qi];
-                sa.q_len[qi] = a.q_len[qi];
-            }
-            int ncb_launch = (col + 31) / 32;
-            // The NEXT groups (<= 4 queries each, up to kMsPassGroups groups = 16 column blocks per pass) ride the same pass
-            // over the token stream: columns packed behind this group's, screen distances in rows 4 g .. 4 g + 3 of dist16
-            // (dims <= 128, the single-launch selection path); their turns then start at the selection.
-            if (nkk == 8 && k <= kMsFastK) {
-                int total_col = col, bn = b, accepted = 1;
-                while (accepted < kMsPassGroups && accepted < idx->maxsim_pass_groups && bn < B &&
-                       q_offsets[bn + 1] - q_offsets[bn] <= cols) {
-                    const Group H = pack(bn, total_col, false);  // its columns follow the previous group's directly
-                    if (H.nql == 0 || !H.finite) {
-                        // (the fragments pack() may have written for H are not used: rebuild the accepted groups alone)
-                        std::fill(qf16.begin(), qf16.end(), (uint16_t)0);
-                        int rb = first, rc = 0;
-                        for (int g2 = 0; g2 < accepted; ++g2) {
-                            const Group R = pack(rb, rc, false);
-                            rb = R.b_end;
-                            rc += R.col;
-                        }
-                        break;
-                    }
-                    for (int qi = 0; qi < 4; ++qi) {
-                        sa.q_col0[4 * accepted + qi] = total_col + H.q_col0[qi];
-                        sa.q_len[4 * accepted + qi] = H.q_len[qi];
-                    }
-                    sa.nq_launch = 4 * accepted + H.nql;  // (rows nql..3 of a group: zero-length queries, never read)
-                    pre_b[n_pre] = bn;
-                    pre_slot[n_pre] = accepted;
-                    ++n_pre;
-                    total_col += H.col;
-                    bn = H.b_end;
-                    ++accepted;
+        Group gs[kMsPassGroups];
+        int gbase[kMsPassGroups] = {0, 0, 0, 0}, gfirst[kMsPassGroups] = {b, 0, 0, 0};
+        gs[0] = pack(b, 0, 0);
+        int n_acc = 1, total_col = gs[0].col, bn = gs[0].b_end;
+        const bool screen = idx->maxsim_screen && m->finite && gs[0].finite && lds16 <= 160 * 1024;
+        if (screen && nkk == 8 && k <= kMsFastK) {
+            // The NEXT groups ride the same pass over the token stream (dims <= 128, the single-launch selection path): their
+            // columns packed behind the previous group's
+            while (n_acc < kMsPassGroups && n_acc < idx->maxsim_pass_groups && bn < B && q_offsets[bn + 1] - q_offsets[bn] <= cols) {
+                const Group H = pack(bn, total_col, total_col);
+                if (H.nql == 0 || !H.finite) {
+                    // (what pack() may have written for H is not used: rebuild the accepted groups alone)
+                    std::fill(qimg, qimg + qimg_n, 0.0f);
+                    std::fill(qf16, qf16 + qf16_n, (uint16_t)0);
+                    for (int g2 = 0; g2 < n_acc; ++g2) (void)pack(gfirst[g2], gbase[g2], gbase[g2]);
+                    break;
                 }
-                ncb_launch = (total_col + 31) / 32;
+                gs[n_acc] = H;
+                gbase[n_acc] = total_col;
+                gfirst[n_acc] = bn;
+                total_col += H.col;
+                bn = H.b_end;
+                ++n_acc;
             }
-            HIPCHECK(idx, hipMemcpyAsync(m->qfrag, qf16.data(), (size_t)std::max(ncb_launch, 4) * nkk * 64 * 8 * sizeof(uint16_t),
-                                         hipMemcpyHostToDevice, s));
-            if (idx->profile) {
-                for (auto& e : idx->ms_ev)
-                    if (!e) HIPCHECK(idx, hipEventCreate(&e));
-                HIPCHECK(idx, hipEventRecord(idx->ms_ev[0], s));
+        }
+        b = bn;
+        // the LIVE queries of the pass (a query without vectors: reference `if not query_vectors: return []`): row r of the
+        // screen distances, of the candidate lists, of the results
+        int pq_n = 0, pq_b[kPQ], pq_col0[kPQ], pq_len[kPQ];
+        double pq_two_e[kPQ];
+        for (int g = 0; g < n_acc; ++g)
+            for (int qi = 0; qi < gs[g].nql; ++qi) {
+                if (gs[g].q_len[qi] == 0) continue;
+                pq_b[pq_n] = gfirst[g] + qi;
+                pq_col0[pq_n] = gbase[g] + gs[g].q_col0[qi];
+                pq_len[pq_n] = gs[g].q_len[qi];
+                pq_two_e[pq_n] = gs[g].two_e[qi];
+                ++pq_n;
             }
-            if (nkk == 8) {  // dims <= 128: the compile-time-unrolled form, only as many column blocks as the pass has
-                CHECK(ms16_d128_launch(idx, s, ncb_launch, m->n_docs, m->n_blocks, idx->maxsim_persistent != 0, sa));
-                idx->s_ms_screen_cols += 32 * (int64_t)ncb_launch;
-            } else {
-                hipLaunchKernelGGL(k_maxsim16, dim3(grid_all), dim3(kMsThreads), lds16, s, sa);
-                idx->s_ms_screen_cols += 32 * (int64_t)((col + 31) / 32);
+        if (pq_n == 0) continue;
+        const size_t img_cols = std::min<size_t>(kImgCols, (size_t)((total_col + 31) / 32 * 32 + 32));
+        HIPCHECK(idx, hipMemcpyAsync(m->qtok, qimg, img_cols * dp * sizeof(float), hipMemcpyHostToDevice, s));
+        if (!screen) {
+            // ---- the exact kernel over every doc for the whole group (one launch, <= 4 queries), then a top-k per query
+            MsArgs a = a0;
+            a.nq_launch = gs[0].nql;
+            for (int qi = 0; qi < 4; ++qi) {
+                a.q_col0[qi] = gs[0].q_col0[qi];
+                a.q_len[qi] = gs[0].q_len[qi];
             }
-            HIPCHECK(idx, hipGetLastError());
-            if (idx->profile) {
-                HIPCHECK(idx, hipEventRecord(idx->ms_ev[1], s));
-                ms_screen_timed = true;
-            }
-        } else {
-            n_pre = 0;
             hipLaunchKernelGGL(k_maxsim, dim3(grid_all), dim3(kMsThreads), lds, s, a);
             HIPCHECK(idx, hipGetLastError());
+            for (int qi = 0; qi < gs[0].nql; ++qi) {
+                if (gs[0].q_len[qi] == 0) continue;
+                int cur = 0;
+                CHECK(ms_topk(idx, m, s, m->dist + (int64_t)qi * m->n_docs, m->n_docs, k, seg, nullptr, nullptr, &cur));
+                CHECK(ms_emit_result(idx, m, s, cur, k, out_dist + (int64_t)(first + qi) * k, out_rows + (int64_t)(first + qi) * k, out_dev));
+                HIPCHECK(idx, hipStreamSynchronize(s));
+            }
+            continue;
         }
-        bool handled[4] = {false, false, false, false};
-        if (screen && k <= kMsFastK) {
-            // ---- fast path: every step handles all queries of the launch at once (grid.y), one host sync per launch
+        // ---- the screen: one launch for every live query of the pass
+        Ms16Args sa{};
+        sa.tok16 = m->tok16;
+        sa.blk_off = m->blk_off;
+        sa.qfrag = m->qfrag;
+        sa.dist = m->dist16;
+        sa.n_docs = m->n_docs;
+        sa.nkk = nkk;
+        sa.nq_launch = pq_n;
+        for (int r = 0; r < pq_n; ++r) {
+            sa.q_col0[r] = pq_col0[r];
+            sa.q_len[r] = pq_len[r];
+        }
+        const int ncb_launch = (total_col + 31) / 32;
+        HIPCHECK(idx, hipMemcpyAsync(m->qfrag, qf16, (size_t)std::max(ncb_launch, 4) * nkk * 64 * 8 * sizeof(uint16_t),
+                                     hipMemcpyHostToDevice, s));
+        if (idx->profile) {
+            for (auto& e : idx->ms_ev)
+                if (!e) HIPCHECK(idx, hipEventCreate(&e));
+            HIPCHECK(idx, hipEventRecord(idx->ms_ev[0], s));
+        }
+        if (nkk == 8) {  // dims <= 128: the compile-time-unrolled forms, only as many column blocks as the pass has
+            CHECK(ms16_d128_launch(idx, s, ncb_launch, m->n_docs, m->n_blocks, idx->maxsim_persistent != 0, sa));
+        } else {
+            hipLaunchKernelGGL(k_maxsim16, dim3(grid_all), dim3(kMsThreads), lds16, s, sa);
+            HIPCHECK(idx, hipGetLastError());
+        }
+        idx->s_ms_screen_cols += 32 * (int64_t)ncb_launch;
+        if (idx->profile) HIPCHECK(idx, hipEventRecord(idx->ms_ev[1], s));
+        bool handled[kPQ];
+        for (int r = 0; r < kPQ; ++r) handled[r] = false;
+        if (k <= kMsFastK) {
+            // ---- fast path: every step handles all queries of the pass at once (grid.y), one host sync per pass
             const int64_t sel_stride = ((m->cap_docs + kMsSelSeg - 1) / kMsSelSeg) * kMsFastK;
             int64_t n_in = m->n_docs;
             int cur = 0;
             bool first_stage = true;
             while (true) {  // k best screen distances per 1024-entry segment, until one segment is left
                 const int64_t nseg = (n_in + kMsSelSeg - 1) / kMsSelSeg;
-                hipLaunchKernelGGL(k_ms_select, dim3((unsigned)nseg, nql), dim3(kWave), 0, s,
-                                   first_stage ? dist16 : nullptr, m->blk_off, first_stage ? nullptr : m->sel[cur ^ 1], n_in,
+                hipLaunchKernelGGL(k_ms_select, dim3((unsigned)nseg, pq_n), dim3(kWave), 0, s,
+                                   first_stage ? m->dist16 : nullptr, m->blk_off, first_stage ? nullptr : m->sel[cur ^ 1], n_in,
                                    first_stage ? m->n_docs : sel_stride, k, m->sel[cur], sel_stride);
                 HIPCHECK(idx, hipGetLastError());
                 first_stage = false;
@@ -1461,130 +1459,121 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
                 n_in = nseg * k;
                 cur ^= 1;
             }
-            float te[4];
-            for (int qi = 0; qi < 4; ++qi) {
-                te[qi] = (float)two_e[qi];
-                if ((double)te[qi] < two_e[qi]) te[qi] = std::nextafter(te[qi], INFINITY);
+            float* const te = hd;  // (staging: pinned; the results overwrite it after the synchronisation below)
+            for (int r = 0; r < pq_n; ++r) {
+                te[r] = (float)pq_two_e[r];
+                if ((double)te[r] < pq_two_e[r]) te[r] = std::nextafter(te[r], INFINITY);
             }
-            HIPCHECK(idx, hipMemcpyAsync(m->two_e_dev, te, sizeof(te), hipMemcpyHostToDevice, s));
-            HIPCHECK(idx, hipMemsetAsync(m->cand_ctl, 0, 8 * sizeof(int), s));
-            hipLaunchKernelGGL(k_ms_candidates_y, dim3((unsigned)((m->n_docs + 255) / 256), nql), dim3(256), 0, s, dist16,
+            HIPCHECK(idx, hipMemcpyAsync(m->two_e_dev, te, pq_n * sizeof(float), hipMemcpyHostToDevice, s));
+            HIPCHECK(idx, hipMemsetAsync(m->cand_ctl, 0, 2 * kPQ * sizeof(int), s));
+            hipLaunchKernelGGL(k_ms_candidates_y, dim3((unsigned)((m->n_docs + 255) / 256), pq_n), dim3(256), 0, s, m->dist16,
                                m->n_docs, m->blk_off, m->n_docs, m->sel[cur], sel_stride, k, m->two_e_dev, m->cand_list,
                                kMsCandCap, m->cand_ctl);
             HIPCHECK(idx, hipGetLastError());
-            MsArgs c = a;
+            MsArgs c = a0;
             c.dist = m->cand_dist;
             c.doc_list = m->cand_list;
             c.n_items = n_cand_max;
             c.n_items_dev = m->cand_ctl;
             c.list_stride = kMsCandCap;
+            c.nq_launch = pq_n;
+            for (int r = 0; r < pq_n; ++r) {
+                c.q_col0[r] = pq_col0[r];
+                c.q_len[r] = pq_len[r];
+            }
             // long documents (>= 8 blocks on average: pages): one workgroup per candidate, its four waves share the blocks
             const bool coop = idx->maxsim_coop < 0 ? m->n_blocks >= 8 * m->n_docs : idx->maxsim_coop != 0;
             c.coop = coop ? 1 : 0;
             c.red_off = (int)lds;
             if (idx->profile) HIPCHECK(idx, hipEventRecord(idx->ms_ev[2], s));
-            hipLaunchKernelGGL(k_maxsim, dim3((unsigned)std::min<int64_t>(coop ? n_cand_max : (n_cand_max + 3) / 4, kMsListGrid), nql),
+            hipLaunchKernelGGL(k_maxsim, dim3((unsigned)std::min<int64_t>(coop ? n_cand_max : (n_cand_max + 3) / 4, kMsListGrid), pq_n),
                                dim3(kMsThreads), lds + kMsRedBytes, s, c);
             HIPCHECK(idx, hipGetLastError());
             if (idx->profile) HIPCHECK(idx, hipEventRecord(idx->ms_ev[3], s));
-            hipLaunchKernelGGL(k_ms_final, dim3(1, nql), dim3(256), (size_t)kMsCandCap * 12, s, m->cand_dist, m->cand_list,
+            hipLaunchKernelGGL(k_ms_final, dim3(1, pq_n), dim3(256), (size_t)kMsCandCap * 12, s, m->cand_dist, m->cand_list,
                                m->cand_ctl, kMsCandCap, k, idx->row_offset, m->out_d, m->out_r);
             HIPCHECK(idx, hipGetLastError());
-            HIPCHECK(idx, hipMemcpyAsync(hd, m->out_d, (size_t)nql * k * sizeof(float), hipMemcpyDeviceToHost, s));
-            HIPCHECK(idx, hipMemcpyAsync(hr, m->out_r, (size_t)nql * k * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-            HIPCHECK(idx, hipMemcpyAsync(m->cand_ctl_host, m->cand_ctl, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPCHECK(idx, hipMemcpyAsync(m->cand_ctl_host, m->cand_ctl, 2 * kPQ * sizeof(int), hipMemcpyDeviceToHost, s));
+            if (!out_dev) {  // (hd also staged `te`: its H2D copy precedes these copies in stream order)
+                HIPCHECK(idx, hipMemcpyAsync(hd, m->out_d, (size_t)pq_n * k * sizeof(float), hipMemcpyDeviceToHost, s));
+                HIPCHECK(idx, hipMemcpyAsync(hr, m->out_r, (size_t)pq_n * k * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+            }
             HIPCHECK(idx, hipStreamSynchronize(s));
             if (idx->profile) {
                 float ms = 0.f;
-                if (ms_screen_timed && hipEventElapsedTime(&ms, idx->ms_ev[0], idx->ms_ev[1]) == hipSuccess) {
+                if (hipEventElapsedTime(&ms, idx->ms_ev[0], idx->ms_ev[1]) == hipSuccess) {
                     idx->s_ms_screen_ns += (int64_t)(ms * 1e6);
                     idx->s_ms_screen_launches++;
                 }
-                ms_screen_timed = false;
                 if (hipEventElapsedTime(&ms, idx->ms_ev[2], idx->ms_ev[3]) == hipSuccess) {
                     idx->s_ms_exact_ns += (int64_t)(ms * 1e6);
                     idx->s_ms_exact_launches++;
                 }
             }
-            for (int qi = 0; qi < nql; ++qi) {
-                if (a.q_len[qi] == 0) {
-                    handled[qi] = true;
-                    continue;
-                }
-                if (m->cand_ctl_host[2 * qi + 1] != 0) continue;  // list overflow: exact full scan below
-                handled[qi] = true;
+            for (int r = 0; r < pq_n; ++r) {
+                if (m->cand_ctl_host[2 * r + 1] != 0) continue;  // list overflow: exact full scan below
+                handled[r] = true;
                 idx->s_ms_screened++;
-                idx->s_ms_candidates += m->cand_ctl_host[2 * qi];
+                idx->s_ms_candidates += m->cand_ctl_host[2 * r];
                 if (out_dev) {
-                    HIPCHECK(idx, hipMemcpyAsync(out_dist + (int64_t)(first + qi) * k, m->out_d + (size_t)qi * k, k * sizeof(float),
+                    HIPCHECK(idx, hipMemcpyAsync(out_dist + (int64_t)pq_b[r] * k, m->out_d + (size_t)r * k, k * sizeof(float),
                                                  hipMemcpyDeviceToDevice, s));
-                    HIPCHECK(idx, hipMemcpyAsync(out_rows + (int64_t)(first + qi) * k, m->out_r + (size_t)qi * k,
+                    HIPCHECK(idx, hipMemcpyAsync(out_rows + (int64_t)pq_b[r] * k, m->out_r + (size_t)r * k,
                                                  k * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
                 } else {
-                    memcpy(out_dist + (int64_t)(first + qi) * k, &hd[(size_t)qi * k], k * sizeof(float));
-                    memcpy(out_rows + (int64_t)(first + qi) * k, &hr[(size_t)qi * k], k * sizeof(int64_t));
+                    memcpy(out_dist + (int64_t)pq_b[r] * k, &hd[(size_t)r * k], k * sizeof(float));
+                    memcpy(out_rows + (int64_t)pq_b[r] * k, &hr[(size_t)r * k], k * sizeof(int64_t));
                 }
+            }
+        } else if (idx->profile) {  // (the screen launch of a slow-path pass is timed too)
+            HIPCHECK(idx, hipStreamSynchronize(s));
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, idx->ms_ev[0], idx->ms_ev[1]) == hipSuccess) {
+                idx->s_ms_screen_ns += (int64_t)(ms * 1e6);
+                idx->s_ms_screen_launches++;
             }
         }
-        for (int qi = 0; qi < nql; ++qi) {
-            if (a.q_len[qi] == 0 || handled[qi]) continue;  // reference: `if not query_vectors: return []`
-            float* od = out_dist + (int64_t)(first + qi) * k;
-            int64_t* orow = out_rows + (int64_t)(first + qi) * k;
-            int cur = 0;
-            bool done = false;
-            const bool overflowed = screen && k <= kMsFastK;  // the fast path gave this query up
-            if (overflowed) {
+        for (int r = 0; r < pq_n; ++r) {
+            if (handled[r]) continue;
+            float* od = out_dist + (int64_t)pq_b[r] * k;
+            int64_t* orow = out_rows + (int64_t)pq_b[r] * k;
+            if (k <= kMsFastK) {  // the fast path gave this query up (candidate list overflow): exact full scan
                 idx->s_ms_fallbacks++;
-                MsArgs f = a;
-                f.nq_launch = 1;
-                f.q_col0[0] = a.q_col0[qi];
-                f.q_len[0] = a.q_len[qi];
-                hipLaunchKernelGGL(k_maxsim, dim3(grid_all), dim3(kMsThreads), lds, s, f);
-                HIPCHECK(idx, hipGetLastError());
-            } else if (screen) {
-                // screen top-k -> candidates -> exact kernel on the candidates -> exact top-k
-                CHECK(ms_topk(idx, m, s, dist16 + (int64_t)qi * m->n_docs, m->n_docs, k, seg, nullptr, nullptr, &cur));
-                HIPCHECK(idx, hipMemsetAsync(m->cand_ctl, 0, 2 * sizeof(int), s));
-                float te = (float)two_e[qi];
-                if ((double)te < two_e[qi]) te = std::nextafter(te, INFINITY);
-                hipLaunchKernelGGL(k_ms_candidates, dim3((unsigned)((m->n_docs + 255) / 256)), dim3(256), 0, s,
-                                   dist16 + (int64_t)qi * m->n_docs, m->blk_off, m->n_docs, m->pk[cur], k, te, m->cand_list,
-                                   kMsCandCap, m->cand_ctl);
-                HIPCHECK(idx, hipGetLastError());
-                MsArgs c = a;
-                c.dist = m->cand_dist;
-                c.doc_list = m->cand_list;
-                c.n_items = n_cand_max;
-                c.n_items_dev = m->cand_ctl;
-                c.nq_launch = 1;
-                c.q_col0[0] = a.q_col0[qi];
-                c.q_len[0] = a.q_len[qi];
-                hipLaunchKernelGGL(k_maxsim, dim3((unsigned)std::min<int64_t>((n_cand_max + 3) / 4, kMsListGrid)),
-                                   dim3(kMsThreads), lds, s, c);
-                HIPCHECK(idx, hipGetLastError());
-                CHECK(ms_topk(idx, m, s, m->cand_dist, n_cand_max, k, seg, m->cand_list, m->cand_ctl, &cur));
-                CHECK(ms_emit_result(idx, m, s, cur, k, od, orow, out_dev));
-                HIPCHECK(idx, hipMemcpyAsync(m->cand_ctl_host, m->cand_ctl, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-                HIPCHECK(idx, hipStreamSynchronize(s));
-                if (m->cand_ctl_host[1] == 0) {
-                    done = true;
-                    idx->s_ms_screened++;
-                    idx->s_ms_candidates += m->cand_ctl_host[0];
-                } else {
-                    idx->s_ms_fallbacks++;  // more candidates than the list holds: this query takes the exact full scan
-                    MsArgs f = a;
-                    f.nq_launch = 1;
-                    f.q_col0[0] = a.q_col0[qi];
-                    f.q_len[0] = a.q_len[qi];
-                    hipLaunchKernelGGL(k_maxsim, dim3(grid_all), dim3(kMsThreads), lds, s, f);
-                    HIPCHECK(idx, hipGetLastError());
-                }
+                CHECK(full_scan_query(pq_col0[r], pq_len[r], od, orow));
+                continue;
             }
-            if (!done) {
-                const float* dist_q = screen ? m->dist : m->dist + (int64_t)qi * m->n_docs;
-                CHECK(ms_topk(idx, m, s, dist_q, m->n_docs, k, seg, nullptr, nullptr, &cur));
-                CHECK(ms_emit_result(idx, m, s, cur, k, od, orow, out_dev));
-                HIPCHECK(idx, hipStreamSynchronize(s));
+            // k above the fast path's: screen top-k -> candidates -> exact kernel on the candidates -> exact top-k
+            int cur = 0;
+            const float* dist16 = m->dist16 + (int64_t)r * m->n_docs;
+            CHECK(ms_topk(idx, m, s, dist16, m->n_docs, k, seg, nullptr, nullptr, &cur));
+            HIPCHECK(idx, hipMemsetAsync(m->cand_ctl, 0, 2 * sizeof(int), s));
+            float te = (float)pq_two_e[r];
+            if ((double)te < pq_two_e[r]) te = std::nextafter(te, INFINITY);
+            hipLaunchKernelGGL(k_ms_candidates, dim3((unsigned)((m->n_docs + 255) / 256)), dim3(256), 0, s, dist16, m->blk_off,
+                               m->n_docs, m->pk[cur], k, te, m->cand_list, kMsCandCap, m->cand_ctl);
+            HIPCHECK(idx, hipGetLastError());
+            MsArgs c = a0;
+            c.qtok = m->qtok + (int64_t)pq_col0[r] * dp;
+            c.dist = m->cand_dist;
+            c.doc_list = m->cand_list;
+            c.n_items = n_cand_max;
+            c.n_items_dev = m->cand_ctl;
+            c.nq_launch = 1;
+            c.q_col0[0] = 0;
+            c.q_len[0] = pq_len[r];
+            hipLaunchKernelGGL(k_maxsim, dim3((unsigned)std::min<int64_t>((n_cand_max + 3) / 4, kMsListGrid)),
+                               dim3(kMsThreads), lds, s, c);
+            HIPCHECK(idx, hipGetLastError());
+            CHECK(ms_topk(idx, m, s, m->cand_dist, n_cand_max, k, seg, m->cand_list, m->cand_ctl, &cur));
+            CHECK(ms_emit_result(idx, m, s, cur, k, od, orow, out_dev));
+            HIPCHECK(idx, hipMemcpyAsync(m->cand_ctl_host, m->cand_ctl, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPCHECK(idx, hipStreamSynchronize(s));
+            if (m->cand_ctl_host[1] == 0) {
+                idx->s_ms_screened++;
+                idx->s_ms_candidates += m->cand_ctl_host[0];
+            } else {
+                idx->s_ms_fallbacks++;  // more candidates than the list holds: this query takes the exact full scan
+                CHECK(full_scan_query(pq_col0[r], pq_len[r], od, orow));
             }
         }
     }

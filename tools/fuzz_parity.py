@@ -180,8 +180,8 @@ def check_maxsim(rng, case):
     if mode == "dirty" and tok.shape[0] > 3:
         tok[rng.integers(0, tok.shape[0])] = np.inf
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-    nq = int(rng.choice([1, 2, 5, 9]))
-    qlens = [int(x) for x in rng.choice([0, 1, 5, 24, 32, 33, 100, 128], size=nq)]
+    nq = int(rng.choice([1, 2, 5, 9, 17, 40]))   # (round 4: up to 16 queries ride one screen pass)
+    qlens = [int(x) for x in rng.choice([0, 1, 5, 24, 32, 33, 100, 128] if nq <= 9 else [0, 7, 24, 24, 32, 32, 32, 33, 100, 200], size=nq)]
     qtok = rng.standard_normal((sum(qlens), d)).astype(np.float32)
     if unit and qtok.shape[0]:
         qtok /= np.linalg.norm(qtok, axis=1, keepdims=True)
@@ -194,6 +194,10 @@ def check_maxsim(rng, case):
     with pkg.Mi355Index(d) as idx:
         idx.set_option("maxsim_screen", screen)
         idx.set_option("maxsim_coop", int(rng.integers(-1, 2)))
+        groups, wg = int(rng.integers(1, 5)), int(rng.integers(0, 2))
+        idx.set_option("maxsim_pass_groups", groups)
+        idx.set_option("maxsim_wg", wg)
+        desc += f" groups={groups} wg={wg}"
         idx.add_multivec(tok, off)
         dist, rows = idx.search_maxsim(qtok, qoff, k)
         stats = {s: idx.stat(s) for s in ("maxsim_screened", "maxsim_fallbacks")}
