@@ -99,8 +99,10 @@ struct mi355dr_index {
     int maxsim_coop = -1;       // exact MaxSim on candidate lists: one workgroup per candidate (1), one wave (0), by document length (-1)
     int maxsim_persistent = 0;  // MaxSim screen (dims <= 128): persistent workgroups walking the docs in rounds.  A/B on one box
                                 // (interleaved A/B through this option, 1 M text docs / 100 k pages): text +-0, pages 4 % SLOWER -- off
-    int maxsim_wg = 1;  // MaxSim screen, 9..16 column blocks: the workgroup-cooperative form (k_maxsim_wg.h); 0: one wave per document
-                        // with the query fragments in LDS (k_maxsim16_d128<NCB, 8>) -- option "maxsim_wg", A/B and tests
+    // MaxSim screen, 9..16 column blocks: the workgroup-cooperative form (k_maxsim_wg.h).  -1 (default): yes, per-document epilogue
+    // by document length; 1: parked epilogue; 2: immediate epilogue; 0: one wave per document with the query fragments in LDS
+    // (k_maxsim16_d128<NCB, 8>) -- option "maxsim_wg", A/B and tests
+    int maxsim_wg = -1;
     int maxsim_pass_groups = 4;  // groups of <= 4 queries one pass of the MaxSim screen serves (1 .. 4; option "maxsim_pass_groups", A/B and tests)
     int maxsim_screen = 1; // 1: bf16 MFMA screen + exact re-score of the candidates, 0: exact kernel over every doc
     int64_t row_offset = 0;

@@ -14,7 +14,8 @@
 //     of a stage's two blocks; every wave reads a block's 8 fragments from LDS once and uses each for its one or two column
 //     blocks: 0.5 .. 1 LDS read per MFMA instead of 1, no token fragment ever crosses a VGPR on its way in;
 //   * the per-document epilogue is shared: the waves' per-column maxima meet in 2 KiB of LDS, wave w then sums the columns of
-//     queries w and w + 8 (one masked butterfly each instead of sixteen).
+//     queries w and w + 8 (one masked butterfly each instead of sixteen) -- behind the ring's NEXT stage barrier, not one of
+//     its own.
 // Column blocks w and w + 8 sit on the same wave, waves w and w + 4 on the same SIMD: 12 column blocks (sixteen 24-vector
 // queries) are 3 per SIMD, 16 are 4 per SIMD -- balanced.
 // The per-document sums add the column maxima in another order than k_maxsim16_d128 and the exact kernel do; the screen's
@@ -27,10 +28,10 @@ namespace mi355 {
 constexpr int kMwStages = 7;                 // ring stages
 constexpr int kMwStageBytes = 2 * 8192;      // two 32-token blocks of 128 dims bf16, fragment order [kk][lane][8]
 constexpr int kMwColmaxOff = kMwStages * kMwStageBytes;
-constexpr int kMwLds = kMwColmaxOff + 2 * 512 * (int)sizeof(float);  // + two parities of 512 column maxima
+constexpr int kMwLds = kMwColmaxOff + 4 * 512 * (int)sizeof(float);  // + four buffers of 512 column maxima (parked documents)
 static_assert(kMwLds <= 160 * 1024, "LDS per workgroup");
 
-template <int NCB>
+template <int NCB, bool DEFER>
 __global__ __launch_bounds__(512, 2) void k_maxsim16_wg(Ms16Args a, int64_t n_blocks) {
     static_assert(NCB >= 9 && NCB <= 16, "this form serves 9..16 column blocks");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -121,35 +122,62 @@ __global__ __launch_bounds__(512, 2) void k_maxsim16_wg(Ms16Args a, int64_t n_bl
     if (n_my == 0) return;
 
     float run0 = -__builtin_inff(), run1 = -__builtin_inff();
-    int par = 0;
+    // A finished document's column maxima are PARKED in one of four 2-KiB buffers and summed after the NEXT stage barrier --
+    // the barrier the ring needs anyway publishes them; a barrier (and an LDS drain) of its own per document cost a text store,
+    // whose documents are two stages long, a tenth of the kernel.  Between two stage barriers lie two blocks, so at most two
+    // documents end; a buffer is rewritten four documents, i.e. at least two barriers, later.
+    int n_fin = 0, pend_n = 0;
+    bool flush_pending_now = false;
+    int64_t pend_doc[2] = {0, 0};
+    int pend_buf[2] = {0, 0};
     auto finish_doc = [&]() {
         // the two halves of the wave hold different token rows of the same query column
         const float r0 = fmaxf(run0, __shfl_xor(run0, 32, kWave));
         const float r1 = fmaxf(run1, __shfl_xor(run1, 32, kWave));
-        float* cm = colmax + par * 512;
+        const int bw = n_fin & 3;
+        float* cm = colmax + bw * 512;
         if (lane < 32) {
             cm[cb0 * 32 + lane] = r0;
             if (two) cm[cb1 * 32 + lane] = r1;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        MI355_BARRIER();
-        float out[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int qi = wave + 8 * s;
-            float part = 0.0f;
-            if (qi < a.nq_launch) {  // wave-uniform
-                const int c0 = a.q_col0[qi], len = a.q_len[qi];
-                if (lane < len) part += cm[c0 + lane];
-                if (lane + 64 < len) part += cm[c0 + 64 + lane];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, kWave);
-            }
-            out[s] = -part;
+        if (pend_n == 0) {
+            pend_doc[0] = cur;
+            pend_buf[0] = bw;
+        } else {
+            pend_doc[1] = cur;
+            pend_buf[1] = bw;
         }
-        write_doc(cur, out[0], out[1]);
-        par ^= 1;  // (the buffer is rewritten two documents later: a barrier of the next document's epilogue lies between)
+        ++pend_n;
+        ++n_fin;
         run0 = run1 = -__builtin_inff();
+        if constexpr (!DEFER) {  // (A/B form: a barrier of its own per document, sums at once)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            MI355_BARRIER();
+            flush_pending_now = true;
+        }
+    };
+    auto flush_pending = [&]() {  // right behind a barrier: the parked maxima of every wave are visible
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            if (p >= pend_n) break;  // workgroup-uniform
+            const float* cm = colmax + pend_buf[p] * 512;
+            float out[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int qi = wave + 8 * s;
+                float part = 0.0f;
+                if (qi < a.nq_launch) {  // wave-uniform
+                    const int c0 = a.q_col0[qi], len = a.q_len[qi];
+                    if (lane < len) part += cm[c0 + lane];
+                    if (lane + 64 < len) part += cm[c0 + 64 + lane];
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, kWave);
+                }
+                out[s] = -part;
+            }
+            write_doc(pend_doc[p], out[0], out[1]);
+        }
+        pend_n = 0;
     };
 
     // ---- staging: wave w moves k-group fragment w of every block (1 KiB per instruction); past the range: the last block again
@@ -200,6 +228,12 @@ __global__ __launch_bounds__(512, 2) void k_maxsim16_wg(Ms16Args a, int64_t n_bl
         ++pos;
         if (pos == end_cur) {  // workgroup-uniform: the document is complete
             finish_doc();
+            if constexpr (!DEFER) {
+                if (flush_pending_now) {
+                    flush_pending();
+                    flush_pending_now = false;
+                }
+            }
             advance_doc();
         }
     };
@@ -220,6 +254,7 @@ __global__ __launch_bounds__(512, 2) void k_maxsim16_wg(Ms16Args a, int64_t n_bl
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         MI355_BARRIER();  // ... everybody's have, and everybody is done reading stage s: its slot is refilled with stage s + 7
         issue_stage();
+        flush_pending();  // the documents that ended since the previous barrier
         const int slot_n = slot + 1 == kMwStages ? 0 : slot + 1;
         read_block(tfA, slot_n, 0);  // block A of stage s + 1: lands under block B's MFMAs
         // ---- block B of stage s (the range may end on block A)
@@ -232,6 +267,8 @@ __global__ __launch_bounds__(512, 2) void k_maxsim16_wg(Ms16Args a, int64_t n_bl
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the dummy stages must land before the LDS is freed
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    MI355_BARRIER();
+    flush_pending();  // the range's last document(s)
 }
 
 }  // namespace mi355

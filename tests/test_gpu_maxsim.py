@@ -293,8 +293,9 @@ def test_sixteen_queries_ride_one_screen_pass(pkg, oracle, tmin, tmax, n_docs):
     rd, rr = oracle.maxsim_topk(tok, off, qtok, qoff, k)
     with pkg.Mi355Index(d) as idx:
         idx.add_multivec(tok, off)
-        for groups in (4, 1, 3, 2):
+        for groups, wg in ((4, -1), (1, -1), (3, 1), (2, 0), (4, 2), (4, 0), (4, 1)):
             idx.set_option("maxsim_pass_groups", groups)
+            idx.set_option("maxsim_wg", wg)   # -1 by document length / 1 parked / 2 immediate epilogue / 0 one wave per document
             idx.reset_stats()
             dist, rows = idx.search_maxsim(qtok, qoff, k)
             live = np.asarray(lens) > 0   # (a query without vectors: the reference returns [] before any SQL, base.py:506-507)
@@ -303,7 +304,7 @@ def test_sixteen_queries_ride_one_screen_pass(pkg, oracle, tmin, tmax, n_docs):
             ok = ~np.isnan(rd) & live[:, None]
             assert np.array_equal(np.isnan(dist[live]), np.isnan(rd[live])), groups
             assert np.array_equal(dist[ok].view(np.uint32), rd[ok].view(np.uint32)), groups
-            if groups == 4:
+            if groups == 4 and wg == -1:
                 # all but the empty one, the long one and the GROUP of the non-finite one (its three neighbours take the exact scan with it)
                 assert idx.stat("maxsim_screened") >= len(lens) - 6
         with pytest.raises(pkg.NativeError):

@@ -194,7 +194,7 @@ def check_maxsim(rng, case):
     with pkg.Mi355Index(d) as idx:
         idx.set_option("maxsim_screen", screen)
         idx.set_option("maxsim_coop", int(rng.integers(-1, 2)))
-        groups, wg = int(rng.integers(1, 5)), int(rng.integers(0, 2))
+        groups, wg = int(rng.integers(1, 5)), int(rng.integers(-1, 3))
         idx.set_option("maxsim_pass_groups", groups)
         idx.set_option("maxsim_wg", wg)
         desc += f" groups={groups} wg={wg}"

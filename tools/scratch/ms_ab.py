@@ -36,5 +36,5 @@ def run(tokens, n_docs, nq, qblock, wg, groups, steps=20):
         print(f"{tokens} docs={n_docs} wg={w} groups={gr}: {steps*qblock/el:8.1f} q/s  step {el/steps*1e3:7.3f} ms  screen launch {ns/max(n,1)*1e-6:7.3f} ms x {n/steps:.1f}/step  issued {flops/(ns/max(n,1)*1e-9)/1e12:6.0f} TF/s  checksum {int(r[1].sum())}", flush=True)
     idx.close()
 if __name__ == "__main__":
-    run("page", 100_000, 24, 16, [1, 0], [4, 2])
-    run("text", 1_000_000, 32, 16, [1, 0], [4, 2])
+    run("page", 100_000, 24, 16, [1, 2, 1, 2], [4])
+    run("text", 1_000_000, 32, 16, [1, 2, 1, 2, 1, 2], [4])
