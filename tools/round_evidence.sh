@@ -1,19 +1,133 @@
 #!/bin/bash
-# On the GPU box: the round's evidence in one job -> gpurun_out/ev/ (copy what is to be judged into profiles/rNN_*).
-#   tests + smoke, default bench line, bf16 line, rocprofv3 kernel stats of the bench, PMC traffic passes, one-step kernel
-#   timelines at 10 M rows and at the 8-way shard size, shard-size table through the gather + merge path, config C2.
+# On the GPU box: a round's evidence, by section -> gpurun_out/ev/ (copy what is to be judged into profiles/rNN_*).
+#   bash tools/round_evidence.sh [section ...]      (no argument = the default set)
+# Sections (each writes gpurun_out/ev/<section>*):
+#   tests      pytest -m gpu + smoke()
+#   bench      the default bench line (what the driver runs) + the bf16-screen line
+#   stats      rocprofv3 --kernel-trace --stats of the bench command
+#   traffic    PMC passes (separate, kernel-trace only) of the bench command: FETCH_SIZE, WRITE_SIZE, L2 hit, SQ busy / LDS
+#   timelines  one-step kernel timelines at N = 10 M and at the 8-way shard size
+#   shards     pass time at the 1/2/4/8-GPU shard sizes, plain and through the all-gather + merge path (world 1)
+#   c2         config C2 stand-in (anisotropic, inner product, k = 100): line + kernel stats
+#   maxsim     the two MaxSim stores as bench lines of their own + kernel stats + PMC (FETCH_SIZE; SQ busy)
+#   power      socket power / clock next to a 600-step bench run
+#   mx         bare MFMA stream by operand format (int8, bf16, MX fp8 / fp6 / fp4) with power, + the int8 gather second stage
+#   kstep      k_screen256c timing builds (no LDS-DMA / no fragment reads / no barrier) on Gaussian operands and on zeros, with power
+#   barrier    grid-barrier cost in the screen kernel's geometry vs a dependent launch
+#   fuzz       tools/fuzz_parity.py campaign (FUZZ_SECONDS, default 600)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/ev; mkdir -p $OUT
-timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; tail -2 $OUT/pytest_gpu.log
-python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log
-python bench.py > $OUT/bench_default.log 2>&1; tail -1 $OUT/bench_default.log > $OUT/bench_default_line.json; cut -c1-500 $OUT/bench_default_line.json
-python bench.py --screen bf16 --no-cpu-baseline --no-extras > $OUT/bench_bf16.log 2>&1; tail -1 $OUT/bench_bf16.log > $OUT/bench_bf16_line.json; cut -c1-200 $OUT/bench_bf16_line.json
-rm -rf $OUT/stats; rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $OUT/stats.log 2>&1
-ls $OUT/stats
-bash tools/collect_traffic.sh > $OUT/traffic.log 2>&1; tail -5 $OUT/traffic.log
-ROWS=10000000 BENCH_ARGS=--no-extras bash tools/step_timeline.sh > $OUT/timeline_10m.txt 2>&1; tail -3 $OUT/timeline_10m.txt
-ROWS=1250000 BENCH_ARGS=--no-extras bash tools/step_timeline.sh > $OUT/timeline_1250k.txt 2>&1; tail -3 $OUT/timeline_1250k.txt
-bash tools/shard_sizes.sh > $OUT/shard_sizes.txt 2>&1; cat $OUT/shard_sizes.txt
-# config C2 (BEIR nq / bge-base stand-in): line + kernel stats
-python bench.py --data anisotropic --metric ip --k 100 --rows 2000000 --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $OUT/bench_c2.log 2>&1; tail -1 $OUT/bench_c2.log > $OUT/bench_c2_line.json; cut -c1-300 $OUT/bench_c2_line.json
-rm -rf $OUT/stats_c2; rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats_c2 -o stats -- python bench.py --data anisotropic --metric ip --k 100 --rows 2000000 --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $OUT/stats_c2.log 2>&1
+SECTIONS="${@:-tests bench stats traffic timelines shards c2 maxsim}"
+BENCH_QUICK="--no-cpu-baseline --no-extras"
+
+smi_poll() {  # smi_poll <file> <samples>: "(<MHz>Mhz) <W>" per line
+  ( for i in $(seq 1 $2); do rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power \(W\)|sclk" | sed 's/.*: //' | tr '\n' ' '; echo; sleep 0.03; done ) > $1 &
+  SMI=$!
+}
+smi_median() {  # smi_median <file>: "<W> W, <MHz> MHz" over the samples behind the first third (the governor's ramp)
+  local n=$(wc -l < $1)
+  local w=$(tail -n +$((n/3+1)) $1 | awk '{print $NF}' | sort -n | awk '{a[NR]=$1} END{print a[int((NR+1)/2)]}')
+  local m=$(tail -n +$((n/3+1)) $1 | grep -o "([0-9]*Mhz)" | tr -d '()Mhz' | sort -n | awk '{a[NR]=$1} END{print a[int((NR+1)/2)]}')
+  echo "${w} W, ${m} MHz"
+}
+timeline() {  # timeline <rows> <outfile>: every kernel of the bench's last step with start offset, gap and duration
+  rm -rf $OUT/tl; MI355DR_BENCH_PMC=0 rocprofv3 --kernel-trace -f csv -d $OUT/tl -- python bench.py --rows $1 --steps 3 --warmup 2 $BENCH_QUICK > $OUT/tl.log 2>&1
+  python - $OUT/tl > $2 <<'PY'
+import csv, glob, sys
+f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
+rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
+idx = [i for i, r in enumerate(rows) if 'k_prep_queries' in r['Kernel_Name']]
+sel = rows[idx[-1]:]
+t0 = int(sel[0]['Start_Timestamp']); prev_end = t0; busy = 0
+for r in sel:
+    s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+    if (s - t0) > 50e6: break
+    print(f"{(s-t0)/1e3:9.1f} us  gap {(s-prev_end)/1e3:7.1f}  dur {(e-s)/1e3:8.1f}  {r['Kernel_Name'][:70]}  grid {r.get('Grid_Size_X', r.get('Grid_Size',''))}")
+    prev_end = max(prev_end, e); busy += e - s
+print('span us', (prev_end - t0) / 1e3, 'busy us', busy / 1e3)
+PY
+  tail -3 $2
+}
+
+for sec in $SECTIONS; do case $sec in
+tests)
+  timeout 1800 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; tail -2 $OUT/pytest_gpu.log
+  python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log ;;
+bench)
+  python bench.py > $OUT/bench_default.log 2>&1; tail -1 $OUT/bench_default.log > $OUT/bench_default_line.json; cut -c1-400 $OUT/bench_default_line.json
+  python bench.py --screen bf16 $BENCH_QUICK > $OUT/bench_bf16.log 2>&1; tail -1 $OUT/bench_bf16.log > $OUT/bench_bf16_line.json; cut -c1-200 $OUT/bench_bf16_line.json ;;
+stats)
+  rm -rf $OUT/stats; MI355DR_BENCH_PMC=0 rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o stats -- python bench.py --steps 5 --warmup 2 $BENCH_QUICK > $OUT/stats.log 2>&1
+  find $OUT/stats -name "*kernel_stats.csv" | head -1 | xargs -r head -8 ;;
+traffic)
+  T=$OUT/traffic; rm -rf $T; mkdir -p $T; ARGS="--steps 3 --warmup 1 $BENCH_QUICK"
+  MI355DR_BENCH_PMC=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $T -o fetch -- python bench.py $ARGS > $T/fetch.log 2>&1
+  MI355DR_BENCH_PMC=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $T -o write -- python bench.py $ARGS > $T/write.log 2>&1
+  MI355DR_BENCH_PMC=0 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -f csv -d $T -o tcc -- python bench.py $ARGS > $T/tcc.log 2>&1
+  MI355DR_BENCH_PMC=0 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -f csv -d $T -o sq -- python bench.py $ARGS > $T/sq.log 2>&1
+  python tools/traffic_summary.py $T | tail -12 ;;
+timelines)
+  timeline 10000000 $OUT/timeline_10m.txt
+  timeline 1250000 $OUT/timeline_1250k.txt ;;
+shards)
+  export MASTER_ADDR=127.0.0.1 MASTER_PORT=29544 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0
+  for rows in 10000000 5000000 2500000 1250000; do
+    a=$(python bench.py --rows $rows --steps 30 --warmup 3 $BENCH_QUICK 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])")
+    b=$(python bench.py --rows $rows --steps 30 --warmup 3 $BENCH_QUICK --force-dist 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])")
+    echo "rows $rows  ms_per_pass $a  with_gather_and_merge $b"
+  done | tee $OUT/shard_sizes.txt
+  unset MASTER_ADDR MASTER_PORT RANK WORLD_SIZE LOCAL_RANK ;;
+c2)
+  C2="--data anisotropic --metric ip --k 100 --rows 2000000"
+  python bench.py $C2 --steps 20 --warmup 3 $BENCH_QUICK > $OUT/bench_c2.log 2>&1; tail -1 $OUT/bench_c2.log > $OUT/bench_c2_line.json; cut -c1-300 $OUT/bench_c2_line.json
+  rm -rf $OUT/stats_c2; MI355DR_BENCH_PMC=0 rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats_c2 -o stats -- python bench.py $C2 --steps 5 --warmup 2 $BENCH_QUICK > $OUT/stats_c2.log 2>&1 ;;
+maxsim)
+  for shape in text page; do
+    docs=1000000; [ $shape = page ] && docs=100000
+    ARGS="--workload maxsim --tokens $shape --docs $docs --warmup 2 --no-cpu-baseline"
+    python bench.py $ARGS --steps 63 > $OUT/maxsim_line_$shape.json 2> $OUT/maxsim_line_$shape.err; cut -c1-600 $OUT/maxsim_line_$shape.json
+    rm -rf $OUT/maxsim_st_$shape $OUT/maxsim_pmc_$shape
+    MI355DR_BENCH_PMC=0 rocprofv3 --kernel-trace --stats -f csv -d $OUT/maxsim_st_$shape -o ms -- python bench.py $ARGS --steps 12 --no-extras > $OUT/maxsim_st_$shape.log 2>&1
+    MI355DR_BENCH_PMC=0 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -f csv -d $OUT/maxsim_pmc_$shape -o sq -- python bench.py $ARGS --steps 6 --no-extras > $OUT/maxsim_pmc_$shape.log 2>&1
+    python tools/pmc_summary.py $OUT/maxsim_pmc_$shape k_maxsim16 > $OUT/maxsim_pmc_${shape}_summary.json 2>/dev/null; cut -c1-600 $OUT/maxsim_pmc_${shape}_summary.json
+  done ;;
+power)
+  smi_poll $OUT/power_samples.txt 500
+  python bench.py --steps 600 --warmup 3 $BENCH_QUICK 2>/dev/null | tail -1 | cut -c1-300 | tee $OUT/power_bench_line.txt
+  kill $SMI 2>/dev/null; wait $SMI 2>/dev/null
+  echo "600-step bench: $(smi_median $OUT/power_samples.txt)" | tee $OUT/power_headline.txt ;;
+mx)
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/mfma_power_probe.hip -o /tmp/mfma_power_probe || exit 1
+  { echo "# bare MFMA stream: 256 workgroups x 8 waves (2 per SIMD), operands in registers, 4 accumulators; ${SECS:-4} s per run;"
+    echo "# rocm-smi polled next to each run, medians behind the first third of the samples"
+    rocm-smi --showmaxpower 2>/dev/null | grep -E "Max Graphics" | head -1
+    for data in gauss zero; do for fmt in i8 bf16 fp8 fp6 fp4; do
+      smi_poll $OUT/smi_mx.txt 200
+      line=$(/tmp/mfma_power_probe $fmt $data ${SECS:-4} | tail -1)
+      kill $SMI 2>/dev/null; wait $SMI 2>/dev/null
+      echo "$line | socket $(smi_median $OUT/smi_mx.txt)"
+    done; done
+    echo; echo "# int8 second stage by GATHER: random rows of a 10 M x 768 B int8 shadow, v_dot4_i32_i8, 16 lanes per row"
+    for c in 7000 700 100; do /tmp/mfma_power_probe gather 10000000 1024 $c | tail -1; done; } 2>&1 | tee $OUT/mx_probe.txt ;;
+kstep)
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -Iautorag_research_amd/csrc -Itools/forms tools/screen_bench.hip -o /tmp/screen_bench || exit 1
+  { echo "# k_screen256c timing builds, int8, N = 10 M x 1024 queries, thresholds parked (tools/screen_bench ABL bits; results of the"
+    echo "# ablated builds are garbage, their instruction stream minus the removed part is what runs):"
+    echo "#   201000 full kernel | 202040 no LDS-DMA | 202041 no LDS-DMA, no fragment reads (MFMAs + tests + loop + barrier) | 202049 ... no barrier"
+    for data in 1 2; do
+      echo "=== DATA=$data ($([ $data = 1 ] && echo 'Gaussian int8, sigma 29: what the shadows hold' || echo zeros)) ==="
+      for v in 201000 202040 202041 202049; do
+        smi_poll $OUT/smi_kstep.txt 120
+        line=$(DATA=$data ROUNDS=60 VARIANTS=$v /tmp/screen_bench 10000000 1024 768 | tail -1)
+        kill $SMI 2>/dev/null; wait $SMI 2>/dev/null
+        echo "alone        $line | $(smi_median $OUT/smi_kstep.txt)"
+      done
+      echo "--- interleaved (every variant once per round, 30 rounds)"
+      DATA=$data ROUNDS=30 VARIANTS=201000,202040,202041,202049 /tmp/screen_bench 10000000 1024 768 | tail -4
+    done; } 2>&1 | tee $OUT/kstep_ab.txt ;;
+barrier)
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/grid_barrier_probe.hip -o /tmp/grid_barrier_probe && timeout 120 /tmp/grid_barrier_probe | tee $OUT/grid_barrier.txt ;;
+fuzz)
+  timeout $(( ${FUZZ_SECONDS:-600} + 120 )) python tools/fuzz_parity.py --seconds ${FUZZ_SECONDS:-600} --seed ${FUZZ_SEED:-4} > $OUT/fuzz.log 2>&1; tail -2 $OUT/fuzz.log | cut -c1-300 ;;
+*) echo "unknown section $sec" ;;
+esac; done
