@@ -49,6 +49,12 @@ MFMA_I8_PEAK_TOPS = 5000.0  # int8 MFMA = 2x the bf16 rate on gfx950 (2xK): the 
 # i8 16x16x64 3944 TOPS (the figure MI355X_MICROARCH.md's MFMA table carries); bf16 32x32x16 2382 TF
 MFMA_I8_UBENCH_TOPS = {"32x32x32": 4404.0, "16x16x64": 3944.0}
 MFMA_BF16_UBENCH_TF = 2382.0
+# What the matrix pipe delivers ON GAUSSIAN OPERANDS with no memory traffic at all: a bare MFMA stream (operands in registers, four
+# accumulators, two waves per SIMD on every CU) settles at the socket power cap -- 1.28 kW, 1.79 / 1.80 GHz -- far below the
+# nominal peaks, which only zero operands reach (tools/mfma_power_probe.hip, profiles/r04_fp4_probe.txt).  The nominal dense peak
+# stays the denominator of `roofline.frac`; `frac_of_power_limited_stream` is the same achieved rate over these.
+MFMA_I8_POWER_LIMITED_TOPS = 3369.0
+MFMA_BF16_POWER_LIMITED_TF = 1743.0
 
 
 def parse_args():
@@ -270,6 +276,7 @@ def run_maxsim(args, n_docs: int, tokens: str, nq: int, steps: int, warmup: int,
                      "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                      "frac": round(alg_flops / scr_s / 1e12 / MFMA_BF16_PEAK_TF, 4) if scr_n else None,
                      "issued_tflops": round(issued_flops / scr_s / 1e12, 2) if scr_n else None,
+                     "frac_of_power_limited_stream": round(issued_flops / scr_s / 1e12 / MFMA_BF16_POWER_LIMITED_TF, 4) if scr_n else None,
                      "traffic": None,
                      "traffic_unit": f"HBM read bytes per launch, vs {round(streamed)} streamed (the bf16 fragment copy) and "
                                      f"algorithmic {round(alg_bytes)} (fp32 token rows, SURVEY 8d)", "traffic_source": None,
@@ -874,7 +881,7 @@ def main() -> None:
     # inside the timed region): bytes per screened row x rows per launch.  See tools/collect_traffic.sh.
     traffic = None
     traffic_src = None
-    for tname in (("r03_traffic_i8.json", "r02_traffic_i8.json", "r01_traffic_i8.json") if i8 else ("r02_traffic.json", "r01_traffic.json")):
+    for tname in (("r04_traffic_i8.json", "r03_traffic_i8.json", "r02_traffic_i8.json") if i8 else ("r02_traffic.json", "r01_traffic.json")):
         tfile = ROOT / "profiles" / tname
         if tfile.exists() and B > 128 and d == 768 and launches:
             per_row = json.loads(tfile.read_text())["hbm_read_bytes_per_screened_row"]
@@ -894,6 +901,10 @@ def main() -> None:
         "unit": "TFLOP/s",
         "frac": round(alg_flops / screen_s / 1e12 / peak, 4) if screen_s > 0 else None,
         "frac_of_ubench_ceiling": round(alg_flops / screen_s / 1e12 / ubench, 4) if screen_s > 0 else None,
+        "frac_of_power_limited_stream": round(alg_flops / screen_s / 1e12 / (MFMA_I8_POWER_LIMITED_TOPS if i8 else MFMA_BF16_POWER_LIMITED_TF), 4) if screen_s > 0 else None,
+        "power_limited_stream": {"rate": MFMA_I8_POWER_LIMITED_TOPS if i8 else MFMA_BF16_POWER_LIMITED_TF,
+                                 "note": "bare MFMA stream of this instruction on Gaussian operands, no memory traffic: the chip at its "
+                                         "1.4 kW socket cap (1.28 kW, 1.79 GHz); tools/mfma_power_probe.hip, profiles/r04_fp4_probe.txt"},
         "ubench_ceiling": {"this_instruction": ubench,
                            "note": "cdna_hip_programming.md MFMA ubench table: i8 32x32x32 4404 TOPS, i8 16x16x64 3944 TOPS "
                                    "(the row MI355X_MICROARCH.md quotes), bf16 32x32x16 2382 TF"},

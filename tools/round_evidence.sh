@@ -27,7 +27,7 @@ smi_poll() {  # smi_poll <file> <samples>: "(<MHz>Mhz) <W>" per line
 smi_median() {  # smi_median <file>: "<W> W, <MHz> MHz" over the samples behind the first third (the governor's ramp)
   local n=$(wc -l < $1)
   local w=$(tail -n +$((n/3+1)) $1 | awk '{print $NF}' | sort -n | awk '{a[NR]=$1} END{print a[int((NR+1)/2)]}')
-  local m=$(tail -n +$((n/3+1)) $1 | grep -o "([0-9]*Mhz)" | tr -d '()Mhz' | sort -n | awk '{a[NR]=$1} END{print a[int((NR+1)/2)]}')
+  local m=$(tail -n +$((n/3+1)) $1 | grep -a -o "([0-9]*Mhz)" | tr -d '()Mhz' | sort -n | awk '{a[NR]=$1} END{print a[int((NR+1)/2)]}')
   echo "${w} W, ${m} MHz"
 }
 timeline() {  # timeline <rows> <outfile>: every kernel of the bench's last step with start offset, gap and duration
@@ -114,11 +114,13 @@ kstep)
   { echo "# k_screen256c timing builds, int8, N = 10 M x 1024 queries, thresholds parked (tools/screen_bench ABL bits; results of the"
     echo "# ablated builds are garbage, their instruction stream minus the removed part is what runs):"
     echo "#   201000 full kernel | 202040 no LDS-DMA | 202041 no LDS-DMA, no fragment reads (MFMAs + tests + loop + barrier) | 202049 ... no barrier"
+    echo "# NOTE: without the LDS-DMA the ring is never filled: the ablated builds multiply whatever the LDS holds (zeros), whatever DATA"
+    echo "# says -- they measure CYCLES of the instruction stream, not its power on real operands; only the full kernel sees DATA."
     for data in 1 2; do
       echo "=== DATA=$data ($([ $data = 1 ] && echo 'Gaussian int8, sigma 29: what the shadows hold' || echo zeros)) ==="
       for v in 201000 202040 202041 202049; do
-        smi_poll $OUT/smi_kstep.txt 120
-        line=$(DATA=$data ROUNDS=60 VARIANTS=$v /tmp/screen_bench 10000000 1024 768 | tail -1)
+        smi_poll $OUT/smi_kstep.txt 200   # (~4 s of launches: the governor settles after ~0.4 s)
+        line=$(DATA=$data ROUNDS=700 VARIANTS=$v /tmp/screen_bench 10000000 1024 768 | tail -1)
         kill $SMI 2>/dev/null; wait $SMI 2>/dev/null
         echo "alone        $line | $(smi_median $OUT/smi_kstep.txt)"
       done
