@@ -178,8 +178,8 @@ __device__ __forceinline__ void wave_queue_flush(const ScreenArgs& a, const int3
 // than the instruction cache holds -- and cost 20 % of the kernel although it almost never runs.  A call spills the caller's
 // live registers around the call site only, i.e. on the rare path.  Returns the wave's new queue fill.
 template <bool I8>
-__device__ __attribute__((noinline)) int screen_queue_hits(f32x16 acc, int any_i, int q, int rbase, int row_end, float th,
-                                                            float m, float ek, unsigned a_q, int que_n, int* status) {
+__device__ __forceinline__ int screen_queue_hits_body(f32x16 acc, int any_i, int q, int rbase, int row_end, float th,
+                                                     float m, float ek, unsigned a_q, int que_n, int* status) {
     const bool any = any_i != 0;
     bool gany[4];
     int thi = 0;
@@ -227,6 +227,11 @@ __device__ __attribute__((noinline)) int screen_queue_hits(f32x16 acc, int any_i
     }
     return que_n;
 }
+template <bool I8>
+__device__ __attribute__((noinline)) int screen_queue_hits(f32x16 acc, int any_i, int q, int rbase, int row_end, float th,
+                                                            float m, float ek, unsigned a_q, int que_n, int* status) {
+    return screen_queue_hits_body<I8>(acc, any_i, q, rbase, row_end, th, m, ek, a_q, que_n, status);
+}
 // the test itself, inline: 15 max + the compare; the call only when some lane passes
 template <bool I8>
 __device__ __forceinline__ void screen_test_block(int* status, f32x16 acc, int q, int rbase, int row_end, float th, I8Blk blk,
@@ -246,6 +251,29 @@ __device__ __forceinline__ void screen_test_block(int* status, f32x16 acc, int q
     }
     if (__builtin_amdgcn_ballot_w64(any) == 0) return;  // wave-uniform: almost always taken
     que_n = screen_queue_hits<I8>(acc, any ? 1 : 0, q, rbase, row_end, th, blk.m, blk.ek, lds_addr(que), que_n, status);
+}
+// A/B form (k_screen256c ABL bit 12): the append path INLINE at every test site but marked unlikely, so that block placement
+// moves the twelve copies behind the loop -- no call, no argument moves, and above all no function entry: the calling
+// convention opens every device function with s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0), which makes a wave with a hit wait for
+// every LDS-DMA piece it has in flight.
+template <bool I8>
+__device__ __forceinline__ void screen_test_block_cold(int* status, f32x16 acc, int q, int rbase, int row_end, float th, I8Blk blk,
+                                                       int32_t* que, int& que_n) {
+    bool any;
+    if constexpr (I8) {
+        const i32x16 v = __builtin_bit_cast(i32x16, acc);
+        int g[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[i] = max(max(v[4 * i], v[4 * i + 1]), max(v[4 * i + 2], v[4 * i + 3]));
+        any = i8_value(max(max(g[0], g[1]), max(g[2], g[3])), blk) >= th;
+    } else {
+        float g[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[i] = fmaxf(fmaxf(acc[4 * i], acc[4 * i + 1]), fmaxf(acc[4 * i + 2], acc[4 * i + 3]));
+        any = fmaxf(fmaxf(g[0], g[1]), fmaxf(g[2], g[3])) >= th;
+    }
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(any) != 0, 0))
+        que_n = screen_queue_hits_body<I8>(acc, any ? 1 : 0, q, rbase, row_end, th, blk.m, blk.ek, lds_addr(que), que_n, status);
 }
 
 // FLAG = false: a full queue falls back to a direct global append (a returning atomic: k_screen256, first form);

@@ -189,7 +189,10 @@ __global__ __launch_bounds__(512, 2) void k_screen256c(ScreenArgs2 a) {
                 const I8Group g__ = ((const I8Group*)(smem + kRecOff + ((RSLOT) & 3) * 256))[4 * wr + 2 * (I) + (RB)]; \
                 blk__ = i8_blk(g__, scq[J], kqq[J]);                                                  \
             }                                                                                         \
-            screen_test_block<I8>(a.status, acc[I][RB][J], q__, rbase__, row_end, th[J], blk__, que, que_n); \
+            if constexpr ((ABL & 4096) != 0)                                                          \
+                screen_test_block_cold<I8>(a.status, acc[I][RB][J], q__, rbase__, row_end, th[J], blk__, que, que_n); \
+            else                                                                                      \
+                screen_test_block<I8>(a.status, acc[I][RB][J], q__, rbase__, row_end, th[J], blk__, que, que_n); \
         }                                                                                             \
     } while (0)
 // one micro-step: [reads for M + 2] [4 MFMAs] [DMA pieces P0, P0 + 1 (NP of them)] [one block test]

@@ -118,7 +118,7 @@ int main(int argc, char** argv) {
 #define SB_FORMS(X) X(3136) X(7232)
 #define SB_ATTR(A) CK(hipFuncSetAttribute((const void*)k_screen256b<A, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
     SB_FORMS(SB_ATTR)
-#define SC_FORMS(X) X(1024) X(1152) X(1280) X(1408) X(3072) X(1040) X(1041) X(1032) X(1056) X(1064) X(1049)
+#define SC_FORMS(X) X(1024) X(1152) X(1280) X(1408) X(3072) X(1040) X(1041) X(1032) X(1056) X(1064) X(1049) X(5120)
 #define SC_ATTR(A) CK(hipFuncSetAttribute((const void*)k_screen256c<A, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreen256Lds));
     SC_FORMS(SC_ATTR)
 #define SD_FORMS(X) X(0) X(16) X(32)
