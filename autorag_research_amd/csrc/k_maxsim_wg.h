@@ -31,6 +31,23 @@ constexpr int kMwColmaxOff = kMwStages * kMwStageBytes;
 constexpr int kMwLds = kMwColmaxOff + 4 * 512 * (int)sizeof(float);  // + four buffers of 512 column maxima (parked documents)
 static_assert(kMwLds <= 160 * 1024, "LDS per workgroup");
 
+// wave-wide fp32 sum by DPP, valid in LANE 63: four row_shr steps (inclusive prefix inside each row of 16 lanes), then
+// row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3 -- six VALU operations where the shuffle butterfly was six
+// dependent ds_bpermute round trips through the LDS (a text document's two query sums: a tenth of the kernel)
+template <int CTRL, int ROWMASK, bool BC>
+__device__ __forceinline__ float mw_dpp(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROWMASK, 0xF, BC));
+}
+__device__ __forceinline__ float mw_wave_sum_lane63(float v) {
+    v += mw_dpp<0x111, 0xF, true>(v);   // row_shr:1
+    v += mw_dpp<0x112, 0xF, true>(v);   // row_shr:2
+    v += mw_dpp<0x114, 0xF, true>(v);   // row_shr:4
+    v += mw_dpp<0x118, 0xF, true>(v);   // row_shr:8 -> lane 15 of every row holds the row's sum
+    v += mw_dpp<0x142, 0xA, false>(v);  // row_bcast:15 -> rows 1, 3
+    v += mw_dpp<0x143, 0xC, false>(v);  // row_bcast:31 -> rows 2, 3: lane 63 holds the wave's sum
+    return v;
+}
+
 template <int NCB, bool DEFER>
 __global__ __launch_bounds__(512, 2) void k_maxsim16_wg(Ms16Args a, int64_t n_blocks) {
     static_assert(NCB >= 9 && NCB <= 16, "this form serves 9..16 column blocks");
@@ -90,7 +107,7 @@ __global__ __launch_bounds__(512, 2) void k_maxsim16_wg(Ms16Args a, int64_t n_bl
     // queries whose sums this wave writes: wave and wave + 8
     const int qa = wave, qb = wave + 8;
     auto write_doc = [&](int64_t doc, float va, float vb) {
-        if (lane == 0) {
+        if (lane == 63) {  // (the lane the DPP sums end in)
             if (qa < a.nq_launch) a.dist[(int64_t)qa * a.n_docs + doc] = va;
             if (qb < a.nq_launch) a.dist[(int64_t)qb * a.n_docs + doc] = vb;
         }
@@ -170,8 +187,7 @@ __global__ __launch_bounds__(512, 2) void k_maxsim16_wg(Ms16Args a, int64_t n_bl
                     const int c0 = a.q_col0[qi], len = a.q_len[qi];
                     if (lane < len) part += cm[c0 + lane];
                     if (lane + 64 < len) part += cm[c0 + 64 + lane];
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, kWave);
+                    part = mw_wave_sum_lane63(part);
                 }
                 out[s] = -part;
             }
