@@ -9,9 +9,9 @@
 // query than 8), so what is left to shave is everything around the MFMAs:
 //   * the query fragments of a wave's OWN column blocks (w and w + 8: at most two) stay in REGISTERS for the whole launch;
 //   * the token blocks go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction = one k-group fragment
-//     of a block, which the fragment-ordered bf16 copy stores contiguously), once per WORKGROUP: a ring of 7 stages of two
-//     blocks, six stages = 96 KiB per CU in flight, counted vmcnt waits, one barrier per stage placed between the MFMA bursts
-//     of a stage's two blocks; every wave reads a block's 8 fragments from LDS once and uses each for its one or two column
+//     of a block, which the fragment-ordered bf16 copy stores contiguously), once per WORKGROUP: a ring of 4 stages of four
+//     blocks (BPS = 4; or 7 stages of two, BPS = 2), 96 KiB per CU in flight either way, counted vmcnt waits, one barrier
+//     per stage placed between the MFMA bursts of a stage's last two blocks; every wave reads a block's 8 fragments from LDS once and uses each for its one or two column
 //     blocks: 0.5 .. 1 LDS read per MFMA instead of 1, no token fragment ever crosses a VGPR on its way in;
 //   * the per-document epilogue is shared: the waves' per-column maxima meet in 2 KiB of LDS, wave w then sums the columns of
 //     queries w and w + 8 (one masked butterfly each instead of sixteen) -- behind the ring's NEXT stage barrier, not one of
@@ -25,11 +25,13 @@
 
 namespace mi355 {
 
-constexpr int kMwStages = 7;                 // ring stages
-constexpr int kMwStageBytes = 2 * 8192;      // two 32-token blocks of 128 dims bf16, fragment order [kk][lane][8]
-constexpr int kMwColmaxOff = kMwStages * kMwStageBytes;
-constexpr int kMwLds = kMwColmaxOff + 4 * 512 * (int)sizeof(float);  // + four buffers of 512 column maxima (parked documents)
-static_assert(kMwLds <= 160 * 1024, "LDS per workgroup");
+// ring geometry by blocks per stage (BPS): 2 -> 7 stages of 16 KiB (6 in flight), 4 -> 4 stages of 32 KiB (3 in flight): 96 KiB
+// of token stream per CU on its way either way; BPS = 4 halves the barriers and hand-overs per block
+__host__ __device__ constexpr int mw_stages(int bps) { return bps == 2 ? 7 : 4; }
+__host__ __device__ constexpr int mw_stage_bytes(int bps) { return bps * 8192; }  // 32-token blocks of 128 dims bf16, fragment order
+__host__ __device__ constexpr int mw_park(int bps) { return 2 * bps; }            // parked documents' buffers (2 KiB each)
+__host__ __device__ constexpr int mw_lds(int bps) { return mw_stages(bps) * mw_stage_bytes(bps) + mw_park(bps) * 512 * (int)sizeof(float); }
+static_assert(mw_lds(2) <= 160 * 1024 && mw_lds(4) <= 160 * 1024, "LDS per workgroup");
 
 // wave-wide fp32 sum by DPP, valid in LANE 63: four row_shr steps (inclusive prefix inside each row of 16 lanes), then
 // row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3 -- six VALU operations where the shuffle butterfly was six
@@ -48,8 +50,11 @@ __device__ __forceinline__ float mw_wave_sum_lane63(float v) {
     return v;
 }
 
-template <int NCB, bool DEFER>
+template <int NCB, bool DEFER, int BPS>
 __global__ __launch_bounds__(512, 2) void k_maxsim16_wg(Ms16Args a, int64_t n_blocks) {
+    static_assert(BPS == 2 || BPS == 4, "blocks per ring stage");
+    constexpr int kMwStages = mw_stages(BPS), kMwStageBytes = mw_stage_bytes(BPS), kMwColmaxOff = kMwStages * kMwStageBytes;
+    constexpr int kPark = mw_park(BPS);
     static_assert(NCB >= 9 && NCB <= 16, "this form serves 9..16 column blocks");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(512, 2) void k_maxsim16_wg(Ms16Args a, int64_t n_bl
     const int64_t b_begin = boff[d0], b_end = boff[d1];
     const int64_t n_my = b_end - b_begin;
     const int64_t b_last = n_my > 0 ? b_end - 1 : 0;
-    const int64_t n_stages = (n_my + 1) >> 1;
+    const int64_t n_stages = (n_my + BPS - 1) / BPS;
 
     const float kNaN = __uint_as_float(0x7FC00000u);
     // queries whose sums this wave writes: wave and wave + 8
@@ -139,31 +144,35 @@ __global__ __launch_bounds__(512, 2) void k_maxsim16_wg(Ms16Args a, int64_t n_bl
     if (n_my == 0) return;
 
     float run0 = -__builtin_inff(), run1 = -__builtin_inff();
-    // A finished document's column maxima are PARKED in one of four 2-KiB buffers and summed after the NEXT stage barrier --
+    // A finished document's column maxima are PARKED in one of 2 BPS 2-KiB buffers and summed after the NEXT stage barrier --
     // the barrier the ring needs anyway publishes them; a barrier (and an LDS drain) of its own per document cost a text store,
-    // whose documents are two stages long, a tenth of the kernel.  Between two stage barriers lie two blocks, so at most two
-    // documents end; a buffer is rewritten four documents, i.e. at least two barriers, later.
+    // whose documents are four blocks long, a tenth of the kernel.  Between two stage barriers lie BPS blocks, so at most BPS
+    // documents end; a buffer is rewritten 2 BPS documents, i.e. at least two barriers, later.
     int n_fin = 0, pend_n = 0;
     bool flush_pending_now = false;
-    int64_t pend_doc[2] = {0, 0};
-    int pend_buf[2] = {0, 0};
+    int64_t pend_doc[BPS];
+    int pend_buf[BPS];
+#pragma unroll
+    for (int i = 0; i < BPS; ++i) {
+        pend_doc[i] = 0;
+        pend_buf[i] = 0;
+    }
     auto finish_doc = [&]() {
         // the two halves of the wave hold different token rows of the same query column
         const float r0 = fmaxf(run0, __shfl_xor(run0, 32, kWave));
         const float r1 = fmaxf(run1, __shfl_xor(run1, 32, kWave));
-        const int bw = n_fin & 3;
+        const int bw = n_fin & (kPark - 1);
         float* cm = colmax + bw * 512;
         if (lane < 32) {
             cm[cb0 * 32 + lane] = r0;
             if (two) cm[cb1 * 32 + lane] = r1;
         }
-        if (pend_n == 0) {
-            pend_doc[0] = cur;
-            pend_buf[0] = bw;
-        } else {
-            pend_doc[1] = cur;
-            pend_buf[1] = bw;
-        }
+#pragma unroll
+        for (int i = 0; i < BPS; ++i)  // (static indices: the arrays stay in registers)
+            if (i == pend_n) {
+                pend_doc[i] = cur;
+                pend_buf[i] = bw;
+            }
         ++pend_n;
         ++n_fin;
         run0 = run1 = -__builtin_inff();
@@ -175,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void k_maxsim16_wg(Ms16Args a, int64_t n_bl
     };
     auto flush_pending = [&]() {  // right behind a barrier: the parked maxima of every wave are visible
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < BPS; ++p) {
             if (p >= pend_n) break;  // workgroup-uniform
             const float* cm = colmax + pend_buf[p] * 512;
             float out[2];
@@ -203,8 +212,8 @@ __global__ __launch_bounds__(512, 2) void k_maxsim16_wg(Ms16Args a, int64_t n_bl
     int slot_issue = 0;
     auto issue_stage = [&]() {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            int64_t bi = b_begin + 2 * s_issue + u;
+        for (int u = 0; u < BPS; ++u) {
+            int64_t bi = b_begin + BPS * s_issue + u;
             if (bi > b_last) bi = b_last;
             glds16_saddr(tokbase + ((bi * 8 + wave) << 10), voff,
                          lds_addr(smem + slot_issue * kMwStageBytes + u * 8192 + wave * 1024));
@@ -254,31 +263,37 @@ __global__ __launch_bounds__(512, 2) void k_maxsim16_wg(Ms16Args a, int64_t n_bl
         }
     };
 
-    // stage 0 has landed (this wave's pieces: the 2 (kMwStages - 1) youngest may still fly) and is visible
-    static_assert(kMwStages == 7, "the counted waits below are 2 * (kMwStages - 1) and 2 * (kMwStages - 2)");
+    // stage 0 has landed (this wave's pieces: the BPS (stages - 1) youngest may still fly) and is visible
+    static_assert(BPS * (kMwStages - 1) == 12, "the counted wait below");
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     MI355_BARRIER();
     int slot = 0;
+    // two fragment buffers: block j of a stage lives in buffer j & 1 and is read two blocks ahead of its MFMAs
     read_block(tfA, 0, 0);
     read_block(tfB, 0, 1);
     for (int64_t s = 0; s < n_stages; ++s) {
-        // ---- block A of stage s
-        mul_block(tfA);
-        after_block();
-        // ---- hand-over: this wave's pieces of stage s + 1 have landed, its last fragments of stage s are in registers
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        MI355_BARRIER();  // ... everybody's have, and everybody is done reading stage s: its slot is refilled with stage s + 7
-        issue_stage();
-        flush_pending();  // the documents that ended since the previous barrier
         const int slot_n = slot + 1 == kMwStages ? 0 : slot + 1;
-        read_block(tfA, slot_n, 0);  // block A of stage s + 1: lands under block B's MFMAs
-        // ---- block B of stage s (the range may end on block A)
-        if (pos < b_end) {  // workgroup-uniform
-            mul_block(tfB);
-            after_block();
+#pragma unroll
+        for (int j = 0; j < BPS; ++j) {
+            if (j == 0 || pos < b_end) {  // workgroup-uniform (the range may end inside a stage)
+                if (j & 1) mul_block(tfB);
+                else mul_block(tfA);
+                after_block();
+            }
+            if (j == BPS - 2) {
+                // ---- hand-over: this wave's pieces of stage s + 1 have landed, its last fragments of stage s are in registers
+                if constexpr (BPS == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                MI355_BARRIER();  // ... everybody's have, and everybody is done reading stage s: its slot takes the stage one ring ahead
+                issue_stage();
+                flush_pending();  // the documents that ended since the previous barrier
+            }
+            // the block two ahead into the buffer just consumed: lands under the next block's MFMAs
+            const int jn = j + 2;
+            if (j & 1) read_block(tfB, jn < BPS ? slot : slot_n, jn < BPS ? jn : jn - BPS);
+            else read_block(tfA, jn < BPS ? slot : slot_n, jn < BPS ? jn : jn - BPS);
         }
-        read_block(tfB, slot_n, 1);  // block B of stage s + 1: lands under its block A's MFMAs
         slot = slot_n;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the dummy stages must land before the LDS is freed

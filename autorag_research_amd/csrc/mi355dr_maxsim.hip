@@ -789,21 +789,23 @@ inline int ms16_waves(int ncb) { return ncb <= 8 ? 4 : 8; }
 
 // the workgroup-cooperative form (k_maxsim_wg.h) for 9 .. 16 column blocks
 typedef void (*Ms16WgKernel)(mi355::Ms16Args, int64_t);
-template <bool DEFER, int... I>
+template <bool DEFER, int BPS, int... I>
 constexpr std::array<Ms16WgKernel, sizeof...(I)> ms16wg_table(std::integer_sequence<int, I...>) {
-    return {mi355::k_maxsim16_wg<I + 9, DEFER>...};
+    return {mi355::k_maxsim16_wg<I + 9, DEFER, BPS>...};
 }
-const std::array<Ms16WgKernel, 8> kMs16WgKernels = ms16wg_table<true>(std::make_integer_sequence<int, 8>{});
-const std::array<Ms16WgKernel, 8> kMs16WgKernelsNow = ms16wg_table<false>(std::make_integer_sequence<int, 8>{});  // option maxsim_wg = 2 (A/B)
+// [blocks per stage: 2, 4][epilogue: parked, at once][NCB - 9]
+const std::array<Ms16WgKernel, 8> kMs16WgKernels[2][2] = {
+    {ms16wg_table<true, 2>(std::make_integer_sequence<int, 8>{}), ms16wg_table<false, 2>(std::make_integer_sequence<int, 8>{})},
+    {ms16wg_table<true, 4>(std::make_integer_sequence<int, 8>{}), ms16wg_table<false, 4>(std::make_integer_sequence<int, 8>{})}};
 
 int ms16_d128_prepare(mi355dr_index* idx) {
     for (int ncb = 1; ncb <= mi355::kMsPassBlocks; ++ncb)
         if (ncb * 8192 > 64 * 1024)
             HIPCHECK(idx, hipFuncSetAttribute((const void*)kMs16Kernels[ncb - 1], hipFuncAttributeMaxDynamicSharedMemorySize, ncb * 8192));
-    for (auto kfn : kMs16WgKernels)
-        HIPCHECK(idx, hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, mi355::kMwLds));
-    for (auto kfn : kMs16WgKernelsNow)
-        HIPCHECK(idx, hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, mi355::kMwLds));
+    for (int b = 0; b < 2; ++b)
+        for (int e = 0; e < 2; ++e)
+            for (auto kfn : kMs16WgKernels[b][e])
+                HIPCHECK(idx, hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, mi355::mw_lds(b ? 4 : 2)));
     return MI355DR_OK;
 }
 
@@ -818,8 +820,9 @@ int ms16_d128_launch(mi355dr_index* idx, hipStream_t s, int ncb, int64_t n_docs,
         const bool now = idx->maxsim_wg == 2 || (idx->maxsim_wg < 0 && n_blocks >= 8 * n_docs);
         // one workgroup per CU, each a contiguous range of documents with ~1/256 of the token blocks (at least 32 blocks each)
         const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(256, (n_blocks + 31) / 32));
-        hipLaunchKernelGGL((now ? kMs16WgKernelsNow : kMs16WgKernels)[ncb - 9], dim3(grid), dim3(512),
-                           (size_t)mi355::kMwLds, s, sa, n_blocks);
+        const int bps = idx->maxsim_wg_bps == 2 ? 2 : 4;
+        hipLaunchKernelGGL(kMs16WgKernels[bps == 4][now ? 1 : 0][ncb - 9], dim3(grid), dim3(512), (size_t)mi355::mw_lds(bps), s, sa,
+                           n_blocks);
         HIPCHECK(idx, hipGetLastError());
         return MI355DR_OK;
     }

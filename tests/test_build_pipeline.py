@@ -157,27 +157,30 @@ def maxsim_asm_text(tmp_path_factory):
     return out.read_text()
 
 
+@pytest.mark.parametrize("bps", [2, 4])
 @pytest.mark.parametrize("ncb", [12, 16])
-def test_maxsim_workgroup_screen_keeps_its_ring_in_flight(maxsim_asm_text, ncb):
-    """k_maxsim16_wg (round 4): the token blocks come through a ring of LDS-DMA stages shared by the workgroup's 8 waves.  Pinned on
-    the generated code: the query fragments live in registers (no ds_read feeds an MFMA's B operand -- 16 fragment reads per
-    stage, all of them token fragments), exactly one counted vector-memory wait inside the stage loop and NO full
-    `s_waitcnt vmcnt(0)` between the prologue's wait and the loop's last MFMA (a per-document vector load of the block offsets
-    -- or the query fragments left to their first use -- put one there and drained 96 KiB of stream per document), block
-    offsets through the scalar cache, no scratch."""
-    name = f"_ZN5mi35513k_maxsim16_wgILi{ncb}ELb1EEEvNS_8Ms16ArgsEl"
+def test_maxsim_workgroup_screen_keeps_its_ring_in_flight(maxsim_asm_text, ncb, bps):
+    """k_maxsim16_wg (round 4): the token blocks come through a ring of LDS-DMA stages shared by the workgroup's 8 waves (stages
+    of `bps` 32-token blocks).  Pinned on the generated code: the query fragments live in registers (no ds_read feeds an MFMA's B
+    operand -- 8 fragment reads per block, all of them token fragments), exactly one counted vector-memory wait inside the stage
+    loop and NO full `s_waitcnt vmcnt(0)` between the prologue's wait and the loop's last MFMA (a per-document vector load of the
+    block offsets -- or the query fragments left to their first use -- put one there and drained 96 KiB of stream per document),
+    block offsets through the scalar cache, no scratch."""
+    name = f"_ZN5mi35513k_maxsim16_wgILi{ncb}ELb1ELi{bps}EEEvNS_8Ms16ArgsEl"
     ops, desc = _whole_kernel(maxsim_asm_text, name)
     assert ".amdhsa_private_segment_fixed_size 0" in desc and not any(o.startswith("scratch_") for o in ops)
+    inloop = 12 - bps   # pieces of (stages - 2) stages may still fly at the hand-over
     w12 = [i for i, o in enumerate(ops) if o.startswith("s_waitcnt") and "vmcnt(12)" in o]
-    w10 = [i for i, o in enumerate(ops) if o.startswith("s_waitcnt") and "vmcnt(10)" in o]
-    assert len(w12) == 1 and len(w10) == 1 and w12[0] < w10[0]
+    wl = [i for i, o in enumerate(ops) if o.startswith("s_waitcnt") and f"vmcnt({inloop})" in o]
+    assert len(w12) == 1 and len(wl) == 1 and w12[0] < wl[0]
     mf = [i for i, o in enumerate(ops) if o.startswith("v_mfma_f32_32x32x16_bf16")]
-    assert len(mf) == 32   # block A and block B of a stage: 8 MFMAs for the wave's first column block + 8 for its second
+    assert len(mf) == 16 * bps   # per block of a stage: 8 MFMAs for the wave's first column block + 8 for its second
     loop = ops[w12[0] + 1:max(mf) + 1]
     assert not any(_is_vm0(o) for o in loop), [o for o in loop if "vmcnt" in o]
-    assert sum(o.startswith("global_load_lds_dwordx4") for o in loop) == 2        # the stage seven ahead: two 1-KiB pieces per wave
+    assert sum(o.startswith("global_load_lds_dwordx4") for o in loop) == bps      # the stage one ring ahead: a 1-KiB piece per block and wave
     assert not any(o.startswith(("global_load_dword", "flat_load")) for o in loop)  # (block offsets: s_load)
-    # token fragments only: 16 reads for stage 0 in front of the loop + 16 per stage inside it (wherever the block layout puts
-    # the loop's last eight); the B operands never come from LDS
-    assert sum(o.startswith("ds_read_b128") for o in ops) == 32 and sum(o.startswith("ds_read_b128") for o in loop) >= 24
+    # token fragments only: 16 reads for the first two blocks in front of the loop + 8 per block inside it (wherever the block
+    # layout puts the loop's last eight); the B operands never come from LDS
+    n_rd = sum(o.startswith("ds_read_b128") for o in ops)
+    assert n_rd == 16 + 8 * bps and sum(o.startswith("ds_read_b128") for o in loop) >= 8 * bps - 8
     assert any(o.startswith("s_load_dwordx2") for o in loop)

@@ -293,9 +293,10 @@ def test_sixteen_queries_ride_one_screen_pass(pkg, oracle, tmin, tmax, n_docs):
     rd, rr = oracle.maxsim_topk(tok, off, qtok, qoff, k)
     with pkg.Mi355Index(d) as idx:
         idx.add_multivec(tok, off)
-        for groups, wg in ((4, -1), (1, -1), (3, 1), (2, 0), (4, 2), (4, 0), (4, 1)):
+        for groups, wg, bps in ((4, -1, 4), (1, -1, 4), (3, 1, 2), (2, 0, 4), (4, 2, 4), (4, 0, 4), (4, 1, 4), (4, 2, 2), (4, 1, 2)):
             idx.set_option("maxsim_pass_groups", groups)
             idx.set_option("maxsim_wg", wg)   # -1 by document length / 1 parked / 2 immediate epilogue / 0 one wave per document
+            idx.set_option("maxsim_wg_bps", bps)   # 32-token blocks per ring stage of the workgroup form
             idx.reset_stats()
             dist, rows = idx.search_maxsim(qtok, qoff, k)
             live = np.asarray(lens) > 0   # (a query without vectors: the reference returns [] before any SQL, base.py:506-507)
@@ -309,6 +310,8 @@ def test_sixteen_queries_ride_one_screen_pass(pkg, oracle, tmin, tmax, n_docs):
                 assert idx.stat("maxsim_screened") >= len(lens) - 6
         with pytest.raises(pkg.NativeError):
             idx.set_option("maxsim_pass_groups", 5)
+        with pytest.raises(pkg.NativeError):
+            idx.set_option("maxsim_wg_bps", 3)
         # k above the fast path's 64: one group per pass, same answers
         idx.set_option("maxsim_pass_groups", 4)
         rd2, rr2 = oracle.maxsim_topk(tok, off, qtok[: qoff[9]], qoff[:10], 70)

@@ -197,7 +197,9 @@ def check_maxsim(rng, case):
         groups, wg = int(rng.integers(1, 5)), int(rng.integers(-1, 3))
         idx.set_option("maxsim_pass_groups", groups)
         idx.set_option("maxsim_wg", wg)
-        desc += f" groups={groups} wg={wg}"
+        bps = int(rng.choice([2, 4]))
+        idx.set_option("maxsim_wg_bps", bps)
+        desc += f" groups={groups} wg={wg} bps={bps}"
         idx.add_multivec(tok, off)
         dist, rows = idx.search_maxsim(qtok, qoff, k)
         stats = {s: idx.stat(s) for s in ("maxsim_screened", "maxsim_fallbacks")}
