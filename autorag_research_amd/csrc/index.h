@@ -103,6 +103,7 @@ struct mi355dr_index {
     // by document length; 1: parked epilogue; 2: immediate epilogue; 0: one wave per document with the query fragments in LDS
     // (k_maxsim16_d128<NCB, 8>) -- option "maxsim_wg", A/B and tests
     int maxsim_wg = -1;
+    int maxsim_tighten = 1;  // MaxSim fast path: narrow the candidate band with the exact distances of the screen's top-k (0: band 2E)
     int maxsim_wg_bps = 4;  // k_maxsim16_wg: 32-token blocks per ring stage (2: 7 stages of 16 KiB, 4: 4 stages of 32 KiB); option, A/B
     int maxsim_pass_groups = 4;  // groups of <= 4 queries one pass of the MaxSim screen serves (1 .. 4; option "maxsim_pass_groups", A/B and tests)
     int maxsim_screen = 1; // 1: bf16 MFMA screen + exact re-score of the candidates, 0: exact kernel over every doc

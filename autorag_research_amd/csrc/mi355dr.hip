@@ -1085,6 +1085,8 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
     } else if (k == "maxsim_wg") {
         if (value < -1 || value > 2) return fail(idx, MI355DR_E_INVALID, "maxsim_wg must be -1 (by document length), 0, 1 or 2");
         idx->maxsim_wg = (int)value;
+    } else if (k == "maxsim_tighten") {
+        idx->maxsim_tighten = value != 0;
     } else if (k == "maxsim_wg_bps") {
         if (value != 2 && value != 4) return fail(idx, MI355DR_E_INVALID, "maxsim_wg_bps must be 2 or 4");
         idx->maxsim_wg_bps = (int)value;

@@ -67,10 +67,13 @@ struct MultiVecStore {
     bool finite = true;            // every stored value is finite (else: no screen)
     uint4* qfrag = nullptr;        // [kMsPassBlocks * nkk * 64] query fragments of one screen launch (up to four groups of <= 4 queries)
     float* dist16 = nullptr;       // [kMsPassQueries, cap_docs] screen distances (rows 4 g ..: the groups screened ahead)
-    int32_t* cand_list = nullptr;  // [kMsCandCap]
-    float* cand_dist = nullptr;    // [kMsCandCap]
-    int* cand_ctl = nullptr;       // [2]: count, overflow flag
-    int* cand_ctl_host = nullptr;  // pinned [2 * 4]
+    // candidate lists of a pass, per query (row stride kMsCandCap): section 0 = the WIDE list (screen distance within 2E of the
+    // k-th best), 1 = the STARTER (the screen's own top-k), 2 = the FINAL list (within E of the starter's k-th best exact distance)
+    int32_t* cand_list = nullptr;  // [3][kMsPassQueries][kMsCandCap]
+    float* cand_dist = nullptr;    // [kMsPassQueries][kMsCandCap] exact distances of the list being re-scored (starter, then final)
+    float* cand_sd = nullptr;      // [kMsPassQueries][kMsCandCap] screen distances of the wide list's entries
+    int* cand_ctl = nullptr;       // [3][kMsPassQueries][2]: count, overflow flag
+    int* cand_ctl_host = nullptr;  // pinned [2 * kMsPassQueries]: the final list's
     uint32_t* sel[2] = {nullptr, nullptr};  // fast path: per-segment k best screen keys, [4, ceil(cap_docs/1024) * 64]
     float* two_e_dev = nullptr;    // [4]
     char* stage_host = nullptr;    // pinned: query image | query fragments | 2E (H2D), results (D2H)
@@ -104,7 +107,7 @@ void multivec_destroy(mi355dr_index* idx) {
     if (!m) return;
     void* ptrs[] = {m->tok, m->blk_off, m->qtok, m->dist, m->pk[0], m->pk[1], m->pr[0], m->pr[1], m->out_d, m->out_r,
                     m->tok16, m->qfrag, m->dist16, m->cand_list, m->cand_dist, m->cand_ctl, m->sel[0], m->sel[1],
-                    m->two_e_dev};
+                    m->two_e_dev, m->cand_sd};
     if (m->cand_ctl_host) (void)hipHostFree(m->cand_ctl_host);
     if (m->stage_host) (void)hipHostFree(m->stage_host);
     for (void* p : ptrs)
@@ -663,10 +666,12 @@ __global__ __launch_bounds__(kWave) void k_ms_select(const float* dist, const in
     }
 }
 
-// candidates of every query of the launch (grid.y): docs whose screen distance is within 2E of the k-th best one
+// candidates of every query of the launch (grid.y): docs whose screen distance is within 2E of the k-th best one -> the WIDE
+// list (+ each entry's screen distance, when sd_out is given); the docs AT OR ABOVE the k-th best screen distance -> the STARTER
+// list (when list_a is given): k_ms_tighten narrows the wide list with the starter's exact distances
 __global__ void k_ms_candidates_y(const float* dist16, int64_t dist_stride, const int64_t* blk_off, int64_t n_docs,
                                   const uint32_t* topk_keys, int64_t key_stride, int k, const float* two_e, int32_t* list,
-                                  int cap, int* ctl) {
+                                  int cap, int* ctl, float* sd_out, int32_t* list_a, int* ctl_a) {
     const int y = blockIdx.y;
     const int64_t doc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (doc >= n_docs || blk_off[doc + 1] <= blk_off[doc]) return;
@@ -678,10 +683,74 @@ __global__ void k_ms_candidates_y(const float* dist16, int64_t dist_stride, cons
         thr = __uint_as_float(ub) + two_e[y];
         thr += fabsf(thr) * 1.2e-7f + 1e-30f;
     }
-    if (!(dist16[(int64_t)y * dist_stride + doc] > thr)) {
+    const float v = dist16[(int64_t)y * dist_stride + doc];
+    if (!(v > thr)) {
         const int slot = atomicAdd(&ctl[2 * y], 1);
-        if (slot < cap) list[(int64_t)y * cap + slot] = (int32_t)doc;
-        else ctl[2 * y + 1] = 1;
+        if (slot < cap) {
+            list[(int64_t)y * cap + slot] = (int32_t)doc;
+            if (sd_out) sd_out[(int64_t)y * cap + slot] = v;
+        } else {
+            ctl[2 * y + 1] = 1;
+        }
+        if (list_a && v == v && f32_order_key(v) <= kth) {  // (the select ranks exactly these keys)
+            const int sa = atomicAdd(&ctl_a[2 * y], 1);
+            if (sa < cap) list_a[(int64_t)y * cap + sa] = (int32_t)doc;
+            else ctl_a[2 * y + 1] = 1;
+        }
+    }
+}
+
+// The wide list -> the final list (grid.y = query, one workgroup).  The starter docs (>= k of them: the screen's top-k and its
+// ties) carry their EXACT distances: their k-th smallest, D, is an upper bound of the true k-th best exact distance, and a doc
+// of the exact top-k (ties included) has exact <= D, hence screen <= exact + E <= D + E.  The wide list's threshold is
+// x_k + 2E with x_k the k-th best SCREEN distance; D <= x_k + E always (every starter doc has exact <= screen + E), and
+// D ~ x_k in practice: the band halves and the docs to re-score drop by ~6 x (the band sits in the tail of the score
+// distribution).  The starter is part of the final list (screen <= x_k <= D + E).  Without a usable starter (fewer than k docs
+// with vectors, a starter list beyond kMsTightenMax entries or overflown) the final list is the wide list.
+constexpr int kMsTightenMax = 1024;
+__global__ __launch_bounds__(256) void k_ms_tighten(const float* dist_a, const int* ctl_a, const int32_t* list_c, const float* sd_c,
+                                                     const int* ctl_c, int cap, int k, const float* two_e, int32_t* list_b, int* ctl_b) {
+    __shared__ uint32_t key_a[kMsTightenMax];
+    __shared__ float thr_s;
+    __shared__ int n_b;
+    const int y = blockIdx.y, tid = threadIdx.x;
+    const int n_c = min(ctl_c[2 * y], cap);
+    if (ctl_c[2 * y + 1] != 0) {  // the wide list overflowed: the caller's exact full scan
+        if (tid == 0) {
+            ctl_b[2 * y] = 0;
+            ctl_b[2 * y + 1] = 1;
+        }
+        return;
+    }
+    const int n_a = ctl_a[2 * y];
+    const bool usable = ctl_a[2 * y + 1] == 0 && n_a >= k && n_a <= kMsTightenMax;  // workgroup-uniform
+    if (tid == 0) {
+        thr_s = __builtin_inff();
+        n_b = 0;
+    }
+    if (usable) {
+        for (int i = tid; i < n_a; i += blockDim.x) key_a[i] = f32_order_key(dist_a[(int64_t)y * cap + i]);
+        __syncthreads();
+        for (int i = tid; i < n_a; i += blockDim.x) {  // rank under the strict order (key, position): exactly one entry has rank k - 1
+            const uint32_t ki = key_a[i];
+            int rank = 0;
+            for (int j = 0; j < n_a; ++j) rank += (key_a[j] < ki || (key_a[j] == ki && j < i)) ? 1 : 0;
+            if (rank == k - 1) {
+                const uint32_t ub = (ki & 0x80000000u) ? (ki & 0x7FFFFFFFu) : ~ki;
+                // D + E rounded UP (two_e holds 2E rounded up); a NaN here keeps every entry (the comparison below)
+                thr_s = __double2float_ru((double)__uint_as_float(ub) + 0.5 * (double)two_e[y]);
+            }
+        }
+    }
+    __syncthreads();
+    const float thr = thr_s;
+    for (int i = tid; i < n_c; i += blockDim.x) {
+        if (!(sd_c[(int64_t)y * cap + i] > thr)) list_b[(int64_t)y * cap + atomicAdd(&n_b, 1)] = list_c[(int64_t)y * cap + i];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        ctl_b[2 * y] = n_b;
+        ctl_b[2 * y + 1] = 0;
     }
 }
 
@@ -1182,9 +1251,10 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
         HIPCHECK(idx, hipMalloc(&m->qfrag, kMsPassGroups * lds16));
         HIPCHECK(idx, hipMalloc(&m->out_d, (size_t)kPQ * kKMax * sizeof(float)));
         HIPCHECK(idx, hipMalloc(&m->out_r, (size_t)kPQ * kKMax * sizeof(int64_t)));
-        HIPCHECK(idx, hipMalloc(&m->cand_list, (size_t)kPQ * kMsCandCap * sizeof(int32_t)));
+        HIPCHECK(idx, hipMalloc(&m->cand_list, (size_t)3 * kPQ * kMsCandCap * sizeof(int32_t)));
         HIPCHECK(idx, hipMalloc(&m->cand_dist, (size_t)kPQ * kMsCandCap * sizeof(float)));
-        HIPCHECK(idx, hipMalloc(&m->cand_ctl, 2 * kPQ * sizeof(int)));
+        HIPCHECK(idx, hipMalloc(&m->cand_sd, (size_t)kPQ * kMsCandCap * sizeof(float)));
+        HIPCHECK(idx, hipMalloc(&m->cand_ctl, 3 * 2 * kPQ * sizeof(int)));
         HIPCHECK(idx, hipMalloc(&m->two_e_dev, kPQ * sizeof(float)));
         HIPCHECK(idx, hipHostMalloc(&m->cand_ctl_host, 2 * kPQ * sizeof(int)));
         HIPCHECK(idx, hipFuncSetAttribute((const void*)k_ms_final, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1475,16 +1545,22 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
                 if ((double)te[r] < pq_two_e[r]) te[r] = std::nextafter(te[r], INFINITY);
             }
             HIPCHECK(idx, hipMemcpyAsync(m->two_e_dev, te, pq_n * sizeof(float), hipMemcpyHostToDevice, s));
-            HIPCHECK(idx, hipMemsetAsync(m->cand_ctl, 0, 2 * kPQ * sizeof(int), s));
+            // wide list (+ starter) -> [starter re-scored exactly -> final list] -> final list re-scored exactly -> exact top-k
+            const bool tighten = idx->maxsim_tighten != 0;
+            int32_t* const list_c = m->cand_list;
+            int32_t* const list_a = m->cand_list + (size_t)kPQ * kMsCandCap;
+            int32_t* const list_b = m->cand_list + (size_t)2 * kPQ * kMsCandCap;
+            int* const ctl_c = m->cand_ctl;
+            int* const ctl_a = m->cand_ctl + 2 * kPQ;
+            int* const ctl_b = m->cand_ctl + 4 * kPQ;
+            HIPCHECK(idx, hipMemsetAsync(m->cand_ctl, 0, 3 * 2 * kPQ * sizeof(int), s));
             hipLaunchKernelGGL(k_ms_candidates_y, dim3((unsigned)((m->n_docs + 255) / 256), pq_n), dim3(256), 0, s, m->dist16,
-                               m->n_docs, m->blk_off, m->n_docs, m->sel[cur], sel_stride, k, m->two_e_dev, m->cand_list,
-                               kMsCandCap, m->cand_ctl);
+                               m->n_docs, m->blk_off, m->n_docs, m->sel[cur], sel_stride, k, m->two_e_dev, list_c, kMsCandCap, ctl_c,
+                               tighten ? m->cand_sd : nullptr, tighten ? list_a : nullptr, tighten ? ctl_a : nullptr);
             HIPCHECK(idx, hipGetLastError());
             MsArgs c = a0;
             c.dist = m->cand_dist;
-            c.doc_list = m->cand_list;
             c.n_items = n_cand_max;
-            c.n_items_dev = m->cand_ctl;
             c.list_stride = kMsCandCap;
             c.nq_launch = pq_n;
             for (int r = 0; r < pq_n; ++r) {
@@ -1495,15 +1571,30 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
             const bool coop = idx->maxsim_coop < 0 ? m->n_blocks >= 8 * m->n_docs : idx->maxsim_coop != 0;
             c.coop = coop ? 1 : 0;
             c.red_off = (int)lds;
+            const dim3 list_grid((unsigned)std::min<int64_t>(coop ? n_cand_max : (n_cand_max + 3) / 4, kMsListGrid), pq_n);
             if (idx->profile) HIPCHECK(idx, hipEventRecord(idx->ms_ev[2], s));
-            hipLaunchKernelGGL(k_maxsim, dim3((unsigned)std::min<int64_t>(coop ? n_cand_max : (n_cand_max + 3) / 4, kMsListGrid), pq_n),
-                               dim3(kMsThreads), lds + kMsRedBytes, s, c);
+            const int32_t* list_f = list_c;
+            const int* ctl_f = ctl_c;
+            if (tighten) {
+                c.doc_list = list_a;
+                c.n_items_dev = ctl_a;
+                hipLaunchKernelGGL(k_maxsim, list_grid, dim3(kMsThreads), lds + kMsRedBytes, s, c);
+                HIPCHECK(idx, hipGetLastError());
+                hipLaunchKernelGGL(k_ms_tighten, dim3(1, pq_n), dim3(256), 0, s, m->cand_dist, ctl_a, list_c, m->cand_sd, ctl_c,
+                                   kMsCandCap, k, m->two_e_dev, list_b, ctl_b);
+                HIPCHECK(idx, hipGetLastError());
+                list_f = list_b;
+                ctl_f = ctl_b;
+            }
+            c.doc_list = list_f;
+            c.n_items_dev = ctl_f;
+            hipLaunchKernelGGL(k_maxsim, list_grid, dim3(kMsThreads), lds + kMsRedBytes, s, c);
             HIPCHECK(idx, hipGetLastError());
             if (idx->profile) HIPCHECK(idx, hipEventRecord(idx->ms_ev[3], s));
-            hipLaunchKernelGGL(k_ms_final, dim3(1, pq_n), dim3(256), (size_t)kMsCandCap * 12, s, m->cand_dist, m->cand_list,
-                               m->cand_ctl, kMsCandCap, k, idx->row_offset, m->out_d, m->out_r);
+            hipLaunchKernelGGL(k_ms_final, dim3(1, pq_n), dim3(256), (size_t)kMsCandCap * 12, s, m->cand_dist, list_f, ctl_f,
+                               kMsCandCap, k, idx->row_offset, m->out_d, m->out_r);
             HIPCHECK(idx, hipGetLastError());
-            HIPCHECK(idx, hipMemcpyAsync(m->cand_ctl_host, m->cand_ctl, 2 * kPQ * sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPCHECK(idx, hipMemcpyAsync(m->cand_ctl_host, ctl_f, 2 * kPQ * sizeof(int), hipMemcpyDeviceToHost, s));
             if (!out_dev) {  // (hd also staged `te`: its H2D copy precedes these copies in stream order)
                 HIPCHECK(idx, hipMemcpyAsync(hd, m->out_d, (size_t)pq_n * k * sizeof(float), hipMemcpyDeviceToHost, s));
                 HIPCHECK(idx, hipMemcpyAsync(hr, m->out_r, (size_t)pq_n * k * sizeof(int64_t), hipMemcpyDeviceToHost, s));

@@ -294,6 +294,7 @@ def test_sixteen_queries_ride_one_screen_pass(pkg, oracle, tmin, tmax, n_docs):
     with pkg.Mi355Index(d) as idx:
         idx.add_multivec(tok, off)
         for groups, wg, bps in ((4, -1, 4), (1, -1, 4), (3, 1, 2), (2, 0, 4), (4, 2, 4), (4, 0, 4), (4, 1, 4), (4, 2, 2), (4, 1, 2)):
+            idx.set_option("maxsim_tighten", int(bps == 4))   # the candidate band narrowed by the starter's exact distances / the 2E band
             idx.set_option("maxsim_pass_groups", groups)
             idx.set_option("maxsim_wg", wg)   # -1 by document length / 1 parked / 2 immediate epilogue / 0 one wave per document
             idx.set_option("maxsim_wg_bps", bps)   # 32-token blocks per ring stage of the workgroup form

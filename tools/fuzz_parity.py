@@ -199,7 +199,9 @@ def check_maxsim(rng, case):
         idx.set_option("maxsim_wg", wg)
         bps = int(rng.choice([2, 4]))
         idx.set_option("maxsim_wg_bps", bps)
-        desc += f" groups={groups} wg={wg} bps={bps}"
+        tighten = int(rng.random() < 0.7)
+        idx.set_option("maxsim_tighten", tighten)
+        desc += f" groups={groups} wg={wg} bps={bps} tighten={tighten}"
         idx.add_multivec(tok, off)
         dist, rows = idx.search_maxsim(qtok, qoff, k)
         stats = {s: idx.stat(s) for s in ("maxsim_screened", "maxsim_fallbacks")}
