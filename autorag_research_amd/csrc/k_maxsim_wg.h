@@ -148,25 +148,27 @@ __global__ __launch_bounds__(512, 2) void k_maxsim16_wg(Ms16Args a, int64_t n_bl
     // the barrier the ring needs anyway publishes them; a barrier (and an LDS drain) of its own per document cost a text store,
     // whose documents are four blocks long, a tenth of the kernel.  Between two stage barriers lie BPS blocks, so at most BPS
     // documents end; a buffer is rewritten 2 BPS documents, i.e. at least two barriers, later.
-    int n_fin = 0, pend_n = 0;
+    // The sums are STAGGERED: waves 0..3 take them right behind the barrier, waves 4..7 one block later -- waves w and w + 4
+    // share a SIMD, so while one of the two walks through its sums (LDS reads, two DPP chains, the store: ~300 cycles in which
+    // it issues no MFMA) the other keeps the matrix pipe busy; all eight at once left the pipe idle for that long per document.
+    int n_fin = 0, pend_n = 0, ready_n = 0;
     bool flush_pending_now = false;
-    int64_t pend_doc[BPS];
-    int pend_buf[BPS];
+    int64_t pend_doc[BPS], ready_doc[BPS];
+    int pend_buf[BPS], ready_buf[BPS];
 #pragma unroll
     for (int i = 0; i < BPS; ++i) {
-        pend_doc[i] = 0;
-        pend_buf[i] = 0;
+        pend_doc[i] = ready_doc[i] = 0;
+        pend_buf[i] = ready_buf[i] = 0;
     }
     auto finish_doc = [&]() {
-        // the two halves of the wave hold different token rows of the same query column
-        const float r0 = fmaxf(run0, __shfl_xor(run0, 32, kWave));
-        const float r1 = fmaxf(run1, __shfl_xor(run1, 32, kWave));
+        // the two halves of the wave hold different token rows of the same query column: one v_permlane32_swap puts the halves
+        // of BOTH running maxima side by side (lanes 0..31: column block cb0, lanes 32..63: cb1)
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(run0), __float_as_uint(run1), false, false);
+        const float r = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
         const int bw = n_fin & (kPark - 1);
         float* cm = colmax + bw * 512;
-        if (lane < 32) {
-            cm[cb0 * 32 + lane] = r0;
-            if (two) cm[cb1 * 32 + lane] = r1;
-        }
+        if (lane < 32) cm[cb0 * 32 + lane] = r;
+        else if (two) cm[cb1 * 32 + lane - 32] = r;
 #pragma unroll
         for (int i = 0; i < BPS; ++i)  // (static indices: the arrays stay in registers)
             if (i == pend_n) {
@@ -182,11 +184,20 @@ __global__ __launch_bounds__(512, 2) void k_maxsim16_wg(Ms16Args a, int64_t n_bl
             flush_pending_now = true;
         }
     };
-    auto flush_pending = [&]() {  // right behind a barrier: the parked maxima of every wave are visible
+    auto publish_pending = [&]() {  // right behind a barrier: the maxima parked before it are visible to every wave
+#pragma unroll
+        for (int i = 0; i < BPS; ++i) {
+            ready_doc[i] = pend_doc[i];
+            ready_buf[i] = pend_buf[i];
+        }
+        ready_n = pend_n;
+        pend_n = 0;
+    };
+    auto flush_ready = [&]() {
 #pragma unroll
         for (int p = 0; p < BPS; ++p) {
-            if (p >= pend_n) break;  // workgroup-uniform
-            const float* cm = colmax + pend_buf[p] * 512;
+            if (p >= ready_n) break;  // workgroup-uniform
+            const float* cm = colmax + ready_buf[p] * 512;
             float out[2];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -200,9 +211,14 @@ __global__ __launch_bounds__(512, 2) void k_maxsim16_wg(Ms16Args a, int64_t n_bl
                 }
                 out[s] = -part;
             }
-            write_doc(pend_doc[p], out[0], out[1]);
+            write_doc(ready_doc[p], out[0], out[1]);
         }
-        pend_n = 0;
+        ready_n = 0;
+    };
+    auto flush_pending = [&]() {  // (the unstaggered form: the immediate epilogue and the end of the range)
+        flush_ready();
+        publish_pending();
+        flush_ready();
     };
 
     // ---- staging: wave w moves k-group fragment w of every block (1 KiB per instruction); past the range: the last block again
@@ -255,7 +271,8 @@ __global__ __launch_bounds__(512, 2) void k_maxsim16_wg(Ms16Args a, int64_t n_bl
             finish_doc();
             if constexpr (!DEFER) {
                 if (flush_pending_now) {
-                    flush_pending();
+                    publish_pending();
+                    flush_ready();
                     flush_pending_now = false;
                 }
             }
@@ -287,8 +304,13 @@ __global__ __launch_bounds__(512, 2) void k_maxsim16_wg(Ms16Args a, int64_t n_bl
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 MI355_BARRIER();  // ... everybody's have, and everybody is done reading stage s: its slot takes the stage one ring ahead
                 issue_stage();
-                flush_pending();  // the documents that ended since the previous barrier
+                if constexpr (DEFER) {
+                    publish_pending();  // the documents that ended since the previous barrier
+                    if (wave < 4) flush_ready();
+                }
             }
+            if constexpr (DEFER)
+                if (j == BPS - 1 && wave >= 4) flush_ready();  // (one block behind the other wave of this SIMD)
             // the block two ahead into the buffer just consumed: lands under the next block's MFMAs
             const int jn = j + 2;
             if (j & 1) read_block(tfB, jn < BPS ? slot : slot_n, jn < BPS ? jn : jn - BPS);
@@ -299,7 +321,7 @@ __global__ __launch_bounds__(512, 2) void k_maxsim16_wg(Ms16Args a, int64_t n_bl
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the dummy stages must land before the LDS is freed
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     MI355_BARRIER();
-    flush_pending();  // the range's last document(s)
+    if constexpr (DEFER) flush_pending();  // the range's last document(s)
 }
 
 }  // namespace mi355
