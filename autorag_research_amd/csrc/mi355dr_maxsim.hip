@@ -669,33 +669,45 @@ __global__ __launch_bounds__(kWave) void k_ms_select(const float* dist, const in
 // candidates of every query of the launch (grid.y): docs whose screen distance is within 2E of the k-th best one -> the WIDE
 // list (+ each entry's screen distance, when sd_out is given); the docs AT OR ABOVE the k-th best screen distance -> the STARTER
 // list (when list_a is given): k_ms_tighten narrows the wide list with the starter's exact distances
-__global__ void k_ms_candidates_y(const float* dist16, int64_t dist_stride, const int64_t* blk_off, int64_t n_docs,
-                                  const uint32_t* topk_keys, int64_t key_stride, int k, const float* two_e, int32_t* list,
-                                  int cap, int* ctl, float* sd_out, int32_t* list_a, int* ctl_a) {
+constexpr int kMsCandPerThread = 4;  // a workgroup of 256 threads looks at 1024 docs
+__global__ __launch_bounds__(256) void k_ms_candidates_y(const float* dist16, int64_t dist_stride, const int64_t* blk_off,
+                                                          int64_t n_docs, const uint32_t* topk_keys, int64_t key_stride, int k,
+                                                          const float* two_e, int32_t* list, int cap, int* ctl, float* sd_out,
+                                                          int32_t* list_a, int* ctl_a) {
+    __shared__ uint32_t kth_s;
     const int y = blockIdx.y;
-    const int64_t doc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (doc >= n_docs || blk_off[doc + 1] <= blk_off[doc]) return;
-    uint32_t kth = 0;
-    for (int i = 0; i < k; ++i) kth = max(kth, topk_keys[(int64_t)y * key_stride + i]);  // all lanes, L1-resident
+    if (threadIdx.x < kWave) {  // k <= kMsFastK = 64: one key per lane of the first wave
+        uint32_t key = threadIdx.x < k ? topk_keys[(int64_t)y * key_stride + threadIdx.x] : 0u;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) key = max(key, (uint32_t)__shfl_xor((int)key, o, kWave));
+        if (threadIdx.x == 0) kth_s = key;
+    }
+    __syncthreads();
+    const uint32_t kth = kth_s;
     float thr = __builtin_inff();
     if (kth != 0xFFFFFFFFu) {
         const uint32_t ub = (kth & 0x80000000u) ? (kth & 0x7FFFFFFFu) : ~kth;
         thr = __uint_as_float(ub) + two_e[y];
         thr += fabsf(thr) * 1.2e-7f + 1e-30f;
     }
-    const float v = dist16[(int64_t)y * dist_stride + doc];
-    if (!(v > thr)) {
-        const int slot = atomicAdd(&ctl[2 * y], 1);
-        if (slot < cap) {
-            list[(int64_t)y * cap + slot] = (int32_t)doc;
-            if (sd_out) sd_out[(int64_t)y * cap + slot] = v;
-        } else {
-            ctl[2 * y + 1] = 1;
-        }
-        if (list_a && v == v && f32_order_key(v) <= kth) {  // (the select ranks exactly these keys)
-            const int sa = atomicAdd(&ctl_a[2 * y], 1);
-            if (sa < cap) list_a[(int64_t)y * cap + sa] = (int32_t)doc;
-            else ctl_a[2 * y + 1] = 1;
+#pragma unroll
+    for (int u = 0; u < kMsCandPerThread; ++u) {
+        const int64_t doc = ((int64_t)blockIdx.x * kMsCandPerThread + u) * blockDim.x + threadIdx.x;
+        if (doc >= n_docs || blk_off[doc + 1] <= blk_off[doc]) continue;
+        const float v = dist16[(int64_t)y * dist_stride + doc];
+        if (!(v > thr)) {
+            const int slot = atomicAdd(&ctl[2 * y], 1);
+            if (slot < cap) {
+                list[(int64_t)y * cap + slot] = (int32_t)doc;
+                if (sd_out) sd_out[(int64_t)y * cap + slot] = v;
+            } else {
+                ctl[2 * y + 1] = 1;
+            }
+            if (list_a && v == v && f32_order_key(v) <= kth) {  // (the select ranks exactly these keys)
+                const int sa = atomicAdd(&ctl_a[2 * y], 1);
+                if (sa < cap) list_a[(int64_t)y * cap + sa] = (int32_t)doc;
+                else ctl_a[2 * y + 1] = 1;
+            }
         }
     }
 }
@@ -1554,7 +1566,8 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
             int* const ctl_a = m->cand_ctl + 2 * kPQ;
             int* const ctl_b = m->cand_ctl + 4 * kPQ;
             HIPCHECK(idx, hipMemsetAsync(m->cand_ctl, 0, 3 * 2 * kPQ * sizeof(int), s));
-            hipLaunchKernelGGL(k_ms_candidates_y, dim3((unsigned)((m->n_docs + 255) / 256), pq_n), dim3(256), 0, s, m->dist16,
+            hipLaunchKernelGGL(k_ms_candidates_y, dim3((unsigned)((m->n_docs + 256 * kMsCandPerThread - 1) / (256 * kMsCandPerThread)), pq_n),
+                               dim3(256), 0, s, m->dist16,
                                m->n_docs, m->blk_off, m->n_docs, m->sel[cur], sel_stride, k, m->two_e_dev, list_c, kMsCandCap, ctl_c,
                                tighten ? m->cand_sd : nullptr, tighten ? list_a : nullptr, tighten ? ctl_a : nullptr);
             HIPCHECK(idx, hipGetLastError());
@@ -1570,15 +1583,23 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
             // long documents (>= 8 blocks on average: pages): one workgroup per candidate, its four waves share the blocks
             const bool coop = idx->maxsim_coop < 0 ? m->n_blocks >= 8 * m->n_docs : idx->maxsim_coop != 0;
             c.coop = coop ? 1 : 0;
-            c.red_off = (int)lds;
-            const dim3 list_grid((unsigned)std::min<int64_t>(coop ? n_cand_max : (n_cand_max + 3) / 4, kMsListGrid), pq_n);
+            // LDS for the column blocks the longest query of the pass has (a workgroup stages ONE query's columns), and grids sized
+            // for the lists that are usual (the workgroups stride over a list until it ends): 256 x 16 workgroups of 68 KiB each,
+            // nearly all of which find nothing to do, cost more than the re-scoring itself
+            int len_max = 1;
+            for (int r = 0; r < pq_n; ++r) len_max = std::max(len_max, pq_len[r]);
+            const size_t lds_list = (size_t)((len_max + 31) / 32) * 32 * (dp + 4) * sizeof(float);
+            c.red_off = (int)lds_list;
+            const int64_t want_a = k + 8, want_f = tighten ? 256 : n_cand_max;  // documents a launch should cover in ONE round
+            const dim3 grid_a((unsigned)std::min<int64_t>({coop ? want_a : (want_a + 3) / 4, n_cand_max, (int64_t)kMsListGrid}), pq_n);
+            const dim3 list_grid((unsigned)std::min<int64_t>({coop ? want_f : (want_f + 3) / 4, n_cand_max, (int64_t)kMsListGrid}), pq_n);
             if (idx->profile) HIPCHECK(idx, hipEventRecord(idx->ms_ev[2], s));
             const int32_t* list_f = list_c;
             const int* ctl_f = ctl_c;
             if (tighten) {
                 c.doc_list = list_a;
                 c.n_items_dev = ctl_a;
-                hipLaunchKernelGGL(k_maxsim, list_grid, dim3(kMsThreads), lds + kMsRedBytes, s, c);
+                hipLaunchKernelGGL(k_maxsim, grid_a, dim3(kMsThreads), lds_list + kMsRedBytes, s, c);
                 HIPCHECK(idx, hipGetLastError());
                 hipLaunchKernelGGL(k_ms_tighten, dim3(1, pq_n), dim3(256), 0, s, m->cand_dist, ctl_a, list_c, m->cand_sd, ctl_c,
                                    kMsCandCap, k, m->two_e_dev, list_b, ctl_b);
@@ -1588,7 +1609,7 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
             }
             c.doc_list = list_f;
             c.n_items_dev = ctl_f;
-            hipLaunchKernelGGL(k_maxsim, list_grid, dim3(kMsThreads), lds + kMsRedBytes, s, c);
+            hipLaunchKernelGGL(k_maxsim, list_grid, dim3(kMsThreads), lds_list + kMsRedBytes, s, c);
             HIPCHECK(idx, hipGetLastError());
             if (idx->profile) HIPCHECK(idx, hipEventRecord(idx->ms_ev[3], s));
             hipLaunchKernelGGL(k_ms_final, dim3(1, pq_n), dim3(256), (size_t)kMsCandCap * 12, s, m->cand_dist, list_f, ctl_f,

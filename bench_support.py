@@ -194,7 +194,7 @@ def run_maxsim(args, n_docs: int, tokens: str, nq: int, steps: int, warmup: int,
         "queries_per_s": round(steps * qblock / el, 2), "ms_per_step": round(el * 1e3 / steps, 3), "steps": steps,
         "queries_per_pass": qblock,
         "includes": "H2D of the query block, D2H of results",
-        "roofline": {"bound": "mfma", "kernel": f"k_maxsim16_d128<{(qblock * nq + 31) // 32}>",
+        "roofline": {"bound": "mfma", "kernel": (lambda ncb: f"k_maxsim16_wg<{ncb}>" if ncb > 8 else f"k_maxsim16_d128<{ncb}>")((qblock * nq + 31) // 32),
                      "op": "bf16 flops (v_mfma_f32_32x32x16_bf16)",
                      "achieved": round(alg_flops / scr_s / 1e12, 2) if scr_n else None,
                      "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
