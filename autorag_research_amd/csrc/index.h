@@ -103,7 +103,9 @@ struct mi355dr_index {
     // by document length; 1: parked epilogue; 2: immediate epilogue; 0: one wave per document with the query fragments in LDS
     // (k_maxsim16_d128<NCB, 8>) -- option "maxsim_wg", A/B and tests
     int maxsim_wg = -1;
+    int maxsim_packed = 0;   // 16-query screen over the packed bf16 copy (k_maxsim_wgp.h; measured slower than the padded copy: off)
     int maxsim_tighten = 1;  // MaxSim fast path: narrow the candidate band with the exact distances of the screen's top-k (0: band 2E)
+    int maxsim_wg_pipe = 1;  // k_maxsim16_wg, 4 blocks per stage: fold block j under the MFMAs of block j + 1 (0: the unpipelined form, A/B)
     int maxsim_wg_bps = 4;  // k_maxsim16_wg: 32-token blocks per ring stage (2: 7 stages of 16 KiB, 4: 4 stages of 32 KiB); option, A/B
     int maxsim_pass_groups = 4;  // groups of <= 4 queries one pass of the MaxSim screen serves (1 .. 4; option "maxsim_pass_groups", A/B and tests)
     int maxsim_screen = 1; // 1: bf16 MFMA screen + exact re-score of the candidates, 0: exact kernel over every doc
@@ -136,7 +138,7 @@ struct mi355dr_index {
     int64_t s_ms_screened = 0, s_ms_candidates = 0, s_ms_fallbacks = 0;  // MaxSim: queries screened, docs re-scored, full re-runs
     // option "profile": HIP-event time of the MaxSim screen launches (k_maxsim16*) and of the exact launches on candidate lists
     int64_t s_ms_screen_ns = 0, s_ms_screen_launches = 0, s_ms_exact_ns = 0, s_ms_exact_launches = 0;
-    int64_t s_ms_screen_cols = 0;  // query-vector columns (whole blocks of 32) the screen launches multiplied every token by
+    int64_t s_ms_packed_launches = 0, s_ms_screen_cols = 0;  // query-vector columns (whole blocks of 32) the screen launches multiplied every token by
     hipEvent_t ms_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<mi355::EventPair> ev_pool, ev_pending;
     hipEvent_t t0 = nullptr, t1 = nullptr;

@@ -21,6 +21,8 @@
 // The per-document sums add the column maxima in another order than k_maxsim16_d128 and the exact kernel do; the screen's
 // bound covers any order (search_maxsim_impl: e_acc).  Bit-exactness of the RESULTS is the exact re-score's business, as before.
 #pragma once
+#include <type_traits>
+
 #include "k_screen256_common.h"
 
 namespace mi355 {
@@ -50,7 +52,7 @@ __device__ __forceinline__ float mw_wave_sum_lane63(float v) {
     return v;
 }
 
-template <int NCB, bool DEFER, int BPS>
+template <int NCB, bool DEFER, int BPS, bool PIPE = false>
 __global__ __launch_bounds__(512, 2) void k_maxsim16_wg(Ms16Args a, int64_t n_blocks) {
     static_assert(BPS == 2 || BPS == 4, "blocks per ring stage");
     constexpr int kMwStages = mw_stages(BPS), kMwStageBytes = mw_stage_bytes(BPS), kMwColmaxOff = kMwStages * kMwStageBytes;
@@ -284,6 +286,98 @@ __global__ __launch_bounds__(512, 2) void k_maxsim16_wg(Ms16Args a, int64_t n_bl
     static_assert(BPS * (kMwStages - 1) == 12, "the counted wait below");
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     MI355_BARRIER();
+    if constexpr (PIPE) {
+        // SOFTWARE-PIPELINED form: the maxima of block j are folded while the MFMAs of block j + 1 run.  A wave's 16 MFMAs
+        // keep the SIMD's matrix pipe busy for 512 cycles; what follows them -- wait for the last result, two chains of 8
+        // dependent v_max3, the bookkeeping, the fragment reads of the block after next -- is ~300 cycles in which THIS wave
+        // issues no MFMA, and the two waves of a SIMD, walking the same stream behind the same barriers, do that at the same
+        // time.  Here the fold sits in the same basic block as the next block's MFMAs (two accumulator sets, by block
+        // parity) and is interleaved with them one VALU operation per MFMA.  Past the range the ring holds the last block
+        // again: the MFMAs of those dummy blocks are issued unconditionally (no branch between MFMAs and fold), their maxima
+        // fall into a running maximum nobody reads.
+        auto stage_loop = [&](auto two_c) __attribute__((always_inline)) {
+            constexpr bool TWO = decltype(two_c)::value;
+            f32x16 x0, x1, y0, y1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x0[r] = x1[r] = y0[r] = y1[r] = -__builtin_inff();
+            bool primed = false;
+            auto slot_body = [&](const ms_bf16x8(&tf)[8], f32x16& n0, f32x16& n1, const f32x16& p0, const f32x16& p1)
+                                 __attribute__((always_inline)) {
+                n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[0], qf0[0], zero, 0, 0, 0);
+#pragma unroll
+                for (int i = 1; i < 8; ++i) n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[i], qf0[i], n0, 0, 0, 0);
+                if constexpr (TWO) {
+                    n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[0], qf1[0], zero, 0, 0, 0);
+#pragma unroll
+                    for (int i = 1; i < 8; ++i) n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[i], qf1[i], n1, 0, 0, 0);
+                }
+                float m0 = p0[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) m0 = fmaxf(m0, p0[r]);
+                run0 = fmaxf(run0, m0);
+                if constexpr (TWO) {
+                    float m1 = p1[0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) m1 = fmaxf(m1, p1[r]);
+                    run1 = fmaxf(run1, m1);
+                }
+#pragma unroll
+                for (int i = 0; i < (TWO ? 16 : 8); ++i) {  // one VALU operation in the shadow of every MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                }
+                if (primed) after_block();
+                primed = true;
+            };
+            int slot = 0;
+            read_block(tfA, 0, 0);
+            read_block(tfB, 0, 1);
+            for (int64_t s = 0; s < n_stages; ++s) {
+                const int slot_n = slot + 1 == kMwStages ? 0 : slot + 1;
+#pragma unroll
+                for (int j = 0; j < BPS; ++j) {
+                    if (j & 1) slot_body(tfB, y0, y1, x0, x1);
+                    else slot_body(tfA, x0, x1, y0, y1);
+                    if (j == BPS - 2) {
+                        if constexpr (BPS == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        MI355_BARRIER();
+                        issue_stage();
+                        if constexpr (DEFER) {
+                            publish_pending();
+                            if (wave < 4) flush_ready();
+                        }
+                    }
+                    if constexpr (DEFER)
+                        if (j == BPS - 1 && wave >= 4) flush_ready();
+                    const int jn = j + 2;
+                    if (j & 1) read_block(tfB, jn < BPS ? slot : slot_n, jn < BPS ? jn : jn - BPS);
+                    else read_block(tfA, jn < BPS ? slot : slot_n, jn < BPS ? jn : jn - BPS);
+                }
+                slot = slot_n;
+            }
+            // the last block's products (BPS is even: they sit in the y set)
+            float m0 = y0[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m0 = fmaxf(m0, y0[r]);
+            run0 = fmaxf(run0, m0);
+            if constexpr (TWO) {
+                float m1 = y1[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) m1 = fmaxf(m1, y1[r]);
+                run1 = fmaxf(run1, m1);
+            }
+            after_block();
+        };
+        if (two) stage_loop(std::true_type{});
+        else stage_loop(std::false_type{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        MI355_BARRIER();
+        if constexpr (DEFER) flush_pending();
+        return;
+    }
     int slot = 0;
     // two fragment buffers: block j of a stage lives in buffer j & 1 and is read two blocks ahead of its MFMAs
     read_block(tfA, 0, 0);

@@ -61,6 +61,12 @@ struct MultiVecStore {
     // holding dims kk*16 + half*8 + 0..7 of token `row` (original column order)
     int nkk = 0;                   // dim rounded up to 16, / 16
     uint4* tok16 = nullptr;        // [cap_blocks * nkk * 64]
+    // PACKED bf16 copy (k_maxsim_wgp.h): the documents' tokens back to back in the same fragment order, blocks of 32 tokens
+    // wherever they fall; built from tok16 when a 16-query pass first wants it, rebuilt after adds
+    uint4* tok16p = nullptr;       // [ceil(n_tok / 32) * 8 * 64] (dims <= 128 only)
+    int64_t* tok_off = nullptr;    // [packed_docs + 1] first token of each doc (device)
+    int64_t packed_docs = -1;      // docs the packed copy holds (-1: none)
+    std::vector<int64_t> tok_off_host{0};
     double tok_norm_max = 0.0;     // largest token norm (double, from the fp32 values)
     double tok16_norm_max = 0.0;   // largest norm of a bf16-rounded token
     double tok_res_max = 0.0;      // largest residual norm |d - bf16(d)| of a token
@@ -107,7 +113,7 @@ void multivec_destroy(mi355dr_index* idx) {
     if (!m) return;
     void* ptrs[] = {m->tok, m->blk_off, m->qtok, m->dist, m->pk[0], m->pk[1], m->pr[0], m->pr[1], m->out_d, m->out_r,
                     m->tok16, m->qfrag, m->dist16, m->cand_list, m->cand_dist, m->cand_ctl, m->sel[0], m->sel[1],
-                    m->two_e_dev, m->cand_sd};
+                    m->two_e_dev, m->cand_sd, m->tok16p, m->tok_off};
     if (m->cand_ctl_host) (void)hipHostFree(m->cand_ctl_host);
     if (m->stage_host) (void)hipHostFree(m->stage_host);
     for (void* p : ptrs)
@@ -332,6 +338,7 @@ struct Ms16Args {
     int nq_launch;
     int q_col0[kMsPassQueries];  // (k_maxsim16_d128 serves up to FOUR groups of <= 4 queries per launch: rows 4 g .. 4 g + 3)
     int q_len[kMsPassQueries];
+    const int64_t* tok_off;  // k_maxsim16_wgp: [n_docs + 1] token offsets of the packed copy (tok16 then points at it)
 };
 
 __device__ __forceinline__ void ms16_load_piece(uint4 (&a)[8], const uint4* blk, int piece, int nkk, int lane) {
@@ -545,6 +552,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_maxsim16_d128(Ms16Args a) {
 
 }  // namespace mi355
 #include "k_maxsim_wg.h"
+#include "k_maxsim_wgp.h"
 namespace mi355 {
 
 // fp32 -> sortable key (distance asc, NaN last)
@@ -870,20 +878,38 @@ inline int ms16_waves(int ncb) { return ncb <= 8 ? 4 : 8; }
 
 // the workgroup-cooperative form (k_maxsim_wg.h) for 9 .. 16 column blocks
 typedef void (*Ms16WgKernel)(mi355::Ms16Args, int64_t);
-template <bool DEFER, int BPS, int... I>
+template <bool DEFER, int BPS, bool PIPE, int... I>
 constexpr std::array<Ms16WgKernel, sizeof...(I)> ms16wg_table(std::integer_sequence<int, I...>) {
-    return {mi355::k_maxsim16_wg<I + 9, DEFER, BPS>...};
+    return {mi355::k_maxsim16_wg<I + 9, DEFER, BPS, PIPE>...};
 }
-// [blocks per stage: 2, 4][epilogue: parked, at once][NCB - 9]
-const std::array<Ms16WgKernel, 8> kMs16WgKernels[2][2] = {
-    {ms16wg_table<true, 2>(std::make_integer_sequence<int, 8>{}), ms16wg_table<false, 2>(std::make_integer_sequence<int, 8>{})},
-    {ms16wg_table<true, 4>(std::make_integer_sequence<int, 8>{}), ms16wg_table<false, 4>(std::make_integer_sequence<int, 8>{})}};
+// [blocks per stage: 2, 4, 4 software-pipelined][epilogue: parked, at once][NCB - 9]
+const std::array<Ms16WgKernel, 8> kMs16WgKernels[3][2] = {
+    {ms16wg_table<true, 2, false>(std::make_integer_sequence<int, 8>{}), ms16wg_table<false, 2, false>(std::make_integer_sequence<int, 8>{})},
+    {ms16wg_table<true, 4, false>(std::make_integer_sequence<int, 8>{}), ms16wg_table<false, 4, false>(std::make_integer_sequence<int, 8>{})},
+    {ms16wg_table<true, 4, true>(std::make_integer_sequence<int, 8>{}), ms16wg_table<false, 4, true>(std::make_integer_sequence<int, 8>{})}};
+
+// ... over the packed copy (k_maxsim_wgp.h), 4 blocks per stage
+template <int... I>
+constexpr std::array<Ms16WgKernel, sizeof...(I)> ms16wgp_table(std::integer_sequence<int, I...>) {
+    return {mi355::k_maxsim16_wgp<I + 9, 4>...};
+}
+const std::array<Ms16WgKernel, 8> kMs16WgpKernels = ms16wgp_table(std::make_integer_sequence<int, 8>{});
+
+int ms16_wgp_launch(mi355dr_index* idx, hipStream_t s, int ncb, int64_t n_tok, const mi355::Ms16Args& sa) {
+    // one workgroup per CU, each a contiguous range of documents with ~1/256 of the tokens (at least 1024 tokens each)
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(256, (n_tok + 1023) / 1024));
+    hipLaunchKernelGGL(kMs16WgpKernels[ncb - 9], dim3(grid), dim3(512), (size_t)mi355::mwp_lds(4), s, sa, n_tok);
+    HIPCHECK(idx, hipGetLastError());
+    return MI355DR_OK;
+}
 
 int ms16_d128_prepare(mi355dr_index* idx) {
+    for (auto kfn : kMs16WgpKernels)
+        HIPCHECK(idx, hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, mi355::mwp_lds(4)));
     for (int ncb = 1; ncb <= mi355::kMsPassBlocks; ++ncb)
         if (ncb * 8192 > 64 * 1024)
             HIPCHECK(idx, hipFuncSetAttribute((const void*)kMs16Kernels[ncb - 1], hipFuncAttributeMaxDynamicSharedMemorySize, ncb * 8192));
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < 3; ++b)
         for (int e = 0; e < 2; ++e)
             for (auto kfn : kMs16WgKernels[b][e])
                 HIPCHECK(idx, hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, mi355::mw_lds(b ? 4 : 2)));
@@ -902,7 +928,7 @@ int ms16_d128_launch(mi355dr_index* idx, hipStream_t s, int ncb, int64_t n_docs,
         // one workgroup per CU, each a contiguous range of documents with ~1/256 of the token blocks (at least 32 blocks each)
         const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(256, (n_blocks + 31) / 32));
         const int bps = idx->maxsim_wg_bps == 2 ? 2 : 4;
-        hipLaunchKernelGGL(kMs16WgKernels[bps == 4][now ? 1 : 0][ncb - 9], dim3(grid), dim3(512), (size_t)mi355::mw_lds(bps), s, sa,
+        hipLaunchKernelGGL(kMs16WgKernels[bps == 4 ? (idx->maxsim_wg_pipe ? 2 : 1) : 0][now ? 1 : 0][ncb - 9], dim3(grid), dim3(512), (size_t)mi355::mw_lds(bps), s, sa,
                            n_blocks);
         HIPCHECK(idx, hipGetLastError());
         return MI355DR_OK;
@@ -1012,6 +1038,7 @@ int mi355dr_add_multivec(mi355dr_index* idx, const float* vecs, const int64_t* o
     HIPCHECK(idx, hipMemcpy(m->blk_off, m->blk_off_host.data(), m->blk_off_host.size() * sizeof(int64_t),
                             hipMemcpyHostToDevice));
     rollback.keep = true;
+    for (int64_t i = 0; i < n_docs; ++i) m->tok_off_host.push_back(m->tok_off_host.back() + (offsets[i + 1] - offsets[i]));
     m->n_blocks += new_blocks;
     m->n_docs += n_docs;
     return MI355DR_OK;
@@ -1160,10 +1187,67 @@ int mi355dr_add_multivec_device(mi355dr_index* idx, const float* vecs_dev, const
     m->tok16_norm_max = std::max(m->tok16_norm_max, v[1]);
     m->tok_res_max = std::max(m->tok_res_max, v[2]);
     if (nf) m->finite = false;
+    for (int64_t i = 0; i < n_docs; ++i) m->tok_off_host.push_back(m->tok_off_host.back() + T[i]);
     m->n_blocks += new_blocks;
     m->n_docs += n_docs;
     return MI355DR_OK;
 }
+
+namespace {
+
+// one workgroup per block of the PACKED stream: row r holds token 32 b + r of the store; its fragments are copied from the padded
+// copy (doc found by binary search over the token offsets, one search per row)
+__global__ __launch_bounds__(512) void k_ms_pack16(const uint4* __restrict__ tok16, const int64_t* __restrict__ blk_off,
+                                                    const int64_t* __restrict__ tok_off, int64_t n_docs, int64_t n_tok,
+                                                    uint4* __restrict__ out) {
+    __shared__ int64_t src[32];  // fragment index base of the row's token in the padded copy: (block * 8) * 64 + row, or -1
+    const int64_t b = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (tid < 32) {
+        const int64_t t = b * 32 + tid;
+        int64_t v = -1;
+        if (t < n_tok) {
+            int64_t lo = 0, hi = n_docs;  // last doc with tok_off[doc] <= t (docs without tokens never win: the NEXT doc starts at t too)
+            while (hi - lo > 1) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (tok_off[mid] <= t) lo = mid;
+                else hi = mid;
+            }
+            const int64_t within = t - tok_off[lo];
+            v = ((blk_off[lo] + (within >> 5)) * 8) * 64 + (within & 31);
+        }
+        src[tid] = v;
+    }
+    __syncthreads();
+    const int kk = tid >> 6, lane = tid & 63;
+    const int64_t sb = src[lane & 31];
+    uint4 val = make_uint4(0u, 0u, 0u, 0u);
+    if (sb >= 0) val = tok16[sb + (int64_t)kk * 64 + 32 * (lane >> 5)];
+    out[(b * 8 + kk) * 64 + lane] = val;
+}
+
+// the packed copy up to date with the store (dims <= 128)
+int ms_pack(mi355dr_index* idx, MultiVecStore* m, hipStream_t s) {
+    if (m->packed_docs == m->n_docs) return MI355DR_OK;
+    const int64_t n_tok = m->tok_off_host.back();
+    const int64_t n_pb = std::max<int64_t>(1, (n_tok + 31) / 32);
+    HIPCHECK(idx, hipStreamSynchronize(s));
+    if (m->tok16p) (void)hipFree(m->tok16p);
+    if (m->tok_off) (void)hipFree(m->tok_off);
+    m->tok16p = nullptr;
+    m->tok_off = nullptr;
+    m->packed_docs = -1;
+    HIPCHECK(idx, hipMalloc(&m->tok16p, (size_t)n_pb * 8 * 64 * sizeof(uint4)));
+    HIPCHECK(idx, hipMalloc(&m->tok_off, (size_t)(m->n_docs + 1) * sizeof(int64_t)));
+    HIPCHECK(idx, hipMemcpyAsync(m->tok_off, m->tok_off_host.data(), (size_t)(m->n_docs + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_ms_pack16, dim3((unsigned)n_pb), dim3(512), 0, s, m->tok16, m->blk_off, m->tok_off, m->n_docs, n_tok, m->tok16p);
+    HIPCHECK(idx, hipGetLastError());
+    HIPCHECK(idx, hipStreamSynchronize(s));
+    m->packed_docs = m->n_docs;
+    return MI355DR_OK;
+}
+
+}  // namespace
 
 int64_t mi355dr_size_multivec(const mi355dr_index* idx) { return idx && idx->mv ? idx->mv->n_docs : 0; }
 
@@ -1524,7 +1608,19 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
                 if (!e) HIPCHECK(idx, hipEventCreate(&e));
             HIPCHECK(idx, hipEventRecord(idx->ms_ev[0], s));
         }
-        if (nkk == 8) {  // dims <= 128: the compile-time-unrolled forms, only as many column blocks as the pass has
+        // 9+ column blocks, dims <= 128: over the PACKED copy on request (option maxsim_packed; measured slower, k_maxsim_wgp.h)
+        const int64_t n_tok_all = m->tok_off_host.back();
+        const bool packed = nkk == 8 && ncb_launch >= 9 && idx->maxsim_wg != 0 && n_tok_all > 0 && idx->maxsim_packed > 0;
+        if (packed) {
+            CHECK(ms_pack(idx, m, s));
+            sa.tok16 = m->tok16p;
+            sa.tok_off = m->tok_off;
+        }
+        if (idx->profile) HIPCHECK(idx, hipEventRecord(idx->ms_ev[0], s));  // (again: behind a possible rebuild of the packed copy)
+        if (packed) {
+            CHECK(ms16_wgp_launch(idx, s, ncb_launch, n_tok_all, sa));
+            idx->s_ms_packed_launches++;
+        } else if (nkk == 8) {  // dims <= 128: the compile-time-unrolled forms, only as many column blocks as the pass has
             CHECK(ms16_d128_launch(idx, s, ncb_launch, m->n_docs, m->n_blocks, idx->maxsim_persistent != 0, sa));
         } else {
             hipLaunchKernelGGL(k_maxsim16, dim3(grid_all), dim3(kMsThreads), lds16, s, sa);

@@ -157,30 +157,39 @@ def maxsim_asm_text(tmp_path_factory):
     return out.read_text()
 
 
-@pytest.mark.parametrize("bps", [2, 4])
+@pytest.mark.parametrize("form", ["bps2", "bps4", "pipelined"])
 @pytest.mark.parametrize("ncb", [12, 16])
-def test_maxsim_workgroup_screen_keeps_its_ring_in_flight(maxsim_asm_text, ncb, bps):
+def test_maxsim_workgroup_screen_keeps_its_ring_in_flight(maxsim_asm_text, ncb, form):
     """k_maxsim16_wg (round 4): the token blocks come through a ring of LDS-DMA stages shared by the workgroup's 8 waves (stages
-    of `bps` 32-token blocks).  Pinned on the generated code: the query fragments live in registers (no ds_read feeds an MFMA's B
-    operand -- 8 fragment reads per block, all of them token fragments), exactly one counted vector-memory wait inside the stage
+    of 2 or 4 32-token blocks).  Pinned on the generated code: the query fragments live in registers (no ds_read feeds an MFMA's B
+    operand -- 8 fragment reads per block, all of them token fragments), exactly one counted vector-memory wait per stage
     loop and NO full `s_waitcnt vmcnt(0)` between the prologue's wait and the loop's last MFMA (a per-document vector load of the
     block offsets -- or the query fragments left to their first use -- put one there and drained 96 KiB of stream per document),
-    block offsets through the scalar cache, no scratch."""
-    name = f"_ZN5mi35513k_maxsim16_wgILi{ncb}ELb1ELi{bps}EEEvNS_8Ms16ArgsEl"
+    block offsets through the scalar cache, no scratch.  The software-pipelined form (the default) has two stage loops (waves
+    with one / two column blocks), and the fold of a block sits BETWEEN the MFMAs of the next one."""
+    bps = 2 if form == "bps2" else 4
+    pipe = form == "pipelined"
+    name = f"_ZN5mi35513k_maxsim16_wgILi{ncb}ELb1ELi{bps}ELb{int(pipe)}EEEvNS_8Ms16ArgsEl"
     ops, desc = _whole_kernel(maxsim_asm_text, name)
     assert ".amdhsa_private_segment_fixed_size 0" in desc and not any(o.startswith("scratch_") for o in ops)
     inloop = 12 - bps   # pieces of (stages - 2) stages may still fly at the hand-over
     w12 = [i for i, o in enumerate(ops) if o.startswith("s_waitcnt") and "vmcnt(12)" in o]
     wl = [i for i, o in enumerate(ops) if o.startswith("s_waitcnt") and f"vmcnt({inloop})" in o]
-    assert len(w12) == 1 and len(wl) == 1 and w12[0] < wl[0]
+    loops = 2 if pipe else 1
+    assert len(w12) == 1 and len(wl) == loops and w12[0] < wl[0]
     mf = [i for i, o in enumerate(ops) if o.startswith("v_mfma_f32_32x32x16_bf16")]
-    assert len(mf) == 16 * bps   # per block of a stage: 8 MFMAs for the wave's first column block + 8 for its second
+    # per block of a stage: 8 MFMAs for the wave's first column block + 8 for its second (pipelined: a loop with 8 + one with 16)
+    assert len(mf) == (24 * bps if pipe else 16 * bps)
     loop = ops[w12[0] + 1:max(mf) + 1]
     assert not any(_is_vm0(o) for o in loop), [o for o in loop if "vmcnt" in o]
-    assert sum(o.startswith("global_load_lds_dwordx4") for o in loop) == bps      # the stage one ring ahead: a 1-KiB piece per block and wave
+    assert sum(o.startswith("global_load_lds_dwordx4") for o in loop) == bps * loops  # the stage one ring ahead: a 1-KiB piece per block and wave
     assert not any(o.startswith(("global_load_dword", "flat_load")) for o in loop)  # (block offsets: s_load)
-    # token fragments only: 16 reads for the first two blocks in front of the loop + 8 per block inside it (wherever the block
+    # token fragments only: 16 reads for the first two blocks in front of the loop(s) + 8 per block inside (wherever the block
     # layout puts the loop's last eight); the B operands never come from LDS
     n_rd = sum(o.startswith("ds_read_b128") for o in ops)
-    assert n_rd == 16 + 8 * bps and sum(o.startswith("ds_read_b128") for o in loop) >= 8 * bps - 8
+    assert n_rd == 16 + 8 * bps * loops and sum(o.startswith("ds_read_b128") for o in loop) >= 8 * bps - 8
+    if pipe:
+        # the fold rides in the shadow of the MFMAs: between the first and the last MFMA of some block's burst sit >= 6 v_max3
+        gaps = [sum(o.startswith("v_max3_f32") for o in ops[mf[i]:mf[i + 7]]) for i in range(0, len(mf) - 7, 8)]
+        assert max(gaps) >= 6, gaps
     assert any(o.startswith("s_load_dwordx2") for o in loop)

@@ -295,6 +295,8 @@ def test_sixteen_queries_ride_one_screen_pass(pkg, oracle, tmin, tmax, n_docs):
         idx.add_multivec(tok, off)
         for groups, wg, bps in ((4, -1, 4), (1, -1, 4), (3, 1, 2), (2, 0, 4), (4, 2, 4), (4, 0, 4), (4, 1, 4), (4, 2, 2), (4, 1, 2)):
             idx.set_option("maxsim_tighten", int(bps == 4))   # the candidate band narrowed by the starter's exact distances / the 2E band
+            idx.set_option("maxsim_packed", int(groups == 4 and bps == 4 and wg != 1))   # the screen over the packed / the padded bf16 copy
+            idx.set_option("maxsim_wg_pipe", int(wg != 2))   # the software-pipelined form / the plain one
             idx.set_option("maxsim_pass_groups", groups)
             idx.set_option("maxsim_wg", wg)   # -1 by document length / 1 parked / 2 immediate epilogue / 0 one wave per document
             idx.set_option("maxsim_wg_bps", bps)   # 32-token blocks per ring stage of the workgroup form
@@ -318,3 +320,47 @@ def test_sixteen_queries_ride_one_screen_pass(pkg, oracle, tmin, tmax, n_docs):
         rd2, rr2 = oracle.maxsim_topk(tok, off, qtok[: qoff[9]], qoff[:10], 70)
         d2, r2 = idx.search_maxsim(qtok[: qoff[9]], qoff[:10], 70)
         assert np.array_equal(r2, rr2) and np.array_equal(d2.view(np.uint32), rd2.view(np.uint32))
+
+
+@pytest.mark.parametrize("shape", ["tiny_docs", "ragged", "long"])
+def test_packed_screen_equals_oracle(pkg, oracle, shape):
+    """The 16-query screen over the PACKED bf16 copy (k_maxsim_wgp.h): blocks of 32 tokens wherever they fall, so a block may
+    hold many short documents (more documents ending between two ring barriers than parking slots: the lot's own barrier), the
+    end of one and the start of the next, documents without vectors, and -- after an add -- a rebuilt copy.  Same answers as the
+    oracle, bit for bit, and the packed launches are counted."""
+    rng = np.random.default_rng({"tiny_docs": 11, "ragged": 12, "long": 13}[shape])
+    d = 128
+    if shape == "tiny_docs":
+        lens = rng.integers(0, 6, size=9000)
+    elif shape == "ragged":
+        lens = rng.integers(0, 200, size=3000)
+        lens[rng.random(3000) < 0.1] = 0
+    else:
+        lens = rng.integers(900, 1100, size=120)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    tok = rng.standard_normal((int(off[-1]), d)).astype(np.float32)
+    tok /= np.maximum(np.linalg.norm(tok, axis=1, keepdims=True), 1e-9)
+    qlens = [32, 24, 32, 17, 32, 32, 5, 32, 32, 32, 1, 32, 32, 31, 32, 32, 32, 32, 24]
+    qtok, qoff = _queries(rng, qlens, d)
+    k = 10
+    rd, rr = oracle.maxsim_topk(tok, off, qtok, qoff, k)
+    half = len(lens) // 2
+    with pkg.Mi355Index(d) as idx:
+        idx.set_option("maxsim_packed", 1)
+        idx.add_multivec(tok[:off[half]], off[:half + 1])
+        d0, r0 = idx.search_maxsim(qtok, qoff, k)             # (packs the first half)
+        rd0, rr0 = oracle.maxsim_topk(tok[:off[half]], off[:half + 1], qtok, qoff, k)
+        assert np.array_equal(r0, rr0)
+        idx.add_multivec(tok[off[half]:], off[half:] - off[half])
+        idx.reset_stats()
+        dist, rows = idx.search_maxsim(qtok, qoff, k)         # (the copy is rebuilt)
+        assert idx.stat("maxsim_packed_launches") >= 1
+        assert np.array_equal(rows, rr)
+        ok = ~np.isnan(rd)
+        assert np.array_equal(np.isnan(dist), np.isnan(rd))
+        assert np.array_equal(dist[ok].view(np.uint32), rd[ok].view(np.uint32))
+        idx.set_option("maxsim_packed", 0)
+        idx.reset_stats()
+        dist2, rows2 = idx.search_maxsim(qtok, qoff, k)
+        assert idx.stat("maxsim_packed_launches") == 0
+        assert np.array_equal(rows2, rows) and np.array_equal(dist2.view(np.uint32), dist.view(np.uint32))

@@ -199,6 +199,10 @@ def check_maxsim(rng, case):
         idx.set_option("maxsim_wg", wg)
         bps = int(rng.choice([2, 4]))
         idx.set_option("maxsim_wg_bps", bps)
+        idx.set_option("maxsim_wg_pipe", int(rng.random() < 0.7))
+        packed = int(rng.integers(0, 2))
+        idx.set_option("maxsim_packed", packed)
+        desc += f" packed={packed}"
         tighten = int(rng.random() < 0.7)
         idx.set_option("maxsim_tighten", tighten)
         desc += f" groups={groups} wg={wg} bps={bps} tighten={tighten}"
