@@ -167,6 +167,11 @@ def run_maxsim(args, n_docs: int, tokens: str, nq: int, steps: int, warmup: int,
     el = time.perf_counter() - t0
     idx.set_option("profile", 0)
     assert (np.diff(res[0], axis=1) >= 0).all()
+    # (the counters of the TIMED steps: the power probe below runs more steps)
+    screened, cands, fb = idx.stat("maxsim_screened"), idx.stat("maxsim_candidates"), idx.stat("maxsim_fallbacks")
+    scr_n, scr_ns = idx.stat("maxsim_screen_launches"), idx.stat("maxsim_screen_ns")
+    ex_n, ex_ns = idx.stat("maxsim_exact_launches"), idx.stat("maxsim_exact_ns")
+    cols_issued = idx.stat("maxsim_screen_cols") / max(scr_n, 1)  # query columns per launch, whole blocks of 32
     probe_out = None
     if probe:  # socket power / shader clock next to ~2 s of the same steps (not timed)
         try:
@@ -177,10 +182,6 @@ def run_maxsim(args, n_docs: int, tokens: str, nq: int, steps: int, warmup: int,
     n_tok = float(lens.sum())
     alg_bytes = n_tok * d * 4                                    # fp32 token rows read once per pass
     streamed = float(blocks) * 32 * d * 2                        # bf16 fragment store the screen streams, per pass
-    screened, cands, fb = idx.stat("maxsim_screened"), idx.stat("maxsim_candidates"), idx.stat("maxsim_fallbacks")
-    scr_n, scr_ns = idx.stat("maxsim_screen_launches"), idx.stat("maxsim_screen_ns")
-    ex_n, ex_ns = idx.stat("maxsim_exact_launches"), idx.stat("maxsim_exact_ns")
-    cols_issued = idx.stat("maxsim_screen_cols") / max(scr_n, 1)  # query columns per launch, whole blocks of 32
     scr_s = scr_ns * 1e-9 / max(scr_n, 1)                        # average duration of one screen launch (= one pass)
     # MaxSim is compute-bound from one 32-vector query up -- "the MFMA roofline is the honest one here".
     # Algorithmic flops of a pass = 2 * (query vectors of the pass) * (doc vectors) * d; the kernel issues the same on whole
