@@ -57,7 +57,7 @@ __global__ __launch_bounds__(512, 2) void k_maxsim16_wg(Ms16Args a, int64_t n_bl
     static_assert(BPS == 2 || BPS == 4, "blocks per ring stage");
     constexpr int kMwStages = mw_stages(BPS), kMwStageBytes = mw_stage_bytes(BPS), kMwColmaxOff = kMwStages * kMwStageBytes;
     constexpr int kPark = mw_park(BPS);
-    static_assert(NCB >= 9 && NCB <= 16, "this form serves 9..16 column blocks");
+    static_assert(NCB >= 8 && NCB <= 16, "this form serves 8..16 column blocks");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

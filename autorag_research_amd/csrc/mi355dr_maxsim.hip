@@ -888,6 +888,12 @@ const std::array<Ms16WgKernel, 8> kMs16WgKernels[3][2] = {
     {ms16wg_table<true, 4, false>(std::make_integer_sequence<int, 8>{}), ms16wg_table<false, 4, false>(std::make_integer_sequence<int, 8>{})},
     {ms16wg_table<true, 4, true>(std::make_integer_sequence<int, 8>{}), ms16wg_table<false, 4, true>(std::make_integer_sequence<int, 8>{})}};
 
+// 8 column blocks (one per wave; the pipelined form only): [epilogue: parked, at once].  Measured (interleaved, round 4): with
+// fewer MFMAs per block the workgroup form has a floor of ~880 cycles per block and CU (6.0 ms per pass over 100 k pages, 7.8 ms
+// over 1 M text docs, whatever the column count) where one wave per document streams at 6.2 TB/s up to 4 column blocks:
+// 8 blocks over short documents 8.17 against 8.97 ms; pages 6.04 against 5.15 ms and 5..7 blocks everywhere: one wave per document.
+const Ms16WgKernel kMs16Wg8Kernels[2] = {mi355::k_maxsim16_wg<8, true, 4, true>, mi355::k_maxsim16_wg<8, false, 4, true>};
+
 // ... over the packed copy (k_maxsim_wgp.h), 4 blocks per stage
 template <int... I>
 constexpr std::array<Ms16WgKernel, sizeof...(I)> ms16wgp_table(std::integer_sequence<int, I...>) {
@@ -906,6 +912,8 @@ int ms16_wgp_launch(mi355dr_index* idx, hipStream_t s, int ncb, int64_t n_tok, c
 int ms16_d128_prepare(mi355dr_index* idx) {
     for (auto kfn : kMs16WgpKernels)
         HIPCHECK(idx, hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, mi355::mwp_lds(4)));
+    for (auto kfn : kMs16Wg8Kernels)
+        HIPCHECK(idx, hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, mi355::mw_lds(4)));
     for (int ncb = 1; ncb <= mi355::kMsPassBlocks; ++ncb)
         if (ncb * 8192 > 64 * 1024)
             HIPCHECK(idx, hipFuncSetAttribute((const void*)kMs16Kernels[ncb - 1], hipFuncAttributeMaxDynamicSharedMemorySize, ncb * 8192));
@@ -921,6 +929,13 @@ int ms16_d128_prepare(mi355dr_index* idx) {
 // idle in the last one)
 int ms16_d128_launch(mi355dr_index* idx, hipStream_t s, int ncb, int64_t n_docs, int64_t n_blocks, bool persistent,
                      const mi355::Ms16Args& sa) {
+    if (ncb == 8 && idx->maxsim_wg && idx->maxsim_wg_min <= 8 && (idx->maxsim_wg > 0 || n_blocks < 8 * n_docs)) {
+        const bool now = idx->maxsim_wg == 2;
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(256, (n_blocks + 31) / 32));
+        hipLaunchKernelGGL(kMs16Wg8Kernels[now ? 1 : 0], dim3(grid), dim3(512), (size_t)mi355::mw_lds(4), s, sa, n_blocks);
+        HIPCHECK(idx, hipGetLastError());
+        return MI355DR_OK;
+    }
     if (ncb >= 9 && idx->maxsim_wg) {
         // per-document epilogue: parked behind the next stage barrier for stores of short documents (text: -3.5 % on the kernel),
         // at once for long ones (pages: the parked form's bookkeeping per stage costs 2 % there) -- interleaved A/B, round 4

@@ -315,6 +315,15 @@ def test_sixteen_queries_ride_one_screen_pass(pkg, oracle, tmin, tmax, n_docs):
             idx.set_option("maxsim_pass_groups", 5)
         with pytest.raises(pkg.NativeError):
             idx.set_option("maxsim_wg_bps", 3)
+        # exactly 8 column blocks (8 queries of 32 vectors): the workgroup form for short documents, either epilogue
+        q8, o8 = _queries(rng, [32] * 8, d)
+        r8d, r8r = oracle.maxsim_topk(tok, off, q8, o8, k)
+        for wg, wmin in ((1, 8), (2, 8), (-1, 8), (-1, 9)):
+            idx.set_option("maxsim_wg", wg)
+            idx.set_option("maxsim_wg_min", wmin)
+            dist, rows = idx.search_maxsim(q8, o8, k)
+            assert np.array_equal(rows, r8r) and np.array_equal(dist.view(np.uint32), r8d.view(np.uint32)), (wg, wmin)
+        idx.set_option("maxsim_wg", -1)
         # k above the fast path's 64: one group per pass, same answers
         idx.set_option("maxsim_pass_groups", 4)
         rd2, rr2 = oracle.maxsim_topk(tok, off, qtok[: qoff[9]], qoff[:10], 70)

@@ -200,6 +200,7 @@ def check_maxsim(rng, case):
         bps = int(rng.choice([2, 4]))
         idx.set_option("maxsim_wg_bps", bps)
         idx.set_option("maxsim_wg_pipe", int(rng.random() < 0.7))
+        idx.set_option("maxsim_wg_min", int(rng.integers(8, 10)))
         packed = int(rng.integers(0, 2))
         idx.set_option("maxsim_packed", packed)
         desc += f" packed={packed}"
