@@ -105,6 +105,7 @@ struct mi355dr_index {
     int maxsim_wg = -1;
     int maxsim_packed = 0;   // 16-query screen over the packed bf16 copy (k_maxsim_wgp.h; measured slower than the padded copy: off)
     int maxsim_tighten = 1;  // MaxSim fast path: narrow the candidate band with the exact distances of the screen's top-k (0: band 2E)
+    int maxsim_aligned = 1;  // k_maxsim16_wg: when every query of a pass is one column block, a wave sums its own two queries (0: A/B)
     int maxsim_wg_min = 8;   // fewest column blocks of a pass that take the workgroup form (8: short documents only; 9)
     int maxsim_wg_pipe = 1;  // k_maxsim16_wg, 4 blocks per stage: fold block j under the MFMAs of block j + 1 (0: the unpipelined form, A/B)
     int maxsim_wg_bps = 4;  // k_maxsim16_wg: 32-token blocks per ring stage (2: 7 stages of 16 KiB, 4: 4 stages of 32 KiB); option, A/B

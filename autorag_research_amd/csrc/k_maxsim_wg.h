@@ -113,6 +113,8 @@ __global__ __launch_bounds__(512, 2) void k_maxsim16_wg(Ms16Args a, int64_t n_bl
     const float kNaN = __uint_as_float(0x7FC00000u);
     // queries whose sums this wave writes: wave and wave + 8
     const int qa = wave, qb = wave + 8;
+    const bool aligned = a.aligned != 0;  // (wave-uniform) query r = column block r
+    const int len_mine = lane < 32 ? (qa < a.nq_launch ? a.q_len[qa] : 0) : (qb < a.nq_launch ? a.q_len[qb] : 0);
     auto write_doc = [&](int64_t doc, float va, float vb) {
         if (lane == 63) {  // (the lane the DPP sums end in)
             if (qa < a.nq_launch) a.dist[(int64_t)qa * a.n_docs + doc] = va;
@@ -167,6 +169,21 @@ __global__ __launch_bounds__(512, 2) void k_maxsim16_wg(Ms16Args a, int64_t n_bl
         // of BOTH running maxima side by side (lanes 0..31: column block cb0, lanes 32..63: cb1)
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(run0), __float_as_uint(run1), false, false);
         const float r = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        if (aligned) {
+            // every query of the pass IS one column block (32-vector queries: ColBERT's padded queries): this wave already
+            // holds every column of its two queries -- lanes 0..31 query `wave`, lanes 32..63 query `wave + 8` -- and sums them
+            // itself: four row_shr steps and one row_bcast:15 leave the two sums in lanes 31 and 63.  No LDS, no parking, no
+            // barrier: the per-document exchange below exists for queries that straddle column blocks.
+            float part = (lane & 31) < len_mine ? r : 0.0f;
+            part += mw_dpp<0x111, 0xF, true>(part);
+            part += mw_dpp<0x112, 0xF, true>(part);
+            part += mw_dpp<0x114, 0xF, true>(part);
+            part += mw_dpp<0x118, 0xF, true>(part);
+            part += mw_dpp<0x142, 0xA, false>(part);
+            if ((lane & 31) == 31 && len_mine > 0) a.dist[(int64_t)(wave + 8 * (lane >> 5)) * a.n_docs + cur] = -part;
+            run0 = run1 = -__builtin_inff();
+            return;
+        }
         const int bw = n_fin & (kPark - 1);
         float* cm = colmax + bw * 512;
         if (lane < 32) cm[cb0 * 32 + lane] = r;

@@ -1090,6 +1090,8 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
         idx->maxsim_packed = (int)value;
     } else if (k == "maxsim_tighten") {
         idx->maxsim_tighten = value != 0;
+    } else if (k == "maxsim_aligned") {
+        idx->maxsim_aligned = value != 0;
     } else if (k == "maxsim_wg_min") {
         if (value < 8 || value > 9) return fail(idx, MI355DR_E_INVALID, "maxsim_wg_min must be 8 or 9");
         idx->maxsim_wg_min = (int)value;

@@ -339,6 +339,7 @@ struct Ms16Args {
     int q_col0[kMsPassQueries];  // (k_maxsim16_d128 serves up to FOUR groups of <= 4 queries per launch: rows 4 g .. 4 g + 3)
     int q_len[kMsPassQueries];
     const int64_t* tok_off;  // k_maxsim16_wgp: [n_docs + 1] token offsets of the packed copy (tok16 then points at it)
+    int aligned;             // k_maxsim16_wg: query r of the launch is exactly column block r (q_col0[r] = 32 r, q_len[r] <= 32)
 };
 
 __device__ __forceinline__ void ms16_load_piece(uint4 (&a)[8], const uint4* blk, int piece, int nkk, int lane) {
@@ -1611,9 +1612,11 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
         sa.n_docs = m->n_docs;
         sa.nkk = nkk;
         sa.nq_launch = pq_n;
+        sa.aligned = idx->maxsim_aligned ? 1 : 0;
         for (int r = 0; r < pq_n; ++r) {
             sa.q_col0[r] = pq_col0[r];
             sa.q_len[r] = pq_len[r];
+            if (pq_col0[r] != 32 * r || pq_len[r] > 32) sa.aligned = 0;
         }
         const int ncb_launch = (total_col + 31) / 32;
         HIPCHECK(idx, hipMemcpyAsync(m->qfrag, qf16, (size_t)std::max(ncb_launch, 4) * nkk * 64 * 8 * sizeof(uint16_t),

@@ -324,6 +324,16 @@ def test_sixteen_queries_ride_one_screen_pass(pkg, oracle, tmin, tmax, n_docs):
             dist, rows = idx.search_maxsim(q8, o8, k)
             assert np.array_equal(rows, r8r) and np.array_equal(dist.view(np.uint32), r8d.view(np.uint32)), (wg, wmin)
         idx.set_option("maxsim_wg", -1)
+        # every query exactly one column block (ColBERT's 32-vector queries; the last one shorter): a wave sums its own two queries
+        qa_, oa_ = _queries(rng, [32] * 15 + [17], d)
+        rad, rar = oracle.maxsim_topk(tok, off, qa_, oa_, k)
+        for aligned, wg in ((1, 1), (0, 1), (1, 2), (1, -1)):
+            idx.set_option("maxsim_aligned", aligned)
+            idx.set_option("maxsim_wg", wg)
+            dist, rows = idx.search_maxsim(qa_, oa_, k)
+            assert np.array_equal(rows, rar) and np.array_equal(dist.view(np.uint32), rad.view(np.uint32)), (aligned, wg)
+        idx.set_option("maxsim_wg", -1)
+        idx.set_option("maxsim_aligned", 1)
         # k above the fast path's 64: one group per pass, same answers
         idx.set_option("maxsim_pass_groups", 4)
         rd2, rr2 = oracle.maxsim_topk(tok, off, qtok[: qoff[9]], qoff[:10], 70)

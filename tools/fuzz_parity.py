@@ -182,6 +182,9 @@ def check_maxsim(rng, case):
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     nq = int(rng.choice([1, 2, 5, 9, 17, 40]))   # (round 4: up to 16 queries ride one screen pass)
     qlens = [int(x) for x in rng.choice([0, 1, 5, 24, 32, 33, 100, 128] if nq <= 9 else [0, 7, 24, 24, 32, 32, 32, 33, 100, 200], size=nq)]
+    if rng.random() < 0.25:  # ColBERT-shaped batch: every query one column block of 32 vectors (the last one may be shorter)
+        qlens = [32] * nq
+        qlens[-1] = int(rng.integers(1, 33))
     qtok = rng.standard_normal((sum(qlens), d)).astype(np.float32)
     if unit and qtok.shape[0]:
         qtok /= np.linalg.norm(qtok, axis=1, keepdims=True)
@@ -201,6 +204,7 @@ def check_maxsim(rng, case):
         idx.set_option("maxsim_wg_bps", bps)
         idx.set_option("maxsim_wg_pipe", int(rng.random() < 0.7))
         idx.set_option("maxsim_wg_min", int(rng.integers(8, 10)))
+        idx.set_option("maxsim_aligned", int(rng.random() < 0.8))
         packed = int(rng.integers(0, 2))
         idx.set_option("maxsim_packed", packed)
         desc += f" packed={packed}"
