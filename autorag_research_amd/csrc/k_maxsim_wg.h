@@ -114,7 +114,9 @@ __global__ __launch_bounds__(512, 2) void k_maxsim16_wg(Ms16Args a, int64_t n_bl
     // queries whose sums this wave writes: wave and wave + 8
     const int qa = wave, qb = wave + 8;
     const bool aligned = a.aligned != 0;  // (wave-uniform) query r = column block r
-    const int len_mine = lane < 32 ? (qa < a.nq_launch ? a.q_len[qa] : 0) : (qb < a.nq_launch ? a.q_len[qb] : 0);
+    const int len_a = qa < a.nq_launch ? a.q_len[qa] : 0, len_b = qb < a.nq_launch ? a.q_len[qb] : 0;  // (scalar loads: wave-uniform indices)
+    int len_mine = lane < 32 ? len_a : len_b;
+    asm volatile("" : "+v"(len_mine));  // (materialised HERE: left to its first use its wait lands behind the ring's prologue)
     auto write_doc = [&](int64_t doc, float va, float vb) {
         if (lane == 63) {  // (the lane the DPP sums end in)
             if (qa < a.nq_launch) a.dist[(int64_t)qa * a.n_docs + doc] = va;
