@@ -210,6 +210,15 @@ int mi355dr_search_sharded_device(mi355dr_index* idx, const float* queries_dev, 
  *          of 32), "maxsim_persistent" (0 [default]), "maxsim_coop" (exact MaxSim on candidate lists: -1 [default] one workgroup per
  *          candidate for stores of long documents, 0 one wave, 1 always one workgroup), "i8_min_budget_x100" (AUTO keeps the int8 screen while the chunk-growth
  *          budget at this k is at least value / 100; default 25 = k <= 133).
+ *          Round 4, MaxSim, all with identical results (A/B switches of the 16-query pass, dims <= 128): "maxsim_pass_groups"
+ *          (1..4 [default 4] groups of <= 4 queries per screen pass), "maxsim_wg" (screen form from 8/9 column blocks of query
+ *          vectors up: -1 [default] workgroup form, per-document sums parked for short documents / at once for long ones,
+ *          0 one wave per document, 1 parked, 2 at once), "maxsim_wg_bps" (4 [default] / 2 token blocks per ring stage),
+ *          "maxsim_wg_pipe" (1 [default]: a block's maxima folded between the next block's MFMAs), "maxsim_wg_min" (8 [default]
+ *          / 9: fewest column blocks that take the workgroup form), "maxsim_aligned" (1 [default]: queries that are exactly
+ *          one 32-column block are summed by the wave that holds them), "maxsim_tighten" (1 [default]: candidate band from the
+ *          exact distances of the screen's top-k), "maxsim_packed" (0 [default] / 1: screen over a packed bf16 copy without
+ *          per-document padding, built on first use).
  * stats:   "screen_launches", "screen_ns" (profile=1), "screen_rows" (all screen launches) and their k_screen256 share
  *          "screen256_launches", "screen256_ns", "screen256_rows"; "candidates", "rescored",
  *          "fallback_queries" (queries recomputed by the exact scan), "retry_queries" (queries whose candidate list
@@ -218,7 +227,9 @@ int mi355dr_search_sharded_device(mi355dr_index* idx, const float* queries_dev, 
  *          block, upwards; smaller k keep int8), "starters", "chunks", "passes", "irregular_rows", "loose_rows" (rows outside the int8 shadow,
  *          irregular ones included), "screen_dtype_active" (MI355DR_SCREEN_BF16 / _I8: what AUTO resolves to now),
  *          "maxsim_screened" (queries served by the MaxSim screen), "maxsim_candidates" (docs re-scored exactly for them),
- *          "maxsim_fallbacks" (queries re-run by the exact full scan),
+ *          "maxsim_fallbacks" (queries re-run by the exact full scan), "maxsim_screen_launches" / "maxsim_screen_ns" /
+ *          "maxsim_exact_launches" / "maxsim_exact_ns" (profile=1), "maxsim_screen_cols" (query columns the screen launches
+ *          multiplied every token by), "maxsim_packed_launches",
  *          "hbm_bytes_resident". */
 int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value);
 int mi355dr_get_stat(mi355dr_index* idx, const char* key, int64_t* out);
