@@ -1,4 +1,3 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/j24
-timeout 900 python -m pytest tests/test_gpu_maxsim.py -m gpu -x -q > gpurun_out/j24/pytest.log 2>&1; tail -3 gpurun_out/j24/pytest.log
-timeout 300 python tools/fuzz_parity.py --seconds 150 --only maxsim --seed 2424 > gpurun_out/j24/fuzz_maxsim.log 2>&1; tail -1 gpurun_out/j24/fuzz_maxsim.log | cut -c1-200
+mkdir -p gpurun_out/j26
+timeout 600 python tools/maxsim_ab.py --docs-scale 0.1 --steps 5 --rounds 1 maxsim_wg_pipe=1 "maxsim_wg_pipe=0,maxsim_aligned=0" > gpurun_out/j26/ab.log 2>&1; tail -5 gpurun_out/j26/ab.log | cut -c1-330
