@@ -139,7 +139,7 @@ struct mi355dr_index {
     int64_t s_retry_queries = 0;  // queries whose candidate list overflowed and that were re-screened with the bf16 bound
     int64_t s_ms_screened = 0, s_ms_candidates = 0, s_ms_fallbacks = 0;  // MaxSim: queries screened, docs re-scored, full re-runs
     // option "profile": HIP-event time of the MaxSim screen launches (k_maxsim16*) and of the exact launches on candidate lists
-    int64_t s_ms_screen_ns = 0, s_ms_screen_launches = 0, s_ms_exact_ns = 0, s_ms_exact_launches = 0;
+    int64_t s_ms_screen_ns = 0, s_ms_screen_launches = 0, s_ms_exact_ns = 0, s_ms_exact_launches = 0, s_ms_pack_ns = 0;
     int64_t s_ms_packed_launches = 0, s_ms_screen_cols = 0;  // query-vector columns (whole blocks of 32) the screen launches multiplied every token by
     hipEvent_t ms_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<mi355::EventPair> ev_pool, ev_pending;

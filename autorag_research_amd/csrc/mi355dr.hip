@@ -1175,6 +1175,7 @@ int mi355dr_get_stat(mi355dr_index* idx, const char* key, int64_t* out) {
     else if (k == "maxsim_candidates") *out = idx->s_ms_candidates;
     else if (k == "maxsim_fallbacks") *out = idx->s_ms_fallbacks;
     else if (k == "maxsim_screen_ns") *out = idx->s_ms_screen_ns;
+    else if (k == "maxsim_pack_ns") *out = idx->s_ms_pack_ns;
     else if (k == "maxsim_screen_launches") *out = idx->s_ms_screen_launches;
     else if (k == "maxsim_exact_ns") *out = idx->s_ms_exact_ns;
     else if (k == "maxsim_exact_launches") *out = idx->s_ms_exact_launches;
@@ -1196,7 +1197,7 @@ int mi355dr_reset_stats(mi355dr_index* idx) {
     idx->s_screen_launches = idx->s_screen_ns = idx->s_screen_rows = idx->s_fallback_queries = idx->s_chunks =
         idx->s_passes = idx->s_big_launches = idx->s_big_ns = idx->s_big_rows = idx->s_starters = 0;
     idx->s_ms_screened = idx->s_ms_candidates = idx->s_ms_fallbacks = idx->s_retry_queries = 0;
-    idx->s_ms_screen_ns = idx->s_ms_screen_launches = idx->s_ms_exact_ns = idx->s_ms_exact_launches = idx->s_ms_screen_cols = idx->s_ms_packed_launches = 0;
+    idx->s_ms_screen_ns = idx->s_ms_screen_launches = idx->s_ms_exact_ns = idx->s_ms_exact_launches = idx->s_ms_screen_cols = idx->s_ms_packed_launches = idx->s_ms_pack_ns = 0;
     if (idx->stat_dev) {
         HIPCHECK(idx, hipSetDevice(idx->device));
         HIPCHECK(idx, hipMemset(idx->stat_dev, 0, 2 * kQBlockMax * sizeof(unsigned long long)));

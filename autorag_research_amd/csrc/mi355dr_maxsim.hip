@@ -26,6 +26,7 @@
 //   per-doc sums.  k docs have T >= x_k (k-th best screen score) hence S >= x_k - E; any doc of the exact top-k
 //   (ties included) has S >= that, hence T >= x_k - 2E: the candidate set.
 #include <array>
+#include <chrono>
 #include <utility>
 
 #include "index.h"
@@ -1539,6 +1540,7 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
             continue;
         }
         // ---- the groups of this pass
+        const auto t_pack0 = std::chrono::steady_clock::now();
         std::fill(qimg, qimg + qimg_n, 0.0f);
         std::fill(qf16, qf16 + qf16_n, (uint16_t)0);
         const int first = b;
@@ -1582,6 +1584,8 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
                 ++pq_n;
             }
         if (pq_n == 0) continue;
+        if (idx->profile)
+            idx->s_ms_pack_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_pack0).count();
         const size_t img_cols = std::min<size_t>(kImgCols, (size_t)((total_col + 31) / 32 * 32 + 32));
         HIPCHECK(idx, hipMemcpyAsync(m->qtok, qimg, img_cols * dp * sizeof(float), hipMemcpyHostToDevice, s));
         if (!screen) {

@@ -86,9 +86,12 @@ def main() -> None:
                 cols = idx.stat("maxsim_screen_cols") / max(n, 1)
                 issued = 2.0 * cols * blocks * 32 * d / scr / 1e12 if scr > 0 else 0.0
                 cand = idx.stat("maxsim_candidates") / max(idx.stat("maxsim_screened"), 1)
+                pack_ms = idx.stat("maxsim_pack_ns") * 1e-6 / args.steps
+                exact_ms = idx.stat("maxsim_exact_ns") * 1e-6 / args.steps
                 print(f"{tokens:4s} {n_docs} docs, {qb} x {nq}-vector queries/step, round {rnd} [{cfg}]: {args.steps * qb / el:8.1f} queries/s  "
                       f"step {el / args.steps * 1e3:7.3f} ms  screen launch {scr * 1e3:7.3f} ms ({blocks * 8192 / scr / 1e12:5.2f} TB/s of the "
-                      f"bf16 copy, issued {issued:6.0f} TF/s)  {cand:5.0f} docs re-scored per query  checksum {int(res[1].sum())}", flush=True)
+                      f"bf16 copy, issued {issued:6.0f} TF/s)  exact {exact_ms:5.3f} ms  host pack {pack_ms:5.3f} ms  {cand:5.0f} docs re-scored per query  "
+                      f"checksum {int(res[1].sum())}", flush=True)
         idx.close()
 
 
