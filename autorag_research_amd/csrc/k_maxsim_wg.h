@@ -1,4 +1,4 @@
-// k_maxsim_wg.h -- the MaxSim bf16 screen for 9..16 column blocks of query vectors per pass (up to 16 queries x 32 vectors),
+// k_maxsim_wg.h -- the MaxSim bf16 screen for 8..16 column blocks of query vectors per pass (up to 16 queries x 32 vectors),
 // dims <= 128: ONE workgroup of 8 waves walks a contiguous range of documents as ONE stream of 32-token blocks; the waves
 // split the query COLUMNS, not the documents.
 //
@@ -6,18 +6,23 @@
 // HBM -> VGPR and multiplies them with every column block, reading each query fragment from LDS -- one ds_read_b128 per MFMA --
 // and pays the per-document epilogue (16 masked butterflies at 16 queries) alone.  At 16 queries per pass the pass is no
 // longer bound by the token stream but by the matrix pipe at the socket power cap (bench: 16 queries per pass ran no faster per
-// query than 8), so what is left to shave is everything around the MFMAs:
+// query than 8), and -- the round's A/Bs: profiles/r04_maxsim_ab.txt -- by the time a wave spends BETWEEN its MFMA bursts:
 //   * the query fragments of a wave's OWN column blocks (w and w + 8: at most two) stay in REGISTERS for the whole launch;
 //   * the token blocks go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction = one k-group fragment
 //     of a block, which the fragment-ordered bf16 copy stores contiguously), once per WORKGROUP: a ring of 4 stages of four
-//     blocks (BPS = 4; or 7 stages of two, BPS = 2), 96 KiB per CU in flight either way, counted vmcnt waits, one barrier
-//     per stage placed between the MFMA bursts of a stage's last two blocks; every wave reads a block's 8 fragments from LDS once and uses each for its one or two column
+//     blocks (BPS = 4; or 7 stages of two, BPS = 2: -3 %), 96 KiB per CU in flight either way, counted vmcnt waits, one
+//     barrier per stage; every wave reads a block's 8 fragments from LDS once and uses each for its one or two column
 //     blocks: 0.5 .. 1 LDS read per MFMA instead of 1, no token fragment ever crosses a VGPR on its way in;
+//   * PIPE (the default): the 16-way maxima of block j are folded between the MFMAs of block j + 1 -- two accumulator sets,
+//     the fold in the burst's own basic block, one VALU operation per MFMA by sched_group_barrier (-5 .. 6 %);
 //   * the per-document epilogue is shared: the waves' per-column maxima meet in 2 KiB of LDS, wave w then sums the columns of
-//     queries w and w + 8 (one masked butterfly each instead of sixteen) -- behind the ring's NEXT stage barrier, not one of
-//     its own.
+//     queries w and w + 8 by DPP -- parked behind the ring's NEXT stage barrier and staggered between the two waves of a SIMD
+//     for short documents (DEFER), behind a barrier of its own for long ones;
+//   * and not at all when every query of the pass IS one column block (`aligned`: ColBERT's 32-vector queries): the wave that
+//     holds a query's columns sums them itself (-5 % on a store of 32..180-token documents).
 // Column blocks w and w + 8 sit on the same wave, waves w and w + 4 on the same SIMD: 12 column blocks (sixteen 24-vector
-// queries) are 3 per SIMD, 16 are 4 per SIMD -- balanced.
+// queries) are 3 per SIMD, 16 are 4 per SIMD -- balanced.  What did NOT help: fewer MFMAs (the packed copy, k_maxsim_wgp.h),
+// wave priorities, interleaving the two accumulator chains.
 // The per-document sums add the column maxima in another order than k_maxsim16_d128 and the exact kernel do; the screen's
 // bound covers any order (search_maxsim_impl: e_acc).  Bit-exactness of the RESULTS is the exact re-score's business, as before.
 #pragma once
