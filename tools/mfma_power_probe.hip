@@ -162,7 +162,17 @@ static int run_stream(const std::string& fmt, const std::string& data, double se
                 const size_t base = (f * 64 + lane) * 8;
                 for (int e = 0; e < elems; ++e) {
                     uint32_t code;
-                    if (fmt == "i8") code = (uint8_t)(int8_t)std::nearbyint(blk[e] * (127.0f / 4.4f) > 127 ? 127 : (blk[e] * (127.0f / 4.4f) < -127 ? -127 : blk[e] * (127.0f / 4.4f)));
+                    if (fmt == "i8") {
+                        // data modes beyond gauss / zero (what the operand bit patterns cost at the power cap): "abs" every operand
+                        // |x|; "absA" the A side only (even fragments); "offA" the A side as 7-bit values + 64 (all in 1..127: what
+                        // an offset-encoded corpus shadow would hold), "off" both sides
+                        const bool a_side = (f & 1) == 0;
+                        float v = blk[e] * (127.0f / 4.4f);
+                        if (data == "abs" || (data == "absA" && a_side)) v = std::fabs(v);
+                        if (data == "off" || (data == "offA" && a_side)) v = blk[e] * (63.0f / 4.4f) + 64.0f;
+                        v = v > 127 ? 127 : (v < -127 ? -127 : v);
+                        code = (uint8_t)(int8_t)std::nearbyint(v);
+                    }
                     else if (fmt == "bf16") {
                         uint32_t u;
                         const float v = blk[e] * 0.036f;
