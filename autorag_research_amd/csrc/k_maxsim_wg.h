@@ -40,22 +40,7 @@ __host__ __device__ constexpr int mw_park(int bps) { return 2 * bps; }          
 __host__ __device__ constexpr int mw_lds(int bps) { return mw_stages(bps) * mw_stage_bytes(bps) + mw_park(bps) * 512 * (int)sizeof(float); }
 static_assert(mw_lds(2) <= 160 * 1024 && mw_lds(4) <= 160 * 1024, "LDS per workgroup");
 
-// wave-wide fp32 sum by DPP, valid in LANE 63: four row_shr steps (inclusive prefix inside each row of 16 lanes), then
-// row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3 -- six VALU operations where the shuffle butterfly was six
-// dependent ds_bpermute round trips through the LDS (a text document's two query sums: a tenth of the kernel)
-template <int CTRL, int ROWMASK, bool BC>
-__device__ __forceinline__ float mw_dpp(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROWMASK, 0xF, BC));
-}
-__device__ __forceinline__ float mw_wave_sum_lane63(float v) {
-    v += mw_dpp<0x111, 0xF, true>(v);   // row_shr:1
-    v += mw_dpp<0x112, 0xF, true>(v);   // row_shr:2
-    v += mw_dpp<0x114, 0xF, true>(v);   // row_shr:4
-    v += mw_dpp<0x118, 0xF, true>(v);   // row_shr:8 -> lane 15 of every row holds the row's sum
-    v += mw_dpp<0x142, 0xA, false>(v);  // row_bcast:15 -> rows 1, 3
-    v += mw_dpp<0x143, 0xC, false>(v);  // row_bcast:31 -> rows 2, 3: lane 63 holds the wave's sum
-    return v;
-}
+// (mw_dpp / mw_wave_sum_lane63: the DPP sums, defined by the including file next to Ms16Args)
 
 template <int NCB, bool DEFER, int BPS, bool PIPE = false>
 __global__ __launch_bounds__(512, 2) void k_maxsim16_wg(Ms16Args a, int64_t n_blocks) {

@@ -343,6 +343,23 @@ struct Ms16Args {
     int aligned;             // k_maxsim16_wg: query r of the launch is exactly column block r (q_col0[r] = 32 r, q_len[r] <= 32)
 };
 
+// wave-wide fp32 sum by DPP, valid in LANE 63: four row_shr steps (inclusive prefix inside each row of 16 lanes), then
+// row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3 -- six VALU operations where the shuffle butterfly was six
+// dependent ds_bpermute round trips through the LDS (a text document's two query sums: a tenth of the kernel)
+template <int CTRL, int ROWMASK, bool BC>
+__device__ __forceinline__ float mw_dpp(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROWMASK, 0xF, BC));
+}
+__device__ __forceinline__ float mw_wave_sum_lane63(float v) {
+    v += mw_dpp<0x111, 0xF, true>(v);   // row_shr:1
+    v += mw_dpp<0x112, 0xF, true>(v);   // row_shr:2
+    v += mw_dpp<0x114, 0xF, true>(v);   // row_shr:4
+    v += mw_dpp<0x118, 0xF, true>(v);   // row_shr:8 -> lane 15 of every row holds the row's sum
+    v += mw_dpp<0x142, 0xA, false>(v);  // row_bcast:15 -> rows 1, 3
+    v += mw_dpp<0x143, 0xC, false>(v);  // row_bcast:31 -> rows 2, 3: lane 63 holds the wave's sum
+    return v;
+}
+
 __device__ __forceinline__ void ms16_load_piece(uint4 (&a)[8], const uint4* blk, int piece, int nkk, int lane) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -525,28 +542,35 @@ __global__ __launch_bounds__(NW * 64, 2) void k_maxsim16_d128(Ms16Args a) {
             }
             parity ^= 1;
         }
+        // The two halves of the wave hold different token rows of the same column: one v_permlane32_swap joins the halves of
+        // TWO column blocks at once (lanes 0..31: block 2 p, lanes 32..63: block 2 p + 1) -- round 4; was one ds_bpermute
+        // round trip per block.
+        float rr[(NCB + 1) / 2];
 #pragma unroll
-        for (int c = 0; c < NCB; ++c) run[c] = fmaxf(run[c], __shfl_xor(run[c], 32, kWave));
-        // per query: the sum of its columns' maxima -- a masked sum over the lanes of the column blocks its columns fall
-        // into: 5 butterfly steps instead of one shuffle per query token (the serial form -- 128 dependent shuffles per
-        // document -- was most of this kernel's time on 3-block documents).  Round 3: the queries of a pass are packed column
-        // after column (eight 24-vector queries = 6 column blocks, not 8 padded ones: a quarter less MFMA and LDS work per token
-        // block), so a query may start anywhere and span a block boundary.
+        for (int p2 = 0; p2 < (NCB + 1) / 2; ++p2) {
+            float hi = 2 * p2 + 1 < NCB ? run[2 * p2 + 1] : -__builtin_inff();
+            asm volatile("" : "+v"(hi));  // (two distinct registers: the swap of a register with itself is miscompiled)
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(run[2 * p2]), __float_as_uint(hi), false, false);
+            rr[p2] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        // per query: the sum of its columns' maxima -- every column lives in exactly one lane now (block cbi in the wave half
+        // cbi & 1), so a masked add per touched block and ONE wave-wide DPP sum (six VALU operations, result in lane 63) do it;
+        // round 3 had five ds_bpermute butterfly steps per query here, and on 3-block text documents at 8 queries per pass that
+        // epilogue was a third of the kernel.  The queries of a pass are packed column after column (eight 24-vector queries =
+        // 6 column blocks, not 8 padded ones), so a query may start anywhere and span a block boundary.
         // The order of the fp32 additions differs from the exact kernel's; the screen's bound covers any order (e_acc).
         for (int qi = 0; qi < a.nq_launch; ++qi) {
             const int c0 = a.q_col0[qi], len = a.q_len[qi];
             float part = 0.0f;
 #pragma unroll
             for (int cbi = 0; cbi < NCB; ++cbi) {
-                // (wave-uniform skip of the blocks the query does not touch: a 32-token query touches one or two of the eight,
-                // and on 3-block text documents this epilogue is a fifth of the kernel)
+                // (wave-uniform skip of the blocks the query does not touch: a 32-token query touches one or two of the eight)
                 if (cbi * 32 + 31 < c0 || cbi * 32 >= c0 + len) continue;
                 const int j = cbi * 32 + (lane & 31) - c0;  // this lane's column of block cbi as a token index of query qi
-                if (j >= 0 && j < len) part += run[cbi];
+                if (j >= 0 && j < len && (lane >> 5) == (cbi & 1)) part += rr[cbi >> 1];
             }
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) part += __shfl_xor(part, o, kWave);
-            if (lane == 0) a.dist[(int64_t)qi * a.n_docs + doc] = nb > 0 ? -part : __uint_as_float(0x7FC00000u);
+            part = mw_wave_sum_lane63(part);
+            if (lane == 63) a.dist[(int64_t)qi * a.n_docs + doc] = nb > 0 ? -part : __uint_as_float(0x7FC00000u);
         }
     }
     }  // rounds
