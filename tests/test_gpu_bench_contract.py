@@ -79,3 +79,15 @@ def test_distributed_code_path_through_the_library_communicator(native_built):
     c = d["config"]["collective"]
     assert c["rccl_comm_count"] == 1 and c["ranks_in_all_gather"] == 1   # ncclCommCount, asked of RCCL itself
     assert d["extra"]["identical_to_one_gpu"] is True
+
+
+def test_maxsim_leg_reports_the_mfma_roofline_from_the_timed_steps(native_built):
+    """`--workload maxsim`: bound "mfma", algorithmic <= issued flops, both below the dense bf16 peak -- the counters are those of
+    the TIMED steps (round 4: they were read behind the power probe's extra steps once and the issued rate came out at 4 PF)."""
+    d = _bench("--workload", "maxsim", "--tokens", "text", "--docs", "60000", "--steps", "6", "--warmup", "1", "--no-cpu-baseline")
+    assert d["metric"] == "queries/sec" and d["value"] > 0 and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["kernel"].startswith("k_maxsim16_wg<16>")
+    assert r["launches"] == 6 and 0 < r["achieved"] <= r["issued_tflops"] * 1.001 < r["peak"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac_of_power_limited_stream"] < 1.3
+    assert d["extra"]["exact_full_scan_fallbacks"] == 0 and 0 < d["extra"]["candidates_per_query"] < 2000
