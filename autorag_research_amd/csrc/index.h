@@ -113,6 +113,7 @@ struct mi355dr_index {
     int maxsim_screen = 1; // 1: bf16 MFMA screen + exact re-score of the candidates, 0: exact kernel over every doc
     int64_t row_offset = 0;
     int round_a = 0;      // k_prune: rows re-scored before the cut is known (0 = max(32, 2k)); tuning option "round_a"
+    int screen_rq = 1;      // query blocks above 128, int8 shadow of <= 768 B per row: k_screen_rq (query operand in registers) instead of k_screen256c (option "screen_rq")
     int screen_stream = 1;  // query blocks of at most 64: k_screen_stream instead of k_screen (option "screen_stream", A/B and tests)
     int prefilter16 = 0;  // int8 screen: bf16 second screen of the surviving candidates inside k_prune (option "prefilter16";
                           // off: measured +1.4 % at 1.25 M rows, +0.2 % at 10 M -- the prune is bound by batch latency, not bytes)
@@ -136,6 +137,7 @@ struct mi355dr_index {
     int64_t s_screen_launches = 0, s_screen_ns = 0, s_screen_rows = 0, s_fallback_queries = 0, s_chunks = 0,
             s_passes = 0, s_candidates = 0, s_rescored = 0, s_starters = 0;
     int64_t s_big_launches = 0, s_big_ns = 0, s_big_rows = 0;  // the k_screen256 share of the three above
+    int64_t s_rq_launches = 0;  // of them: k_screen_rq launches (stat "screen_rq_launches")
     int64_t s_retry_queries = 0;  // queries whose candidate list overflowed and that were re-screened with the bf16 bound
     int64_t s_ms_screened = 0, s_ms_candidates = 0, s_ms_fallbacks = 0;  // MaxSim: queries screened, docs re-scored, full re-runs
     // option "profile": HIP-event time of the MaxSim screen launches (k_maxsim16*) and of the exact launches on candidate lists

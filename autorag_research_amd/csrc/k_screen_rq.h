@@ -1,0 +1,286 @@
+// k_screen_rq.h -- the large-block screen with the QUERY operand resident in registers ("rq"): rows are the only operand
+// that goes through the LDS.
+//
+// Why (round-4 timing builds of k_screen256c, profiles/r04_kstep_ab.txt): 1.7-2.0 ms of its 6.2 ms are the L2 -> LDS staging,
+// and half of the staged bytes are the QUERY half-tiles, fetched again from L2 for every K-step of every corpus tile although
+// a persistent workgroup never changes its query tile.  At d <= 768 int8 a query is <= 768 B: the 24 16-byte MFMA fragments
+// of 32 queries are 96 registers per lane, loaded ONCE per launch.
+//
+//   * Workgroup tile 128 corpus rows x 256 queries, 8 waves (two per SIMD); wave w owns queries [32 w, +32) for ALL 128
+//     rows: 4 accumulator blocks (64 registers) + 4 KS query fragments (KS = K-steps of 128 B; 96 registers at d = 768) + a
+//     ring of row fragments (32).  Every row byte staged into the LDS feeds 256 queries, as in k_screen256c, but nothing
+//     else is staged: 16 KiB per K-step and CU instead of 64 KiB per K-step of a tile of twice the rows -- HALF the L2 -> LDS
+//     bytes per multiply-add (1/256 B), 2 LDS-DMA pieces per wave and K-step instead of 9.  LDS reads: one ds_read_b128 per
+//     MFMA (128 B/clk/CU at the MFMA peak, half of what ds_read_b128 delivers on gfx950).
+//   * The LDS holds a ring of NST stages of 16 KiB (one K-step of the tile's 128 rows each; NST = 6 at KS = 6: a whole
+//     tile), filled NST K-steps ahead: a piece has ~5 K-steps (~3000 cycles) to land, counted vmcnt never waits in steady
+//     state.  ONE barrier per K-step (hand-over of the stage just read), placed between two MFMA bursts of the same wave.
+//   * K-step = 8 micro-steps m = 4 I + kk of 2 MFMAs (row blocks 2 I, 2 I + 1; K sub-step kk): row-half-major as in
+//     k_screen256c, so that a finished tile's blocks are tested UNDER MFMAs of the other row half (both waves of a SIMD
+//     reach a tile's end together: tests behind the last MFMA would idle the matrix pipe).  Row fragments are read three
+//     micro-steps ahead under counted lgkmcnt.
+//   * Same epilogue as k_screen256c (per-wave LDS queue, out-of-line append), same persistent XCD-aware walk (the query
+//     tiles of one row tile run on one XCD: the shadow comes from HBM once), same int8 row-group records by one small LDS-DMA
+//     piece per tile.
+// Restrictions: row_bytes = 128 KS with KS a template parameter (the fragments are indexed at compile time); instantiated
+// for the int8 shadow at d <= 768 (the bf16 shadow of d = 768 would need 192 query registers).  Everything else keeps
+// k_screen256c.  ct0 / n_ctiles of the arguments count 128-ROW tiles here.
+// Measured (tools/screen_ab, interleaved with k_screen256c on the same operands, profiles/r05_kstep_ab.txt): Gaussian int8
+// -6 ... -15 % per launch (both kernels run at the socket power cap: the gain is the energy of the L2 -> LDS bytes no longer
+// moved), zeros -24 % (4.2 POP/s = 0.85 of the int8 peak: in cycles the staging no longer shows).
+#pragma once
+#include "k_screen256_common.h"
+
+namespace mi355 {
+
+constexpr int kRqRows = 128;                         // corpus rows per tile
+constexpr int kRqStageBytes = kRqRows * kRowB;       // 16 KiB: one K-step of the tile
+__host__ __device__ constexpr int rq_stages(int ks) { return ks == 4 ? 8 : ks == 5 ? 5 : 6; }  // a multiple of KS
+constexpr int kRqRecSlots = 8;                       // ring of row-group records (one 256-B slot per tile)
+__host__ __device__ constexpr int rq_que_off(int ks) { return rq_stages(ks) * kRqStageBytes; }
+__host__ __device__ constexpr int rq_rec_off(int ks) { return rq_que_off(ks) + 8 * kWaveQueueCap * 12; }
+__host__ __device__ constexpr int rq_lds(int ks) { return rq_rec_off(ks) + kRqRecSlots * 256; }
+static_assert(rq_lds(4) <= 160 * 1024, "LDS per workgroup");
+
+// persistent grid in 128-row tiles: 8 XCDs x L workgroups (same rule as screen256_grid)
+__host__ __device__ inline unsigned screen_rq_grid(int n_ctiles, int n_qtiles) { return screen256_grid(n_ctiles, n_qtiles); }
+
+// ABL (timing builds for the A/B table; 0 = the kernel): 1 no fragment reads, 4 no tests, 8 no barrier, 16 no LDS-DMA in the
+// loop, 32 no vmcnt at the hand-over.  (Cache policies nt / sc0 / sc1 on the row pieces, measured in round 5:
+// +1 ... +3 % on Gaussian operands, profiles/r05_kstep_ab.txt -- the default policy stays.)
+template <int KS, int ABL, bool I8>
+__global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
+    constexpr int NST = rq_stages(KS);
+    static_assert(NST % KS == 0, "a tile never wraps the ring");
+    static_assert((NST + KS - 1) / KS + 2 <= kRqRecSlots, "records ring");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int32_t* const que = (int32_t*)(smem + rq_que_off(KS) + wave * (kWaveQueueCap * 12));  // [q | row | value bits]
+    int que_n = 0;                                                                          // wave-uniform
+
+    const int b = blockIdx.x;
+    const int xcd = b & 7;
+    const int l = b >> 3;
+    const int cslot = l / a.n_qtiles;
+    const int qt = l - cslot * a.n_qtiles;
+    const int cstep = ((int)(gridDim.x >> 3) / a.n_qtiles) * 8;  // row tiles between two visits
+    int ctl = cslot * 8 + xcd;
+    if (ctl >= a.n_ctiles) return;
+    const int q0 = qt * kT2 + 32 * wave;  // this wave's first query
+    const int row_bytes = a.row_bytes;
+
+    // ---- the wave's query operand: 4 KS fragments of 16 B per lane (query lane & 31, K bytes 32 i + 16 (lane >> 5))
+    bf16x8 fB[4 * KS];
+    {
+        const char* qp = (const char*)a.qhat + (int64_t)(q0 + (lane & 31)) * row_bytes + 16 * (lane >> 5);
+#pragma unroll
+        for (int i = 0; i < 4 * KS; ++i) fB[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(qp + 32 * i));
+        // the fragments are complete HERE: left to the waitcnt pass, the waits for these loads land in front of their first use
+        // inside the tile loop -- a vmcnt(23) ... vmcnt(0) ladder that drains the LDS-DMA ring on every tile
+#pragma unroll
+        for (int i = 0; i < 4 * KS; ++i) asm volatile("" : "+v"(fB[i]));
+    }
+    // ---- DMA sources: this wave stages local rows [16 wave + 8 u, +8) of every stage
+    unsigned voff[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int r = (2 * wave + u) * 8 + (lane >> 3);  // local row 0..127
+        const int c = (lane & 7) ^ ((r >> 1) & 7);       // source chunk for this LDS slot (swizzle)
+        voff[u] = (unsigned)(r * row_bytes + c * 16);
+    }
+    // ---- fragment read offset inside a stage: row block rb adds 4096 (the key (r >> 1) & 7 does not see it), K sub-step kk
+    // flips bits 5, 6
+    int offA;
+    {
+        const int r = lane & 31, g = lane >> 5;
+        offA = r * kRowB + ((g ^ ((r >> 1) & 7)) << 4);
+    }
+    const int q_lane = q0 + (lane & 31);
+    float th = a.thr[q_lane];
+    float scq = I8 ? a.sc[q_lane] : 1.0f, kqq = I8 ? a.kq[q_lane] : 1.0f;
+    asm volatile("" ::"v"(th), "v"(kqq), "v"(scq));
+
+    f32x16 acc[4];  // row blocks 0..3 of the tile
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
+    const unsigned lds0 = lds_addr(smem);
+    const unsigned rec_lds = lds0 + rq_rec_off(KS);
+    const unsigned rec_voff = (unsigned)((lane & 7) * 4);  // the tile's 4 records = 8 dwords, eight copies per slot
+
+#define RQ_PIN() __builtin_amdgcn_sched_barrier(0)
+    // staging cursor: the NEXT K-step to stage = (tile base, K offset, K-steps done in that tile, ring stage, tile counter);
+    // past the last tile it stays on it (dummy re-stage of valid memory, drained before the exit)
+    const int64_t tile_bytes = (int64_t)kRqRows * row_bytes;
+    const char* c_base = (const char*)a.shadow + (int64_t)(a.ct0 + ctl) * tile_bytes;
+    const int64_t tile_stride_bytes = (int64_t)cstep * tile_bytes;
+    int c_k = 0, c_n = 0, c_ctl = ctl, c_tc = 0;
+    unsigned c_dst = lds0 + (unsigned)(2 * wave) * 1024u;  // LDS address of this wave's first piece in the cursor's stage
+#define RQ_PIECE(U)                                                                                   \
+    do {                                                                                              \
+        if constexpr ((ABL & 16) == 0) glds16_saddr(c_base + c_k, voff[U], c_dst + (U) * 1024u);       \
+    } while (0)
+#define RQ_REC()                                                                                      \
+    do {                                                                                              \
+        if constexpr (I8 && (ABL & 16) == 0)                                                          \
+            if (c_n == 0)                                                                             \
+                glds4_saddr((const char*)a.grp + (int64_t)(a.ct0 + c_ctl) * (kRqRows / kI8GroupRows * (int)sizeof(I8Group)), \
+                            rec_voff, rec_lds + (unsigned)(c_tc & (kRqRecSlots - 1)) * 256u);         \
+    } while (0)
+#define RQ_ADVANCE()                                                                                  \
+    do {                                                                                              \
+        c_k += kRowB;                                                                                 \
+        c_dst += kRqStageBytes;                                                                       \
+        if (c_dst >= lds0 + (unsigned)(NST * kRqStageBytes)) c_dst -= (unsigned)(NST * kRqStageBytes); \
+        if (++c_n == KS) {                                                                            \
+            c_n = 0;                                                                                  \
+            c_k = 0;                                                                                  \
+            ++c_tc;                                                                                   \
+            if (c_ctl + cstep < a.n_ctiles) {                                                         \
+                c_ctl += cstep;                                                                       \
+                c_base += tile_stride_bytes;                                                          \
+            }                                                                                         \
+        }                                                                                             \
+    } while (0)
+
+    // ---- row fragments: ring of four micro-steps x 2 blocks, read kPF micro-steps ahead
+    constexpr int kPF = 3;
+    bf16x8 fAq[4][2];
+    if constexpr ((ABL & 1) != 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" : "=v"(fAq[i][j]));
+    }
+// reads of micro-step M2 (0..7 this K-step, 8..10 = micro-steps 0..2 of the next one) from stage byte offsets SB / SBN
+#define RQ_PREFETCH(M2, SB, SBN)                                                                      \
+    do {                                                                                              \
+        if constexpr ((ABL & 1) == 0) {                                                               \
+            constexpr int m2__ = (M2) & 7;                                                            \
+            const char* r__ = smem + ((M2) >= 8 ? (SBN) : (SB)) + (2 * (m2__ >> 2)) * 4096;           \
+            _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                          \
+                fAq[m2__ & 3][rb] = __builtin_bit_cast(bf16x8, *(const uint4*)(r__ + rb * 4096 + (offA ^ ((m2__ & 3) * 32)))); \
+        }                                                                                             \
+    } while (0)
+#define RQ_MM(M, TT, ZERO)                                                                            \
+    do {                                                                                              \
+        _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                              \
+            acc[2 * ((M) >> 2) + rb] = screen_mfma<I8>(fAq[(M) & 3][rb], fB[4 * (TT) + ((M) & 3)],    \
+                                                       (ZERO) ? zero16 : acc[2 * ((M) >> 2) + rb]);   \
+    } while (0)
+// test row block RB of the tile whose first row is ROW0 (records slot of tile counter TC)
+#define RQ_TEST(RB, ROW0, TC)                                                                         \
+    do {                                                                                              \
+        if constexpr ((ABL & 4) == 0) {                                                               \
+            int lane_e = lane;                                                                        \
+            asm volatile("" : "+v"(lane_e));                                                          \
+            const int q__ = q0 + (lane_e & 31);                                                       \
+            const int rbase__ = (ROW0) + 32 * (RB) + 4 * (lane_e >> 5);                               \
+            I8Blk blk__{1.0f, 0.0f};                                                                  \
+            if constexpr (I8) {                                                                       \
+                const I8Group g__ = ((const I8Group*)(smem + rq_rec_off(KS) + ((TC) & (kRqRecSlots - 1)) * 256))[RB]; \
+                blk__ = i8_blk(g__, scq, kqq);                                                        \
+            }                                                                                         \
+            screen_test_block<I8>(a.status, acc[RB], q__, rbase__, row_end, th, blk__, que, que_n);   \
+        }                                                                                             \
+    } while (0)
+#define RQ_MICRO(M, TT, ZERO, SB, SBN)                                                                \
+    do {                                                                                              \
+        RQ_PREFETCH((M) + kPF, SB, SBN);                                                              \
+        RQ_PIN();                                                                                     \
+        RQ_MM(M, TT, ZERO);                                                                           \
+        RQ_PIN();                                                                                     \
+    } while (0)
+
+    // ---- prologue: K-steps 0 .. NST-1 into the ring; K-step 0 landed and visible; fragments of micro-steps 0..2
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+        RQ_PIECE(0);
+        RQ_PIECE(1);
+        RQ_REC();
+        RQ_ADVANCE();
+    }
+    if constexpr ((ABL & 16) == 0) {
+        // this wave's pieces of K-step 0 (the oldest) have landed: at most the 2 (NST - 1) younger ones (+ records) are out
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NST - 1)) : "memory");
+    }
+    MI355_BARRIER();
+    int s0b = 0;  // ring byte offset of the tile's first K-step (compile-time 0 when a tile is the whole ring)
+    int tc = 0;   // tile counter of this workgroup (records slot)
+    RQ_PREFETCH(0, 0, 0);
+    RQ_PREFETCH(1, 0, 0);
+    RQ_PREFETCH(2, 0, 0);
+
+    const int row_end = (int)a.row_end;
+    int row0_cur = (a.ct0 + ctl) * kRqRows, row0_prev = row0_cur;  // rows < 2^31 (checked by the host)
+    bool have_prev = false;  // a finished tile's row half 1 is waiting for its tests
+    for (;;) {
+        if (que_n > kWaveQueueCap / 2) {  // wave-uniform, rare: this wave stalls on vector memory once
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wave_queue_flush(a, que, min(que_n, kWaveQueueCap));
+            que_n = 0;
+        }
+        const int tile_sb = (NST == KS) ? 0 : s0b;
+        const int next_tile_sb = (NST == KS) ? 0 : (s0b + KS * kRqStageBytes >= NST * kRqStageBytes ? 0 : s0b + KS * kRqStageBytes);
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            const bool first = t == 0, last = t + 1 == KS;
+            const int sb = tile_sb + t * kRqStageBytes;
+            const int sbn = last ? next_tile_sb : sb + kRqStageBytes;
+            const bool tp = first && have_prev;  // test the previous tile's row half 1 under this K-step's row half 0
+            RQ_MICRO(0, t, first, sb, sbn);
+            if (tp) RQ_TEST(2, row0_prev, tc - 1);
+            RQ_MICRO(1, t, false, sb, sbn);
+            RQ_MICRO(2, t, false, sb, sbn);
+            if (tp) RQ_TEST(3, row0_prev, tc - 1);
+            RQ_MICRO(3, t, false, sb, sbn);
+            RQ_MICRO(4, t, first, sb, sbn);
+            if (last) RQ_TEST(0, row0_cur, tc);
+            // ---- hand-over: every read of this K-step's stage has been issued (the last ones kPF micro-steps before its end)
+            if constexpr ((ABL & 48) == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NST - 2)) : "memory");  // own pieces of the next K-step landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and the last fragments of this one are in registers
+            if constexpr ((ABL & 8) == 0) MI355_BARRIER();
+            RQ_PIN();
+            RQ_MICRO(5, t, false, sb, sbn);
+            RQ_PIECE(0);
+            RQ_PIN();
+            RQ_MICRO(6, t, false, sb, sbn);
+            RQ_PIECE(1);
+            RQ_PIN();
+            if (last) RQ_TEST(1, row0_cur, tc);
+            RQ_MICRO(7, t, false, sb, sbn);
+            RQ_REC();
+            RQ_ADVANCE();
+            RQ_PIN();
+        }
+        row0_prev = row0_cur;
+        have_prev = true;
+        ++tc;
+        if constexpr (NST != KS) s0b = next_tile_sb;
+        if (ctl + cstep >= a.n_ctiles) break;
+        ctl += cstep;
+        row0_cur = (a.ct0 + ctl) * kRqRows;
+    }
+    // the last tile's row half 1
+    RQ_TEST(2, row0_prev, tc - 1);
+    RQ_TEST(3, row0_prev, tc - 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the dummy prefetches must land before the LDS is freed
+    wave_queue_flush(a, que, min(que_n, kWaveQueueCap));
+    if constexpr ((ABL & 4) != 0) {  // timing build without tests: the accumulators stay live
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(acc[i]));
+    }
+
+#undef RQ_PIN
+#undef RQ_PIECE
+#undef RQ_REC
+#undef RQ_ADVANCE
+#undef RQ_PREFETCH
+#undef RQ_MM
+#undef RQ_TEST
+#undef RQ_MICRO
+}
+
+}  // namespace mi355

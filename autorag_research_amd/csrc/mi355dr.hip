@@ -6,6 +6,11 @@
 #include "k_scan.h"
 #include "k_screen.h"
 #include "k_screen256c.h"
+#include "k_screen_rq.h"
+
+// K-step counts k_screen_rq is built for (int8 shadow rows of 128 ... 768 bytes)
+#define MI355_RQ_FORMS(X) X(1) X(2) X(3) X(4) X(5) X(6)
+inline bool screen_rq_has(int ksteps) { return ksteps >= 1 && ksteps <= 6; }
 #include "k_screen_stream.h"
 #include "k_select.h"
 
@@ -146,6 +151,10 @@ int ensure_qstate(mi355dr_index* idx) {
                                       kScreen256Lds));
     HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen256c<kScreen256cAbl, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kScreen256Lds));
+#define MI355_RQ_ATTR(KS)                                                                                              \
+    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen_rq<KS, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, rq_lds(KS)));
+    MI355_RQ_FORMS(MI355_RQ_ATTR)
+#undef MI355_RQ_ATTR
     HIPCHECK(idx, hipFuncSetAttribute((const void*)k_merge_topk, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kSortMax * 12));
     idx->qstate_ready = true;
@@ -303,7 +312,19 @@ int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t 
     sa.row0 = r0;
     sa.emit_all = emit_mode;
     const int64_t grid = round_up(sa.n_ctiles, 8) * sa.n_qtiles;
-    if (tile == kT2) {
+    if (tile == kT2 && i8 && idx->screen_rq && screen_rq_has(sa.ksteps)) {
+        // query operand resident in registers, 128-row tiles (k_screen_rq.h): int8 shadows of at most 768 bytes per row
+        sa.ct0 = (int)(r0 / kRqRows);
+        sa.n_ctiles = (int)(round_up(r_end, kRqRows) / kRqRows) - sa.ct0;
+        const unsigned g2 = screen_rq_grid(sa.n_ctiles, sa.n_qtiles);
+        idx->s_rq_launches++;
+        switch (sa.ksteps) {
+#define MI355_RQ_LAUNCH(KS) \
+    case KS: hipLaunchKernelGGL((k_screen_rq<KS, 0, true>), dim3(g2), dim3(512), rq_lds(KS), s, sa); break;
+            MI355_RQ_FORMS(MI355_RQ_LAUNCH)
+#undef MI355_RQ_LAUNCH
+        }
+    } else if (tile == kT2) {
         const unsigned g2 = screen256_grid(sa.n_ctiles, sa.n_qtiles);  // persistent: <= one workgroup per CU
         if (i8) hipLaunchKernelGGL((k_screen256c<kScreen256cAbl, true>), dim3(g2), dim3(512), kScreen256Lds, s, sa);
         else hipLaunchKernelGGL((k_screen256c<kScreen256cAbl, false>), dim3(g2), dim3(512), kScreen256Lds, s, sa);
@@ -1125,6 +1146,8 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
         idx->chunk_growth_set = 1;
     } else if (k == "screen_stream") {
         idx->screen_stream = value != 0;
+    } else if (k == "screen_rq") {
+        idx->screen_rq = value != 0;
     } else if (k == "small_chunk_rows") {
         if (value < 0) return fail(idx, MI355DR_E_INVALID, "small_chunk_rows must be >= 0");
         idx->small_chunk_rows = value;
@@ -1162,6 +1185,7 @@ int mi355dr_get_stat(mi355dr_index* idx, const char* key, int64_t* out) {
     else if (k == "screen_ns") *out = idx->s_screen_ns;
     else if (k == "screen_rows") *out = idx->s_screen_rows;
     else if (k == "screen256_launches") *out = idx->s_big_launches;
+    else if (k == "screen_rq_launches") *out = idx->s_rq_launches;
     else if (k == "screen256_ns") *out = idx->s_big_ns;
     else if (k == "screen256_rows") *out = idx->s_big_rows;
     else if (k == "fallback_queries") *out = idx->s_fallback_queries;
@@ -1195,7 +1219,7 @@ int mi355dr_reset_stats(mi355dr_index* idx) {
     if (!idx) return fail(nullptr, MI355DR_E_INVALID, "null index");
     std::lock_guard<std::mutex> g(idx->mu);
     idx->s_screen_launches = idx->s_screen_ns = idx->s_screen_rows = idx->s_fallback_queries = idx->s_chunks =
-        idx->s_passes = idx->s_big_launches = idx->s_big_ns = idx->s_big_rows = idx->s_starters = 0;
+        idx->s_passes = idx->s_rq_launches = idx->s_big_launches = idx->s_big_ns = idx->s_big_rows = idx->s_starters = 0;
     idx->s_ms_screened = idx->s_ms_candidates = idx->s_ms_fallbacks = idx->s_retry_queries = 0;
     idx->s_ms_screen_ns = idx->s_ms_screen_launches = idx->s_ms_exact_ns = idx->s_ms_exact_launches = idx->s_ms_screen_cols = idx->s_ms_packed_launches = idx->s_ms_pack_ns = 0;
     if (idx->stat_dev) {

@@ -67,6 +67,8 @@ def parse_args():
     ap.add_argument("--chunk0", type=int, default=0, help="override the first (emit-all) chunk size")
     ap.add_argument("--growth", type=int, default=0, help="override the chunk growth factor")
     ap.add_argument("--screen", choices=["auto", "bf16", "i8"], default="auto", help="screen element type")
+    ap.add_argument("--screen-rq", type=int, default=None, help="0/1: large-block int8 screen with the query operand in registers "
+                    "(k_screen_rq, default) / through the LDS (k_screen256c) (A/B)")
     ap.add_argument("--round-a", type=int, default=None, help="k_prune: rows re-scored before the cut is known (tuning)")
     ap.add_argument("--prefilter16", type=int, default=None, help="0/1: bf16 second screen inside the prune (default: library default)")
     ap.add_argument("--metric", choices=["cosine", "ip"], default="cosine", help="cosine (headline) or inner product")
@@ -153,6 +155,8 @@ def main() -> None:
     if args.growth:
         idx.set_option("chunk_growth", args.growth)
     idx.set_option("screen_dtype", args.screen)
+    if args.screen_rq is not None:
+        idx.set_option("screen_rq", args.screen_rq)
     if args.prefilter16 is not None:
         idx.set_option("prefilter16", args.prefilter16)
     if args.round_a is not None:
@@ -318,6 +322,8 @@ def main() -> None:
         screen_rows = idx.stat("screen256_rows")
     else:
         launches, screen_ns, screen_rows = all_launches, all_screen_ns, idx.stat("screen_rows")
+    # which large-block form ran: k_screen_rq (int8 shadow <= 768 B per row: query operand in registers) or k_screen256c
+    dominant = ("k_screen_rq" if idx.stat("screen_rq_launches") > 0 else "k_screen256c") if B > 128 else "k_screen"
     fallback = idx.stat("fallback_queries")
     cand = idx.stat("candidates")
     resc = idx.stat("rescored")
@@ -346,8 +352,7 @@ def main() -> None:
     ubench = (MFMA_I8_UBENCH_TOPS["32x32x32"] if i8 else MFMA_BF16_UBENCH_TF)
     roof = {
         "bound": "mfma",
-        "kernel": ("k_screen256c" if B > 128
-                   else "k_screen") + ("<int8>" if i8 else "<bf16>"),
+        "kernel": dominant + ("<int8>" if i8 else "<bf16>"),
         "op": "int8 multiply-add ops (v_mfma_i32_32x32x32_i8)" if i8 else "bf16 flops (v_mfma_f32_32x32x16_bf16)",
         "achieved": round(alg_flops / screen_s / 1e12, 2) if screen_s > 0 else None,
         "peak": peak,
@@ -677,14 +682,17 @@ def main() -> None:
         # (every index of this process is closed by now: the sub-run builds its own copy of the corpus)
         sub = ["--rows", n_total, "--dim", d, "--block", B, "--k", k, "--metric", args.metric, "--data", args.data,
                "--screen", args.screen]
-        per_launch, n_prof, note = pmc_fetch_subrun(sub, "k_screen256c")
+        dom = result["roofline"]["kernel"].split("<")[0]
+        if args.screen_rq is not None:
+            sub += ["--screen-rq", args.screen_rq]
+        per_launch, n_prof, note = pmc_fetch_subrun(sub, dom)
         rl = result["roofline"]
         if per_launch is not None:
             rl["traffic_replayed"] = rl.get("traffic")
             rl["traffic"] = round(per_launch)
             rl["traffic_source"] = (
                 f"MEASURED in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE sub-run of this workload (3 steps, {n_prof} "
-                "k_screen256c launches; KiB x 1024 x 2: the gfx950 correction of MI355X_MICROARCH.md), mean per launch -- the "
+                f"{dom} launches; KiB x 1024 x 2: the gfx950 correction of MI355X_MICROARCH.md), mean per launch -- the "
                 "launches of a pass differ in size exactly as in the timed region")
         else:
             rl["traffic_source"] = (rl.get("traffic_source") or "") + f" [live PMC sub-run: {note}]"

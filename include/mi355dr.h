@@ -202,7 +202,9 @@ int mi355dr_search_sharded_device(mi355dr_index* idx, const float* queries_dev, 
  *          screen of the surviving candidates before the exact re-score; default 0, same results), "maxsim_screen" (1: bf16 MFMA screen
  *          over every doc + exact re-score of the candidates [default], 0: exact kernel over every doc; same results),
  *          "screen_stream" (1 [default]: query blocks of at most 64 are screened by the streaming kernel -- resident query
- *          block, ring of row stages --, 0: by the tile kernel; same results).
+ *          block, ring of row stages --, 0: by the tile kernel; same results), "screen_rq" (1 [default]: query blocks of more
+ *          than 128 over an int8 shadow of at most 768 bytes per row are screened by k_screen_rq -- query operand resident in
+ *          registers, rows alone through the LDS --, 0: by k_screen256c; same results).
  *          Round 3, all with identical results (A/B switches of the pass schedule): "starter" (1 [default]: sampled threshold
  *          estimator instead of the three smallest chunks, k <= 32), "defer_round_b" (1 [default]: prunes before the last one
  *          carry their survivors over instead of re-scoring them), "prune_companion" (1 [default]: general-form prune launch

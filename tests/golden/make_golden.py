@@ -33,6 +33,15 @@ Fixtures written next to this file:
   pgtext_golden.json       VectorArray.process_bind_param / process_result_value (orm/types.py:210-277), _vec_to_pg_literal /
                            _vecs_to_pg_array (orm/repository/base.py:54-76): the text forms of VECTOR(d) / VECTOR(d)[].
   rerank_golden.npz        ColBERTReranker._maxsim_score (rerankers/colbert.py:63-84) on seeded padded token tensors.
+  embeddings_golden.npz    every public method of the reference's ColPaliEmbeddings (embeddings/colpali.py:88-245) and
+                           BiPaliEmbeddings (embeddings/bipali.py:95-255) over the stand-in `colpali_engine` module of
+                           tests/helpers_hf.py (a seeded tiny ColPaliForRetrieval), float32 on the CPU.
+  evaluation_golden.json   build_retrieval_gt_from_relations and RetrievalEvaluationService._get_execution_results
+                           (orm/service/retrieval_evaluation.py:23-78, 161-217) over a fake Unit of Work: ranked-list order,
+                           chunk / image-chunk ties, NULL scores, AND / OR ground truth.
+  ingest_golden.json       BaseIngestionService._embed_entities (orm/service/base_ingestion.py:326-495) over a fake Unit of
+                           Work: NULL-content image chunks skipped, failed items remembered and the rest embedded, single and
+                           multi-vector columns.
   gqr_golden.npz / .json   Guided Query Refinement: outputs of GQRHybridRetrievalPipeline._optimize_query_embedding /
                            _optimize_query_multi_embedding / _optimize_in_score_space (pipelines/retrieval/
                            gqr_hybrid.py:306-362) on seeded pools, and of _retrieve_by_id (:472-489) over the fake
@@ -773,6 +782,276 @@ def make_pgtext() -> dict:
             "preparsed": va.process_result_value([[1, 2], np.array([3.5, 4.5])], None)}
 
 
+# --------------------------------------------------------------------------------------
+# 11. ColPali / BiPali embedding wrappers (embeddings/colpali.py:88-245, embeddings/bipali.py:53-255)
+# --------------------------------------------------------------------------------------
+
+
+def make_embeddings() -> dict[str, np.ndarray]:
+    """The REFERENCE's ColPaliEmbeddings / BiPaliEmbeddings run over the stand-in `colpali_engine` module of
+    tests/helpers_hf.py (transformers' own ColPaliForRetrieval from a small seeded config behind colpali_engine's call shape;
+    the dependency itself is not installed) in float32 on the CPU: every public embedding method, frozen as arrays.
+    Ragged outputs are stored flat with offsets.  BiPaliEmbeddings' constructor forwards its keyword arguments to
+    `langchain_core.embeddings.Embeddings.__init__` (bipali.py:91-93) -- a plain ABC in langchain-core, stubbed here --, so the
+    object is allocated with __new__ and `_load_model()` (bipali.py:95-111) is called on it: the loading and embedding code under
+    test is the reference's."""
+    sys.path.insert(0, str(REPO / "tests"))
+    import helpers_hf as hf
+    import torch
+
+    from autorag_research.embeddings.bipali import BiPaliEmbeddings
+    from autorag_research.embeddings.colpali import ColPaliEmbeddings
+
+    torch.set_num_threads(1)
+    seen: dict = {}
+    hf.install_colpali_engine(seen=seen)
+    out: dict[str, np.ndarray] = {}
+
+    def ragged(name: str, docs: list) -> None:
+        lens = [len(d) for d in docs]
+        out[name] = np.asarray([v for d in docs for v in d], dtype=np.float32).reshape(sum(lens), -1)
+        out[name + "_off"] = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+
+    texts = hf.EMBED_TEXTS
+    imgs = hf.images(3)
+    pngs = [hf.png_bytes(a) for a in imgs]
+    for i, a in enumerate(imgs):
+        out[f"image{i}"] = a
+    col = ColPaliEmbeddings(model_name="tiny/colpali", model_type="pali", device="cpu", torch_dtype="float32")
+    assert seen["name"] == "tiny/colpali" and seen["dtype"] == torch.float32 and seen["trust_remote_code"] is True
+    out["col_embed_batch_size"] = np.asarray(col.embed_batch_size)
+    ragged("col_embed_text", [col.embed_text(t) for t in texts[:4]])
+    ragged("col_embed_query", [col.embed_query(t) for t in texts[:4]])
+    ragged("col_aembed_query", [asyncio.run(col.aembed_query(texts[0]))])
+    ragged("col_embed_documents", col.embed_documents(texts))            # ONE padded batch of 12 (colpali.py:189-216)
+    ragged("col_embed_documents_batch", col.embed_documents_batch(texts))  # batches of embed_batch_size = 10 (base.py:77-83)
+    ragged("col_embed_image", [col.embed_image(pngs[0])])
+    ragged("col_embed_images", col.embed_images(pngs))
+    assert col.embed_documents([]) == [] and col.embed_images([]) == []
+    bi = BiPaliEmbeddings.__new__(BiPaliEmbeddings)
+    bi.model_name, bi.model_type, bi.device, bi.torch_dtype, bi.embed_batch_size = "tiny/bipali", "pali", "cpu", "float32", 5
+    bi._load_model()
+    out["bi_embed_query"] = np.asarray([bi.embed_query(t) for t in texts[:4]], dtype=np.float32)
+    out["bi_embed_documents"] = np.asarray(bi.embed_documents(texts), dtype=np.float32)   # batches of 5 (bipali.py:236-255)
+    out["bi_embed_image"] = np.asarray(bi.embed_image(pngs[1]), dtype=np.float32)
+    out["bi_embed_images"] = np.asarray(bi.embed_images(pngs), dtype=np.float32)
+    out["bi_aembed_image"] = np.asarray(asyncio.run(bi.aembed_image(pngs[1])), dtype=np.float32)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# 12. evaluation ordering + ground truth (orm/service/retrieval_evaluation.py:23-78, 161-217)
+# --------------------------------------------------------------------------------------
+
+
+def make_evaluation() -> dict:
+    """`build_retrieval_gt_from_relations` on relation rows (group_index = AND, group_order = OR order, both id kinds, NULL
+    scores, rows with neither id, an id listed in two groups), and `RetrievalEvaluationService._get_execution_results` over a
+    fake Unit of Work whose result repositories answer like the reference's (`ORDER BY rel_score DESC`,
+    orm/repository/chunk_retrieved_result.py:34-38): chunk and image-chunk rows of one query merged by the stable Python
+    re-sort (ties: chunk rows first), NULL rel_score as 0.0, a query with no rows, a query with no ground truth."""
+    from autorag_research.orm.service.retrieval_evaluation import (
+        RetrievalEvaluationService,
+        build_retrieval_gt_from_relations,
+    )
+
+    rel_cases = [
+        [dict(group_index=0, group_order=0, chunk_id=1, image_chunk_id=None, score=2),
+         dict(group_index=0, group_order=1, chunk_id=None, image_chunk_id=2, score=1),
+         dict(group_index=1, group_order=0, chunk_id=3, image_chunk_id=None, score=None)],
+        [dict(group_index=2, group_order=1, chunk_id="b", image_chunk_id=None, score=0),
+         dict(group_index=2, group_order=0, chunk_id="a", image_chunk_id=None, score=3),
+         dict(group_index=0, group_order=5, chunk_id=None, image_chunk_id="p9", score=None),
+         dict(group_index=0, group_order=2, chunk_id="a", image_chunk_id=None, score=1),   # same id again: later score wins
+         dict(group_index=1, group_order=0, chunk_id=None, image_chunk_id=None, score=2)],  # neither id: dropped
+        [],
+        [dict(group_index=0, group_order=0, chunk_id=7, image_chunk_id=8, score=None)],     # both ids: the chunk id is taken
+        [dict(group_index=5, group_order=1, chunk_id=10, image_chunk_id=None, score=1),
+         dict(group_index=5, group_order=1, chunk_id=11, image_chunk_id=None, score=1),     # equal group_order: input order kept
+         dict(group_index=5, group_order=0, chunk_id=12, image_chunk_id=None, score=2)],
+    ]
+    out: dict = {"relations": []}
+    for rows in rel_cases:
+        gt, rel = build_retrieval_gt_from_relations([_Obj(**r) for r in rows])
+        out["relations"].append({"rows": rows, "retrieval_gt": gt, "relevance_scores": rel})
+
+    pid = 3
+    chunk_rows = [  # (query_id, chunk_id, rel_score) in INSERTION order
+        ("q1", 11, 0.9), ("q1", 12, 0.5), ("q1", 13, 0.7), ("q1", 14, 0.5), ("q1", 15, None),
+        ("q2", 21, 0.25), ("q2", 22, 0.75),
+        ("q4", 41, -0.5), ("q4", 42, 0.0), ("q4", 43, None),
+        ("q9", 91, 1.0),                        # a query nobody asks for
+    ]
+    image_rows = [("q1", "img-a", 0.7), ("q1", "img-b", 0.95), ("q1", "img-c", 0.5),
+                  ("q3", "img-d", 0.1), ("q3", "img-e", 0.1), ("q4", "img-f", 0.0)]
+    other_pipeline_rows = [("q1", 99, 5.0)]
+    relations = {"q1": rel_cases[0], "q2": rel_cases[4], "q3": rel_cases[1], "q4": [], "q5": rel_cases[3]}
+
+    class _Results:
+        def __init__(self, rows, key):
+            self.rows, self.key = rows, key
+
+        def get_by_query_and_pipeline(self, query_ids, pipeline_id):
+            qs = set(query_ids)
+            sel = [r for r in self.rows if r[0] == pipeline_id and r[1] in qs]
+            # ORDER BY rel_score DESC (PostgreSQL: NULLs first on DESC); ties in insertion order
+            sel.sort(key=lambda r: (r[3] is None, r[3] if r[3] is not None else 0.0), reverse=True)
+            return [_Obj(query_id=r[1], pipeline_id=r[0], rel_score=r[3], **{self.key: r[2]}) for r in sel]
+
+    class _Relations:
+        def get_by_query_id(self, qid):
+            return [_Obj(**r) for r in relations.get(qid, [])]
+
+    class _Uow:
+        chunk_results = _Results([(pid, q, c, s) for q, c, s in chunk_rows] + [(pid + 1, q, c, s) for q, c, s in other_pipeline_rows],
+                                 "chunk_id")
+        image_chunk_results = _Results([(pid, q, c, s) for q, c, s in image_rows], "image_chunk_id")
+        retrieval_relations = _Relations()
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    svc = RetrievalEvaluationService.__new__(RetrievalEvaluationService)
+    svc._create_uow = lambda: _Uow()
+    qids = ["q1", "q2", "q3", "q4", "q5"]
+    res = svc._get_execution_results(pid, qids)
+    out["execution"] = {"pipeline_id": pid, "query_ids": qids, "chunk_rows": [list(r) for r in chunk_rows],
+                        "image_chunk_rows": [list(r) for r in image_rows],
+                        "other_pipeline_rows": [list(r) for r in other_pipeline_rows], "relations": relations,
+                        "results": {q: res[q] for q in qids}}
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# 13. ingestion: BaseIngestionService._embed_entities (orm/service/base_ingestion.py:326-495)
+# --------------------------------------------------------------------------------------
+
+
+def ingest_vector(data, dim: int = 6) -> list[float]:
+    """Deterministic stand-in embedding of a text / image payload (shared with the test through the fixture: the expected
+    vectors are stored, this function only has to be a function)."""
+    b = data if isinstance(data, bytes) else str(data).encode()
+    h = np.frombuffer(__import__("hashlib").sha256(b).digest()[: 4 * dim], dtype=np.uint32).astype(np.float64)
+    return [float(x) for x in (h / 2.0**32 - 0.5)]
+
+
+def make_ingest() -> dict:
+    """The reference's `_embed_entities` driven over a fake Unit of Work (repositories answering `count_without_*`,
+    `get_without_*(limit, excluded_ids)`, `get_by_id`, `set_multi_vector_embeddings_batch` like orm/repository/base.py:459-485,
+    587-689): rows that already have embeddings, an image chunk with NULL content (skipped and counted, :44,400-406), items
+    whose embedding function raises or returns None (remembered for the run, not retried, the others still embedded,
+    :59-71,461-495), single- and multi-vector columns, batches smaller than the table.  Frozen: the return value, every row's
+    final embedding, which payloads the embedding function was called with and in which order per batch."""
+    import logging
+
+    from autorag_research.orm.service.base_ingestion import BaseIngestionService
+
+    logging.getLogger("AutoRAG-Research").setLevel(logging.CRITICAL)
+    out: dict = {"cases": []}
+
+    def run(entity, emb_type, rows, batch_size, bad_raise=(), bad_none=()):
+        table = [_Obj(id=r["id"], contents=r["contents"], embedding=r.get("embedding"), embeddings=r.get("embeddings")) for r in rows]
+        col = "embedding" if emb_type == "single" else "embeddings"
+        calls: list = []
+        fetches: list = []
+
+        class _Repo:
+            session = object()
+
+            def _missing(self):
+                return [e for e in table if getattr(e, col) is None]
+
+            def count_without_embeddings(self):
+                return len(self._missing())
+
+            count_without_multi_embeddings = count_without_embeddings
+
+            def get_without_embeddings(self, limit=None, offset=None, excluded_ids=None):
+                rows_ = [e for e in self._missing() if not excluded_ids or e.id not in excluded_ids]
+                fetches.append([e.id for e in rows_[: limit]])
+                return rows_[: limit]
+
+            get_without_multi_embeddings = get_without_embeddings
+
+            def get_by_id(self, pk):
+                return next((e for e in table if e.id == pk), None)
+
+            def set_multi_vector_embeddings_batch(self, entity_ids, embeddings_list, vector_column="embeddings", id_column="id"):
+                n = 0
+                for pk, emb in zip(entity_ids, embeddings_list, strict=True):
+                    e = self.get_by_id(pk)
+                    if e is not None:
+                        setattr(e, vector_column, emb)
+                        n += 1
+                return n
+
+        repo = _Repo()
+
+        class _Uow:
+            session = object()
+            queries = chunks = image_chunks = repo
+
+            def __enter__(self):
+                return self
+
+            def __exit__(self, *a):
+                return False
+
+            def commit(self):
+                pass
+
+        async def embed(data):
+            key = data.decode() if isinstance(data, bytes) else data
+            calls.append(key)
+            if key in bad_raise:
+                raise RuntimeError(f"cannot embed {key}")
+            if key in bad_none:
+                return None
+            v = ingest_vector(data)
+            return v if emb_type == "single" else [v, [x * 0.5 for x in v]]
+
+        class _Svc(BaseIngestionService):   # the two abstract hooks of BaseService; nothing of the code under test
+            def _create_uow(self):
+                return _Uow()
+
+            def _get_schema_classes(self):
+                return {}
+
+        svc = _Svc.__new__(_Svc)
+        n = svc._embed_entities(entity, emb_type, embed, batch_size=batch_size, max_concurrency=3, bm25_tokenizer=None)
+        out["cases"].append({
+            "entity_type": entity, "embedding_type": emb_type, "batch_size": batch_size,
+            "rows": [{k: (v.decode() if isinstance(v, bytes) else v) for k, v in r.items()} | {"bytes": isinstance(r["contents"], bytes)}
+                     for r in rows],
+            "bad_raise": list(bad_raise), "bad_none": list(bad_none), "returned": n, "embed_calls": sorted(calls),
+            "n_embed_calls": len(calls), "fetches": fetches,
+            "final": [{"id": e.id, col: getattr(e, col)} for e in table]})
+
+    pre = ingest_vector("already there")
+    run("chunk", "single",
+        [{"id": 1, "contents": "alpha"}, {"id": 2, "contents": "beta", "embedding": pre}, {"id": 3, "contents": "RAISE"},
+         {"id": 4, "contents": "gamma"}, {"id": 5, "contents": "NONE"}, {"id": 6, "contents": "delta"}, {"id": 7, "contents": "epsilon"}],
+        batch_size=3, bad_raise=("RAISE",), bad_none=("NONE",))
+    run("query", "multi_vector",
+        [{"id": "q1", "contents": "what is late interaction"}, {"id": "q2", "contents": "RAISE"},
+         {"id": "q3", "contents": "second query", "embeddings": [pre]}, {"id": "q4", "contents": "third"}],
+        batch_size=2, bad_raise=("RAISE",))
+    run("image_chunk", "single",
+        [{"id": "i1", "contents": b"png-bytes-1"}, {"id": "i2", "contents": None}, {"id": "i3", "contents": b"png-bytes-3"},
+         {"id": "i4", "contents": None}, {"id": "i5", "contents": b"NONE"}, {"id": "i6", "contents": b"png-bytes-6"}],
+        batch_size=2, bad_none=("NONE",))
+    run("image_chunk", "multi_vector",
+        [{"id": 10, "contents": None}, {"id": 11, "contents": None}, {"id": 12, "contents": b"page-12"}],
+        batch_size=2)
+    run("chunk", "single", [{"id": 1, "contents": "RAISE"}, {"id": 2, "contents": "NONE"}], batch_size=8,
+        bad_raise=("RAISE",), bad_none=("NONE",))                      # nothing can be embedded: the loop still ends
+    run("chunk", "multi_vector", [{"id": 1, "contents": "x", "embeddings": [pre]}], batch_size=4)   # nothing to do: returns 0
+    return out
+
+
 def main() -> None:
     (HERE / "metrics_golden.json").write_text(json.dumps(make_metrics(), indent=1))
     np.savez_compressed(HERE / "scores_golden.npz", **make_scores())
@@ -784,6 +1063,9 @@ def main() -> None:
     (HERE / "executor_golden.json").write_text(json.dumps(make_executor(), indent=1))
     np.savez_compressed(HERE / "rerank_golden.npz", **make_rerank())
     (HERE / "pgtext_golden.json").write_text(json.dumps(make_pgtext(), indent=1))
+    np.savez_compressed(HERE / "embeddings_golden.npz", **make_embeddings())
+    (HERE / "evaluation_golden.json").write_text(json.dumps(make_evaluation(), indent=1))
+    (HERE / "ingest_golden.json").write_text(json.dumps(make_ingest(), indent=1))
     print("wrote", sorted(p.name for p in HERE.iterdir()))
 
 

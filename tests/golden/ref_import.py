@@ -37,6 +37,10 @@ def import_reference() -> None:
         import torch  # noqa: F401
     except ImportError:
         pass
+    try:  # ... and transformers probes optional packages (nltk, evaluate, ...) by name when a model class is first imported
+        from transformers import AutoModel, BertModel, ColPaliForRetrieval  # noqa: F401
+    except Exception:  # noqa: BLE001 - only the embedding fixtures need it
+        pass
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
     for n in STUBBED:

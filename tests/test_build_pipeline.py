@@ -102,6 +102,40 @@ def test_screen256c_structure(screen_asm, i8):
     assert any(o.startswith("s_swappc_b64") for o in ops)
 
 
+@pytest.mark.parametrize("ks", [1, 2, 3, 4, 5, 6])
+def test_screen_rq_structure(screen_asm, ks):
+    """k_screen_rq (round 5; the form the library launches for int8 shadows of at most 768 B per row): the query fragments are
+    registers -- loaded by 4 KS global loads BEFORE the loop and waited for there (left to the waitcnt pass their waits land in
+    front of the first use inside the tile loop and drain the LDS-DMA ring on every tile) --, every LDS read inside the loop is
+    a ROW fragment (one ds_read_b128 per MFMA), two 1-KiB row pieces per K-step and wave, one barrier per K-step with the
+    counted hand-over wait vmcnt(2 (stages - 2)) and no full vmcnt(0) between the first and the last MFMA outside the rare
+    queue flush, the append path out of line, no scratch."""
+    names = [n for n in screen_asm if f"k_screen_rqILi{ks}ELi0ELb1E" in n]
+    assert len(names) == 1, sorted(screen_asm)
+    ops = screen_asm[names[0]]
+    stages = {4: 8, 5: 5}.get(ks, 6)
+    assert not any(o.startswith("scratch_") for o in ops), "register spill in the screen kernel"
+    mf = [i for i, o in enumerate(ops) if o.startswith("v_mfma")]
+    assert len(mf) == 16 * ks and all(ops[i].startswith("v_mfma_i32_32x32x32_i8") for i in mf)
+    assert sum(ops[i].rstrip().endswith(", 0") for i in mf) == 4   # a tile's four blocks start from C = 0 (inline constant)
+    pre = ops[:mf[0]]
+    assert sum(o.startswith("global_load_dwordx4") for o in pre) == 4 * ks
+    assert sum(o.startswith("global_load_lds_dwordx4") for o in pre) == 2 * stages  # the prologue fills the ring
+    loop = ops[mf[0]:mf[-1] + 1]
+    assert not any(o.startswith(("global_load_dwordx4", "s_load")) for o in loop)
+    assert sum(o.startswith("ds_read_b128") for o in loop) >= 16 * ks - 8
+    assert sum(o.startswith("ds_read_b128") for o in ops) == 16 * ks + 6   # + the three micro-steps read ahead of the loop
+    assert sum(o.startswith("s_barrier") for o in loop) == ks
+    assert sum(o.startswith("global_load_lds_dwordx4") for o in loop) == 2 * ks
+    hand = [o for o in loop if o.startswith("s_waitcnt") and f"vmcnt({2 * (stages - 2)})" in o]
+    assert len(hand) == ks, [o for o in loop if "vmcnt" in o]
+    # full drains inside the loop: only the flush of a half-full queue (one site, wave-uniform branch at a tile's start)
+    assert sum(_is_vm0(o) for o in loop) <= 2, [o for o in loop if "vmcnt" in o]
+    counted = [o for o in loop if o.startswith("s_waitcnt") and "lgkmcnt(" in o and "lgkmcnt(0)" not in o and "vmcnt" not in o]
+    assert len(counted) >= 9 * ks, counted
+    assert any(o.startswith("s_swappc_b64") for o in ops)
+
+
 def _whole_kernel(asm: str, name: str) -> tuple[list[str], str]:
     """(instructions, .amdhsa descriptor text) of one kernel."""
     a = asm.index(f"\n{name}:")

@@ -197,6 +197,31 @@ def test_persistent_screen_shapes(pkg, oracle, screen, n, d, B, k):
         assert idx.stat("fallback_queries") == 0
 
 
+@pytest.mark.parametrize("n,d,B,k", [(70_000, 768, 1024, 10), (40_000, 384, 300, 10), (33_000, 128, 257, 7), (26_000, 200, 513, 3),
+                                      (30_000, 500, 700, 10), (90_000, 640, 129, 20), (9_100, 768, 600, 100), (30_000, 896, 400, 10)])
+def test_register_resident_query_screen_equals_tile_screen(pkg, oracle, n, d, B, k):
+    """Query blocks above 128 over an int8 shadow of at most 768 B per row go through k_screen_rq (query operand resident in
+    registers, 128-row tiles); option screen_rq = 0 keeps k_screen256c: same results either way, equal to the oracle's.
+    Shapes: every K-step count 1..6 (d = 128, 200, 384, 500, 640, 768), 1-4 query tiles, ragged last row tile and last query
+    tile, rows of very different norms, k = 100; d = 896 (7 K-steps) has no register-resident form and must not take it."""
+    rng = np.random.default_rng(n * 3 + d + B)
+    C = rng.standard_normal((n, d)).astype(np.float32)
+    C *= rng.uniform(0.1, 5.0, size=(n, 1)).astype(np.float32)
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    res = []
+    for rq in (1, 0):
+        with pkg.Mi355Index(d) as idx:
+            idx.set_option("screen_dtype", "i8")
+            idx.set_option("path", "screen")
+            idx.set_option("screen_rq", rq)
+            idx.add(C)
+            idx.reset_stats()
+            res.append(_check(idx, oracle, C, Q, k))
+            assert idx.stat("fallback_queries") == 0
+            assert (idx.stat("screen_rq_launches") > 0) == (rq == 1 and d <= 768)
+    assert np.array_equal(res[0][1], res[1][1])
+
+
 @pytest.mark.parametrize("screen", SCREENS)
 @pytest.mark.parametrize("n,d,B,k", [(30000, 768, 1, 10), (20000, 768, 33, 10), (9000, 100, 64, 5), (50000, 384, 17, 20),
                                       (3000, 1536, 32, 10), (2100, 2048, 5, 10)])

@@ -69,6 +69,20 @@ __global__ __launch_bounds__(512, 2) void k_stream(const v8i* __restrict__ ops, 
                 if constexpr (FMT == 100) {
                     const v4i aa = {a[s][0], a[s][1], a[s][2], a[s][3]}, bb = {b[(s + i) % kSets][0], b[(s + i) % kSets][1], b[(s + i) % kSets][2], b[(s + i) % kSets][3]};
                     acc[i] = __builtin_bit_cast(v16f, __builtin_amdgcn_mfma_i32_32x32x32_i8(aa, bb, __builtin_bit_cast(v16i, acc[i]), 0, 0, 0));
+                } else if constexpr (FMT == 102) {  // i8, NO operand shared by consecutive instructions (100 keeps A for four)
+                    const int sa = (s + i) % kSets, sb = (s + 3 * i + 1) % kSets;
+                    const v4i aa = {a[sa][0], a[sa][1], a[sa][2], a[sa][3]}, bb = {b[sb][0], b[sb][1], b[sb][2], b[sb][3]};
+                    acc[i] = __builtin_bit_cast(v16f, __builtin_amdgcn_mfma_i32_32x32x32_i8(aa, bb, __builtin_bit_cast(v16i, acc[i]), 0, 0, 0));
+                } else if constexpr (FMT == 103) {  // i8, BOTH operands kept for four consecutive instructions
+                    const v4i aa = {a[s][0], a[s][1], a[s][2], a[s][3]}, bb = {b[s][0], b[s][1], b[s][2], b[s][3]};
+                    acc[i] = __builtin_bit_cast(v16f, __builtin_amdgcn_mfma_i32_32x32x32_i8(aa, bb, __builtin_bit_cast(v16i, acc[i]), 0, 0, 0));
+                } else if constexpr (FMT == 104) {  // i8 as v_mfma_i32_16x16x64_i8 (same operand bytes, half the multiply-adds, 4 accumulator registers)
+                    const v4i aa = {a[s][0], a[s][1], a[s][2], a[s][3]}, bb = {b[(s + i) % kSets][0], b[(s + i) % kSets][1], b[(s + i) % kSets][2], b[(s + i) % kSets][3]};
+                    typedef int v4acc __attribute__((ext_vector_type(4)));
+                    v4acc c4 = {__builtin_bit_cast(int, acc[i][0]), __builtin_bit_cast(int, acc[i][1]), __builtin_bit_cast(int, acc[i][2]), __builtin_bit_cast(int, acc[i][3])};
+                    c4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(aa, bb, c4, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][r] = __builtin_bit_cast(float, c4[r]);
                 } else if constexpr (FMT == 101) {
                     const v4i aa = {a[s][0], a[s][1], a[s][2], a[s][3]}, bb = {b[(s + i) % kSets][0], b[(s + i) % kSets][1], b[(s + i) % kSets][2], b[(s + i) % kSets][3]};
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aa), __builtin_bit_cast(bf16x8, bb), acc[i], 0, 0, 0);
@@ -77,7 +91,7 @@ __global__ __launch_bounds__(512, 2) void k_stream(const v8i* __restrict__ ops, 
                 }
             }
         }
-        if constexpr (FMT == 100) {  // keep the int32 accumulators from saturating into one stuck pattern
+        if constexpr (FMT == 100 || FMT == 102 || FMT == 103 || FMT == 104) {  // keep the int32 accumulators from saturating into one stuck pattern
             if ((it & 255) == 255)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -145,7 +159,8 @@ static int run_stream(const std::string& fmt, const std::string& data, double se
                                    2, 2.25f, 2.5f, 2.75f, 3, 3.25f, 3.5f, 3.75f, 4, 4.5f, 5, 5.5f, 6, 6.5f, 7, 7.5f};
     static const float e2m1[8] = {0, 0.5f, 1, 1.5f, 2, 3, 4, 6};
     int elems = 32, bits = 8;  // elements per lane and bits per element of one operand fragment
-    if (fmt == "i8") elems = 16, bits = 8;
+    const bool is_i8 = fmt.rfind("i8", 0) == 0;  // i8, i8_nos (no operand shared), i8_ab (both kept), i8_16 (16x16x64)
+    if (is_i8) elems = 16, bits = 8;
     else if (fmt == "bf16") elems = 8, bits = 16;
     else if (fmt == "fp6") bits = 6;
     else if (fmt == "fp4") bits = 4;
@@ -162,7 +177,7 @@ static int run_stream(const std::string& fmt, const std::string& data, double se
                 const size_t base = (f * 64 + lane) * 8;
                 for (int e = 0; e < elems; ++e) {
                     uint32_t code;
-                    if (fmt == "i8") {
+                    if (is_i8) {
                         // data modes beyond gauss / zero (what the operand bit patterns cost at the power cap): "abs" every operand
                         // |x|; "absA" the A side only (even fragments); "offA" the A side as 7-bit values + 64 (all in 1..127: what
                         // an offset-encoded corpus shadow would hold), "off" both sides
@@ -196,12 +211,15 @@ static int run_stream(const std::string& fmt, const std::string& data, double se
     CK(hipEventCreate(&e1));
     auto launch = [&](int iters) {
         if (fmt == "i8") hipLaunchKernelGGL(k_stream<100>, dim3(grid), dim3(block), 0, 0, ops, out, iters);
+        else if (fmt == "i8_nos") hipLaunchKernelGGL(k_stream<102>, dim3(grid), dim3(block), 0, 0, ops, out, iters);
+        else if (fmt == "i8_ab") hipLaunchKernelGGL(k_stream<103>, dim3(grid), dim3(block), 0, 0, ops, out, iters);
+        else if (fmt == "i8_16") hipLaunchKernelGGL(k_stream<104>, dim3(grid), dim3(block), 0, 0, ops, out, iters);
         else if (fmt == "bf16") hipLaunchKernelGGL(k_stream<101>, dim3(grid), dim3(block), 0, 0, ops, out, iters);
         else if (fmt == "fp8") hipLaunchKernelGGL(k_stream<0>, dim3(grid), dim3(block), 0, 0, ops, out, iters);
         else if (fmt == "fp6") hipLaunchKernelGGL(k_stream<2>, dim3(grid), dim3(block), 0, 0, ops, out, iters);
         else hipLaunchKernelGGL(k_stream<4>, dim3(grid), dim3(block), 0, 0, ops, out, iters);
     };
-    const double ops_per_inst = fmt == "i8" ? 2.0 * 32 * 32 * 32 : fmt == "bf16" ? 2.0 * 32 * 32 * 16 : 2.0 * 32 * 32 * 64;
+    const double ops_per_inst = fmt == "i8_16" ? 2.0 * 16 * 16 * 64 : is_i8 ? 2.0 * 32 * 32 * 32 : fmt == "bf16" ? 2.0 * 32 * 32 * 16 : 2.0 * 32 * 32 * 64;
     launch(2000);
     CK(hipDeviceSynchronize());
     // calibrate to ~100 ms per launch
