@@ -3,8 +3,11 @@
 Mirrors the part of RetrievalEvaluationService the nDCG@10 number depends on
 (autorag_research/orm/service/retrieval_evaluation.py):
   build_retrieval_gt_from_relations   :23-78    group_index = AND, group_order = OR order, `chunk_` / `image_chunk_` prefixes
-  _get_execution_results              :161-217  ranked list = persisted rows sorted by rel_score DESC (stable),
-                                                ids prefixed; chunk rows listed before image_chunk rows on ties
+  _get_execution_results              :161-217  ranked list = persisted rows as the repositories hand them out (`ORDER BY
+                                                rel_score DESC`, orm/repository/chunk_retrieved_result.py:34-38: PostgreSQL
+                                                puts NULL scores FIRST on DESC), chunk rows then image_chunk rows, re-sorted
+                                                by `(rel_score or 0.0)` DESC with Python's stable sort; ids prefixed
+Pinned by tests/golden/evaluation_golden.json (the reference's two functions over a fake Unit of Work).
   evaluate -> mean of per-query scores, None results skipped   orm/service/base_evaluation.py:290-375
 """
 
@@ -36,9 +39,14 @@ def build_retrieval_gt_from_relations(relations: list[RetrievalRelation]) -> tup
 
 def get_execution_results(store: InMemoryStore, pipeline_id: int, query_ids: list) -> dict[Any, dict[str, Any]]:
     out: dict[Any, dict[str, Any]] = {}
+
+    def sql_order(rows):  # ORDER BY rel_score DESC over rows in insertion order: NULLs first, ties as inserted
+        return sorted(rows, key=lambda r: (r[1] is None, r[1] if r[1] is not None else 0.0), reverse=True)
+
     for qid in query_ids:
-        rows = [(s or 0.0, f"chunk_{cid}") for cid, s in store.chunk_results.get((pipeline_id, qid), [])]
-        rows += [(s or 0.0, f"image_chunk_{cid}") for cid, s in store.image_chunk_results.get((pipeline_id, qid), [])]
+        rows = [(s or 0.0, f"chunk_{cid}") for cid, s in sql_order(store.chunk_results.get((pipeline_id, qid), []))]
+        rows += [(s or 0.0, f"image_chunk_{cid}")
+                 for cid, s in sql_order(store.image_chunk_results.get((pipeline_id, qid), []))]
         rows.sort(key=lambda x: x[0], reverse=True)  # stable, like the reference's python re-sort
         gt, rel = build_retrieval_gt_from_relations(store.relations.get(qid, []))
         out[qid] = {"retrieved_ids": [pid for _, pid in rows], "retrieval_gt": gt, "relevance_scores": rel}

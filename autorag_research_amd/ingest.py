@@ -1,18 +1,35 @@
-"""Batched embedding of un-embedded rows (the encode half of the path).
+"""Embedding of un-embedded rows (the encode half of the path), batched.
 
-Mirrors BaseIngestionService._embed_entities / embed_all_queries / embed_all_chunks
-(autorag_research/orm/service/base_ingestion.py:326-495, 542-624) and TextEmbeddingDataIngestor.embed_all /
-embed_all_late_interaction (autorag_research/data/base.py:57-72, 110-125): find rows whose embedding is NULL,
-embed them, store the vectors.  The reference embeds ONE text per model forward (`aembed_query` under a semaphore) -- and it
-feeds the model's QUERY side to queries AND chunks (data/base.py:63-71): for asymmetric encoders (query / passage
-prefixes, instructions) the stored vectors, hence rankings and nDCG, depend on that.  The default `side="query"` here
-does the same, batched through `embed_queries` when the model offers it; `side="document"` (the model's
-`embed_documents`) is an explicit deviation for callers that want passage-side chunk vectors.  Multi-vector models
-fill the ragged store.  Returns the number of rows embedded, like the reference.
+Mirrors, behaviour for behaviour (pinned by tests/golden/ingest_golden.json, which is the reference's own `_embed_entities`
+run over a fake Unit of Work):
+  BaseIngestionService._embed_entities / _fetch_unembedded_batch / _embed_batch / _set_embeddings
+      autorag_research/orm/service/base_ingestion.py:199-247, 326-495
+  embed_all_queries / embed_all_chunks / ..._multi_vector          base_ingestion.py:542-624
+  TextEmbeddingDataIngestor.embed_all, MultiModalEmbeddingDataIngestor.embed_all / embed_all_late_interaction
+      autorag_research/data/base.py:57-72, 95-125
+What the reference does and this does too: rows lacking the column are fetched `batch_size` at a time, EXCLUDING the ids that
+already failed in this run; image chunks whose content is NULL are skipped and counted (never handed to the model); an item
+whose embedding raised or came back as None is remembered for the run and the rest of its batch is still stored; the loop ends
+when a fetch comes back empty or a batch made no progress; the return value is the number of rows stored.  Queries AND chunks
+go through the model's QUERY side (`aembed_query`, data/base.py:63-71), image chunks through `aembed_image`.
+
+What is different: the model runs ONE forward per batch (`embed_queries` / `embed_documents` / `embed_images`) instead of one
+per item under a semaphore; when a batch forward raises, its items are retried one by one so that the failing item alone is
+recorded -- the outcome (which rows are stored, which ids failed) is the reference's.  A coroutine function `data -> embedding`
+(the reference's call shape) is accepted as well and is then gathered under `max_concurrency` exactly like
+`util.run_with_concurrency_limit` (util.py:184-244).
+
+Two targets: `StoreTarget` (the in-memory tables of store.py) and `UowTarget` (the REFERENCE's repositories behind any service
+with `_create_uow()`: `count_without_*`, `get_without_*(limit, excluded_ids)`, `get_by_id` + attribute assignment + commit for
+`embedding VECTOR(d)`, `set_multi_vector_embeddings_batch` for `embeddings VECTOR(d)[]` -- the calls base_ingestion.py makes).
 """
 
 from __future__ import annotations
 
+import asyncio
+import inspect
+import logging
+from dataclasses import dataclass, field
 from typing import Any
 
 import numpy as np
@@ -20,60 +37,347 @@ import numpy as np
 from .embeddings import MultiVectorBaseEmbedding
 from .store import ChunkTable, InMemoryStore
 
+logger = logging.getLogger("AutoRAG-Research")
 
-def _embed_texts(model: Any, texts: list[str], batch_size: int, side: str = "query") -> list:
+# entity_type -> (repository attribute, data attribute, display name, skip rows whose data is None); base_ingestion.py:40-46
+ENTITY_CONFIG: dict[str, tuple[str, str, str, bool]] = {
+    "query": ("queries", "contents", "queries", False),
+    "chunk": ("chunks", "contents", "chunks", False),
+    "image_chunk": ("image_chunks", "contents", "image chunks", True),
+}
+
+
+@dataclass
+class IngestReport:
+    """What one `_embed_entities` run did (the reference logs these three numbers and returns the first)."""
+
+    total_embedded: int = 0
+    failed_ids: list = field(default_factory=list)      # embedding raised / returned None; not retried in this run
+    skipped_none_content: int = 0                         # image chunks with NULL content
+    skipped_ids: list = field(default_factory=list)
+
+
+# ---- targets ---------------------------------------------------------------------------------------------------------
+class StoreTarget:
+    """`InMemoryStore` tables: NULL = a NaN row of `embedding`, an empty span of the ragged store, None on a query row."""
+
+    def __init__(self, store: InMemoryStore):
+        self.store = store
+        self._pending_mv: dict[str, dict[int, np.ndarray]] = {"chunk": {}, "image_chunk": {}}
+
+    def _table(self, entity: str) -> ChunkTable:
+        return self.store.image_chunks if entity == "image_chunk" else self.store.chunks
+
+    def _missing(self, entity: str, emb_type: str):
+        """(id, data) of every row lacking the column, in table order."""
+        if entity == "query":
+            attr = "embedding" if emb_type == "single" else "embeddings"
+            for qid in self.store.query_order:
+                q = self.store.queries[qid]
+                if getattr(q, attr) is None:
+                    yield qid, q.contents
+            return
+        t = self._table(entity)
+        pend = self._pending_mv[entity]
+        for i, pk in enumerate(t.ids):
+            if emb_type == "single":
+                null = t.embedding is None or bool(np.isnan(t.embedding[i]).all())
+            else:
+                null = i not in pend and (t.mv_offsets is None or t.mv_offsets[i + 1] == t.mv_offsets[i])
+            if null:
+                yield pk, t.contents[i]
+
+    def count_without(self, entity: str, emb_type: str) -> int:
+        return sum(1 for _ in self._missing(entity, emb_type))
+
+    def fetch_without(self, entity: str, emb_type: str, limit: int, excluded: set) -> list[tuple[Any, Any]]:
+        out = []
+        for pk, data in self._missing(entity, emb_type):
+            if pk not in excluded:
+                out.append((pk, data))
+                if len(out) >= limit:
+                    break
+        return out
+
+    def set_embeddings(self, entity: str, emb_type: str, ids: list, embeddings: list) -> int:
+        if len(ids) != len(embeddings):
+            raise ValueError("Length mismatch: entity_ids and embeddings")   # LengthMismatchError in the reference
+        if entity == "query":
+            n = 0
+            for qid, e in zip(ids, embeddings):
+                q = self.store.queries.get(qid)
+                if q is not None:
+                    setattr(q, "embedding" if emb_type == "single" else "embeddings", np.ascontiguousarray(e, dtype=np.float32))
+                    n += 1
+            return n
+        t = self._table(entity)
+        pos = getattr(t, "_pos", None)
+        if pos is None or len(pos) != len(t.ids):
+            pos = {pk: i for i, pk in enumerate(t.ids)}
+            t._pos = pos  # type: ignore[attr-defined]
+        n = 0
+        for pk, e in zip(ids, embeddings):
+            i = pos.get(pk)
+            if i is None:
+                continue
+            v = np.ascontiguousarray(e, dtype=np.float32)
+            if emb_type == "single":
+                if t.embedding is None:
+                    t.embedding = np.full((len(t.ids), v.shape[0]), np.nan, dtype=np.float32)
+                t.embedding[i] = v
+            else:
+                self._pending_mv[entity][i] = v.reshape(-1, v.shape[-1])
+            n += 1
+        return n
+
+    def finish(self) -> None:
+        """Merge the multi-vector rows stored during the run into the ragged arrays (once, not per batch)."""
+        for entity, pend in self._pending_mv.items():
+            if not pend:
+                continue
+            t = self._table(entity)
+            n = len(t.ids)
+            docs: list = [None] * n
+            if t.mv_offsets is not None:
+                for i in range(n):
+                    if t.mv_offsets[i + 1] > t.mv_offsets[i]:
+                        docs[i] = t.mv_tokens[t.mv_offsets[i]: t.mv_offsets[i + 1]]
+            for i, m in pend.items():
+                docs[i] = m
+            d = next(x.shape[1] for x in docs if x is not None)
+            lens = [0 if x is None else x.shape[0] for x in docs]
+            t.mv_offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            t.mv_tokens = np.concatenate([x for x in docs if x is not None], axis=0) if any(lens) else np.zeros((0, d), np.float32)
+            pend.clear()
+
+
+class UowTarget:
+    """The reference's own repositories behind a service object with `_create_uow()` (its ingestion services, or the
+    RetrievalPipelineService the Executor builds): the statements base_ingestion.py issues, one Unit of Work per call."""
+
+    def __init__(self, ref_service: Any):
+        self._svc = ref_service
+
+    def _repo(self, uow, entity: str):
+        repo_attr = ENTITY_CONFIG[entity][0]
+        repo = getattr(uow, repo_attr, None)
+        if repo is None:
+            raise RuntimeError(f"Repository '{repo_attr}' is not supported by {type(uow).__name__}")  # RepositoryNotSupportedError
+        return repo
+
+    def count_without(self, entity: str, emb_type: str) -> int:
+        with self._svc._create_uow() as uow:
+            repo = self._repo(uow, entity)
+            return (repo.count_without_embeddings if emb_type == "single" else repo.count_without_multi_embeddings)()
+
+    def fetch_without(self, entity: str, emb_type: str, limit: int, excluded: set) -> list[tuple[Any, Any]]:
+        data_attr = ENTITY_CONFIG[entity][1]
+        with self._svc._create_uow() as uow:
+            repo = self._repo(uow, entity)
+            fetch = repo.get_without_embeddings if emb_type == "single" else repo.get_without_multi_embeddings
+            return [(e.id, getattr(e, data_attr)) for e in fetch(limit=limit, excluded_ids=excluded)]
+
+    def set_embeddings(self, entity: str, emb_type: str, ids: list, embeddings: list) -> int:
+        if len(ids) != len(embeddings):
+            raise ValueError("Length mismatch: entity_ids and embeddings")
+        n = 0
+        with self._svc._create_uow() as uow:
+            if getattr(uow, "session", True) is None:
+                raise RuntimeError("Session is not set")   # SessionNotSetError
+            repo = self._repo(uow, entity)
+            if emb_type == "multi_vector":
+                n = repo.set_multi_vector_embeddings_batch(ids, embeddings, vector_column="embeddings", id_column="id")
+            else:
+                for pk, e in zip(ids, embeddings, strict=True):
+                    row = repo.get_by_id(pk)
+                    if row:
+                        row.embedding = e
+                        n += 1
+            uow.commit()
+        return n
+
+    def finish(self) -> None:
+        pass
+
+
+def as_target(where: Any):
+    if hasattr(where, "count_without") and hasattr(where, "fetch_without"):
+        return where
+    if isinstance(where, InMemoryStore):
+        return StoreTarget(where)
+    if hasattr(where, "_create_uow"):
+        return UowTarget(where)
+    raise TypeError("expected an InMemoryStore, a service with _create_uow(), or an ingest target")
+
+
+# ---- embedders ---------------------------------------------------------------------------------------------------------
+def _to_lists(x: Any) -> Any:
+    return x.tolist() if hasattr(x, "tolist") else x
+
+
+class BatchEmbedder:
+    """`list[data] -> list[embedding | None]` over a model object: ONE forward per batch; a batch that raises is retried item
+    by item so that only the failing items come back as None (what the reference gets from one call per item)."""
+
+    def __init__(self, model: Any, kind: str = "query"):
+        if kind not in ("query", "document", "image"):
+            raise ValueError("kind must be 'query' (the reference's text side), 'document' or 'image'")
+        self.model, self.kind = model, kind
+
+    def _batch(self, items: list) -> list:
+        m = self.model
+        if self.kind == "image":
+            return list(m.embed_images(items))
+        if self.kind == "document":
+            return list(m.embed_documents(items))
+        if hasattr(m, "embed_queries"):
+            return list(m.embed_queries(items))
+        return [m.embed_query(t) for t in items]
+
+    def _one(self, item: Any):
+        m = self.model
+        if self.kind == "image":
+            return m.embed_image(item)
+        if self.kind == "document":
+            return m.embed_documents([item])[0]
+        return m.embed_query(item)
+
+    def __call__(self, items: list, error_msg: str = "Failed to embed") -> list:
+        try:
+            out = self._batch(items)
+            if len(out) == len(items):
+                return [None if e is None else _to_lists(e) for e in out]
+        except Exception:  # noqa: BLE001 - isolate the failing item(s) below
+            pass
+        res = []
+        for it in items:
+            try:
+                e = self._one(it)
+                res.append(None if e is None else _to_lists(e))
+            except Exception:  # noqa: BLE001
+                logger.exception(error_msg)
+                res.append(None)
+        return res
+
+
+async def _gather_limited(items: list, func, max_concurrency: int, error_msg: str) -> list:
+    """util.run_with_concurrency_limit (util.py:184-244): exceptions are logged and become None, order is kept."""
+    sem = asyncio.Semaphore(max_concurrency)
+
+    async def one(item):
+        async with sem:
+            try:
+                return await func(item)
+            except Exception:  # noqa: BLE001
+                logger.exception(error_msg)
+                return None
+
+    return list(await asyncio.gather(*[one(i) for i in items]))
+
+
+def _run_embed(embed: Any, items: list, max_concurrency: int, error_msg: str) -> list:
+    if isinstance(embed, BatchEmbedder):
+        return embed(items, error_msg)
+    if inspect.iscoroutinefunction(embed) or inspect.iscoroutinefunction(getattr(embed, "__call__", None)):
+        return asyncio.run(_gather_limited(items, embed, max_concurrency, error_msg))
+    raise TypeError("embed must be a BatchEmbedder or a coroutine function `data -> embedding`")
+
+
+# ---- the loop (base_ingestion.py:326-437, 461-495) ---------------------------------------------------------------------
+def embed_entities_report(where: Any, entity_type: str, embedding_type: str, embed: Any, batch_size: int = 128,
+                          max_concurrency: int = 16) -> IngestReport:
+    if entity_type not in ENTITY_CONFIG:
+        raise KeyError(entity_type)
+    if embedding_type not in ("single", "multi_vector"):
+        raise ValueError("embedding_type must be 'single' or 'multi_vector'")
+    target = as_target(where)
+    _, _, display, filter_none = ENTITY_CONFIG[entity_type]
+    suffix = " with multi-vector" if embedding_type == "multi_vector" else ""
+    error_msg = f"Failed to embed {'image' if entity_type == 'image_chunk' else 'text'}{suffix}"
+    rep = IngestReport()
+    if target.count_without(entity_type, embedding_type) == 0:
+        logger.info(f"No {display} to embed{suffix}")
+        return rep
+    failed: set = set()
+    try:
+        while True:
+            items = target.fetch_without(entity_type, embedding_type, batch_size, failed)
+            if not items:
+                break
+            if filter_none:
+                none_rows = [(pk, d) for pk, d in items if d is None]
+                items = [(pk, d) for pk, d in items if d is not None]
+                if none_rows:
+                    failed.update(pk for pk, _ in none_rows)
+                    rep.skipped_none_content += len(none_rows)
+                    rep.skipped_ids.extend(pk for pk, _ in none_rows)
+                if not items:
+                    continue
+            items = items[:batch_size]
+            embs = _run_embed(embed, [d for _, d in items], max_concurrency, error_msg)
+            good = [(pk, e) for (pk, _), e in zip(items, embs, strict=True) if e is not None]
+            bad = [pk for (pk, _), e in zip(items, embs, strict=True) if e is None]
+            if bad:
+                failed.update(bad)
+                rep.failed_ids.extend(bad)
+                logger.warning(f"Skipping {len(bad)} {display} that failed to embed in this run "
+                               f"(IDs: {bad[:5]}{'...' if len(bad) > 5 else ''})")
+            if good:
+                rep.total_embedded += target.set_embeddings(entity_type, embedding_type, [pk for pk, _ in good], [e for _, e in good])
+            elif not bad:
+                break
+    finally:
+        target.finish()
+    logger.info(f"Total {display} embedded{suffix}: {rep.total_embedded} (skipped_failed={len(rep.failed_ids)}, "
+                f"skipped_empty_content={rep.skipped_none_content})")
+    return rep
+
+
+def embed_entities(where: Any, entity_type: str, embedding_type: str, embed: Any, batch_size: int = 128,
+                   max_concurrency: int = 16) -> int:
+    """`BaseIngestionService._embed_entities`: the number of rows embedded and stored."""
+    return embed_entities_report(where, entity_type, embedding_type, embed, batch_size, max_concurrency).total_embedded
+
+
+def _embedder(model_or_func: Any, kind: str):
+    if isinstance(model_or_func, BatchEmbedder) or inspect.iscoroutinefunction(model_or_func):
+        return model_or_func
+    return BatchEmbedder(model_or_func, kind)
+
+
+def _emb_type(model_or_func: Any, embedding_type: str | None) -> str:
+    if embedding_type is not None:
+        return embedding_type
+    model = model_or_func.model if isinstance(model_or_func, BatchEmbedder) else model_or_func
+    return "multi_vector" if isinstance(model, MultiVectorBaseEmbedding) else "single"
+
+
+def embed_all_queries(where: Any, model: Any, batch_size: int = 128, max_concurrency: int = 16,
+                      embedding_type: str | None = None) -> int:
+    """embed_all_queries / embed_all_queries_multi_vector (base_ingestion.py:542-582): by the model's kind unless told."""
+    return embed_entities(where, "query", _emb_type(model, embedding_type), _embedder(model, "query"), batch_size, max_concurrency)
+
+
+def embed_all_chunks(where: Any, model: Any, batch_size: int = 128, max_concurrency: int = 16, unit: str = "chunk",
+                     side: str = "query", embedding_type: str | None = None) -> int:
+    """embed_all_chunks[_multi_vector] (base_ingestion.py:584-624) and, with `unit="image_chunk"`, embed_all_image_chunks
+    [_multi_vector]: text chunks through the model's QUERY side like the reference (data/base.py:68-72; `side="document"` is an
+    explicit deviation for passage-side vectors), image chunks' bytes through the image embedder (data/base.py:110-124)."""
     if side not in ("query", "document"):
         raise ValueError("side must be 'query' (the reference's behaviour) or 'document'")
-    out: list = []
-    for i in range(0, len(texts), batch_size):
-        part = texts[i: i + batch_size]
-        if side == "document":
-            out.extend(model.embed_documents(part))
-        elif hasattr(model, "embed_queries"):
-            out.extend(model.embed_queries(part))
-        else:
-            out.extend(model.embed_query(t) for t in part)
-    return out
+    if unit == "image_chunk":
+        return embed_entities(where, "image_chunk", _emb_type(model, embedding_type), _embedder(model, "image"), batch_size,
+                              max_concurrency)
+    return embed_entities(where, "chunk", _emb_type(model, embedding_type), _embedder(model, side), batch_size, max_concurrency)
 
 
-def embed_all_chunks(store: InMemoryStore, model: Any, batch_size: int = 128, unit: str = "chunk",
-                     side: str = "query") -> int:
-    """Fill `embedding` (single-vector model) or `embeddings` (multi-vector model) of every row that lacks it."""
-    table: ChunkTable = store.image_chunks if unit == "image_chunk" else store.chunks
-    n = len(table)
-    if n == 0:
-        return 0
-    texts = [c if c is not None else "" for c in table.contents]
-    if isinstance(model, MultiVectorBaseEmbedding):
-        have = table.mv_offsets is not None
-        todo = [i for i in range(n) if not have or table.mv_offsets[i + 1] == table.mv_offsets[i]]
-        if not todo:
-            return 0
-        new = _embed_texts(model, [texts[i] for i in todo], batch_size, side)
-        docs = [None] * n
-        if have:
-            for i in range(n):
-                if table.mv_offsets[i + 1] > table.mv_offsets[i]:
-                    docs[i] = table.mv_tokens[table.mv_offsets[i]: table.mv_offsets[i + 1]]
-        for i, m in zip(todo, new):
-            docs[i] = np.asarray(m, dtype=np.float32)
-        d = next(x.shape[1] for x in docs if x is not None)
-        lens = [0 if x is None else x.shape[0] for x in docs]
-        table.mv_offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-        table.mv_tokens = (np.concatenate([x for x in docs if x is not None], axis=0)
-                           if any(x is not None for x in docs) else np.zeros((0, d), np.float32))
-        return len(todo)
-    if table.embedding is None:
-        todo = list(range(n))
-    else:
-        todo = [i for i in range(n) if np.isnan(table.embedding[i]).all()]
-    if not todo:
-        return 0
-    vecs = np.asarray(_embed_texts(model, [texts[i] for i in todo], batch_size, side), dtype=np.float32)
-    if table.embedding is None:
-        table.embedding = np.full((n, vecs.shape[1]), np.nan, dtype=np.float32)
-    table.embedding[todo] = vecs
-    return len(todo)
+def embed_all(where: Any, model: Any, max_concurrency: int = 16, batch_size: int = 128, unit: str = "chunk") -> None:
+    """TextEmbeddingDataIngestor.embed_all (unit "chunk") / MultiModalEmbeddingDataIngestor.embed_all (unit "image_chunk") and,
+    for a multi-vector model, embed_all_late_interaction: queries first, then the corpus table."""
+    if model is None:
+        raise RuntimeError("Embedding model is not set")   # EmbeddingError
+    embed_all_queries(where, model, batch_size, max_concurrency)
+    embed_all_chunks(where, model, batch_size, max_concurrency, unit=unit)
 
 
 def index_texts_on_device(model: Any, texts: list[str], index: Any, batch_size: int = 1024) -> int:
@@ -100,19 +404,3 @@ def index_texts_on_device(model: Any, texts: list[str], index: Any, batch_size: 
         index.add_device(v.data_ptr(), v.shape[0])
         done += v.shape[0]
     return done
-
-
-def embed_all_queries(store: InMemoryStore, model: Any, batch_size: int = 128) -> int:
-    multi = isinstance(model, MultiVectorBaseEmbedding)
-    todo = [q for q in store.query_order
-            if (store.queries[q].embeddings if multi else store.queries[q].embedding) is None]
-    if not todo:
-        return 0
-    texts = [store.queries[q].contents or "" for q in todo]
-    out = _embed_texts(model, texts, batch_size, "query")
-    for q, v in zip(todo, out):
-        if multi:
-            store.queries[q].embeddings = np.asarray(v, dtype=np.float32)
-        else:
-            store.queries[q].embedding = np.asarray(v, dtype=np.float32)
-    return len(todo)

@@ -36,8 +36,9 @@ COL_MODEL_REGISTRY: dict[str, tuple[str, str]] = {  # reference colpali.py:22-29
     "qwen2": ("ColQwen2", "ColQwen2Processor"),
     "qwen2_5": ("ColQwen2_5", "ColQwen2_5_Processor"),
 }
-BI_MODEL_REGISTRY: dict[str, tuple[str, str]] = {  # reference bipali.py
+BI_MODEL_REGISTRY: dict[str, tuple[str, str]] = {  # reference bipali.py:19-25
     "modernvbert": ("BiModernVBert", "BiModernVBertProcessor"),
+    "smolvlm": ("BiIdefics3", "BiIdefics3Processor"),
     "pali": ("BiPali", "BiPaliProcessor"),
     "qwen2": ("BiQwen2", "BiQwen2Processor"),
     "qwen2_5": ("BiQwen2_5", "BiQwen2_5_Processor"),
@@ -110,8 +111,9 @@ class Mi355ColPaliEmbeddings(_EngineBacked, MultiVectorMultiModalEmbedding):
     SUPPORTED_MODEL_TYPES = list(COL_MODEL_REGISTRY.keys())
 
     def __init__(self, model_name: str = "vidore/colpali-v1.3", model_type: str = "pali", device: str = "cpu",
-                 torch_dtype: Any = "bfloat16", model: Any | None = None, processor: Any | None = None, batch_size: int = 8,
-                 drop_padding: bool = False):
+                 torch_dtype: Any = "bfloat16", model: Any | None = None, processor: Any | None = None, batch_size: int = 10,
+                 drop_padding: bool = False, embed_batch_size: int | None = None):
+        batch_size = batch_size if embed_batch_size is None else embed_batch_size   # (the reference's YAML key, colpali.yaml)
         self._setup(COL_MODEL_REGISTRY, "ColPaliEmbeddings", model_name, model_type, device, torch_dtype, model, processor,
                     batch_size)
         # The reference keeps EVERY row the model returns for an item of a batch, the padded positions included
@@ -136,21 +138,25 @@ class Mi355ColPaliEmbeddings(_EngineBacked, MultiVectorMultiModalEmbedding):
             flat = h.reshape(-1, h.shape[-1])
         return flat.contiguous(), np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
 
-    def encode_texts_to_device(self, texts: list[str], query: bool = False):
+    def encode_texts_to_device(self, texts: list[str], query: bool = False, batch_size: int | None = None):
+        """`batch_size` texts per forward (default `embed_batch_size`).  Texts of one forward are padded to its longest, and the
+        reference keeps the padded rows: how a list is cut into batches is therefore part of the result."""
         torch = self._torch
+        bs = max(1, batch_size or self.embed_batch_size)
         parts, offs = [], [np.zeros((1,), np.int64)]
-        for i in range(0, len(texts), self.embed_batch_size):
-            flat, off = self._ragged(*self._run(self._text_inputs(texts[i: i + self.embed_batch_size], query)))
+        for i in range(0, len(texts), bs):
+            flat, off = self._ragged(*self._run(self._text_inputs(texts[i: i + bs], query)))
             parts.append(flat)
             offs.append(off[1:] + offs[-1][-1])
         d = parts[0].shape[1] if parts else 0
         return (torch.cat(parts, 0) if parts else torch.empty((0, d), device=self.device)), np.concatenate(offs)
 
-    def encode_images_to_device(self, images: list[Any]):
+    def encode_images_to_device(self, images: list[Any], batch_size: int | None = None):
         torch = self._torch
+        bs = max(1, batch_size or self.embed_batch_size)
         parts, offs = [], [np.zeros((1,), np.int64)]
-        for i in range(0, len(images), self.embed_batch_size):
-            batch = [load_image(p) for p in images[i: i + self.embed_batch_size]]
+        for i in range(0, len(images), bs):
+            batch = [load_image(p) for p in images[i: i + bs]]
             flat, off = self._ragged(*self._run(self._processor.process_images(batch)))
             parts.append(flat)
             offs.append(off[1:] + offs[-1][-1])
@@ -193,10 +199,12 @@ class Mi355ColPaliEmbeddings(_EngineBacked, MultiVectorMultiModalEmbedding):
         return await asyncio.to_thread(self.embed_image, img_file_path)
 
     def embed_documents(self, texts: list[str]) -> list[MultiVectorEmbedding]:
-        return self._lists(*self.encode_texts_to_device(texts, query=False)) if texts else []
+        # ONE padded batch, like the reference (colpali.py:189-216); `embed_documents_batch` cuts a list into `embed_batch_size`
+        return self._lists(*self.encode_texts_to_device(texts, query=False, batch_size=len(texts))) if texts else []
 
     def embed_images(self, img_file_paths: list[Any]) -> list[MultiVectorEmbedding]:
-        return self._lists(*self.encode_images_to_device(img_file_paths)) if img_file_paths else []
+        # ONE batch (colpali.py:218-245); `embed_images_batch` cuts
+        return self._lists(*self.encode_images_to_device(img_file_paths, batch_size=len(img_file_paths))) if img_file_paths else []
 
 
 class Mi355BiPaliEmbeddings(_EngineBacked, SingleVectorMultiModalEmbedding):
@@ -205,7 +213,9 @@ class Mi355BiPaliEmbeddings(_EngineBacked, SingleVectorMultiModalEmbedding):
     SUPPORTED_MODEL_TYPES = list(BI_MODEL_REGISTRY.keys())
 
     def __init__(self, model_name: str = "vidore/bipali", model_type: str = "pali", device: str = "cpu",
-                 torch_dtype: Any = "bfloat16", model: Any | None = None, processor: Any | None = None, batch_size: int = 8):
+                 torch_dtype: Any = "bfloat16", model: Any | None = None, processor: Any | None = None, batch_size: int = 10,
+                 embed_batch_size: int | None = None):
+        batch_size = batch_size if embed_batch_size is None else embed_batch_size   # (the reference's field, bipali.py:84)
         self._setup(BI_MODEL_REGISTRY, "BiPaliEmbeddings", model_name, model_type, device, torch_dtype, model, processor,
                     batch_size)
 
@@ -231,10 +241,11 @@ class Mi355BiPaliEmbeddings(_EngineBacked, SingleVectorMultiModalEmbedding):
         return len(images)
 
     def embed_query(self, text: str) -> list[float]:
-        return self.encode_texts_to_device([text], query=True)[0].cpu().tolist()
+        # the reference's BiPali sends queries through `process_texts` too (bipali.py:113-122, 218-234 `_embed_text`)
+        return self.encode_texts_to_device([text], query=False)[0].cpu().tolist()
 
     def embed_queries(self, texts: list[str]) -> list[list[float]]:
-        return self.encode_texts_to_device(texts, query=True).cpu().tolist() if texts else []
+        return self.encode_texts_to_device(texts, query=False).cpu().tolist() if texts else []
 
     async def aembed_query(self, text: str) -> list[float]:
         return await asyncio.to_thread(self.embed_query, text)

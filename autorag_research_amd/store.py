@@ -98,8 +98,9 @@ class InMemoryStore:
     def set_chunks(self, ids, contents=None, embedding=None, multivec=None) -> None:
         self._fill(self.chunks, ids, contents, embedding, multivec)
 
-    def set_image_chunks(self, ids, embedding=None, multivec=None) -> None:
-        self._fill(self.image_chunks, ids, None, embedding, multivec)
+    def set_image_chunks(self, ids, embedding=None, multivec=None, contents=None) -> None:
+        """`contents` = the image bytes of each row (image_chunk.contents BYTEA in the reference; None = NULL)."""
+        self._fill(self.image_chunks, ids, contents, embedding, multivec)
 
     def add_relations(self, rels: list[RetrievalRelation]) -> None:
         for r in rels:

@@ -40,7 +40,7 @@ class PaliInputs:
 
         px = []
         for im in images:
-            a = torch.as_tensor(np.asarray(im)).permute(2, 0, 1).float() / 255.0
+            a = torch.as_tensor(np.array(im)).permute(2, 0, 1).float() / 255.0
             px.append(torch.nn.functional.interpolate(a[None], size=(IMG, IMG), mode="bilinear", align_corners=False)[0])
         ids = torch.full((len(images), N_IMG_TOK + 3), IMAGE_TOKEN, dtype=torch.long)
         ids[:, N_IMG_TOK:] = torch.tensor([2, 7, 9])        # <bos> "Describe the image." stand-in

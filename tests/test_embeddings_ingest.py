@@ -104,3 +104,52 @@ def test_embed_all_fills_only_missing_rows_and_search_runs(monkeypatch, oracle):
     pm = Mi355VectorSearchRetrievalPipeline(lambda: store, "ing_multi", search_mode="multi")
     out = asyncio.run(pm._retrieve_by_id("qa", 4))
     assert len(out) == 4 and out[0]["score"] >= out[-1]["score"] and out[0]["score"] <= 1.0 + 1e-6
+
+
+@pytest.mark.gpu
+def test_ingest_on_the_gpu_then_search_equals_the_oracle(native_built, oracle):
+    """Row a12 end to end on the MI355X: `embed_all` (queries, then chunks, through the model's query side like
+    data/base.py:57-72) with the encoder on cuda:0 and one row the model cannot embed -- remembered, the rest stored, a second
+    run retries it --, then the pipeline's block search over the stored vectors equals the oracle on the same vectors."""
+    from autorag_research_amd.embeddings import TorchEncoderEmbeddings
+    from autorag_research_amd.ingest import StoreTarget, embed_all, embed_entities_report, BatchEmbedder
+    from autorag_research_amd.pipelines import Mi355VectorSearchRetrievalPipeline
+    from autorag_research_amd.store import InMemoryStore
+
+    store = InMemoryStore()
+    texts = [f"chunk {i} talks about subject {i % 7} and item {i}" for i in range(300)]
+    store.set_chunks(list(range(1000, 1300)), texts)
+    store.add_queries([f"q{i}" for i in range(5)], contents=[f"subject {i} item {i * 11}" for i in range(5)])
+    enc = TorchEncoderEmbeddings(_TinyEnc(), _TinyTok(), pooling="mean", device="cuda:0", batch_size=64)
+
+    class Flaky:
+        """fails on one text the first time it sees it (a transient model / service error)"""
+
+        def __init__(self):
+            self.failed_once = False
+
+        def embed_queries(self, items):
+            if not self.failed_once and texts[123] in items:
+                raise RuntimeError("transient")
+            return enc.embed_queries(items)
+
+        def embed_query(self, t):
+            if not self.failed_once and t == texts[123]:
+                self.failed_once = True
+                raise RuntimeError("transient")
+            return enc.embed_query(t)
+
+    rep = embed_entities_report(StoreTarget(store), "chunk", "single", BatchEmbedder(Flaky(), "query"), batch_size=64)
+    assert rep.total_embedded == 299 and rep.failed_ids == [1123] and np.isnan(store.chunks.embedding[123]).all()
+    embed_all(store, enc, batch_size=64)     # the next ingest call retries the row and embeds the queries
+    assert not np.isnan(store.chunks.embedding).any() and all(store.queries[q].embedding is not None for q in store.query_order)
+    p = Mi355VectorSearchRetrievalPipeline(lambda: store, "ing_gpu", search_mode="single")
+    stats = p.run(top_k=7)
+    assert stats["total_queries"] == 5 and stats["failed_queries"] == []
+    Q = np.stack([store.queries[q].embedding for q in store.query_order])
+    od, orow = oracle.topk_search(store.chunks.embedding, Q, 7)
+    for qi, q in enumerate(store.query_order):
+        got = store.chunk_results[(p.pipeline_id, q)]
+        assert [c for c, _ in got] == [1000 + int(r) for r in orow[qi]]
+        assert [s for _, s in got] == [1.0 - float(d) for d in od[qi]]
+    p.close()

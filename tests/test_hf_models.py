@@ -24,20 +24,10 @@ import pytest
 torch = pytest.importorskip("torch")
 transformers = pytest.importorskip("transformers")
 
-IMAGE_TOKEN, VOCAB, IMG, PATCH = 500, 512, 56, 14
-N_IMG_TOK = (IMG // PATCH) ** 2
-
-
-def _colpali_config():
-    from transformers import ColPaliConfig, GemmaConfig, PaliGemmaConfig, SiglipVisionConfig
-
-    vis = SiglipVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4, image_size=IMG,
-                             patch_size=PATCH, projection_dim=96)
-    txt = GemmaConfig(vocab_size=VOCAB, hidden_size=96, intermediate_size=192, num_hidden_layers=2, num_attention_heads=4,
-                      num_key_value_heads=1, head_dim=24, max_position_embeddings=256)
-    vlm = PaliGemmaConfig(vision_config=vis, text_config=txt, image_token_index=IMAGE_TOKEN, vocab_size=VOCAB, projection_dim=96,
-                          hidden_size=96)
-    return ColPaliConfig(vlm_config=vlm, embedding_dim=128)
+from helpers_hf import IMAGE_TOKEN, IMG, N_IMG_TOK, PATCH, VOCAB  # noqa: E402,F401
+from helpers_hf import PaliInputs as _PaliInputs  # noqa: E402
+from helpers_hf import colpali_config as _colpali_config  # noqa: E402
+from helpers_hf import images as _images  # noqa: E402
 
 
 def _colpali(dtype):
@@ -45,39 +35,6 @@ def _colpali(dtype):
 
     torch.manual_seed(0)
     return ColPaliForRetrieval(_colpali_config()).to(dtype).eval()
-
-
-class _PaliInputs:
-    """The tensors ColPaliProcessor hands the model: images -> N_IMG_TOK image-token placeholders + a short text suffix and
-    `pixel_values`; texts -> right-padded ids + attention_mask (ids hashed from the words: no tokenizer files offline)."""
-
-    def process_images(self, images):
-        px = []
-        for im in images:
-            a = torch.as_tensor(np.asarray(im)).permute(2, 0, 1).float() / 255.0
-            px.append(torch.nn.functional.interpolate(a[None], size=(IMG, IMG), mode="bilinear", align_corners=False)[0])
-        ids = torch.full((len(images), N_IMG_TOK + 3), IMAGE_TOKEN, dtype=torch.long)
-        ids[:, N_IMG_TOK:] = torch.tensor([2, 7, 9])        # <bos> "Describe the image." stand-in
-        return {"input_ids": ids, "pixel_values": torch.stack(px), "attention_mask": torch.ones_like(ids)}
-
-    def _tok(self, texts):
-        rows = [[2] + [10 + zlib.crc32(w.encode()) % 400 for w in t.split()] for t in texts]
-        L = max(len(r) for r in rows)
-        ids, mask = torch.zeros((len(rows), L), dtype=torch.long), torch.zeros((len(rows), L), dtype=torch.long)
-        for i, r in enumerate(rows):
-            ids[i, : len(r)], mask[i, : len(r)] = torch.tensor(r), 1
-        return {"input_ids": ids, "attention_mask": mask}
-
-    def process_queries(self, texts):
-        return self._tok(texts)
-
-    def process_texts(self, texts):
-        return self._tok(texts)
-
-
-def _images(n, seed=0):
-    rng = np.random.default_rng(seed)
-    return [rng.integers(0, 255, size=(60 + 6 * i, 80, 3), dtype=np.uint8) for i in range(n)]
 
 
 def _reference_post(model, inputs, device):
@@ -168,33 +125,12 @@ def test_colpali_engine_loading_branch(monkeypatch):
     """`model=None`: the reference's own loading path (colpali.py:88-108) -- `colpali_engine.models.<Class>.from_pretrained(name,
     dtype=<torch dtype>, trust_remote_code=True)` + `<Processor>.from_pretrained(name)`.  colpali_engine is not installed here; a
     module of that name serves transformers' ColPaliForRetrieval behind colpali_engine's call shape (forward returns the tensor)."""
-    from transformers import ColPaliForRetrieval
+    import helpers_hf
 
     from autorag_research_amd.multimodal import Mi355ColPaliEmbeddings
 
     seen = {}
-
-    class ColPali(ColPaliForRetrieval):
-        @classmethod
-        def from_pretrained(cls, name, dtype=None, trust_remote_code=False, **kw):
-            seen.update(name=name, dtype=dtype, trust_remote_code=trust_remote_code)
-            torch.manual_seed(0)
-            return cls(_colpali_config()).to(dtype)
-
-        def forward(self, *a, **kw):
-            return super().forward(*a, **kw).embeddings
-
-    class ColPaliProcessor(_PaliInputs):
-        @classmethod
-        def from_pretrained(cls, name):
-            seen["processor"] = name
-            return cls()
-
-    eng, models = types.ModuleType("colpali_engine"), types.ModuleType("colpali_engine.models")
-    models.ColPali, models.ColPaliProcessor = ColPali, ColPaliProcessor
-    eng.models = models
-    monkeypatch.setitem(sys.modules, "colpali_engine", eng)
-    monkeypatch.setitem(sys.modules, "colpali_engine.models", models)
+    helpers_hf.install_colpali_engine(monkeypatch, seen)
     col = Mi355ColPaliEmbeddings(model_name="vidore/colpali-v1.3", model_type="pali", device="cpu")   # torch_dtype: "bfloat16"
     assert seen == {"name": "vidore/colpali-v1.3", "dtype": torch.bfloat16, "trust_remote_code": True,
                     "processor": "vidore/colpali-v1.3"}
@@ -203,6 +139,76 @@ def test_colpali_engine_loading_branch(monkeypatch):
     assert len(v) == N_IMG_TOK + 3 and v == _reference_post(col._model, _PaliInputs().process_images(_images(1)), "cpu")[0]
     with pytest.raises(AttributeError, match="Could not find"):
         Mi355ColPaliEmbeddings(model_type="qwen2")   # the module has no ColQwen2
+
+
+# ---- against the REFERENCE's classes: tests/golden/embeddings_golden.npz (make_golden.py:make_embeddings) --------------------
+def _golden():
+    from pathlib import Path
+
+    return np.load(Path(__file__).parent / "golden" / "embeddings_golden.npz")
+
+
+def _ragged_eq(g, name, docs, atol):
+    off = g[name + "_off"]
+    assert [len(d) for d in docs] == list(np.diff(off)), name          # the padded rows the reference keeps, row for row
+    flat = np.asarray([v for d in docs for v in d], dtype=np.float32).reshape(int(off[-1]), -1)
+    assert flat.shape == g[name].shape and np.abs(flat - g[name]).max() <= atol, (name, np.abs(flat - g[name]).max())
+
+
+def _check_against_reference_fixture(monkeypatch, device, atol):
+    """Every public method of Mi355ColPaliEmbeddings / Mi355BiPaliEmbeddings, loaded through the same `colpali_engine` stand-in,
+    against what the reference's ColPaliEmbeddings / BiPaliEmbeddings returned for the same inputs (float32)."""
+    import helpers_hf
+
+    from autorag_research_amd.multimodal import Mi355BiPaliEmbeddings, Mi355ColPaliEmbeddings
+
+    g = _golden()
+    helpers_hf.install_colpali_engine(monkeypatch)
+    texts = helpers_hf.EMBED_TEXTS
+    pngs = [helpers_hf.png_bytes(g[f"image{i}"]) for i in range(3)]
+    col = Mi355ColPaliEmbeddings(model_name="tiny/colpali", model_type="pali", device=device, torch_dtype="float32")
+    assert col.embed_batch_size == int(g["col_embed_batch_size"])       # the reference's default (base.py:50)
+    _ragged_eq(g, "col_embed_text", [col.embed_text(t) for t in texts[:4]], atol)
+    _ragged_eq(g, "col_embed_query", [col.embed_query(t) for t in texts[:4]], atol)
+    _ragged_eq(g, "col_aembed_query", [asyncio.run(col.aembed_query(texts[0]))], atol)
+    _ragged_eq(g, "col_embed_documents", col.embed_documents(texts), atol)              # one padded batch of 12
+    _ragged_eq(g, "col_embed_documents_batch", col.embed_documents_batch(texts), atol)  # 10 + 2: other paddings
+    _ragged_eq(g, "col_embed_image", [col.embed_image(pngs[0])], atol)
+    _ragged_eq(g, "col_embed_images", col.embed_images(pngs), atol)
+    _ragged_eq(g, "col_embed_images", col.embed_images_batch(pngs), atol)
+    assert col.embed_documents([]) == [] and col.embed_images([]) == []
+    bi = Mi355BiPaliEmbeddings(model_name="tiny/bipali", model_type="pali", device=device, torch_dtype="float32", embed_batch_size=5)
+    close = lambda a, name: np.abs(np.asarray(a, dtype=np.float32) - g[name]).max() <= atol  # noqa: E731
+    assert close([bi.embed_query(t) for t in texts[:4]], "bi_embed_query")
+    assert close(bi.embed_documents(texts), "bi_embed_documents")
+    assert close(asyncio.run(bi.aembed_documents(texts)), "bi_embed_documents")
+    assert close(bi.embed_image(pngs[1]), "bi_embed_image") and close(asyncio.run(bi.aembed_image(pngs[1])), "bi_aembed_image")
+    assert close(bi.embed_images(pngs), "bi_embed_images")
+    return col, bi, texts, pngs
+
+
+def test_wrappers_equal_the_reference_classes_cpu(monkeypatch):
+    _check_against_reference_fixture(monkeypatch, "cpu", 2e-6)
+    with pytest.raises(AttributeError, match="Could not find"):
+        from autorag_research_amd.multimodal import Mi355BiPaliEmbeddings
+
+        Mi355BiPaliEmbeddings(model_type="smolvlm")   # in the reference's registry (bipali.py:21), not in this stand-in module
+
+
+@pytest.mark.gpu
+def test_wrappers_equal_the_reference_classes_on_the_gpu(monkeypatch, native_built, oracle):
+    """The same fixture with the model on the MI355X (fp32; GPU GEMMs round differently: 5e-4 on unit vectors), then the BiPali
+    page vectors go to the index by device pointer and are searched."""
+    import autorag_research_amd as pkg
+
+    col, bi, texts, pngs = _check_against_reference_fixture(monkeypatch, "cuda:0", 5e-4)
+    with pkg.Mi355Index(128) as idx:
+        assert bi.index_images_on_device(idx, pngs) == 3
+        C = bi.encode_images_to_device(pngs).cpu().numpy()
+        Q = np.asarray(bi.embed_documents(texts[:3]), dtype=np.float32)
+        d, r = idx.search(Q, 3)
+    od, orow = oracle.topk_search(C, Q, 3)
+    assert np.array_equal(r, orow) and np.array_equal(d, od)
 
 
 @pytest.mark.gpu

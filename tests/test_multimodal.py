@@ -38,10 +38,12 @@ def test_colpali_interface_and_shapes(col):
     assert np.allclose(asyncio.run(col.aembed_image(imgs[1])), many[1], atol=1e-6)
     q = col.embed_query("what is on the page")
     assert len(q) == 5 and len(q[0]) == 128 and col.embed_text("what is on the page") == q
-    # batches of 2: like the reference (`[emb.cpu().tolist() for emb in embeddings]`, colpali.py:218), every row the model
-    # returns for an item is kept -- the padded positions of the shorter item of a batch as zero vectors
+    # like the reference (`[emb.cpu().tolist() for emb in embeddings]`, colpali.py:189-216), every row the model returns for an
+    # item is kept -- the padded positions of the shorter items as zero vectors --, and `embed_documents` is ONE padded batch;
+    # `embed_documents_batch` cuts the list into `embed_batch_size` (2 here), each padded to its own longest (base.py:77-83)
     docs = col.embed_documents(["a b c", "d", ""])
-    assert [len(x) for x in docs] == [3, 3, 1] and col.embed_documents([]) == [] and col.embed_images([]) == []
+    assert [len(x) for x in docs] == [3, 3, 3] and col.embed_documents([]) == [] and col.embed_images([]) == []
+    assert [len(x) for x in col.embed_documents_batch(["a b c", "d", ""])] == [3, 3, 1]
     assert np.allclose(docs[1][1:], 0.0) and abs(np.linalg.norm(docs[1][0]) - 1.0) < 1e-5
     col.drop_padding = True      # the ragged form: attended positions only
     assert [len(x) for x in col.embed_documents(["a b c", "d", ""])] == [3, 1, 1]

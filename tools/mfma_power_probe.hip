@@ -183,6 +183,9 @@ static int run_stream(const std::string& fmt, const std::string& data, double se
                         // an offset-encoded corpus shadow would hold), "off" both sides
                         const bool a_side = (f & 1) == 0;
                         float v = blk[e] * (127.0f / 4.4f);
+                        // "g7A" / "g6A" / "g5A": the A side at 7 / 6 / 5 bits (sigma 14.5 / 7.2 / 3.6), "g7" ... both sides
+                        if (data.rfind("g", 0) == 0 && data != "gauss" && (a_side || data.back() != 'A'))
+                            v = blk[e] * (127.0f / 4.4f) / (float)(1 << (8 - (data[1] - '0')));
                         if (data == "abs" || (data == "absA" && a_side)) v = std::fabs(v);
                         if (data == "off" || (data == "offA" && a_side)) v = blk[e] * (63.0f / 4.4f) + 64.0f;
                         v = v > 127 ? 127 : (v < -127 ? -127 : v);
