@@ -194,26 +194,57 @@ int mi355dr_search_sharded_device(mi355dr_index* idx, const float* queries_dev, 
         idx->comm_done_armed[p.buf] = true;
         return MI355DR_OK;
     };
+    // An error anywhere below must not leave work behind the caller's back: every ticket still open is waited for, and `s` is
+    // ordered behind whatever the communication stream was already given (merges of earlier blocks write the caller's
+    // outputs) before the error code is returned -- the outputs are then garbage, but nothing writes them after the return.
+    auto drain = [&](int64_t t_a, int64_t t_b) {
+        if (t_a >= 0) (void)mi355dr_search_wait(idx, t_a);
+        if (t_b >= 0) (void)mi355dr_search_wait(idx, t_b);
+        if (idx->comm_stream) (void)hipStreamSynchronize(idx->comm_stream);
+        for (int b = 0; b < 2; ++b) idx->comm_done_armed[b] = false;   // (everything they stood for has completed)
+    };
+#define SHARDED_TRY(expr, TA, TB)        \
+    do {                                 \
+        const int rc__ = (expr);         \
+        if (rc__ != MI355DR_OK) {        \
+            drain((TA), (TB));           \
+            return rc__;                 \
+        }                                \
+    } while (0)
     int i = 0;
     for (int b0 = 0; b0 < B; b0 += mi355::kQBlockMax, ++i) {
         const int nb = std::min(mi355::kQBlockMax, B - b0), buf = i & 1;
         const size_t plane = (size_t)nb * k;
         // the gather that read this packed block two blocks (or one call) ago
-        if (idx->comm_done_armed[buf]) HIPCHECK(idx, hipStreamWaitEvent(s, idx->comm_done[buf], 0));
+        if (idx->comm_done_armed[buf] && hipStreamWaitEvent(s, idx->comm_done[buf], 0) != hipSuccess) {
+            drain(pend.ticket, -1);
+            return mi355::fail(idx, MI355DR_E_HIP, "hipStreamWaitEvent failed in the sharded search");
+        }
         InFlight cur;
         cur.buf = buf;
         cur.b0 = b0;
         cur.nb = nb;
         // the shard's list goes straight into the packed block (the float8 plane is written as doubles)
-        CHECK(mi355dr_search_device_async(idx, queries_dev + (int64_t)b0 * idx->dim, nb, k, (double*)idx->comm_packed[buf],
-                                          idx->comm_packed[buf] + plane, s, &cur.ticket));
-        if (pend.ticket >= 0) CHECK(finish(pend));
+        SHARDED_TRY(mi355dr_search_device_async(idx, queries_dev + (int64_t)b0 * idx->dim, nb, k, (double*)idx->comm_packed[buf],
+                                                idx->comm_packed[buf] + plane, s, &cur.ticket), pend.ticket, -1);
+        if (pend.ticket >= 0) {
+            const int64_t t = pend.ticket;
+            pend.ticket = -1;   // finish() waits for it first thing: whatever happens inside, it is no longer open
+            (void)t;
+            InFlight done = pend;
+            done.ticket = t;
+            SHARDED_TRY(finish(done), cur.ticket, -1);
+        }
         pend = cur;
     }
-    if (pend.ticket >= 0) CHECK(finish(pend));
+    if (pend.ticket >= 0) SHARDED_TRY(finish(pend), -1, -1);
+#undef SHARDED_TRY
     // outputs ordered behind the caller's stream
     for (int b = 0; b < 2; ++b)
-        if (idx->comm_done_armed[b]) HIPCHECK(idx, hipStreamWaitEvent(s, idx->comm_done[b], 0));
+        if (idx->comm_done_armed[b] && hipStreamWaitEvent(s, idx->comm_done[b], 0) != hipSuccess) {
+            drain(-1, -1);
+            return mi355::fail(idx, MI355DR_E_HIP, "hipStreamWaitEvent failed in the sharded search");
+        }
     return MI355DR_OK;  // asynchronous on `s`: the last merges run on the communication stream, `s` waits for them
 }
 

@@ -175,8 +175,11 @@ class Mi355HEAVENRetrievalPipeline(Mi355BaseRetrievalPipeline):
     async def _retrieve_by_text(self, query_text: str, top_k: int) -> list[dict[str, Any]]:
         if self._single_vector_embedding_model is None or self._multi_vector_embedding_model is None:
             raise EmbeddingError
-        single_vec = await self._single_vector_embedding_model.aembed_query(query_text)
-        multi_vecs = await self._multi_vector_embedding_model.aembed_query(query_text)
+        async def embed_both():
+            return (await self._single_vector_embedding_model.aembed_query(query_text),
+                    await self._multi_vector_embedding_model.aembed_query(query_text))
+
+        single_vec, multi_vecs = await self._service.on_root(embed_both)   # one process per GPU: rank 0 embeds, all ranks search
         return self._search(query_text, single_vec, multi_vecs, top_k)
 
     def run(self, top_k: int = 10, batch_size: int = 128, max_concurrency: int = 16, max_retries: int = 3,

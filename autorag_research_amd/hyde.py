@@ -101,51 +101,71 @@ class Mi355HyDERetrievalPipeline(Mi355BaseRetrievalPipeline):
         return await self._retrieve_by_text(self._query_text(query_id), top_k)
 
     async def _retrieve_by_text(self, query_text: str, top_k: int) -> list[dict[str, Any]]:
-        passage = await self._generate_hypothetical_document(query_text)
-        embedding = await self.embedding.aembed_query(passage)
+        async def passage_embedding():
+            passage = await self._generate_hypothetical_document(query_text)
+            return await self.embedding.aembed_query(passage)
+
+        # One process per GPU: the LLM and the embedding model answer on rank 0 alone and the vector (or the exception)
+        # reaches every rank -- an LLM samples, so two ranks would otherwise search DIFFERENT vectors, and a rank-local
+        # failure would send one rank down the retry path while the others sit in the search's all-gather.
+        embedding = await self._service.on_root(passage_embedding)
         return self._service.vector_search_by_embedding(embedding=embedding, top_k=top_k)
 
     def _retrieve_block(self, query_ids: list, top_k: int) -> list[list[dict] | None]:
         """A page: passages generated concurrently, embedded, searched as one GPU block."""
+        # ONE read of the page's query rows, before anything asynchronous: under a process group `get_queries` is a
+        # collective (rank 0 reads, everybody receives), and collectives issued from concurrently scheduled coroutines --
+        # let alone from inside a per-passage retry loop -- would differ in number and order between ranks.
+        rows = self._service.get_queries(list(query_ids))
 
-        async def passages():
-            attempts, delay0 = getattr(self, "_run_retry", (1, 0.0))
+        def generate_and_embed():
+            async def passages():
+                attempts, delay0 = getattr(self, "_run_retry", (1, 0.0))
 
-            async def one(qid):
-                # the reference retries a failing query with exponential backoff before it gives it up
-                # (retrieval_pipeline.py:222-236); so does the block form, per passage
-                delay = delay0
-                for attempt in range(attempts):
-                    try:
-                        return await self._generate_hypothetical_document(self._query_text(qid))
-                    except Exception:  # noqa: BLE001
-                        if attempt + 1 >= attempts:
-                            logger.exception(f"HyDE passage generation failed for query {qid} after {attempts} attempts")
-                            return None  # that query is reported as failed
-                        await asyncio.sleep(min(max(delay, delay0), 60))
-                        delay *= 2
-                return None
+                async def one(qid, row):
+                    # the reference retries a failing query with exponential backoff before it gives it up
+                    # (retrieval_pipeline.py:222-236); so does the block form, per passage
+                    delay = delay0
+                    for attempt in range(attempts):
+                        try:
+                            if row is None:
+                                raise ValueError(f"Query {qid} not found")  # noqa: TRY003, TRY301
+                            return await self._generate_hypothetical_document(row.contents)
+                        except Exception:  # noqa: BLE001
+                            if attempt + 1 >= attempts:
+                                logger.exception(f"HyDE passage generation failed for query {qid} after {attempts} attempts")
+                                return None  # that query is reported as failed
+                            await asyncio.sleep(min(max(delay, delay0), 60))
+                            delay *= 2
+                    return None
 
-            return await asyncio.gather(*[one(q) for q in query_ids])
+                return await asyncio.gather(*[one(q, r) for q, r in zip(query_ids, rows)])
 
-        docs = asyncio.run(passages())
-        live = [i for i, p in enumerate(docs) if p is not None]
+            docs = asyncio.run(passages())
+            live = [i for i, p in enumerate(docs) if p is not None]
+            if not live:
+                return live, None
+            texts = [docs[i] for i in live]
+            # the passages go through `aembed_query` like in the reference (hyde.py:229-230) -- NOT `embed_documents`:
+            # asymmetric models encode queries and documents differently, and the block form must return what the
+            # per-query form returns.  A model may offer `embed_queries` (a batch of query-side embeddings) to batch this.
+            if hasattr(self.embedding, "embed_queries"):
+                vecs = self.embedding.embed_queries(texts)
+            else:
+                async def embed_all():
+                    return await asyncio.gather(*[self.embedding.aembed_query(t) for t in texts])
+
+                vecs = asyncio.run(embed_all())
+            return live, np.asarray(vecs, dtype=np.float32)
+
+        # generation + embedding: rank-local work that samples and may fail -> rank 0 alone, one broadcast of (live, vectors);
+        # the retries above issue no collective
+        world = getattr(self._service, "_world", None)
+        live, vecs = world.from_root(generate_and_embed) if world is not None else generate_and_embed()
         out: list[list[dict] | None] = [None] * len(query_ids)
         if not live:
             return out
-        texts = [docs[i] for i in live]
-
-        # the passages go through `aembed_query` like in the reference (hyde.py:229-230) -- NOT `embed_documents`:
-        # asymmetric models encode queries and documents differently, and the block form must return what the
-        # per-query form returns.  A model may offer `embed_queries` (a batch of query-side embeddings) to batch this.
-        if hasattr(self.embedding, "embed_queries"):
-            vecs = self.embedding.embed_queries(texts)
-        else:
-            async def embed_all():
-                return await asyncio.gather(*[self.embedding.aembed_query(t) for t in texts])
-
-            vecs = asyncio.run(embed_all())
-        block = self._service._single_block(np.asarray(vecs, dtype=np.float32), top_k, "chunk")
+        block = self._service._single_block(vecs, top_k, "chunk")
         for i, res in zip(live, block):
             out[i] = res
         return out

@@ -248,7 +248,7 @@ class Mi355RetrievalService:
                 raise TypeError(
                     f"session_factory() returned a {type(probe).__name__}, not a store; a SQLAlchemy sessionmaker is served "
                     "through the reference's RetrievalPipelineService, which needs `autorag_research` importable") from e
-            self._uow_store = UowStore(RetrievalPipelineService(session_factory, schema))
+            self._uow_store = UowStore(RetrievalPipelineService(session_factory, schema), require_total_order=self._world is not None)
 
     # ---- plumbing ----
     def _store(self) -> Any:
@@ -599,7 +599,11 @@ class Mi355RetrievalService:
                     results = block_func(qids, top_k)
                 except Exception as e:  # noqa: BLE001
                     block_err = e
-                # (one process per GPU: the page is answered as a block only if every rank's block succeeded)
+                # (one process per GPU: the page is answered as a block only if every rank's block succeeded.  LIMIT of this
+                # agreement: it reconciles failures that happen OUTSIDE a collective.  A rank that dies, or raises from a
+                # rank-local HIP / out-of-memory error, while its peers are already inside the block's all-gather leaves them
+                # blocked there -- what ends that is the process group's own timeout (`init_process_group(timeout=...)`,
+                # torchrun's failure detection), not this code; INTEGRATION.md "one process per GPU" says so.)
                 if not ((block_err is None) if world is None else world.agree(block_err is None)):
                     # one bad query (missing / malformed embedding, too many query vectors for a block, an embedding-batch
                     # error) must not abort the run: the page falls back to the reference's per-query path, where retries,

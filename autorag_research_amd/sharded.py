@@ -280,8 +280,10 @@ class ShardedSearcher:
             packed = torch.empty((2, B, k), dtype=torch.int64, device=dev)
             cur = torch.cuda.current_stream(dev)
             # torch's default stream has handle 0, which the library reads as "no stream to wait for": the upload of `qd` and
-            # the caching allocator's reuse of `d32` / `packed` are ordered against the index's own stream by the host instead
-            cur.synchronize()
+            # the caching allocator's reuse of `d32` / `packed` are then ordered against the index's own stream by the host;
+            # a real stream handle is ordered by the library itself (it makes its stream wait for the caller's)
+            if cur.cuda_stream == 0:
+                cur.synchronize()
             self.index.search_maxsim_device(qd.data_ptr(), q_offsets, k, d32.data_ptr(), packed[1].data_ptr(), cur.cuda_stream)
             packed[0].view(torch.float64).copy_(d32)
             gathered = torch.empty((self.world, 2, B, k), dtype=torch.int64, device=dev)

@@ -186,9 +186,14 @@ class UowStore:
 
     EXPORT_PAGE = 50_000
 
-    def __init__(self, ref_service: Any):
+    def __init__(self, ref_service: Any, require_total_order: bool = False):
         self._svc = ref_service
         self._tables: dict[str, ChunkTable] = {}
+        # one process per GPU: every rank must export the SAME order (global row ids are positions in it) -> primary-key order
+        # is enforced and keys that cannot be ordered are an error.  One process: the order the repository returned is kept
+        # when it is already the key order (the keyed path: `ORDER BY id`) -- no O(n log n) Python sort over millions of rows
+        # -- and unorderable keys only cost a warning.
+        self.require_total_order = require_total_order
 
     # ---- pipelines ----
     def get_or_create_pipeline(self, name: str, config: dict[str, Any]):
@@ -267,11 +272,19 @@ class UowStore:
         # table still pages with an unordered `get_all(limit, offset)`; N ranks scanning it at once is exactly what
         # PostgreSQL's synchronize_seqscans reorders.  (Ties between equal distances fall to the smaller key -- the
         # reference leaves that order to the database.)  service._unit() compares a digest of the result across ranks.
+        order = None
         try:
-            order = sorted(range(len(ids)), key=ids.__getitem__)
+            if not all(ids[i] <= ids[i + 1] for i in range(len(ids) - 1)):   # one linear pass; usually already ordered
+                order = sorted(range(len(ids)), key=ids.__getitem__)
         except TypeError as e:  # mixed key types cannot be ordered: no deterministic export exists
-            raise RuntimeError(f"{repo_name}: primary keys of mixed types cannot be ordered") from e
-        if order != list(range(len(ids))):
+            if self.require_total_order:
+                raise RuntimeError(f"{repo_name}: primary keys of mixed types cannot be ordered") from e
+            import logging  # noqa: PLC0415
+
+            logging.getLogger("AutoRAG-Research").warning(
+                f"{repo_name}: primary keys of mixed types cannot be ordered; keeping the order the repository returned "
+                "(ties between equal distances then follow that order)")
+        if order is not None:
             ids, contents = [ids[i] for i in order], [contents[i] for i in order]
             single, multi = [single[i] for i in order], [multi[i] for i in order]
         t = ChunkTable(ids=ids, contents=contents)

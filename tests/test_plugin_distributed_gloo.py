@@ -307,3 +307,91 @@ def test_candidate_rescorers_run_on_the_sharded_stores(tmp_path, oracle):
             got = r["heaven"][qid]
             assert [x["doc_id"] for x in got] == [e["doc_id"] for e in exp]
             assert np.allclose([x["score"] for x in got], [e["score"] for e in exp], rtol=0, atol=1e-6)
+
+
+def _hyde_worker(rank: int, world: int, port: int, out_dir: str):
+    """HyDE under a _World: the LLM samples and may fail per rank -- rank 0 alone generates and embeds, every
+    rank searches the same vectors, and a rank-local LLM fault on rank 1 (which never calls its LLM) or a flaky LLM on rank 0
+    (retried inside the page, no collective per retry) leaves both ranks in step."""
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import asyncio
+
+    import torch.distributed as dist
+
+    import autorag_research_amd.service as svc
+    from helpers import OracleIndex, build_golden_stores
+    from autorag_research_amd.hyde import Mi355HyDEPipelineConfig
+
+    svc.Mi355Index = OracleIndex
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    store, _ = build_golden_stores()
+    del store.queries["q_noemb"]
+    store.query_order.remove("q_noemb")
+    calls = {"llm": 0, "embed": 0}
+
+    class LLM:
+        """rank 1's model is broken outright; rank 0's fails on its first call for q2 and then answers -- with a rank-dependent
+        text, so that ranks that each asked their own model would search different vectors"""
+
+        def __init__(self):
+            self.seen = set()
+
+        async def ainvoke(self, prompt):
+            calls["llm"] += 1
+            if rank == 1:
+                raise RuntimeError("this rank's LLM endpoint is down")
+            q = prompt.split("Question: ")[1].split("\n")[0]
+            if q == "query text 2" and q not in self.seen:
+                self.seen.add(q)
+                raise TimeoutError("transient")
+            return f"passage written on rank {rank} about: {q}"
+
+    class Emb:
+        async def aembed_query(self, text):
+            calls["embed"] += 1
+            seed = sum((i + 1) * b for i, b in enumerate(text.encode())) % (2**32)
+            return [float(x) for x in np.random.default_rng(seed).standard_normal(32).astype(np.float32)]
+
+    cfg = Mi355HyDEPipelineConfig(name="hyde_world", llm=LLM(), embedding=Emb(), top_k=3, batch_size=4, max_retries=3, retry_delay=0.0)
+    p = cfg.get_pipeline_class()(session_factory=lambda: store, name=cfg.name, schema=None, **cfg.get_pipeline_kwargs())
+    out = {"run": p.run(**cfg.get_run_kwargs())}
+    out["rows"] = sorted(((str(q), c, s) for (pid, q), lst in store.chunk_results.items() for c, s in lst))
+    out["calls_after_run"] = dict(calls)
+    out["by_text"] = asyncio.run(p.retrieve("a question nobody stored", top_k=3))
+    out["by_id"] = asyncio.run(p._retrieve_by_id("q1", 3))
+    out["calls"] = dict(calls)
+    p.close()
+    with open(os.path.join(out_dir, f"h{rank}.json"), "w") as f:
+        json.dump(out, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_hyde_generates_on_rank_zero_only_and_survives_rank_local_llm_faults(tmp_path, oracle):
+    import torch.multiprocessing as mp
+
+    world, port = 2, _free_port()
+    mp.spawn(_hyde_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (json.loads((tmp_path / f"h{r}.json").read_text()) for r in range(world))
+    for r in (r0, r1):
+        assert r["run"]["total_queries"] == 6 and r["run"]["failed_queries"] == [] and r["run"]["total_results"] == 18
+    assert r1["rows"] == [] and len(r0["rows"]) == 18        # rank 0 alone persists
+    # rank 1's broken LLM was never asked; rank 0 asked 6 + 1 retry in the run, then once per ad-hoc call
+    assert r1["calls"] == {"llm": 0, "embed": 0}
+    assert r0["calls_after_run"] == {"llm": 7, "embed": 6} and r0["calls"] == {"llm": 9, "embed": 8}
+    # every rank returned the SAME ad-hoc answers (rank 0's passage, rank 0's vector, all shards searched)
+    assert r0["by_text"] == r1["by_text"] and len(r0["by_text"]) == 3
+    assert r0["by_id"] == r1["by_id"] and len(r0["by_id"]) == 3
+    # and they are the exact top-3 of rank 0's vectors over the WHOLE table
+    from helpers import build_golden_stores
+
+    store, g = build_golden_stores()
+    text = "passage written on rank 0 about: query text 1"
+    seed = sum((i + 1) * b for i, b in enumerate(text.encode())) % (2**32)
+    v = np.random.default_rng(seed).standard_normal(32).astype(np.float32)
+    od, orow = oracle.topk_search(g["C"], v[None, :], 3)
+    assert [d["doc_id"] for d in r0["by_id"]] == [g["ids"][int(i)] for i in orow[0]]
+    assert [d["score"] for d in r0["by_id"]] == [1.0 - float(x) for x in od[0]]
