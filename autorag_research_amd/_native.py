@@ -28,6 +28,7 @@ ABI_SYMBOLS = [
     "mi355dr_search_sharded_device", "mi355dr_set_option", "mi355dr_get_stat",
     "mi355dr_reset_stats", "mi355dr_timer_start", "mi355dr_timer_stop", "mi355dr_synchronize",
     "mi355dr_dev_alloc", "mi355dr_dev_free", "mi355dr_dev_upload", "mi355dr_dev_download",
+    "mi355dr_diag_mfma_stream",
     "mi355dr_debug_screen_dense", "mi355dr_debug_screen_bound", "mi355dr_debug_i8_state", "mi355dr_debug_rescore",
 ]
 
@@ -174,8 +175,19 @@ def load() -> ctypes.CDLL:
     L.mi355dr_debug_i8_state.argtypes = [vp, f32p, c_int, f32p, f32p, i64, i64, f32p, f32p]
     L.mi355dr_debug_rescore.restype = c_int
     L.mi355dr_debug_rescore.argtypes = [vp, f32p, c_int, i32p, i64p, i64, f32p, f64p]
+    L.mi355dr_diag_mfma_stream.restype = c_int
+    L.mi355dr_diag_mfma_stream.argtypes = [c_int, c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
     _lib = L
     return L
+
+
+def diag_mfma_stream(device: int, fmt: str, seconds: float) -> float:
+    """Bare MFMA stream rate in TOP/s (`fmt`: "i8" | "bf16") measured for `seconds` on `device` (mi355dr_diag_mfma_stream)."""
+    out = ctypes.c_double(0.0)
+    rc = load().mi355dr_diag_mfma_stream(int(device), {"i8": 0, "bf16": 1}[fmt], float(seconds), ctypes.byref(out))
+    if rc != 0:
+        raise NativeError(rc, "mi355dr_diag_mfma_stream failed")
+    return float(out.value)
 
 
 def check(handle, rc: int) -> None:

@@ -144,7 +144,10 @@ def run_maxsim(args, n_docs: int, tokens: str, nq: int, steps: int, warmup: int,
         torch.cuda.synchronize()
         idx.add_multivec_device(x.data_ptr(), np.concatenate([[0], np.cumsum(ln)]).astype(np.int64))
         if keep is None and cpu_sample_docs:
-            S = min(cpu_sample_docs, len(ln))
+            # the CPU baseline's sample: the first docs of the store, about `cpu_sample_docs` x 106 token vectors of them (the
+            # mean text doc) whatever the document length -- 5 ... 10 s of oracle work at 16 queries (the
+            # 1 500-doc sample was 0.4 s, too small to be a baseline)
+            S = max(1, min(int(np.searchsorted(np.cumsum(ln), cpu_sample_docs * 106)), len(ln)))
             keep = (x[: int(ln[:S].sum())].cpu().numpy(), np.concatenate([[0], np.cumsum(ln[:S])]).astype(np.int64))
         del x
     torch.cuda.synchronize()
@@ -237,10 +240,42 @@ def run_maxsim(args, n_docs: int, tokens: str, nq: int, steps: int, warmup: int,
     if probe_out is not None:
         out["power_probe"] = probe_out
     idx.close()
+    if probe and scr_n:
+        # the denominator of frac_of_power_limited_stream measured in this run (bare bf16 MFMA stream on this chip)
+        try:
+            bs = bare_stream_probe(dev.index, False)
+            out["roofline"]["bare_stream"] = bs
+            if bs.get("tops"):
+                out["roofline"]["frac_of_power_limited_stream_replayed"] = out["roofline"]["frac_of_power_limited_stream"]
+                out["roofline"]["frac_of_power_limited_stream"] = round(issued_flops / scr_s / 1e12 / bs["tops"], 4)
+        except Exception as e:  # noqa: BLE001
+            out["roofline"]["bare_stream"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 
-def power_probe(run_n_steps, s_per_step: float, seconds: float = 2.0) -> dict:
+def bare_stream_probe(device: int, i8: bool, seconds: float = 2.5) -> dict:
+    """The matrix pipe's rate on THIS chip, in THIS run, with nothing but the screen's MFMA instruction on Gaussian operands
+    (mi355dr_diag_mfma_stream), and the socket power / clock it settles at: the denominator of
+    `roofline.frac_of_power_limited_stream`."""
+    from autorag_research_amd import _native
+
+    box = {}
+
+    def run(_n):
+        box["tops"] = _native.diag_mfma_stream(device, "i8" if i8 else "bf16", seconds)
+
+    pp = power_probe(run, seconds, seconds, min_steps=1)
+    if "tops" not in box:
+        return {"error": pp.get("error", "the stream did not run")}
+    return {"tops": round(box["tops"], 1), "watts": pp.get("socket_power_W_median"), "mhz": pp.get("sclk_MHz_median"),
+            "power_cap_W": pp.get("power_cap_W"), "seconds": seconds,
+            "instruction": "v_mfma_i32_32x32x32_i8" if i8 else "v_mfma_f32_32x32x16_bf16",
+            "note": "bare MFMA stream measured in this run after the timed region: operands in registers (Gaussian, as the "
+                    "shadows hold), four accumulators, two waves per SIMD on every CU, no memory traffic; settled rate of the "
+                    "second half of the launches; rocm-smi polled next to it"}
+
+
+def power_probe(run_n_steps, s_per_step: float, seconds: float = 2.0, min_steps: int = 20) -> dict:
     """Socket power and shader clock WHILE the steps run: `rocm-smi --showpower --showclocks` polled from a thread next to
     ~`seconds` of back-to-back steps.  Medians over the samples taken after the first 0.4 s (the governor's ramp)."""
     import re
@@ -271,7 +306,7 @@ def power_probe(run_n_steps, s_per_step: float, seconds: float = 2.0) -> dict:
     th = threading.Thread(target=poll, daemon=True)
     th.start()
     t0 = time.perf_counter()
-    n = max(20, int(seconds / max(s_per_step, 1e-4)))
+    n = max(min_steps, int(seconds / max(s_per_step, 1e-4)))
     run_n_steps(n)
     dt = time.perf_counter() - t0
     stop.set()
@@ -343,7 +378,7 @@ def maxsim_traffic(roof: dict, tokens: str, docs: int) -> None:
 def main_maxsim(args) -> None:
     """Secondary workload as the whole bench line: `python bench.py --workload maxsim [--docs N] [--tokens text|page]`."""
     r = run_maxsim(args, args.docs, args.tokens, 32 if args.tokens == "text" else 24, args.steps, args.warmup,
-                   0 if args.no_cpu_baseline else 2000, probe=not args.no_extras)
+                   0 if args.no_cpu_baseline else 20000, probe=not args.no_extras)
     out = {"metric": "queries/sec", "value": r["queries_per_s"], "unit": "queries/s", "n_gpus": 1, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",

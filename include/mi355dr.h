@@ -261,6 +261,13 @@ int mi355dr_debug_i8_state(mi355dr_index* idx, const float* queries, int B, floa
 int mi355dr_debug_rescore(mi355dr_index* idx, const float* queries, int B, const int32_t* pair_q,
                           const int64_t* pair_row, int64_t n_pairs, float* out_dot, double* out_dist);
 
+/* ---- measurement support (bench.py; SURVEY 8(d): "re-measure with ... an MFMA microbench on the box and use the measured
+ * peaks in the report") -- no reference counterpart.  A BARE stream of the MFMA instruction a screen kernel issues (format 0:
+ * v_mfma_i32_32x32x32_i8 on Gaussian int8 operands like the int8 shadow's; 1: v_mfma_f32_32x32x16_bf16), operands in registers,
+ * every CU busy, no memory traffic, for `seconds`; *out_tops = the settled rate in 10^12 operations per second.  Needs no
+ * index; allocates and frees its own 4 MiB. */
+int mi355dr_diag_mfma_stream(int device, int format, double seconds, double* out_tops);
+
 #ifdef __cplusplus
 }
 #endif

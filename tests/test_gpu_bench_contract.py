@@ -52,7 +52,16 @@ def test_default_shape_line_on_a_small_corpus(native_built):
     # the PCIe-inclusive rate is a top-level sibling of `value`; the >= 2 s sustained figure sits next to the burst
     v = d["value_pcie_inclusive"]
     assert v["unit"] == "queries/s" and 0 < v["value"] < d["value"] * 1.05 and v["ms_per_step"] > 0
+    # the power-cap argument is observable in the line itself: the bare stream of the screen's MFMA instruction, measured in this
+    # run on this chip, and the screen's fraction of it DERIVED from that measurement (not from a constant of another box)
+    bs = r["bare_stream"]
+    assert "error" not in bs, bs
+    assert bs["instruction"] == "v_mfma_i32_32x32x32_i8" and 1500 < bs["tops"] < 5100 and bs["seconds"] >= 2
+    assert abs(r["frac_of_power_limited_stream"] - r["achieved"] / bs["tops"]) < 1e-3
+    assert r["power_limited_stream"]["rate"] == bs["tops"]
+    assert r["kernel"].startswith("k_screen_rq<int8>")        # d = 768 int8: the register-resident-query form
     if "error" not in x["power_probe"]:
+        assert d["sustained"] == x["sustained"]               # top-level: the driver's parsed record keeps it
         su = x["sustained"]
         assert su["seconds"] >= 1.5 and su["steps"] >= 20 and su["ms_per_step"] > 0
         assert abs(su["queries_per_s"] - su["steps"] * d["config"]["queries_per_step"] / su["seconds"]) <= 1e-3 * su["queries_per_s"]
