@@ -200,17 +200,32 @@ __device__ __forceinline__ void ms_compute_piece(f32x16 (&acc)[4], const float4 
 // B fragments: LDS image [col][dpad + 4] floats (the +4 pad makes the 16-lane groups of ds_read_b128 hit 16
 // distinct 16-B slots).  The doc-token piece (32 rows x 128 dims = 16 float4 per lane) is register-resident
 // and reused for every query column block; the next piece is prefetched while the current one is consumed.
-__global__ __launch_bounds__(kMsThreads, 2) void k_maxsim(MsArgs a) {
+__global__ __launch_bounds__(kMsThreads, 2) void k_maxsim(const MsArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* qs = (float*)smem;
     const int ld = a.dpad + 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // The argument block is read-only and its two small arrays are only ever indexed at compile time (unrolled selects):
+    // a kernel that writes its by-value arguments, or indexes them with a run-time value, gets the whole block copied to the
+    // stack first (65 scratch instructions in the round-4 build; pinned by tests/test_build_pipeline.py).
+    const int32_t* doc_list = a.doc_list;
+    float* dist = a.dist;
+    const float* dist_in = a.dist_in;
+    const int* n_items_dev = a.n_items_dev;
+    const float* qtok = a.qtok;
+    int nql = a.nq_launch;           // queries scored together by this workgroup: <= 4 (list mode: the one of blockIdx.y)
+    int qc0[4], qln[4];              // their first column / token count (registers: every index below is a constant)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        qc0[i] = a.q_col0[i];
+        qln[i] = a.q_len[i];
+    }
     if (a.list_stride > 0) {  // per-query candidate lists
         const int y = blockIdx.y;
-        a.doc_list += (int64_t)y * a.list_stride;
-        a.dist += (int64_t)y * a.list_stride;
-        if (a.dist_in) a.dist_in += (int64_t)y * a.list_stride;
-        a.n_items_dev += 2 * y;
+        doc_list += (int64_t)y * a.list_stride;
+        dist += (int64_t)y * a.list_stride;
+        if (dist_in) dist_in += (int64_t)y * a.list_stride;
+        n_items_dev += 2 * y;
         int c0 = a.q_col0[0], ln = a.q_len[0];
 #pragma unroll
         for (int i = 1; i < kMsPassQueries; ++i)
@@ -218,20 +233,22 @@ __global__ __launch_bounds__(kMsThreads, 2) void k_maxsim(MsArgs a) {
                 c0 = a.q_col0[i];
                 ln = a.q_len[i];
             }
-        a.qtok += (int64_t)c0 * a.dpad;  // this query's columns become columns 0.. of the staged image (any c0)
-        a.q_col0[0] = 0;
-        a.q_len[0] = ln;
-        a.nq_launch = 1;
+        qtok += (int64_t)c0 * a.dpad;  // this query's columns become columns 0.. of the staged image (any c0)
+        qc0[0] = 0;
+        qln[0] = ln;
+        nql = 1;
     }
-    const int64_t n_items = a.n_items_dev ? min((int64_t)*a.n_items_dev, a.n_items) : a.n_items;
+    const int64_t n_items = n_items_dev ? min((int64_t)*n_items_dev, a.n_items) : a.n_items;
     const bool coop = a.coop != 0;
     if ((int64_t)blockIdx.x * (coop ? 1 : 4) >= n_items) return;  // nothing for this workgroup: skip staging the query block
     float* red = (float*)(smem + a.red_off);
     int ncb = 0;   // column blocks in use
-    for (int qi = 0; qi < a.nq_launch; ++qi) ncb = max(ncb, (a.q_col0[qi] + a.q_len[qi] + 31) / 32);
+#pragma unroll
+    for (int qi = 0; qi < 4; ++qi)
+        if (qi < nql) ncb = max(ncb, (qc0[qi] + qln[qi] + 31) / 32);
     for (int i = tid; i < ncb * 32 * (a.dpad / 4); i += kMsThreads) {
         const int c = i / (a.dpad / 4), k4 = i - c * (a.dpad / 4);
-        *(float4*)(qs + c * ld + k4 * 4) = *(const float4*)(a.qtok + (int64_t)c * a.dpad + k4 * 4);
+        *(float4*)(qs + c * ld + k4 * 4) = *(const float4*)(qtok + (int64_t)c * a.dpad + k4 * 4);
     }
     __syncthreads();
     const int half = lane >> 5, col = lane & 31;
@@ -239,13 +256,13 @@ __global__ __launch_bounds__(kMsThreads, 2) void k_maxsim(MsArgs a) {
     // docs are dealt round-robin to the waves of the grid so long and short docs mix
     // (with a doc list the grid is small and fixed -- the real list length is only known on the device -- and the
     // waves stride over the list until it ends)
-    for (int dw = 0; a.doc_list || dw < kMsDocsPerWave; ++dw) {
+    for (int dw = 0; doc_list || dw < kMsDocsPerWave; ++dw) {
     const int64_t item = coop ? (int64_t)dw * gridDim.x + blockIdx.x : ((int64_t)dw * gridDim.x + blockIdx.x) * 4 + wave;
     if (item >= n_items) break;  // (cooperative: the same item in all four waves -- every branch on it is workgroup-uniform)
-    const int64_t doc = a.doc_list ? (int64_t)a.doc_list[item] : item;
+    const int64_t doc = doc_list ? (int64_t)doc_list[item] : item;
     if (doc < 0 || doc >= a.n_docs) {  // (subset scoring) not a stored doc
         if (lane == 0 && (!coop || wave == 0))
-            for (int qi = 0; qi < a.nq_launch; ++qi) a.dist[(int64_t)qi * a.n_items + item] = __uint_as_float(0x7FC00000u);
+            for (int qi = 0; qi < nql; ++qi) dist[(int64_t)qi * a.n_items + item] = __uint_as_float(0x7FC00000u);
         continue;
     }
     const int64_t b0 = a.blk_off[doc], b1 = a.blk_off[doc + 1];
@@ -308,10 +325,12 @@ __global__ __launch_bounds__(kMsThreads, 2) void k_maxsim(MsArgs a) {
         if (wave != 0) continue;
     }
     // per query: distance = sum over its tokens (in order) of -(max dot); empty docs are skipped by the select
-    for (int qi = 0; qi < a.nq_launch; ++qi) {
-        float accd = a.dist_in ? a.dist_in[(int64_t)qi * a.n_items + item] : 0.0f;  // (wave-uniform address)
-        for (int j = 0; j < a.q_len[qi]; ++j) {
-            const int c = a.q_col0[qi] + j;
+#pragma unroll
+    for (int qi = 0; qi < 4; ++qi) {
+        if (qi >= nql) break;
+        float accd = dist_in ? dist_in[(int64_t)qi * a.n_items + item] : 0.0f;  // (wave-uniform address)
+        for (int j = 0; j < qln[qi]; ++j) {
+            const int c = qc0[qi] + j;
             float v = 0.0f;
 #pragma unroll
             for (int cbi = 0; cbi < 4; ++cbi)
@@ -320,7 +339,7 @@ __global__ __launch_bounds__(kMsThreads, 2) void k_maxsim(MsArgs a) {
             if (a.clamp0) v = fmaxf(v, 0.0f);
             accd = accd + (-v);
         }
-        if (lane == 0) a.dist[(int64_t)qi * a.n_items + item] = b1 > b0 ? accd : __uint_as_float(0x7FC00000u);
+        if (lane == 0) dist[(int64_t)qi * a.n_items + item] = b1 > b0 ? accd : __uint_as_float(0x7FC00000u);
     }
     }  // docs of this wave
 }

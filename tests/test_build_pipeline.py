@@ -191,6 +191,21 @@ def maxsim_asm_text(tmp_path_factory):
     return out.read_text()
 
 
+def test_no_kernel_of_the_library_touches_the_stack(lib_asm_text, maxsim_asm_text):
+    """Not one `scratch_*` instruction and a zero private segment in EVERY kernel of mi355dr.hip and mi355dr_maxsim.hip.  Round 4's
+    k_maxsim -- the exact MaxSim kernel behind every candidate re-score and `mi355dr_maxsim_subset` -- carried 65 of them: it
+    wrote to its by-value argument block and indexed the block's arrays with run-time values, so the whole block was copied to
+    the stack at entry and read back from there."""
+    import re
+
+    for text in (lib_asm_text, maxsim_asm_text):
+        kernels = re.findall(r"\n(_ZN5mi355[^\n:]+):[^\n]*\n(.*?)\.end_amdhsa_kernel", text, re.S)
+        assert len(kernels) >= 20
+        for name, body in kernels:
+            assert not re.search(r"^\s*scratch_", body, re.M), name
+            assert ".amdhsa_private_segment_fixed_size 0" in body, name
+
+
 @pytest.mark.parametrize("form", ["bps2", "bps4", "pipelined"])
 @pytest.mark.parametrize("ncb", [12, 16])
 def test_maxsim_workgroup_screen_keeps_its_ring_in_flight(maxsim_asm_text, ncb, form):

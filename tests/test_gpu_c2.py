@@ -61,31 +61,35 @@ def test_c2_slice_matches_oracle(pkg, oracle, torch_cuda, metric):
     print("C2 slice stats", metric, stats)
 
 
-def test_c2_two_million_rows_properties(pkg, torch_cuda):
-    """N = 2 M, d = 768, inner product, k = 100 (the C2 shape at a size the oracle cannot finish): size-independent checks --
+def test_c2_full_size_properties(pkg, torch_cuda):
+    """N = 2 681 468 (BEIR-NQ's corpus size), d = 768, inner product, k = 100 -- config C2 at FULL size, which the
+    oracle cannot finish: size-independent checks --
     (1) screen path == guaranteed exact-scan path on a query subset, bit for bit; (2) the index searched as two halves with
     row offsets and merged by (distance, row) == the index searched whole; (3) every list is sorted by (distance, row)."""
     from autorag_research_amd import synth
 
     torch = torch_cuda
-    d, k, n_chunks = 768, 100, 8
+    d, k, n_total = 768, 100, 2_681_468
+    n_chunks = (n_total + synth.CHUNK_ROWS - 1) // synth.CHUNK_ROWS
     an = synth.Anisotropic(torch, d, "cuda")
     Q = an.queries(256)
     whole = pkg.Mi355Index(d, "ip")
     lo, hi = pkg.Mi355Index(d, "ip"), pkg.Mi355Index(d, "ip")
-    n = 0
+    n, n_lo = 0, 0
     for c in range(n_chunks):
-        x = an.chunk(c, synth.CHUNK_ROWS)
+        x = an.chunk(c, min(synth.CHUNK_ROWS, n_total - c * synth.CHUNK_ROWS))
         torch.cuda.synchronize()
         whole.add_device(x.data_ptr(), x.shape[0])
         (lo if c < n_chunks // 2 else hi).add_device(x.data_ptr(), x.shape[0])
         n += x.shape[0]
+        n_lo += x.shape[0] if c < n_chunks // 2 else 0
         del x
-    hi.set_option("row_offset", n // 2)
+    assert n == n_total
+    hi.set_option("row_offset", n_lo)
     Qh = Q.cpu().numpy()
     dist, rows = whole.search(Qh, k)
     stats = {s: whole.stat(s) for s in ("candidates", "rescored", "retry_queries", "fallback_queries", "screen_dtype_active")}
-    print("C2 2M stats", stats)
+    print("C2 full-size stats", stats)
     assert rows.min() >= 0 and rows.max() < n
     key = np.stack([dist, rows.astype(np.float64)], axis=-1)
     assert (np.diff(dist, axis=1) >= 0).all()

@@ -198,7 +198,7 @@ def test_persistent_screen_shapes(pkg, oracle, screen, n, d, B, k):
 
 
 @pytest.mark.parametrize("n,d,B,k", [(70_000, 768, 1024, 10), (40_000, 384, 300, 10), (33_000, 128, 257, 7), (26_000, 200, 513, 3),
-                                      (30_000, 500, 700, 10), (90_000, 640, 129, 20), (9_100, 768, 600, 100), (30_000, 896, 400, 10)])
+                                      (30_000, 500, 700, 10), (90_000, 640, 129, 20), (120_000, 768, 600, 100), (30_000, 896, 400, 10)])
 def test_register_resident_query_screen_equals_tile_screen(pkg, oracle, n, d, B, k):
     """Query blocks above 128 over an int8 shadow of at most 768 B per row go through k_screen_rq (query operand resident in
     registers, 128-row tiles); option screen_rq = 0 keeps k_screen256c: same results either way, equal to the oracle's.
