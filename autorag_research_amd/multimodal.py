@@ -22,11 +22,12 @@ from __future__ import annotations
 import asyncio
 import io
 from pathlib import Path
-from typing import Any
+from typing import Any, ClassVar
 
 import numpy as np
 
-from .embeddings import MultiVectorEmbedding, MultiVectorMultiModalEmbedding, SingleVectorMultiModalEmbedding
+from .embeddings import (MultiVectorEmbedding, MultiVectorMultiModalEmbedding, SingleVectorMultiModalEmbedding,
+                         init_multivector_base)
 
 COL_MODEL_REGISTRY: dict[str, tuple[str, str]] = {  # reference colpali.py:22-29
     "flor": ("ColFlor", "ColFlorProcessor"),
@@ -108,12 +109,13 @@ class _EngineBacked:
 class Mi355ColPaliEmbeddings(_EngineBacked, MultiVectorMultiModalEmbedding):
     """ColPali-style late-interaction embeddings (text and page images), same interface as `ColPaliEmbeddings`."""
 
-    SUPPORTED_MODEL_TYPES = list(COL_MODEL_REGISTRY.keys())
+    SUPPORTED_MODEL_TYPES: ClassVar[list[str]] = list(COL_MODEL_REGISTRY.keys())
 
     def __init__(self, model_name: str = "vidore/colpali-v1.3", model_type: str = "pali", device: str = "cpu",
                  torch_dtype: Any = "bfloat16", model: Any | None = None, processor: Any | None = None, batch_size: int = 10,
                  drop_padding: bool = False, embed_batch_size: int | None = None):
         batch_size = batch_size if embed_batch_size is None else embed_batch_size   # (the reference's YAML key, colpali.yaml)
+        init_multivector_base(self, model_name, batch_size)
         self._setup(COL_MODEL_REGISTRY, "ColPaliEmbeddings", model_name, model_type, device, torch_dtype, model, processor,
                     batch_size)
         # The reference keeps EVERY row the model returns for an item of a batch, the padded positions included
@@ -210,7 +212,7 @@ class Mi355ColPaliEmbeddings(_EngineBacked, MultiVectorMultiModalEmbedding):
 class Mi355BiPaliEmbeddings(_EngineBacked, SingleVectorMultiModalEmbedding):
     """BiPali-style single-vector embeddings (text and page images), same interface as `BiPaliEmbeddings`."""
 
-    SUPPORTED_MODEL_TYPES = list(BI_MODEL_REGISTRY.keys())
+    SUPPORTED_MODEL_TYPES: ClassVar[list[str]] = list(BI_MODEL_REGISTRY.keys())
 
     def __init__(self, model_name: str = "vidore/bipali", model_type: str = "pali", device: str = "cpu",
                  torch_dtype: Any = "bfloat16", model: Any | None = None, processor: Any | None = None, batch_size: int = 10,

@@ -13,7 +13,8 @@ embeddings.
 What is compared (reference file:line) and the tolerance each check is held to:
 
   bge / MiniLM     sentence_transformers.SentenceTransformer(path).encode(texts, normalize_embeddings=True)   vs
-                   embeddings.TorchEncoderEmbeddings(AutoModel, AutoTokenizer, pooling="cls" | "mean")
+                   embeddings.load_embedding_model("mi355_bge_base" | "mi355_minilm")  (the YAML names: TorchEncoderEmbeddings
+                   .from_pretrained, pooling "cls" | "mean")
                    (the reference loads such models through langchain HuggingFaceEmbeddings configs, configs/embedding/*.yaml;
                    bge-base: CLS pooling + L2 norm, MiniLM: mean pooling + L2 norm)
                    max |delta| <= 2e-5 (fp32 on both sides, different kernels), cosine >= 1 - 1e-6 per text
@@ -60,16 +61,20 @@ def report(name: str, ok: bool, details: str) -> None:
 
 
 def check_single_vector(path: str, pooling: str, device: str) -> None:
-    import torch
-    from sentence_transformers import SentenceTransformer
-    from transformers import AutoModel, AutoTokenizer
+    import os
 
-    from autorag_research_amd.embeddings import TorchEncoderEmbeddings
+    from sentence_transformers import SentenceTransformer
+
+    from autorag_research_amd.embeddings import load_embedding_model
 
     ref = SentenceTransformer(path, device=device)
     want = ref.encode(TEXTS + QUERIES, normalize_embeddings=True, convert_to_numpy=True).astype(np.float32)
-    enc = TorchEncoderEmbeddings(AutoModel.from_pretrained(path).to(torch.float32), AutoTokenizer.from_pretrained(path),
-                                 pooling=pooling, normalize=True, device=device)
+    # the model BY CONFIG NAME, the way a pipeline YAML's `embedding_model:` string resolves it (configs/embedding/mi355_*.yaml ->
+    # TorchEncoderEmbeddings.from_pretrained), with the YAML's environment variables pointed at the given directory
+    name, var = ("mi355_bge_base", "MI355_BGE_PATH") if pooling == "cls" else ("mi355_minilm", "MI355_MINILM_PATH")
+    os.environ.update({var: path, "MI355_ENCODER_DEVICE": device, "MI355_ENCODER_DTYPE": "float32"})
+    enc = load_embedding_model(name)
+    assert enc.pooling == pooling
     got = np.asarray(enc.embed_documents(TEXTS) + [enc.embed_query(q) for q in QUERIES], dtype=np.float32)
     delta = float(np.abs(got - want).max())
     cos = float((got * want).sum(axis=1).min())
