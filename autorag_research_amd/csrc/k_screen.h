@@ -276,6 +276,188 @@ __device__ __forceinline__ void screen_test_block_cold(int* status, f32x16 acc, 
         que_n = screen_queue_hits_body<I8>(acc, any ? 1 : 0, q, rbase, row_end, th, blk.m, blk.ek, lds_addr(que), que_n, status);
 }
 
+// ---- k_screen_rq's form of the hit path (round 5): a per-wave queue of HIT LANES -----------------------------------------
+// What a hit cost before (tools/screen_ab THRZ, profiles/r05_hit_path.txt): the out-of-line append is entered through the
+// calling convention's `s_waitcnt vmcnt(0)` -- the wave waits for every LDS-DMA piece it has in flight, the youngest issued a
+// few hundred cycles earlier -- and then walks its sixteen registers with a scalar branch each, while the other seven waves of
+// the workgroup wait at the next K-step barrier: 0.22 ns per hit chip-wide in a hit-dense chunk (3 hits per block), 0.67 ns
+// in the last chunks (one hit per ten blocks: one call per hit) -- ~0.55 ms of a 6.9 ms pass at N = 10 M.
+// Now a block with a hit costs the hot loop five LDS stores and no call: every lane whose float test passed writes ITS OWN
+// sixteen accumulators + (query, first row, m, ek) -- 80 bytes -- to entry `rank` of the wave's queue (ballot + mbcnt; inline
+// asm stores, no vector memory, no wait).  The queue is expanded into candidates at a tile's start once it holds more than 24
+// entries, and at the kernel's end: one LANE per entry, all entries in parallel.
+constexpr int kLaneQueueCap = 64;          // entries per wave: a block's hit lanes always fit an empty queue (one lane = one entry at the flush)
+constexpr int kLaneQueueEntryBytes = 80;   // 16 accumulators (64 B, entry e at 64 e) + (q, rbase, m, ek) (16 B, at 64 cap + 16 e)
+constexpr int kLaneQueueBytes = kLaneQueueCap * kLaneQueueEntryBytes;  // 5 KiB per wave
+
+__device__ __forceinline__ void lds_store16(unsigned addr, i32x4 v) {
+    asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+
+// expand entries [0, n) of the wave's lane queue into the global candidate lists (lane e = entry e).  INLINED at one site per
+// tile (a call there made the allocator park query fragments in scratch and reload them inside the hot loop; at a tile's
+// start two accumulator blocks are dead, which is the room this body lives in).  The caller has waited for its LDS-DMA before.
+template <bool I8>
+__device__ __forceinline__ void lane_queue_flush(const ScreenArgs& a, unsigned lq_addr, int n, int row_end) {
+    const int lane = threadIdx.x & 63;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the entries were written with inline-asm stores the compiler does not track)
+    if (lane < n) {
+        const __attribute__((address_space(3))) int* e =
+            (const __attribute__((address_space(3))) int*)(unsigned long)(lq_addr + (unsigned)lane * 64u);
+        const __attribute__((address_space(3))) int* em =
+            (const __attribute__((address_space(3))) int*)(unsigned long)(lq_addr + (unsigned)(kLaneQueueCap * 64) + (unsigned)lane * 16u);
+        const int q = em[0], rbase = em[1];
+        const float m = __int_as_float(em[2]), ek = __int_as_float(em[3]);
+        const float th = a.thr[q];
+        int thi = 0;
+        if constexpr (I8) thi = i8_block_threshold(th, m, ek);
+        // sixteen values in four 16-byte reads, ONE returning atomic per entry (it reserves the slots of all its hits: the
+        // atomic's round trip is the flush's longest step), then the stores
+        typedef __attribute__((address_space(3))) const i32x4 lds_i32x4;
+        i32x4 w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = ((lds_i32x4*)e)[i];
+        unsigned mask = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int v = w[r >> 2][r & 3];
+            bool hit;
+            if constexpr (I8) hit = v >= thi;
+            else hit = __int_as_float(v) >= th;
+            if (hit && rbase + (r & 3) + 8 * (r >> 2) < row_end) mask |= 1u << r;
+        }
+        if (mask != 0) {
+            int slot = atomicAdd(&a.cnt[q], (int)__builtin_popcount(mask));
+            int32_t* const cr = a.cand_row + (int64_t)q * a.cap;
+            float* const cv = a.cand_val + (int64_t)q * a.cap;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if ((mask >> r) & 1u) {
+                    if (slot < a.cap) {
+                        const int v = w[r >> 2][r & 3];
+                        cr[slot] = rbase + (r & 3) + 8 * (r >> 2);
+                        cv[slot] = I8 ? __builtin_fmaf((float)v, m, ek) : __int_as_float(v);
+                    }
+                    ++slot;
+                }
+            }
+        }
+    }
+}
+
+// The same expansion with a small register footprint (the sixteen values read back one at a time in a rolled loop, one atomic
+// per hit): for the test sites, where every accumulator is live and the unrolled body above would spill.  It runs when a
+// block's hit lanes do not fit the queue any more -- the queue is flushed at a tile's start whenever it holds more than
+// kLaneQueueFlushAt entries, so ONE tile has to bring more than 64 - 24 hit lanes to one wave: thresholds still loose (small k
+// over few rows, the chunks right behind an emit-all ladder) or a burst of near-duplicate rows.
+template <bool I8>
+__device__ __forceinline__ void lane_queue_flush_small(const ScreenArgs& a, unsigned lq_addr, int n, int row_end) {
+    const int lane = threadIdx.x & 63;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane < n) {
+        const __attribute__((address_space(3))) int* e =
+            (const __attribute__((address_space(3))) int*)(unsigned long)(lq_addr + (unsigned)lane * 64u);
+        const __attribute__((address_space(3))) int* em =
+            (const __attribute__((address_space(3))) int*)(unsigned long)(lq_addr + (unsigned)(kLaneQueueCap * 64) + (unsigned)lane * 16u);
+        const int q = em[0], rbase = em[1];
+        const float m = __int_as_float(em[2]), ek = __int_as_float(em[3]);
+        const float th = a.thr[q];
+        int thi = 0;
+        if constexpr (I8) thi = i8_block_threshold(th, m, ek);
+#pragma unroll 1
+        for (int r = 0; r < 16; ++r) {
+            const int v = e[r];
+            bool hit;
+            if constexpr (I8) hit = v >= thi;
+            else hit = __int_as_float(v) >= th;
+            const int row = rbase + (r & 3) + 8 * (r >> 2);
+            if (hit && row < row_end) {
+                const int slot = atomicAdd(&a.cnt[q], 1);
+                if (slot < a.cap) {
+                    a.cand_row[(int64_t)q * a.cap + slot] = row;
+                    a.cand_val[(int64_t)q * a.cap + slot] = I8 ? __builtin_fmaf((float)v, m, ek) : __int_as_float(v);
+                }
+            }
+        }
+    }
+}
+constexpr int kLaneQueueFlushAt = 24;
+
+// the test of one 32 x 32 block + the enqueue of its hit lanes (k_screen_rq).  `lq_n` = entries in the wave's queue (wave-uniform).
+// What a hit costs is NOT its instructions but the barrier: the eight waves of a workgroup meet every K-step, so whatever delays
+// ONE wave -- even a taken branch alone, measured -- is paid by all eight, and with one hit per 3 ... 30 blocks some wave of the
+// eight has one at most test sites (profiles/r05_hit_path.txt: this queue behind a branch costs the same as the out-of-line
+// append it replaced; k_screen_rq's answer is its hand-over schedule -- all tests of a tile between two barriers).
+// MODE (timing builds / A-B): 0 = the stores behind a wave-uniform branch (the kernel), 1 = bookkeeping without the stores,
+// 2 = BRANCH-FREE: the five stores always issued under EXEC = hit lanes (uniform cost for every wave; measured +15 % with the
+// thresholds parked: stores under an empty EXEC are not free -- not adopted), 3 = as 0 with the block laid out as fall-through.
+template <bool I8, int MODE = 0>
+__device__ __forceinline__ void screen_test_block_lq(const ScreenArgs& a, int* status, int row_end, f32x16 acc, int q, int rbase, float th,
+                                                     I8Blk blk, unsigned lq_addr, int& lq_n, int& lq_ovf) {
+    bool any;
+    if constexpr (I8) {
+        const i32x16 v = __builtin_bit_cast(i32x16, acc);
+        int g[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[i] = max(max(v[4 * i], v[4 * i + 1]), max(v[4 * i + 2], v[4 * i + 3]));
+        any = i8_value(max(max(g[0], g[1]), max(g[2], g[3])), blk) >= th;
+    } else {
+        float g[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[i] = fmaxf(fmaxf(acc[4 * i], acc[4 * i + 1]), fmaxf(acc[4 * i + 2], acc[4 * i + 3]));
+        any = fmaxf(fmaxf(g[0], g[1]), fmaxf(g[2], g[3])) >= th;
+    }
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(any);
+    const int n = __builtin_popcountll(bal);
+    const i32x16 v = __builtin_bit_cast(i32x16, acc);
+    if constexpr (MODE == 0 || MODE == 3) {
+        // (MODE 3: the block laid out as the FALL-THROUGH path -- the common case takes one short forward branch over it and a
+        // hit never leaves the loop's code for a cold block at the kernel's end and back)
+        if (__builtin_expect(bal != 0, MODE == 3 ? 1 : 0)) {  // wave-uniform, rare
+            if (__builtin_expect(lq_n + n > kLaneQueueCap, 0)) {  // a burst the per-tile flush did not foresee: make room now
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                lane_queue_flush_small<I8>(a, lq_addr, lq_n, row_end);
+                lq_n = 0;
+            }
+            if (any) {
+                const unsigned e = (unsigned)lq_n + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+                const unsigned addr = lq_addr + (e << 6);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lds_store16(addr + 16u * i, i32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]});
+                lds_store16(lq_addr + (unsigned)(kLaneQueueCap * 64) + (e << 4), i32x4{q, rbase, (int)__float_as_uint(blk.m), (int)__float_as_uint(blk.ek)});
+            }
+            lq_n += n;
+        }
+        return;
+    }
+    // does the block's hit lanes fit?  (Never false in practice -- see kLaneQueueFlushAt.)  If not, nothing is stored and the
+    // wave remembers it in `lq_ovf`: at the next tile start it flags its 32 queries kStOverflow (the host re-screens them).
+    const bool fits = lq_n + n <= kLaneQueueCap;
+    const unsigned long long mask = fits ? bal : 0ull;   // s_cselect: no branch
+    lq_ovf |= fits ? 0 : 1;
+    const unsigned e = (unsigned)lq_n + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+    if constexpr (MODE == 2) {
+        const unsigned addr = lq_addr + (e << 6), addr_m = lq_addr + (unsigned)(kLaneQueueCap * 64) + (e << 4);
+        const i32x4 meta{q, rbase, (int)__float_as_uint(blk.m), (int)__float_as_uint(blk.ek)};
+        unsigned long long saved;
+        asm volatile(
+            "s_mov_b64 %[sv], exec\n\t"
+            "s_and_b64 exec, exec, %[mask]\n\t"
+            "ds_write_b128 %[ad], %[v0]\n\t"
+            "ds_write_b128 %[ad], %[v1] offset:16\n\t"
+            "ds_write_b128 %[ad], %[v2] offset:32\n\t"
+            "ds_write_b128 %[ad], %[v3] offset:48\n\t"
+            "ds_write_b128 %[am], %[mt]\n\t"
+            "s_mov_b64 exec, %[sv]"
+            : [sv] "=&s"(saved)
+            : [mask] "s"(mask), [ad] "v"(addr), [am] "v"(addr_m), [v0] "v"(i32x4{v[0], v[1], v[2], v[3]}),
+              [v1] "v"(i32x4{v[4], v[5], v[6], v[7]}), [v2] "v"(i32x4{v[8], v[9], v[10], v[11]}),
+              [v3] "v"(i32x4{v[12], v[13], v[14], v[15]}), [mt] "v"(meta)
+            : "memory");
+    }
+    lq_n += fits ? n : 0;
+}
+
 // FLAG = false: a full queue falls back to a direct global append (a returning atomic: k_screen256, first form);
 // FLAG = true: it only flags the query in `status` (no returning atomic inside the K loop: k_screen256b) -- the host
 // re-screens flagged queries with the tighter bound.

@@ -10,8 +10,9 @@
 //    neighbouring corpus tiles, so the shadow is fetched from HBM once per pass and re-read from that XCD's L2.
 //  * Hits go to a per-wave LDS queue (k_screen.h: screen_queue_hits) that is flushed to the global candidate lists when it
 //    fills up and when the workgroup is done: the epilogue never touches the vector-memory counter while DMA is in flight.
-// (The first, second and fourth forms of the kernel that were built on this geometry -- DESIGN.md 4.1, 4.1b, 4.1c -- live
-// under tools/forms/ for A/B runs with tools/screen_bench; the library builds and launches only k_screen256c.)
+// (The first, second and fourth forms of the kernel that were built on this geometry -- docs/LAB_NOTES_r1_r3.md 4.1, 4.1b,
+// 4.1c -- are in the history only.  Round 5: k_screen_rq.h keeps the QUERY operand in registers and serves int8 shadows of at
+// most 768 B per row; k_screen256c stays for the bf16 shadow and wider rows.  A/B harness: tools/screen_ab.hip.)
 #pragma once
 #include "k_screen.h"
 

@@ -32,7 +32,7 @@ namespace mi355 {
 constexpr int kScreen256cAbl = 1024;  // SADDR (the only staging form this kernel has)
 
 // LDS-DMA pieces per micro-step slot {5, 6, 7 | 0, 1, 2, 3, 4} for schedule id (0 = what the library runs; the others are the
-// A/B of round 2 (tools/screen_bench, interleaved): +1.5 ... +5 %.  More pieces right behind the hand-over, or a thinner, longer spread: both lose.)
+// A/B of round 2 (interleaved): +1.5 ... +5 %.  More pieces right behind the hand-over, or a thinner, longer spread: both lose.)
 __host__ __device__ constexpr int kc_sched(int id, int slot) {
     constexpr int t[4][8] = {{2, 2, 0, 2, 2, 1, 0, 0}, {2, 2, 0, 1, 1, 1, 1, 1}, {1, 1, 1, 1, 1, 2, 2, 0}, {2, 2, 0, 2, 1, 1, 1, 0}};
     return t[id][slot];

@@ -14,12 +14,15 @@
 //     MFMA (128 B/clk/CU at the MFMA peak, half of what ds_read_b128 delivers on gfx950).
 //   * The LDS holds a ring of NST stages of 16 KiB (one K-step of the tile's 128 rows each; NST = 6 at KS = 6: a whole
 //     tile), filled NST K-steps ahead: a piece has ~5 K-steps (~3000 cycles) to land, counted vmcnt never waits in steady
-//     state.  ONE barrier per K-step (hand-over of the stage just read), placed between two MFMA bursts of the same wave.
+//     state.  One barrier per K-step (hand-over of the stage just read), placed between two MFMA bursts of the same wave --
+//     except in a tile's last K-step, whose stage is handed over with the next one's (so that all four block tests of a tile
+//     fall between two barriers: see kSkipLast).
 //   * K-step = 8 micro-steps m = 4 I + kk of 2 MFMAs (row blocks 2 I, 2 I + 1; K sub-step kk): row-half-major as in
 //     k_screen256c, so that a finished tile's blocks are tested UNDER MFMAs of the other row half (both waves of a SIMD
 //     reach a tile's end together: tests behind the last MFMA would idle the matrix pipe).  Row fragments are read three
 //     micro-steps ahead under counted lgkmcnt.
-//   * Same epilogue as k_screen256c (per-wave LDS queue, out-of-line append), same persistent XCD-aware walk (the query
+//   * Hits: a per-wave queue of HIT LANES (k_screen.h: screen_test_block_lq) -- five LDS stores per lane and no call in the hot
+//     loop, expanded into candidates 64 entries at a time --; same persistent XCD-aware walk as k_screen256c (the query
 //     tiles of one row tile run on one XCD: the shadow comes from HBM once), same int8 row-group records by one small LDS-DMA
 //     piece per tile.
 // Restrictions: row_bytes = 128 KS with KS a template parameter (the fragments are indexed at compile time); instantiated
@@ -35,18 +38,18 @@ namespace mi355 {
 
 constexpr int kRqRows = 128;                         // corpus rows per tile
 constexpr int kRqStageBytes = kRqRows * kRowB;       // 16 KiB: one K-step of the tile
-__host__ __device__ constexpr int rq_stages(int ks) { return ks == 4 ? 8 : ks == 5 ? 5 : 6; }  // a multiple of KS
+__host__ __device__ constexpr int rq_stages(int ks) { return ks == 4 ? 4 : ks == 5 ? 5 : 6; }  // a multiple of KS
 constexpr int kRqRecSlots = 8;                       // ring of row-group records (one 256-B slot per tile)
 __host__ __device__ constexpr int rq_que_off(int ks) { return rq_stages(ks) * kRqStageBytes; }
-__host__ __device__ constexpr int rq_rec_off(int ks) { return rq_que_off(ks) + 8 * kWaveQueueCap * 12; }
+__host__ __device__ constexpr int rq_rec_off(int ks) { return rq_que_off(ks) + 8 * kLaneQueueBytes; }  // + one lane queue per wave
 __host__ __device__ constexpr int rq_lds(int ks) { return rq_rec_off(ks) + kRqRecSlots * 256; }
-static_assert(rq_lds(4) <= 160 * 1024, "LDS per workgroup");
+static_assert(rq_lds(6) <= 160 * 1024, "LDS per workgroup");
 
 // persistent grid in 128-row tiles: 8 XCDs x L workgroups (same rule as screen256_grid)
 __host__ __device__ inline unsigned screen_rq_grid(int n_ctiles, int n_qtiles) { return screen256_grid(n_ctiles, n_qtiles); }
 
 // ABL (timing builds for the A/B table; 0 = the kernel): 1 no fragment reads, 4 no tests, 8 no barrier, 16 no LDS-DMA in the
-// loop, 32 no vmcnt at the hand-over.  (Cache policies nt / sc0 / sc1 on the row pieces, measured in round 5:
+// loop, 32 no vmcnt at the hand-over, 64 every test reads its own row-group record (the form before RQ_LOAD_REC); 2048 a hand-over in EVERY K-step (the form before kSkipLast); bits 8, 9: the hit path without its stores (256) / its stores ALWAYS issued under EXEC = hit lanes instead of behind a branch (512: measured +15 % with thresholds parked -- stores under an empty EXEC are not free).  (Cache policies nt / sc0 / sc1 on the row pieces, measured in round 5:
 // +1 ... +3 % on Gaussian operands, profiles/r05_kstep_ab.txt -- the default policy stays.)
 template <int KS, int ABL, bool I8>
 __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
@@ -57,8 +60,8 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int32_t* const que = (int32_t*)(smem + rq_que_off(KS) + wave * (kWaveQueueCap * 12));  // [q | row | value bits]
-    int que_n = 0;                                                                          // wave-uniform
+    const unsigned lq = lds_addr(smem + rq_que_off(KS) + wave * kLaneQueueBytes);  // this wave's queue of hit lanes (k_screen.h)
+    int lq_n = 0, lq_ovf = 0;                                                       // entries in it; "a block did not fit" (wave-uniform)
 
     const int b = blockIdx.x;
     const int xcd = b & 7;
@@ -103,6 +106,7 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
     asm volatile("" ::"v"(th), "v"(kqq), "v"(scq));
 
     f32x16 acc[4];  // row blocks 0..3 of the tile
+    float rec_m[4] = {1.0f, 1.0f, 1.0f, 1.0f}, rec_e[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // their int8 constants (RQ_LOAD_REC)
     f32x16 zero16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
@@ -170,6 +174,19 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
             acc[2 * ((M) >> 2) + rb] = screen_mfma<I8>(fAq[(M) & 3][rb], fB[4 * (TT) + ((M) & 3)],    \
                                                        (ZERO) ? zero16 : acc[2 * ((M) >> 2) + rb]);   \
     } while (0)
+// The four blocks' constants (m = S_g S_q, ek = e_g kq) of the tile under test, read from the records ring ONE micro-step
+// before the tile's first test instead of inside each test: a test that reads its record itself waits with lgkmcnt(0) for a
+// read queued BEHIND the six to eight fragment reads in flight (LDS returns in order) -- ~150 cycles of this wave, four times
+// per tile.  (ABL bit 6: the old form, for the A/B.)
+#define RQ_LOAD_REC(TC)                                                                               \
+    do {                                                                                              \
+        if constexpr (I8 && (ABL & 4) == 0 && (ABL & 64) == 0) {                                      \
+            const float4* rp__ = (const float4*)(smem + rq_rec_off(KS) + ((TC) & (kRqRecSlots - 1)) * 256); \
+            const float4 r0__ = rp__[0], r1__ = rp__[1];                                              \
+            rec_m[0] = r0__.x * scq, rec_e[0] = r0__.y * kqq, rec_m[1] = r0__.z * scq, rec_e[1] = r0__.w * kqq; \
+            rec_m[2] = r1__.x * scq, rec_e[2] = r1__.y * kqq, rec_m[3] = r1__.z * scq, rec_e[3] = r1__.w * kqq; \
+        }                                                                                             \
+    } while (0)
 // test row block RB of the tile whose first row is ROW0 (records slot of tile counter TC)
 #define RQ_TEST(RB, ROW0, TC)                                                                         \
     do {                                                                                              \
@@ -179,11 +196,13 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
             const int q__ = q0 + (lane_e & 31);                                                       \
             const int rbase__ = (ROW0) + 32 * (RB) + 4 * (lane_e >> 5);                               \
             I8Blk blk__{1.0f, 0.0f};                                                                  \
-            if constexpr (I8) {                                                                       \
+            if constexpr (I8 && (ABL & 64) != 0) {                                                    \
                 const I8Group g__ = ((const I8Group*)(smem + rq_rec_off(KS) + ((TC) & (kRqRecSlots - 1)) * 256))[RB]; \
                 blk__ = i8_blk(g__, scq, kqq);                                                        \
+            } else if constexpr (I8) {                                                                \
+                blk__ = I8Blk{rec_m[RB], rec_e[RB]};                                                  \
             }                                                                                         \
-            screen_test_block<I8>(a.status, acc[RB], q__, rbase__, row_end, th, blk__, que, que_n);   \
+            screen_test_block_lq<I8, (ABL >> 8) & 3>(a, a.status, row_end, acc[RB], q__, rbase__, th, blk__, lq, lq_n, lq_ovf); \
         }                                                                                             \
     } while (0)
 #define RQ_MICRO(M, TT, ZERO, SB, SBN)                                                                \
@@ -194,17 +213,25 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
         RQ_PIN();                                                                                     \
     } while (0)
 
-    // ---- prologue: K-steps 0 .. NST-1 into the ring; K-step 0 landed and visible; fragments of micro-steps 0..2
+    // Hand-over schedule.  kSkipLast (KS >= 2; ABL bit 11 = the per-K-step form, A/B): NO hand-over in a tile's LAST K-step -- the
+    // ring stage it reads is handed over together with the next K-step's, in the next tile's first K-step.  The four block tests
+    // of a tile sit in its last K-step (row half 0) and in the next tile's first (row half 1), i.e. now BETWEEN two consecutive
+    // barriers: a wave with hits is late once per tile instead of once per test site, and the delays of different waves overlap
+    // instead of adding up (the eight waves meet at every barrier: whatever a hit costs one wave is paid by all -- with one hit
+    // per 3 ... 30 blocks some wave of the eight has one at most test sites; profiles/r05_hit_path.txt).
+    constexpr bool kSkipLast = KS >= 2 && (ABL & 2048) == 0;
+    constexpr int kPrologueSteps = kSkipLast ? NST - 1 : NST;  // (the first hand-over then frees two stages like every tile's first)
+    // ---- prologue: K-steps 0 .. kPrologueSteps-1 into the ring; K-step 0 landed and visible; fragments of micro-steps 0..2
 #pragma unroll
-    for (int s = 0; s < NST; ++s) {
+    for (int s = 0; s < kPrologueSteps; ++s) {
         RQ_PIECE(0);
         RQ_PIECE(1);
         RQ_REC();
         RQ_ADVANCE();
     }
     if constexpr ((ABL & 16) == 0) {
-        // this wave's pieces of K-step 0 (the oldest) have landed: at most the 2 (NST - 1) younger ones (+ records) are out
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NST - 1)) : "memory");
+        // this wave's pieces of K-step 0 (the oldest) have landed: at most the younger ones (+ records) are out
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (kPrologueSteps - 1)) : "memory");
     }
     MI355_BARRIER();
     int s0b = 0;  // ring byte offset of the tile's first K-step (compile-time 0 when a tile is the whole ring)
@@ -217,10 +244,14 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
     int row0_cur = (a.ct0 + ctl) * kRqRows, row0_prev = row0_cur;  // rows < 2^31 (checked by the host)
     bool have_prev = false;  // a finished tile's row half 1 is waiting for its tests
     for (;;) {
-        if (que_n > kWaveQueueCap / 2) {  // wave-uniform, rare: this wave stalls on vector memory once
+        if (((ABL >> 8) & 3) != 1 && lq_n > kLaneQueueFlushAt) {  // wave-uniform, rare: this wave stalls on vector memory once per ~25 hit lanes
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            wave_queue_flush(a, que, min(que_n, kWaveQueueCap));
-            que_n = 0;
+            if constexpr (((ABL >> 8) & 3) != 1) lane_queue_flush<I8>(a, lq, lq_n, row_end);
+            lq_n = 0;
+        }
+        if (((ABL >> 8) & 3) == 2 && lq_ovf) {  // (branch-free A/B form only) a burst did not fit the queue -- this wave's queries are re-screened by the host
+            __hip_atomic_fetch_or(&a.status[q_lane], kStOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lq_ovf = 0;
         }
         const int tile_sb = (NST == KS) ? 0 : s0b;
         const int next_tile_sb = (NST == KS) ? 0 : (s0b + KS * kRqStageBytes >= NST * kRqStageBytes ? 0 : s0b + KS * kRqStageBytes);
@@ -236,23 +267,46 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
             RQ_MICRO(2, t, false, sb, sbn);
             if (tp) RQ_TEST(3, row0_prev, tc - 1);
             RQ_MICRO(3, t, false, sb, sbn);
+            if (last) RQ_LOAD_REC(tc);  // (behind the previous tile's last test -- micro-step 2 of ITS next K-step -- also at KS = 1)
             RQ_MICRO(4, t, first, sb, sbn);
             if (last) RQ_TEST(0, row0_cur, tc);
             // ---- hand-over: every read of this K-step's stage has been issued (the last ones kPF micro-steps before its end)
-            if constexpr ((ABL & 48) == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NST - 2)) : "memory");  // own pieces of the next K-step landed
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and the last fragments of this one are in registers
-            if constexpr ((ABL & 8) == 0) MI355_BARRIER();
+            const bool hand = !(kSkipLast && last);
+            if (hand) {
+                // own pieces landed: of the next K-step -- and of the one after it when that one has no hand-over of its own
+                // (t = KS - 2).  In flight before this K-step's issue: through K-step g + NST - 1 (g + NST - 2 in a tile's first
+                // K-step: the previous one issued nothing).  Record pieces only make the wait stricter.
+                const int allowed = 2 * (NST - 2 - ((kSkipLast && first) ? 1 : 0) - ((kSkipLast && t == KS - 2) ? 1 : 0));
+                if constexpr ((ABL & 48) == 0) {
+                    if (allowed >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else if (allowed == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else if (allowed == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else if (allowed == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and the last fragments of this one are in registers
+                if constexpr ((ABL & 8) == 0) MI355_BARRIER();
+            }
             RQ_PIN();
             RQ_MICRO(5, t, false, sb, sbn);
-            RQ_PIECE(0);
+            if (hand) RQ_PIECE(0);
             RQ_PIN();
             RQ_MICRO(6, t, false, sb, sbn);
-            RQ_PIECE(1);
+            if (hand) RQ_PIECE(1);
             RQ_PIN();
             if (last) RQ_TEST(1, row0_cur, tc);
+            if (hand && kSkipLast && first) {  // two stages were handed over: the second K-step's pieces ride micro-step 7
+                RQ_REC();
+                RQ_ADVANCE();
+                RQ_PIECE(0);
+                RQ_PIN();
+            }
             RQ_MICRO(7, t, false, sb, sbn);
-            RQ_REC();
-            RQ_ADVANCE();
+            if (hand && kSkipLast && first) RQ_PIECE(1);
+            if (hand) {
+                RQ_REC();
+                RQ_ADVANCE();
+            }
             RQ_PIN();
         }
         row0_prev = row0_cur;
@@ -267,7 +321,7 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
     RQ_TEST(2, row0_prev, tc - 1);
     RQ_TEST(3, row0_prev, tc - 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the dummy prefetches must land before the LDS is freed
-    wave_queue_flush(a, que, min(que_n, kWaveQueueCap));
+    lane_queue_flush<I8>(a, lq, lq_n, row_end);
     if constexpr ((ABL & 4) != 0) {  // timing build without tests: the accumulators stay live
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(acc[i]));

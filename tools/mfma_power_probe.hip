@@ -76,6 +76,11 @@ __global__ __launch_bounds__(512, 2) void k_stream(const v8i* __restrict__ ops, 
                 } else if constexpr (FMT == 103) {  // i8, BOTH operands kept for four consecutive instructions
                     const v4i aa = {a[s][0], a[s][1], a[s][2], a[s][3]}, bb = {b[s][0], b[s][1], b[s][2], b[s][3]};
                     acc[i] = __builtin_bit_cast(v16f, __builtin_amdgcn_mfma_i32_32x32x32_i8(aa, bb, __builtin_bit_cast(v16i, acc[i]), 0, 0, 0));
+                } else if constexpr (FMT == 105 || FMT == 106) {  // i8, dependent chains: ONE accumulator for all 16 instructions of an
+                    // iteration (105), or two used in runs of eight (106) -- does accumulating in place cost less than cycling four?
+                    const int ai = FMT == 105 ? 0 : (s >> 1);
+                    const v4i aa = {a[s][0], a[s][1], a[s][2], a[s][3]}, bb = {b[(s + i) % kSets][0], b[(s + i) % kSets][1], b[(s + i) % kSets][2], b[(s + i) % kSets][3]};
+                    acc[ai] = __builtin_bit_cast(v16f, __builtin_amdgcn_mfma_i32_32x32x32_i8(aa, bb, __builtin_bit_cast(v16i, acc[ai]), 0, 0, 0));
                 } else if constexpr (FMT == 104) {  // i8 as v_mfma_i32_16x16x64_i8 (same operand bytes, half the multiply-adds, 4 accumulator registers)
                     const v4i aa = {a[s][0], a[s][1], a[s][2], a[s][3]}, bb = {b[(s + i) % kSets][0], b[(s + i) % kSets][1], b[(s + i) % kSets][2], b[(s + i) % kSets][3]};
                     typedef int v4acc __attribute__((ext_vector_type(4)));
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(512, 2) void k_stream(const v8i* __restrict__ ops, 
                 }
             }
         }
-        if constexpr (FMT == 100 || FMT == 102 || FMT == 103 || FMT == 104) {  // keep the int32 accumulators from saturating into one stuck pattern
+        if constexpr (FMT == 100 || FMT == 102 || FMT == 103 || FMT == 104 || FMT == 105 || FMT == 106) {  // keep the int32 accumulators from saturating into one stuck pattern
             if ((it & 255) == 255)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -216,6 +221,8 @@ static int run_stream(const std::string& fmt, const std::string& data, double se
         if (fmt == "i8") hipLaunchKernelGGL(k_stream<100>, dim3(grid), dim3(block), 0, 0, ops, out, iters);
         else if (fmt == "i8_nos") hipLaunchKernelGGL(k_stream<102>, dim3(grid), dim3(block), 0, 0, ops, out, iters);
         else if (fmt == "i8_ab") hipLaunchKernelGGL(k_stream<103>, dim3(grid), dim3(block), 0, 0, ops, out, iters);
+        else if (fmt == "i8_dep") hipLaunchKernelGGL(k_stream<105>, dim3(grid), dim3(block), 0, 0, ops, out, iters);
+        else if (fmt == "i8_dep2") hipLaunchKernelGGL(k_stream<106>, dim3(grid), dim3(block), 0, 0, ops, out, iters);
         else if (fmt == "i8_16") hipLaunchKernelGGL(k_stream<104>, dim3(grid), dim3(block), 0, 0, ops, out, iters);
         else if (fmt == "bf16") hipLaunchKernelGGL(k_stream<101>, dim3(grid), dim3(block), 0, 0, ops, out, iters);
         else if (fmt == "fp8") hipLaunchKernelGGL(k_stream<0>, dim3(grid), dim3(block), 0, 0, ops, out, iters);

@@ -12,7 +12,7 @@
 #   maxsim     the two MaxSim stores as bench lines of their own + kernel stats + PMC (FETCH_SIZE; SQ busy)
 #   power      socket power / clock next to a 600-step bench run
 #   mx         bare MFMA stream by operand format (int8, bf16, MX fp8 / fp6 / fp4) with power, + the int8 gather second stage
-#   kstep      k_screen256c timing builds (no LDS-DMA / no fragment reads / no barrier) on Gaussian operands and on zeros, with power
+#   kstep      k_screen256c vs k_screen_rq interleaved + k_screen_rq timing builds (no LDS-DMA / fragment reads / tests / barrier), Gaussian operands and zeros, with power
 #   barrier    grid-barrier cost in the screen kernel's geometry vs a dependent launch
 #   fuzz       tools/fuzz_parity.py campaign (FUZZ_SECONDS, default 600)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -110,22 +110,22 @@ mx)
     echo; echo "# int8 second stage by GATHER: random rows of a 10 M x 768 B int8 shadow, v_dot4_i32_i8, 16 lanes per row"
     for c in 7000 700 100; do /tmp/mfma_power_probe gather 10000000 1024 $c | tail -1; done; } 2>&1 | tee $OUT/mx_probe.txt ;;
 kstep)
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -Iautorag_research_amd/csrc -Itools/forms tools/screen_bench.hip -o /tmp/screen_bench || exit 1
-  { echo "# k_screen256c timing builds, int8, N = 10 M x 1024 queries, thresholds parked (tools/screen_bench ABL bits; results of the"
-    echo "# ablated builds are garbage, their instruction stream minus the removed part is what runs):"
-    echo "#   201000 full kernel | 202040 no LDS-DMA | 202041 no LDS-DMA, no fragment reads (MFMAs + tests + loop + barrier) | 202049 ... no barrier"
-    echo "# NOTE: without the LDS-DMA the ring is never filled: the ablated builds multiply whatever the LDS holds (zeros), whatever DATA"
-    echo "# says -- they measure CYCLES of the instruction stream, not its power on real operands; only the full kernel sees DATA."
+  # the A/B of the two large-block int8 screens + the timing builds of the new one, each with power / clock next to a sustained run
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -Iautorag_research_amd/csrc tools/screen_ab.hip -o /tmp/screen_ab || exit 1
+  { echo "# k_screen256c (variant 0: 256 x 256 tile, both operands through the LDS) against k_screen_rq (variant 100: 128 rows x 256"
+    echo "# queries, query operand resident in registers), int8, ${KROWS:-10000000} rows x 1024 queries x d 768, thresholds parked; timing builds of"
+    echo "# k_screen_rq: 101 no fragment reads | 104 no tests | 108 no barrier | 116 no LDS-DMA | 117 no LDS-DMA, no fragment reads"
+    echo "# (results of the ablated builds are garbage; without the LDS-DMA the ring is never filled: those builds multiply zeros)"
     for data in 1 2; do
       echo "=== DATA=$data ($([ $data = 1 ] && echo 'Gaussian int8, sigma 29: what the shadows hold' || echo zeros)) ==="
-      for v in 201000 202040 202041 202049; do
-        smi_poll $OUT/smi_kstep.txt 200   # (~4 s of launches: the governor settles after ~0.4 s)
-        line=$(DATA=$data ROUNDS=700 VARIANTS=$v /tmp/screen_bench 10000000 1024 768 | tail -1)
-        kill $SMI 2>/dev/null; wait $SMI 2>/dev/null
-        echo "alone        $line | $(smi_median $OUT/smi_kstep.txt)"
-      done
       echo "--- interleaved (every variant once per round, 30 rounds)"
-      DATA=$data ROUNDS=30 VARIANTS=201000,202040,202041,202049 /tmp/screen_bench 10000000 1024 768 | tail -4
+      DATA=$data ROUNDS=30 VARIANTS=0,100,101,104,108,116,117 /tmp/screen_ab ${KROWS:-10000000} 1024 768 | grep -E "^variant|candidate set"
+      for v in 0 100; do
+        smi_poll $OUT/smi_kstep.txt 14
+        line=$(DATA=$data VARIANTS=$v SECONDS_RUN=4 /tmp/screen_ab ${KROWS:-10000000} 1024 768 | tail -1)
+        wait $SMI 2>/dev/null
+        echo "sustained    $line | $(smi_median $OUT/smi_kstep.txt)"
+      done
     done; } 2>&1 | tee $OUT/kstep_ab.txt ;;
 barrier)
   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/grid_barrier_probe.hip -o /tmp/grid_barrier_probe && timeout 120 /tmp/grid_barrier_probe | tee $OUT/grid_barrier.txt ;;

@@ -61,7 +61,7 @@ struct Cand {
     bool operator<(const Cand& o) const { return q != o.q ? q < o.q : row < o.row; }
 };
 
-#define RQ_FORMS(X) X(0) X(1) X(4) X(8) X(16) X(17) X(21)
+#define RQ_FORMS(X) X(0) X(1) X(4) X(8) X(16) X(17) X(21) X(64) X(256) X(512) X(768) X(2048)
 
 int main(int argc, char** argv) {
     const int64_t N = argc > 1 ? atoll(argv[1]) : (1 << 21);
@@ -181,15 +181,32 @@ int main(int argc, char** argv) {
                ops / (el / n) / 1e12);
         return 0;
     }
-    // ---- interleaved timing, thresholds parked
+    // ---- interleaved timing, thresholds parked (or, THRZ=<z>: at z sigma of the score distribution -- the cost of the hit path;
+    // the candidate counters are reset before every launch, outside the timed events)
     {
         hipLaunchKernelGGL(k_fillf, dim3((Bpad + 255) / 256), dim3(256), 0, 0, thr, Bpad, INFINITY);
+        const bool hits = getenv("THRZ") != nullptr;
+        if (hits) {
+            hipLaunchKernelGGL(k_fillf, dim3((Bpad + 255) / 256), dim3(256), 0, 0, thr, B, (float)atof(getenv("THRZ")) / sqrtf((float)d));
+            printf("thresholds at %.2f sigma\n", atof(getenv("THRZ")));
+        }
         std::vector<std::vector<float>> ms(variants.size());
         for (int w = 0; w < 3; ++w)
             for (int variant : variants) launch(variant);
         CK(hipDeviceSynchronize());
+        if (hits) {
+            std::vector<int> hc(B);
+            CK(hipMemset(cnt, 0, Bpad * 4));
+            launch(variants[0]);
+            CK(hipMemcpy(hc.data(), cnt, B * 4, hipMemcpyDeviceToHost));
+            long long tot = 0;
+            for (int q = 0; q < B; ++q) tot += hc[q];
+            printf("%lld hits per launch (%.1f per query, %.2f per 32 x 32 block)\n", tot, (double)tot / B, (double)tot / ((double)N / 32 * B / 32));
+            CK(hipMemset(status, 0, Bpad * 4));
+        }
         for (int r = 0; r < rounds; ++r)
             for (size_t v = 0; v < variants.size(); ++v) {
+                if (hits) CK(hipMemsetAsync(cnt, 0, Bpad * 4, 0));
                 CK(hipEventRecord(e0));
                 launch(variants[v]);
                 CK(hipEventRecord(e1));
@@ -212,7 +229,7 @@ int main(int argc, char** argv) {
     std::vector<std::vector<Cand>> sets;
     std::vector<int> set_variant;
     for (int variant : variants) {
-        if (variant != 0 && variant != 100) continue;
+        if (variant != 0 && variant != 100 && variant != 164 && variant != 612 && variant != 868 && variant != 2148) continue;
         const float T0 = 4.6f / sqrtf((float)d);
         hipLaunchKernelGGL(k_fillf, dim3((Bpad + 255) / 256), dim3(256), 0, 0, thr, Bpad, INFINITY);
         hipLaunchKernelGGL(k_fillf, dim3((Bpad + 255) / 256), dim3(256), 0, 0, thr, B, T0);
