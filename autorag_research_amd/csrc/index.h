@@ -137,6 +137,9 @@ struct mi355dr_index {
     int64_t s_screen_launches = 0, s_screen_ns = 0, s_screen_rows = 0, s_fallback_queries = 0, s_chunks = 0,
             s_passes = 0, s_candidates = 0, s_rescored = 0, s_starters = 0;
     int64_t s_big_launches = 0, s_big_ns = 0, s_big_rows = 0;  // the k_screen256 share of the three above
+    int screen_drift = 3;   // k_screen_rq: tiles a workgroup may run ahead of its slowest sibling (0 = no limiter; option "screen_drift")
+    int* rq_progress = nullptr;  // [kRqProgressWords] the limiter's progress words
+    int rq_epoch = 0;            // launch stamp of the last k_screen_rq launch (1 ... 4095)
     int64_t s_rq_launches = 0;  // of them: k_screen_rq launches (stat "screen_rq_launches")
     int64_t s_retry_queries = 0;  // queries whose candidate list overflowed and that were re-screened with the bf16 bound
     int64_t s_ms_screened = 0, s_ms_candidates = 0, s_ms_fallbacks = 0;  // MaxSim: queries screened, docs re-scored, full re-runs

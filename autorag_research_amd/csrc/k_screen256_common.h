@@ -43,6 +43,10 @@ __host__ __device__ inline unsigned screen256_grid(int n_ctiles, int n_qtiles) {
 
 struct ScreenArgs2 : ScreenArgs {
     int* status;  // [Bpad] per-query status bits (kStOverflow is set when a wave's queue overflows)
+    // k_screen_rq's sibling drift limiter (k_screen_rq.h); drift = 0 or progress = nullptr: off
+    int* progress = nullptr;  // [kRqProgressWords] tile counters of the persistent workgroups, 8 words per row-tile slot
+    int epoch = 0;            // launch stamp (12 bits) in the words' high bits: words of other launches are ignored
+    int drift = 0;            // tiles a workgroup may run ahead of the slowest workgroup on the same row tiles
 };
 
 // ---- one 1-KiB piece (U = 0,1) of half-tile type S into ring parity `par`; src = the half-tile's first row + K offset
@@ -57,6 +61,11 @@ __device__ __forceinline__ void glds16_saddr(const char* sbase, unsigned voff, u
 // 256 B (one dword per lane) through the same path: the int8 row-group records of a tile (k_screen256c)
 __device__ __forceinline__ void glds4_saddr(const char* sbase, unsigned voff, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+// ... the same at agent scope (sc1: not served from this CU's vector L1): words that other workgroups keep writing
+__device__ __forceinline__ void glds4_saddr_sc1(const char* sbase, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1 sc1" ::"v"(voff), "s"(sbase), "s"(lds_dst)
                  : "memory");
 }
 template <int S, bool SADDR>

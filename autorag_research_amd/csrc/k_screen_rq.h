@@ -42,14 +42,27 @@ __host__ __device__ constexpr int rq_stages(int ks) { return ks == 4 ? 4 : ks ==
 constexpr int kRqRecSlots = 8;                       // ring of row-group records (one 256-B slot per tile)
 __host__ __device__ constexpr int rq_que_off(int ks) { return rq_stages(ks) * kRqStageBytes; }
 __host__ __device__ constexpr int rq_rec_off(int ks) { return rq_que_off(ks) + 8 * kLaneQueueBytes; }  // + one lane queue per wave
-__host__ __device__ constexpr int rq_lds(int ks) { return rq_rec_off(ks) + kRqRecSlots * 256; }
+__host__ __device__ constexpr int rq_prog_off(int ks) { return rq_rec_off(ks) + kRqRecSlots * 256; }  // + 256 B of sibling progress words
+__host__ __device__ constexpr int rq_lds(int ks) { return rq_prog_off(ks) + 256; }
+// Sibling drift limiter.  The n_qtiles workgroups that walk the same row tiles (same XCD: the tile is meant to come from HBM
+// once and from that XCD's L2 for the others) are independent programs: every flush of a hit-lane queue sets one of them back
+// by ~3 us, and over a launch of hundreds of tiles the gaps add up until the laggard finds the tile evicted (measured before the
+// limiter: L2 hit rate 60 % instead of 75 %, 1.8 x the shadow from HBM in the 7.2 M-row launch, profiles/r05_traffic_i8.json).
+// Each workgroup publishes (launch stamp, tiles begun) in a global word per tile; wave 0 fetches its siblings' words with one
+// LDS-DMA dword piece per tile (agent scope; no register, no vector-memory wait in the loop -- it is older than the pieces the
+// next hand-over waits for) and, when a sibling of THIS launch is more than `drift` tiles behind, sleeps until it has caught
+// up.  Progress only: no result depends on it; a wait is capped (kRqSpinCap polls) and a capped wait switches the limiter off
+// for the rest of the launch (a sibling that is not resident -- never the case on an idle GPU: the grid is one workgroup per CU).
+constexpr int kRqProgressWords = 32 * 8 * 8;  // row-tile slots per XCD x XCDs x query tiles (limiter off above 8 query tiles)
+constexpr int kRqSpinCap = 256;
+constexpr int kRqDoneTiles = 0xFFFFF;
 static_assert(rq_lds(6) <= 160 * 1024, "LDS per workgroup");
 
 // persistent grid in 128-row tiles: 8 XCDs x L workgroups (same rule as screen256_grid)
 __host__ __device__ inline unsigned screen_rq_grid(int n_ctiles, int n_qtiles) { return screen256_grid(n_ctiles, n_qtiles); }
 
 // ABL (timing builds for the A/B table; 0 = the kernel): 1 no fragment reads, 4 no tests, 8 no barrier, 16 no LDS-DMA in the
-// loop, 32 no vmcnt at the hand-over, 64 every test reads its own row-group record (the form before RQ_LOAD_REC); 2048 a hand-over in EVERY K-step (the form before kSkipLast); bits 8, 9: the hit path without its stores (256) / its stores ALWAYS issued under EXEC = hit lanes instead of behind a branch (512: measured +15 % with thresholds parked -- stores under an empty EXEC are not free).  (Cache policies nt / sc0 / sc1 on the row pieces, measured in round 5:
+// loop, 32 no vmcnt at the hand-over, 64 every test reads its own row-group record (the form before RQ_LOAD_REC); 2048 a hand-over in EVERY K-step (the form before kSkipLast); 4096 no drift limiter; bits 8, 9: the hit path without its stores (256) / its stores ALWAYS issued under EXEC = hit lanes instead of behind a branch (512: measured +15 % with thresholds parked -- stores under an empty EXEC are not free).  (Cache policies nt / sc0 / sc1 on the row pieces, measured in round 5:
 // +1 ... +3 % on Gaussian operands, profiles/r05_kstep_ab.txt -- the default policy stays.)
 template <int KS, int ABL, bool I8>
 __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
@@ -113,6 +126,12 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
     const unsigned lds0 = lds_addr(smem);
     const unsigned rec_lds = lds0 + rq_rec_off(KS);
     const unsigned rec_voff = (unsigned)((lane & 7) * 4);  // the tile's 4 records = 8 dwords, eight copies per slot
+    // drift limiter (wave 0): the slot's 8 progress words, this workgroup's is word qt
+    bool lim = (ABL & 4096) == 0 && a.drift > 0 && a.progress != nullptr && a.n_qtiles > 1 && a.n_qtiles <= 8 && wave == 0;
+    const char* const prog_base = (const char*)(a.progress + (cslot * 8 + xcd) * 8);
+    const unsigned prog_lds = lds0 + rq_prog_off(KS);
+    const unsigned prog_voff = (unsigned)(((lane & 7) < a.n_qtiles ? (lane & 7) : 0) * 4);
+    const int stamp = a.epoch << 20;
 
 #define RQ_PIN() __builtin_amdgcn_sched_barrier(0)
     // staging cursor: the NEXT K-step to stage = (tile base, K offset, K-steps done in that tile, ring stage, tile counter);
@@ -253,6 +272,23 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
             __hip_atomic_fetch_or(&a.status[q_lane], kStOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             lq_ovf = 0;
         }
+        if (lim) {  // wave 0
+            const int mine = stamp | (tc + 1);
+            if (lane == 0) asm volatile("global_store_dword %0, %1, %2 sc1" ::"v"(qt * 4), "v"(mine), "s"(prog_base) : "memory");
+            if (tc > 0) {  // the words fetched one tile ago (landed: twelve younger pieces have been issued and waited down to 8)
+                int w = *(const int*)(smem + rq_prog_off(KS) + (lane & 7) * 4);
+                if (__builtin_amdgcn_ballot_w64((w >> 20) == a.epoch && (w & kRqDoneTiles) + a.drift < tc + 1)) {
+                    int spins = 0;
+                    do {
+                        __builtin_amdgcn_s_sleep(16);
+                        w = __hip_atomic_load((const int*)(prog_base + prog_voff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } while (__builtin_amdgcn_ballot_w64((w >> 20) == a.epoch && (w & kRqDoneTiles) + a.drift < tc + 1) &&
+                             ++spins < kRqSpinCap);
+                    if (spins >= kRqSpinCap) lim = false;
+                }
+            }
+            glds4_saddr_sc1(prog_base, prog_voff, prog_lds);
+        }
         const int tile_sb = (NST == KS) ? 0 : s0b;
         const int next_tile_sb = (NST == KS) ? 0 : (s0b + KS * kRqStageBytes >= NST * kRqStageBytes ? 0 : s0b + KS * kRqStageBytes);
 #pragma unroll
@@ -321,6 +357,8 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
     RQ_TEST(2, row0_prev, tc - 1);
     RQ_TEST(3, row0_prev, tc - 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the dummy prefetches must land before the LDS is freed
+    if ((ABL & 4096) == 0 && a.drift > 0 && a.progress != nullptr && wave == 0 && lane == 0)  // done: nobody waits for this one
+        __hip_atomic_store((int*)prog_base + qt, stamp | kRqDoneTiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     lane_queue_flush<I8>(a, lq, lq_n, row_end);
     if constexpr ((ABL & 4) != 0) {  // timing build without tests: the accumulators stay live
 #pragma unroll

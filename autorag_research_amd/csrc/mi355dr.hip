@@ -110,6 +110,8 @@ int ensure_qstate(mi355dr_index* idx) {
     HIPCHECK(idx, hipMalloc(&idx->st.E16, B * sizeof(float)));
     HIPCHECK(idx, hipMalloc(&idx->st.sc, B * sizeof(float)));
     HIPCHECK(idx, hipMalloc(&idx->st.kq, B * sizeof(float)));
+    HIPCHECK(idx, hipMalloc(&idx->rq_progress, kRqProgressWords * sizeof(int)));
+    HIPCHECK(idx, hipMemset(idx->rq_progress, 0, kRqProgressWords * sizeof(int)));
     HIPCHECK(idx, hipMalloc(&idx->st.qhat8, B * idx->dpad8));
     HIPCHECK(idx, hipMalloc(&idx->st.carry, B * sizeof(int)));
     HIPCHECK(idx, hipMalloc(&idx->qdev, B * idx->dim * sizeof(float)));
@@ -318,6 +320,9 @@ int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t 
         sa.n_ctiles = (int)(round_up(r_end, kRqRows) / kRqRows) - sa.ct0;
         const unsigned g2 = screen_rq_grid(sa.n_ctiles, sa.n_qtiles);
         idx->s_rq_launches++;
+        sa.progress = idx->rq_progress;  // sibling drift limiter: words of older launches carry another stamp and are ignored
+        sa.epoch = idx->rq_epoch = idx->rq_epoch % 4095 + 1;
+        sa.drift = idx->screen_drift;
         switch (sa.ksteps) {
 #define MI355_RQ_LAUNCH(KS) \
     case KS: hipLaunchKernelGGL((k_screen_rq<KS, 0, true>), dim3(g2), dim3(512), rq_lds(KS), s, sa); break;
@@ -852,7 +857,7 @@ void mi355dr_destroy(mi355dr_index* idx) {
                     idx->rows, idx->shadow, idx->nrm2, idx->irr_rows, idx->irr_count, idx->st.qn, idx->st.qhat,
                     idx->st.thr, idx->st.cnt, idx->st.best_n, idx->st.best_key, idx->st.best_row, idx->st.thr_key,
                     idx->st.thr_row, idx->st.status, idx->qdev, idx->cand_row, idx->cand_val, idx->qlist_dev,
-                    idx->out_dist_dev, idx->out_rows_dev, idx->stat_dev, idx->prune_skip};
+                    idx->out_dist_dev, idx->out_rows_dev, idx->stat_dev, idx->prune_skip, idx->rq_progress};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     multivec_destroy(idx);
@@ -1151,6 +1156,9 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
         idx->screen_stream = value != 0;
     } else if (k == "screen_rq") {
         idx->screen_rq = value != 0;
+    } else if (k == "screen_drift") {
+        if (value < 0 || value > 1024) return fail(idx, MI355DR_E_INVALID, "screen_drift: 0 ... 1024 tiles");
+        idx->screen_drift = (int)value;
     } else if (k == "small_chunk_rows") {
         if (value < 0) return fail(idx, MI355DR_E_INVALID, "small_chunk_rows must be >= 0");
         idx->small_chunk_rows = value;

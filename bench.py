@@ -69,6 +69,7 @@ def parse_args():
     ap.add_argument("--screen", choices=["auto", "bf16", "i8"], default="auto", help="screen element type")
     ap.add_argument("--screen-rq", type=int, default=None, help="0/1: large-block int8 screen with the query operand in registers "
                     "(k_screen_rq, default) / through the LDS (k_screen256c) (A/B)")
+    ap.add_argument("--screen-drift", type=int, default=None, help="k_screen_rq: tiles a workgroup may lead its siblings by (0 = no limiter; A/B)")
     ap.add_argument("--round-a", type=int, default=None, help="k_prune: rows re-scored before the cut is known (tuning)")
     ap.add_argument("--prefilter16", type=int, default=None, help="0/1: bf16 second screen inside the prune (default: library default)")
     ap.add_argument("--metric", choices=["cosine", "ip"], default="cosine", help="cosine (headline) or inner product")
@@ -157,6 +158,8 @@ def main() -> None:
     idx.set_option("screen_dtype", args.screen)
     if args.screen_rq is not None:
         idx.set_option("screen_rq", args.screen_rq)
+    if args.screen_drift is not None:
+        idx.set_option("screen_drift", args.screen_drift)
     if args.prefilter16 is not None:
         idx.set_option("prefilter16", args.prefilter16)
     if args.round_a is not None:
@@ -697,6 +700,8 @@ def main() -> None:
         dom = result["roofline"]["kernel"].split("<")[0]
         if args.screen_rq is not None:
             sub += ["--screen-rq", args.screen_rq]
+        if args.screen_drift is not None:
+            sub += ["--screen-drift", args.screen_drift]
         per_launch, n_prof, note = pmc_fetch_subrun(sub, dom)
         rl = result["roofline"]
         if per_launch is not None:

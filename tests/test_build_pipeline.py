@@ -141,6 +141,13 @@ def test_screen_rq_structure(screen_asm, ks):
     # the hit path: 4 test sites per copy of the tile loop + 2 behind it (the last tile's row half 1), 5 stores each
     n_st = sum(o.startswith("ds_write_b128") for o in ops)
     assert n_st % 5 == 0 and n_st >= 20, n_st
+    # the sibling drift limiter: per tile one agent-scope store of the own progress word and ONE LDS-DMA dword fetch of the
+    # siblings' (no register, no wait of its own); the polling loads live in the cold spin block next to an s_sleep
+    n_pub = sum(o.startswith("global_store_dword") and o.endswith("sc1") for o in ops)   # (+ the "done" word behind the loop)
+    n_get = sum(o.startswith("global_load_lds_dword ") and o.endswith("sc1") for o in ops)
+    assert 1 <= n_get <= 2 and n_get <= n_pub <= n_get + 1, (n_pub, n_get)
+    polls = [o for o in ops if o.startswith("global_load_dword ") and o.endswith("sc1")]
+    assert polls and sum(o.startswith("s_sleep") for o in ops) == len(polls)
 
 
 def _whole_kernel(asm: str, name: str) -> tuple[list[str], str]:

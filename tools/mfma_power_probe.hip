@@ -332,7 +332,18 @@ static int run_gather(long rows, int nq, int cand_per_q) {
     return 0;
 }
 
+#ifdef WITH_LIB_DIAG  // (built together with csrc/mi355dr_diag.hip: the library's own stream inside THIS process, for comparison)
+extern "C" int mi355dr_diag_mfma_stream(int device, int format, double seconds, double* out_tops);
+#endif
 int main(int argc, char** argv) {
+#ifdef WITH_LIB_DIAG
+    if (argc >= 4 && std::string(argv[1]).rfind("lib_", 0) == 0) {
+        double tops = 0;
+        const int rc = mi355dr_diag_mfma_stream(0, std::string(argv[1]) == "lib_bf16" ? 1 : 0, atof(argv[3]), &tops);
+        printf("library stream %s: rc %d, %.0f TOP/s settled\n", argv[1], rc, tops);
+        return rc;
+    }
+#endif
     if (argc >= 5 && std::string(argv[1]) == "gather") return run_gather(atol(argv[2]), atoi(argv[3]), atoi(argv[4]));
     if (argc < 4) {
         fprintf(stderr, "usage: %s <i8|bf16|fp8|fp6|fp4> <gauss|zero> <seconds>   |   %s gather <rows> <queries> <cand per query>\n", argv[0], argv[0]);

@@ -61,7 +61,7 @@ struct Cand {
     bool operator<(const Cand& o) const { return q != o.q ? q < o.q : row < o.row; }
 };
 
-#define RQ_FORMS(X) X(0) X(1) X(4) X(8) X(16) X(17) X(21) X(64) X(256) X(512) X(768) X(2048)
+#define RQ_FORMS(X) X(0) X(1) X(4) X(8) X(16) X(17) X(21) X(64) X(256) X(512) X(768) X(2048) X(4096)
 
 int main(int argc, char** argv) {
     const int64_t N = argc > 1 ? atoll(argv[1]) : (1 << 21);
@@ -116,9 +116,17 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
 
+    int* progress = nullptr;  // drift limiter of k_screen_rq (env DRIFT = tiles, 0 = off; variant 100 + 4096 = built without it)
+    CK(hipMalloc(&progress, kRqProgressWords * 4));
+    CK(hipMemset(progress, 0, kRqProgressWords * 4));
+    const int drift = getenv("DRIFT") ? atoi(getenv("DRIFT")) : 3;
+    int epoch = 0;
     auto launch = [&](int variant) {
         ScreenArgs2 sa{};
         sa.status = status;
+        sa.progress = progress;
+        sa.drift = drift;
+        sa.epoch = epoch = epoch % 4095 + 1;
         sa.shadow = shadow;
         sa.qhat = qhat;
         sa.thr = thr;
@@ -229,7 +237,7 @@ int main(int argc, char** argv) {
     std::vector<std::vector<Cand>> sets;
     std::vector<int> set_variant;
     for (int variant : variants) {
-        if (variant != 0 && variant != 100 && variant != 164 && variant != 612 && variant != 868 && variant != 2148) continue;
+        if (variant != 0 && variant != 100 && variant != 164 && variant != 612 && variant != 868 && variant != 2148 && variant != 4196) continue;
         const float T0 = 4.6f / sqrtf((float)d);
         hipLaunchKernelGGL(k_fillf, dim3((Bpad + 255) / 256), dim3(256), 0, 0, thr, Bpad, INFINITY);
         hipLaunchKernelGGL(k_fillf, dim3((Bpad + 255) / 256), dim3(256), 0, 0, thr, B, T0);
