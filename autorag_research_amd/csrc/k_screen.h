@@ -391,22 +391,39 @@ constexpr int kLaneQueueFlushAt = 24;
 // MODE (timing builds / A-B): 0 = the stores behind a wave-uniform branch (the kernel), 1 = bookkeeping without the stores,
 // 2 = BRANCH-FREE: the five stores always issued under EXEC = hit lanes (uniform cost for every wave; measured +15 % with the
 // thresholds parked: stores under an empty EXEC are not free -- not adopted), 3 = as 0 with the block laid out as fall-through.
+// The block's largest value, in four PARTS of two v_max3 each (k_screen_rq issues one part behind each of four MFMAs: a test in
+// one piece is ~14 dependent vector instructions during which its wave feeds the matrix pipe nothing -- and the other wave of
+// the SIMD, in lockstep behind the same barriers, is at its own test).  `g` = the running maximum (int32 bits / float bits).
+template <bool I8, int PART>
+__device__ __forceinline__ int screen_block_max_part(const f32x16& acc, int g) {
+    if constexpr (I8) {
+        const i32x16 v = __builtin_bit_cast(i32x16, acc);
+        if constexpr (PART == 0) return max(max(max(v[0], v[1]), v[2]), v[3]);
+        else return max(max(max(max(g, v[4 * PART]), v[4 * PART + 1]), v[4 * PART + 2]), v[4 * PART + 3]);  // two v_max3_i32
+    } else {
+        if constexpr (PART == 0) return __float_as_int(fmaxf(fmaxf(fmaxf(acc[0], acc[1]), acc[2]), acc[3]));
+        else return __float_as_int(fmaxf(fmaxf(fmaxf(fmaxf(__int_as_float(g), acc[4 * PART]), acc[4 * PART + 1]), acc[4 * PART + 2]), acc[4 * PART + 3]));
+    }
+}
+template <bool I8, int MODE = 0>
+__device__ __forceinline__ void screen_test_block_lq_max(const ScreenArgs& a, int* status, int row_end, f32x16 acc, int gmax, int q, int rbase,
+                                                         float th, I8Blk blk, unsigned lq_addr, int& lq_n, int& lq_ovf);
 template <bool I8, int MODE = 0>
 __device__ __forceinline__ void screen_test_block_lq(const ScreenArgs& a, int* status, int row_end, f32x16 acc, int q, int rbase, float th,
                                                      I8Blk blk, unsigned lq_addr, int& lq_n, int& lq_ovf) {
+    int g = screen_block_max_part<I8, 0>(acc, 0);
+    g = screen_block_max_part<I8, 1>(acc, g);
+    g = screen_block_max_part<I8, 2>(acc, g);
+    g = screen_block_max_part<I8, 3>(acc, g);
+    screen_test_block_lq_max<I8, MODE>(a, status, row_end, acc, g, q, rbase, th, blk, lq_addr, lq_n, lq_ovf);
+}
+// ... the rest of the test, given the block's largest value
+template <bool I8, int MODE>
+__device__ __forceinline__ void screen_test_block_lq_max(const ScreenArgs& a, int* status, int row_end, f32x16 acc, int gmax, int q, int rbase,
+                                                         float th, I8Blk blk, unsigned lq_addr, int& lq_n, int& lq_ovf) {
     bool any;
-    if constexpr (I8) {
-        const i32x16 v = __builtin_bit_cast(i32x16, acc);
-        int g[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) g[i] = max(max(v[4 * i], v[4 * i + 1]), max(v[4 * i + 2], v[4 * i + 3]));
-        any = i8_value(max(max(g[0], g[1]), max(g[2], g[3])), blk) >= th;
-    } else {
-        float g[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) g[i] = fmaxf(fmaxf(acc[4 * i], acc[4 * i + 1]), fmaxf(acc[4 * i + 2], acc[4 * i + 3]));
-        any = fmaxf(fmaxf(g[0], g[1]), fmaxf(g[2], g[3])) >= th;
-    }
+    if constexpr (I8) any = i8_value(gmax, blk) >= th;
+    else any = __int_as_float(gmax) >= th;
     const unsigned long long bal = __builtin_amdgcn_ballot_w64(any);
     const int n = __builtin_popcountll(bal);
     const i32x16 v = __builtin_bit_cast(i32x16, acc);

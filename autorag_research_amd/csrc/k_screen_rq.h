@@ -62,7 +62,7 @@ static_assert(rq_lds(6) <= 160 * 1024, "LDS per workgroup");
 __host__ __device__ inline unsigned screen_rq_grid(int n_ctiles, int n_qtiles) { return screen256_grid(n_ctiles, n_qtiles); }
 
 // ABL (timing builds for the A/B table; 0 = the kernel): 1 no fragment reads, 4 no tests, 8 no barrier, 16 no LDS-DMA in the
-// loop, 32 no vmcnt at the hand-over, 64 every test reads its own row-group record (the form before RQ_LOAD_REC); 2048 a hand-over in EVERY K-step (the form before kSkipLast); 4096 no drift limiter; bits 8, 9: the hit path without its stores (256) / its stores ALWAYS issued under EXEC = hit lanes instead of behind a branch (512: measured +15 % with thresholds parked -- stores under an empty EXEC are not free).  (Cache policies nt / sc0 / sc1 on the row pieces, measured in round 5:
+// loop, 32 no vmcnt at the hand-over, 64 every test reads its own row-group record (the form before RQ_LOAD_REC); 2048 a hand-over in EVERY K-step (the form before kSkipLast); 4096 no drift limiter; 8192 every test in one piece (the form before the maxima rode the MFMAs); bits 8, 9: the hit path without its stores (256) / its stores ALWAYS issued under EXEC = hit lanes instead of behind a branch (512: measured +15 % with thresholds parked -- stores under an empty EXEC are not free).  (Cache policies nt / sc0 / sc1 on the row pieces, measured in round 5:
 // +1 ... +3 % on Gaussian operands, profiles/r05_kstep_ab.txt -- the default policy stays.)
 template <int KS, int ABL, bool I8>
 __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
@@ -119,10 +119,12 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
     asm volatile("" ::"v"(th), "v"(kqq), "v"(scq));
 
     f32x16 acc[4];  // row blocks 0..3 of the tile
+    int tg = 0;     // running maximum of the block under test (screen_block_max_part)
     float rec_m[4] = {1.0f, 1.0f, 1.0f, 1.0f}, rec_e[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // their int8 constants (RQ_LOAD_REC)
     f32x16 zero16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
+    acc[2] = zero16, acc[3] = zero16;  // (the first tile takes the maxima of "the previous tile's" row half 1 like every other)
     const unsigned lds0 = lds_addr(smem);
     const unsigned rec_lds = lds0 + rq_rec_off(KS);
     const unsigned rec_voff = (unsigned)((lane & 7) * 4);  // the tile's 4 records = 8 dwords, eight copies per slot
@@ -193,6 +195,23 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
             acc[2 * ((M) >> 2) + rb] = screen_mfma<I8>(fAq[(M) & 3][rb], fB[4 * (TT) + ((M) & 3)],    \
                                                        (ZERO) ? zero16 : acc[2 * ((M) >> 2) + rb]);   \
     } while (0)
+// ... the same with the running maximum of finished block TB folded in behind the two MFMAs (parts 2 (M & 1), 2 (M & 1) + 1 of
+// screen_block_max_part: a block's four parts ride two consecutive micro-steps).  ABL bit 13: the test in one piece (the form
+// before, A/B).
+#define RQ_MM_T(M, TT, ZERO, TB)                                                                      \
+    do {                                                                                              \
+        if constexpr ((ABL & 4) != 0 || (ABL & 8192) != 0) {                                          \
+            RQ_MM(M, TT, ZERO);                                                                       \
+        } else {                                                                                      \
+            acc[2 * ((M) >> 2)] = screen_mfma<I8>(fAq[(M) & 3][0], fB[4 * (TT) + ((M) & 3)], (ZERO) ? zero16 : acc[2 * ((M) >> 2)]); \
+            RQ_PIN();                                                                                 \
+            tg = screen_block_max_part<I8, 2 * ((M) & 1)>(acc[TB], tg);                               \
+            RQ_PIN();                                                                                 \
+            acc[2 * ((M) >> 2) + 1] = screen_mfma<I8>(fAq[(M) & 3][1], fB[4 * (TT) + ((M) & 3)], (ZERO) ? zero16 : acc[2 * ((M) >> 2) + 1]); \
+            RQ_PIN();                                                                                 \
+            tg = screen_block_max_part<I8, 2 * ((M) & 1) + 1>(acc[TB], tg);                           \
+        }                                                                                             \
+    } while (0)
 // The four blocks' constants (m = S_g S_q, ek = e_g kq) of the tile under test, read from the records ring ONE micro-step
 // before the tile's first test instead of inside each test: a test that reads its record itself waits with lgkmcnt(0) for a
 // read queued BEHIND the six to eight fragment reads in flight (LDS returns in order) -- ~150 cycles of this wave, four times
@@ -221,7 +240,10 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
             } else if constexpr (I8) {                                                                \
                 blk__ = I8Blk{rec_m[RB], rec_e[RB]};                                                  \
             }                                                                                         \
-            screen_test_block_lq<I8, (ABL >> 8) & 3>(a, a.status, row_end, acc[RB], q__, rbase__, th, blk__, lq, lq_n, lq_ovf); \
+            if constexpr ((ABL & 8192) != 0)                                                          \
+                screen_test_block_lq<I8, (ABL >> 8) & 3>(a, a.status, row_end, acc[RB], q__, rbase__, th, blk__, lq, lq_n, lq_ovf); \
+            else                                                                                      \
+                screen_test_block_lq_max<I8, (ABL >> 8) & 3>(a, a.status, row_end, acc[RB], tg, q__, rbase__, th, blk__, lq, lq_n, lq_ovf); \
         }                                                                                             \
     } while (0)
 #define RQ_MICRO(M, TT, ZERO, SB, SBN)                                                                \
@@ -229,6 +251,13 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
         RQ_PREFETCH((M) + kPF, SB, SBN);                                                              \
         RQ_PIN();                                                                                     \
         RQ_MM(M, TT, ZERO);                                                                           \
+        RQ_PIN();                                                                                     \
+    } while (0)
+#define RQ_MICRO_T(M, TT, ZERO, SB, SBN, TB)                                                          \
+    do {                                                                                              \
+        RQ_PREFETCH((M) + kPF, SB, SBN);                                                              \
+        RQ_PIN();                                                                                     \
+        RQ_MM_T(M, TT, ZERO, TB);                                                                     \
         RQ_PIN();                                                                                     \
     } while (0)
 
@@ -297,15 +326,25 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
             const int sb = tile_sb + t * kRqStageBytes;
             const int sbn = last ? next_tile_sb : sb + kRqStageBytes;
             const bool tp = first && have_prev;  // test the previous tile's row half 1 under this K-step's row half 0
-            RQ_MICRO(0, t, first, sb, sbn);
-            if (tp) RQ_TEST(2, row0_prev, tc - 1);
-            RQ_MICRO(1, t, false, sb, sbn);
-            RQ_MICRO(2, t, false, sb, sbn);
-            if (tp) RQ_TEST(3, row0_prev, tc - 1);
-            RQ_MICRO(3, t, false, sb, sbn);
-            if (last) RQ_LOAD_REC(tc);  // (behind the previous tile's last test -- micro-step 2 of ITS next K-step -- also at KS = 1)
-            RQ_MICRO(4, t, first, sb, sbn);
-            if (last) RQ_TEST(0, row0_cur, tc);
+            // (the previous tile's row half 1 -- blocks 2, 3 -- is tested under this tile's first K-step, row half 0: the blocks'
+            // maxima ride micro-steps 0, 1 / 2, 3, the rest of each test follows its second micro-step.  In the first tile
+            // the maxima are taken of zeros and dropped)
+            if (first) {
+                RQ_MICRO_T(0, t, first, sb, sbn, 2);
+                RQ_MICRO_T(1, t, false, sb, sbn, 2);
+                if (tp) RQ_TEST(2, row0_prev, tc - 1);
+                RQ_MICRO_T(2, t, false, sb, sbn, 3);
+                RQ_MICRO_T(3, t, false, sb, sbn, 3);
+                if (tp) RQ_TEST(3, row0_prev, tc - 1);
+            } else {
+                RQ_MICRO(0, t, first, sb, sbn);
+                RQ_MICRO(1, t, false, sb, sbn);
+                RQ_MICRO(2, t, false, sb, sbn);
+                RQ_MICRO(3, t, false, sb, sbn);
+            }
+            if (last) RQ_LOAD_REC(tc);  // (behind the previous tile's last test -- micro-step 3 of ITS next K-step -- also at KS = 1)
+            if (last) RQ_MICRO_T(4, t, first, sb, sbn, 0);
+            else RQ_MICRO(4, t, first, sb, sbn);
             // ---- hand-over: every read of this K-step's stage has been issued (the last ones kPF micro-steps before its end)
             const bool hand = !(kSkipLast && last);
             if (hand) {
@@ -324,20 +363,24 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
                 if constexpr ((ABL & 8) == 0) MI355_BARRIER();
             }
             RQ_PIN();
-            RQ_MICRO(5, t, false, sb, sbn);
+            if (last) RQ_MICRO_T(5, t, false, sb, sbn, 0);
+            else RQ_MICRO(5, t, false, sb, sbn);
+            if (last) RQ_TEST(0, row0_cur, tc);
             if (hand) RQ_PIECE(0);
             RQ_PIN();
-            RQ_MICRO(6, t, false, sb, sbn);
+            if (last) RQ_MICRO_T(6, t, false, sb, sbn, 1);
+            else RQ_MICRO(6, t, false, sb, sbn);
             if (hand) RQ_PIECE(1);
             RQ_PIN();
-            if (last) RQ_TEST(1, row0_cur, tc);
             if (hand && kSkipLast && first) {  // two stages were handed over: the second K-step's pieces ride micro-step 7
                 RQ_REC();
                 RQ_ADVANCE();
                 RQ_PIECE(0);
                 RQ_PIN();
             }
-            RQ_MICRO(7, t, false, sb, sbn);
+            if (last) RQ_MICRO_T(7, t, false, sb, sbn, 1);
+            else RQ_MICRO(7, t, false, sb, sbn);
+            if (last) RQ_TEST(1, row0_cur, tc);
             if (hand && kSkipLast && first) RQ_PIECE(1);
             if (hand) {
                 RQ_REC();
@@ -353,9 +396,20 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
         ctl += cstep;
         row0_cur = (a.ct0 + ctl) * kRqRows;
     }
-    // the last tile's row half 1
-    RQ_TEST(2, row0_prev, tc - 1);
-    RQ_TEST(3, row0_prev, tc - 1);
+    // the last tile's row half 1 (no MFMAs left to hide under: the maxima in one piece)
+#define RQ_TEST_WHOLE(RB)                                                                             \
+    do {                                                                                              \
+        if constexpr ((ABL & 4) == 0 && (ABL & 8192) == 0) {                                          \
+            tg = screen_block_max_part<I8, 0>(acc[RB], tg);                                           \
+            tg = screen_block_max_part<I8, 1>(acc[RB], tg);                                           \
+            tg = screen_block_max_part<I8, 2>(acc[RB], tg);                                           \
+            tg = screen_block_max_part<I8, 3>(acc[RB], tg);                                           \
+        }                                                                                             \
+        RQ_TEST(RB, row0_prev, tc - 1);                                                               \
+    } while (0)
+    RQ_TEST_WHOLE(2);
+    RQ_TEST_WHOLE(3);
+#undef RQ_TEST_WHOLE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the dummy prefetches must land before the LDS is freed
     if ((ABL & 4096) == 0 && a.drift > 0 && a.progress != nullptr && wave == 0 && lane == 0)  // done: nobody waits for this one
         __hip_atomic_store((int*)prog_base + qt, stamp | kRqDoneTiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -371,6 +425,8 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
 #undef RQ_ADVANCE
 #undef RQ_PREFETCH
 #undef RQ_MM
+#undef RQ_MM_T
+#undef RQ_MICRO_T
 #undef RQ_TEST
 #undef RQ_MICRO
 }

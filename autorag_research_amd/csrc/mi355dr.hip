@@ -157,6 +157,7 @@ int ensure_qstate(mi355dr_index* idx) {
     HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen_rq<KS, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, rq_lds(KS)));
     MI355_RQ_FORMS(MI355_RQ_ATTR)
 #undef MI355_RQ_ATTR
+    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen_rq<6, 8192, true>, hipFuncAttributeMaxDynamicSharedMemorySize, rq_lds(6)));
     HIPCHECK(idx, hipFuncSetAttribute((const void*)k_merge_topk, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kSortMax * 12));
     idx->qstate_ready = true;
@@ -320,14 +321,26 @@ int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t 
         sa.n_ctiles = (int)(round_up(r_end, kRqRows) / kRqRows) - sa.ct0;
         const unsigned g2 = screen_rq_grid(sa.n_ctiles, sa.n_qtiles);
         idx->s_rq_launches++;
+        if (idx->debug_park > 0 && r_end - r0 >= idx->debug_park) {  // (diagnostic: thresholds at +inf for a launch of at least that many rows -- its cost without a single hit; results are WRONG)
+            if (!idx->park_thr) {
+                std::vector<float> inf(kQBlockMax, INFINITY);
+                HIPCHECK(idx, hipMalloc(&idx->park_thr, kQBlockMax * sizeof(float)));
+                HIPCHECK(idx, hipMemcpy(idx->park_thr, inf.data(), kQBlockMax * sizeof(float), hipMemcpyHostToDevice));
+            }
+            sa.thr = idx->park_thr;
+        }
         sa.progress = idx->rq_progress;  // sibling drift limiter: words of older launches carry another stamp and are ignored
         sa.epoch = idx->rq_epoch = idx->rq_epoch % 4095 + 1;
         sa.drift = idx->screen_drift;
-        switch (sa.ksteps) {
+        if (sa.ksteps == 6 && !idx->screen_rq_split_tests) {  // (A/B form, d = 768 only: every block test in one piece)
+            hipLaunchKernelGGL((k_screen_rq<6, 8192, true>), dim3(g2), dim3(512), rq_lds(6), s, sa);
+        } else {
+            switch (sa.ksteps) {
 #define MI355_RQ_LAUNCH(KS) \
     case KS: hipLaunchKernelGGL((k_screen_rq<KS, 0, true>), dim3(g2), dim3(512), rq_lds(KS), s, sa); break;
-            MI355_RQ_FORMS(MI355_RQ_LAUNCH)
+                MI355_RQ_FORMS(MI355_RQ_LAUNCH)
 #undef MI355_RQ_LAUNCH
+            }
         }
     } else if (tile == kT2) {
         const unsigned g2 = screen256_grid(sa.n_ctiles, sa.n_qtiles);  // persistent: <= one workgroup per CU
@@ -857,7 +870,7 @@ void mi355dr_destroy(mi355dr_index* idx) {
                     idx->rows, idx->shadow, idx->nrm2, idx->irr_rows, idx->irr_count, idx->st.qn, idx->st.qhat,
                     idx->st.thr, idx->st.cnt, idx->st.best_n, idx->st.best_key, idx->st.best_row, idx->st.thr_key,
                     idx->st.thr_row, idx->st.status, idx->qdev, idx->cand_row, idx->cand_val, idx->qlist_dev,
-                    idx->out_dist_dev, idx->out_rows_dev, idx->stat_dev, idx->prune_skip, idx->rq_progress};
+                    idx->out_dist_dev, idx->out_rows_dev, idx->stat_dev, idx->prune_skip, idx->rq_progress, idx->park_thr};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     multivec_destroy(idx);
@@ -1156,6 +1169,10 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
         idx->screen_stream = value != 0;
     } else if (k == "screen_rq") {
         idx->screen_rq = value != 0;
+    } else if (k == "debug_park_thresholds") {
+        idx->debug_park = value;
+    } else if (k == "screen_rq_split_tests") {
+        idx->screen_rq_split_tests = value != 0;
     } else if (k == "screen_drift") {
         if (value < 0 || value > 1024) return fail(idx, MI355DR_E_INVALID, "screen_drift: 0 ... 1024 tiles");
         idx->screen_drift = (int)value;

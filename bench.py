@@ -69,6 +69,9 @@ def parse_args():
     ap.add_argument("--screen", choices=["auto", "bf16", "i8"], default="auto", help="screen element type")
     ap.add_argument("--screen-rq", type=int, default=None, help="0/1: large-block int8 screen with the query operand in registers "
                     "(k_screen_rq, default) / through the LDS (k_screen256c) (A/B)")
+    ap.add_argument("--screen-rq-split-tests", type=int, default=None, help="k_screen_rq: 0 = every block test in one piece (A/B)")
+    ap.add_argument("--debug-park", type=int, default=0, help="diagnostic: k_screen_rq launches of at least this many rows run with every "
+                    "threshold at +inf (what such a launch costs without hits; the results of such a run are WRONG)")
     ap.add_argument("--screen-drift", type=int, default=None, help="k_screen_rq: tiles a workgroup may lead its siblings by (0 = no limiter; A/B)")
     ap.add_argument("--round-a", type=int, default=None, help="k_prune: rows re-scored before the cut is known (tuning)")
     ap.add_argument("--prefilter16", type=int, default=None, help="0/1: bf16 second screen inside the prune (default: library default)")
@@ -160,6 +163,10 @@ def main() -> None:
         idx.set_option("screen_rq", args.screen_rq)
     if args.screen_drift is not None:
         idx.set_option("screen_drift", args.screen_drift)
+    if args.debug_park:
+        idx.set_option("debug_park_thresholds", args.debug_park)
+    if args.screen_rq_split_tests is not None:
+        idx.set_option("screen_rq_split_tests", args.screen_rq_split_tests)
     if args.prefilter16 is not None:
         idx.set_option("prefilter16", args.prefilter16)
     if args.round_a is not None:

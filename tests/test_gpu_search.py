@@ -222,6 +222,33 @@ def test_register_resident_query_screen_equals_tile_screen(pkg, oracle, n, d, B,
     assert np.array_equal(res[0][1], res[1][1])
 
 
+@pytest.mark.parametrize("drift", [0, 1, 3, 1024])
+def test_sibling_drift_limiter_changes_no_result(pkg, oracle, drift):
+    """k_screen_rq's drift limiter (option screen_drift: tiles a workgroup may lead the slowest workgroup on the same row tiles
+    by; 0 = off) is progress control only: every setting -- off, the tightest (a leader waits at every flush of a sibling's
+    hit-lane queue), the default, one that never engages -- returns the oracle's answer, over several launches of one handle
+    (the launch stamp in the progress words advances; words of older launches must be ignored, not waited for)."""
+    n, d, B, k = 600_000, 768, 1024, 10
+    rng = np.random.default_rng(4242)
+    C = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    with pkg.Mi355Index(d) as idx:
+        idx.set_option("screen_dtype", "i8")
+        idx.set_option("path", "screen")
+        idx.set_option("screen_drift", drift)
+        idx.add(C)
+        idx.reset_stats()
+        first = _check(idx, oracle, C, Q[:512], k)
+        for _ in range(3):   # the same block again and a full block: launch stamps 2, 3, ...
+            d2, r2 = idx.search(Q[:512], k)
+            assert np.array_equal(r2, first[1])
+        _check(idx, oracle, C, Q, k)
+        assert idx.stat("fallback_queries") == 0 and idx.stat("screen_rq_launches") > 0
+    with pytest.raises(Exception):
+        with pkg.Mi355Index(d) as idx:
+            idx.set_option("screen_drift", -1)
+
+
 @pytest.mark.parametrize("screen", SCREENS)
 @pytest.mark.parametrize("n,d,B,k", [(30000, 768, 1, 10), (20000, 768, 33, 10), (9000, 100, 64, 5), (50000, 384, 17, 20),
                                       (3000, 1536, 32, 10), (2100, 2048, 5, 10)])

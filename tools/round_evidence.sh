@@ -97,7 +97,7 @@ power)
   kill $SMI 2>/dev/null; wait $SMI 2>/dev/null
   echo "600-step bench: $(smi_median $OUT/power_samples.txt)" | tee $OUT/power_headline.txt ;;
 mx)
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/mfma_power_probe.hip -o /tmp/mfma_power_probe || exit 1
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iautorag_research_amd/csrc tools/mfma_power_probe.hip -o /tmp/mfma_power_probe || exit 1
   { echo "# bare MFMA stream: 256 workgroups x 8 waves (2 per SIMD), operands in registers, 4 accumulators; ${SECS:-4} s per run;"
     echo "# rocm-smi polled next to each run, medians behind the first third of the samples"
     rocm-smi --showmaxpower 2>/dev/null | grep -E "Max Graphics" | head -1

@@ -40,7 +40,10 @@ __device__ inline uint32_t hash32(uint64_t x) {
     x ^= x >> 33;
     return (uint32_t)x;
 }
-__global__ void k_fill8(int8_t* p, int64_t n, int mode, uint64_t seed) {
+// mode 1: sum of four uniforms, sigma 29 (light tails); mode 2: zeros; mode 3: a TRUE Gaussian (Box-Muller) of sigma `sigma` -- what
+// the library's shadows hold for unit Gaussian rows: rows sigma 31.4 (127 at the largest of a 32-row group's 24 576 components),
+// queries sigma 40 (127 at the largest of a query's 768)
+__global__ void k_fill8(int8_t* p, int64_t n, int mode, uint64_t seed, float sigma) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t h = hash32(i * 4 + seed), h2 = hash32(i * 4 + 1 + seed);
@@ -48,6 +51,11 @@ __global__ void k_fill8(int8_t* p, int64_t n, int mode, uint64_t seed) {
     const float g = u * sqrtf(3.0f);
     int v = 0;
     if (mode == 1) v = (int)rintf(fminf(fmaxf(g * 29.0f, -127.f), 127.f));
+    if (mode == 3) {
+        const float u1 = ((float)h + 1.0f) * (1.0f / 4294967296.0f), u2 = (float)h2 * (1.0f / 4294967296.0f);
+        const float z = sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
+        v = (int)rintf(fminf(fmaxf(z * sigma, -127.f), 127.f));
+    }
     p[i] = (int8_t)v;
 }
 __global__ void k_fillf(float* p, int n, float v) {
@@ -61,7 +69,7 @@ struct Cand {
     bool operator<(const Cand& o) const { return q != o.q ? q < o.q : row < o.row; }
 };
 
-#define RQ_FORMS(X) X(0) X(1) X(4) X(8) X(16) X(17) X(21) X(64) X(256) X(512) X(768) X(2048) X(4096)
+#define RQ_FORMS(X) X(0) X(1) X(4) X(8) X(16) X(17) X(21) X(32) X(64) X(256) X(512) X(768) X(2048) X(4096) X(8192)
 
 int main(int argc, char** argv) {
     const int64_t N = argc > 1 ? atoll(argv[1]) : (1 << 21);
@@ -95,15 +103,16 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&grp, (size_t)(Npad / 32) * sizeof(I8Group)));
     {
         const int64_t nb = (int64_t)Npad * dpad8, nq = (int64_t)Bpad * dpad8;
-        hipLaunchKernelGGL(k_fill8, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, 0, shadow, nb, mode, 1234ull);
-        hipLaunchKernelGGL(k_fill8, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, 0, qhat, nq, mode, 99ull);
+        const float sig_r = mode == 3 ? 31.4f : 29.0f, sig_q = mode == 3 ? 40.0f : 29.0f;
+        hipLaunchKernelGGL(k_fill8, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, 0, shadow, nb, mode, 1234ull, sig_r);
+        hipLaunchKernelGGL(k_fill8, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, 0, qhat, nq, mode, 99ull, sig_q);
         std::vector<float> one(Bpad, 1.0f);
         CK(hipMemcpy(scv, one.data(), Bpad * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(kqv, one.data(), Bpad * 4, hipMemcpyHostToDevice));
         // acc ~ N(0, d 29^4): with S_q = 1 and every group's step 1 / (d 841) the screen value is N(0, 1/d); the group's
         // residual term differs from group to group so that a wrong record shows up in the values
         std::vector<I8Group> hg((size_t)(Npad / 32));
-        for (size_t g = 0; g < hg.size(); ++g) hg[g] = I8Group{1.0f / ((float)d * 841.0f), 1e-4f * (float)(g % 7)};
+        for (size_t g = 0; g < hg.size(); ++g) hg[g] = I8Group{1.0f / ((float)d * sig_r * sig_q), 1e-4f * (float)(g % 7)};
         CK(hipMemcpy(grp, hg.data(), hg.size() * sizeof(I8Group), hipMemcpyHostToDevice));
     }
     CK(hipDeviceSynchronize());
@@ -175,12 +184,17 @@ int main(int argc, char** argv) {
     if (getenv("SECONDS_RUN")) {  // sustained run of the first variant (read the power next to it)
         const double secs = atof(getenv("SECONDS_RUN"));
         hipLaunchKernelGGL(k_fillf, dim3((Bpad + 255) / 256), dim3(256), 0, 0, thr, Bpad, INFINITY);
+        const bool hits = getenv("THRZ") != nullptr;  // (thresholds at THRZ sigma instead of parked; counters reset before every launch)
+        if (hits) hipLaunchKernelGGL(k_fillf, dim3((Bpad + 255) / 256), dim3(256), 0, 0, thr, B, (float)atof(getenv("THRZ")) / sqrtf((float)d));
         CK(hipDeviceSynchronize());
         const auto t0 = std::chrono::steady_clock::now();
         long n = 0;
         double el = 0;
         do {
-            for (int i = 0; i < 20; ++i) launch(variants[0]);
+            for (int i = 0; i < 20; ++i) {
+                if (hits) CK(hipMemsetAsync(cnt, 0, Bpad * 4, 0));
+                launch(variants[0]);
+            }
             CK(hipDeviceSynchronize());
             n += 20;
             el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -237,7 +251,7 @@ int main(int argc, char** argv) {
     std::vector<std::vector<Cand>> sets;
     std::vector<int> set_variant;
     for (int variant : variants) {
-        if (variant != 0 && variant != 100 && variant != 164 && variant != 612 && variant != 868 && variant != 2148 && variant != 4196) continue;
+        if (variant != 0 && variant != 100 && variant != 164 && variant != 612 && variant != 868 && variant != 2148 && variant != 4196 && variant != 8292) continue;
         const float T0 = 4.6f / sqrtf((float)d);
         hipLaunchKernelGGL(k_fillf, dim3((Bpad + 255) / 256), dim3(256), 0, 0, thr, Bpad, INFINITY);
         hipLaunchKernelGGL(k_fillf, dim3((Bpad + 255) / 256), dim3(256), 0, 0, thr, B, T0);
