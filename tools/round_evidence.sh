@@ -116,10 +116,13 @@ kstep)
     echo "# queries, query operand resident in registers), int8, ${KROWS:-10000000} rows x 1024 queries x d 768, thresholds parked; timing builds of"
     echo "# k_screen_rq: 101 no fragment reads | 104 no tests | 108 no barrier | 116 no LDS-DMA | 117 no LDS-DMA, no fragment reads"
     echo "# (results of the ablated builds are garbage; without the LDS-DMA the ring is never filled: those builds multiply zeros)"
-    for data in 1 2; do
-      echo "=== DATA=$data ($([ $data = 1 ] && echo 'Gaussian int8, sigma 29: what the shadows hold' || echo zeros)) ==="
-      echo "--- interleaved (every variant once per round, 30 rounds)"
-      DATA=$data ROUNDS=30 VARIANTS=0,100,101,104,108,116,117 /tmp/screen_ab ${KROWS:-10000000} 1024 768 | grep -E "^variant|candidate set"
+    echo "# 132 no vmcnt at the hand-over | 8292 block tests in one piece | 4196 no drift limiter"
+    echo "# Operands written by a grid-stride fill and CHECKED (tools/screen_ab: a refused one-thread-per-byte fill left the runs above"
+    echo "# 5.59 M rows of the earlier tables partly unwritten -- their absolute times were too fast; profiles/r05_harness_fill_fix.txt)"
+    for data in 3 2; do
+      echo "=== DATA=$data ($([ $data = 3 ] && echo 'true Gaussian int8, rows sigma 31.4, queries sigma 40: what the shadows hold' || echo zeros)) ==="
+      echo "--- interleaved (every variant once per round, 24 rounds)"
+      DATA=$data ROUNDS=24 VARIANTS=0,100,101,104,108,116,117,132,8292,4196 /tmp/screen_ab ${KROWS:-10000000} 1024 768 | grep -E "^variant|candidate set"
       for v in 0 100; do
         smi_poll $OUT/smi_kstep.txt 14
         line=$(DATA=$data VARIANTS=$v SECONDS_RUN=4 /tmp/screen_ab ${KROWS:-10000000} 1024 768 | tail -1)

@@ -43,9 +43,11 @@ __device__ inline uint32_t hash32(uint64_t x) {
 // mode 1: sum of four uniforms, sigma 29 (light tails); mode 2: zeros; mode 3: a TRUE Gaussian (Box-Muller) of sigma `sigma` -- what
 // the library's shadows hold for unit Gaussian rows: rows sigma 31.4 (127 at the largest of a 32-row group's 24 576 components),
 // queries sigma 40 (127 at the largest of a query's 768)
+// (grid-stride: a grid of one thread per byte exceeds 2^32 work-items above 5.59 M rows of 768 B -- the launch is then refused and,
+// unchecked, left the operands of every larger run partly unwritten: the absolute times of rounds 4 / 5 at 7.2 M and 10 M rows
+// were too fast for that reason; profiles/r05_harness_fill_fix.txt)
 __global__ void k_fill8(int8_t* p, int64_t n, int mode, uint64_t seed, float sigma) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     uint32_t h = hash32(i * 4 + seed), h2 = hash32(i * 4 + 1 + seed);
     const float u = ((h & 0xFFFF) + (h >> 16) + (h2 & 0xFFFF) + (h2 >> 16)) * (1.0f / 65536.0f) - 2.0f;  // var 1/3
     const float g = u * sqrtf(3.0f);
@@ -57,6 +59,7 @@ __global__ void k_fill8(int8_t* p, int64_t n, int mode, uint64_t seed, float sig
         v = (int)rintf(fminf(fmaxf(z * sigma, -127.f), 127.f));
     }
     p[i] = (int8_t)v;
+  }
 }
 __global__ void k_fillf(float* p, int n, float v) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -104,8 +107,19 @@ int main(int argc, char** argv) {
     {
         const int64_t nb = (int64_t)Npad * dpad8, nq = (int64_t)Bpad * dpad8;
         const float sig_r = mode == 3 ? 31.4f : 29.0f, sig_q = mode == 3 ? 40.0f : 29.0f;
-        hipLaunchKernelGGL(k_fill8, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, 0, shadow, nb, mode, 1234ull, sig_r);
-        hipLaunchKernelGGL(k_fill8, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, 0, qhat, nq, mode, 99ull, sig_q);
+        CK(hipMemset(shadow, 0, (size_t)nb));
+        hipLaunchKernelGGL(k_fill8, dim3(1 << 16), dim3(256), 0, 0, shadow, nb, mode, 1234ull, sig_r);
+        CK(hipGetLastError());
+        hipLaunchKernelGGL(k_fill8, dim3(1 << 12), dim3(256), 0, 0, qhat, nq, mode, 99ull, sig_q);
+        CK(hipGetLastError());
+        CK(hipDeviceSynchronize());
+        if (mode != 2) {  // the LAST row must hold data (a refused or truncated fill leaves it zero)
+            std::vector<int8_t> tail(dpad8);
+            CK(hipMemcpy(tail.data(), shadow + (size_t)(N - 1) * dpad8, dpad8, hipMemcpyDeviceToHost));
+            int nz = 0;
+            for (int i = 0; i < d; ++i) nz += tail[i] != 0;
+            if (nz < d / 2) { fprintf(stderr, "operand fill incomplete: last row has %d non-zero bytes\n", nz); exit(1); }
+        }
         std::vector<float> one(Bpad, 1.0f);
         CK(hipMemcpy(scv, one.data(), Bpad * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(kqv, one.data(), Bpad * 4, hipMemcpyHostToDevice));
@@ -135,6 +149,7 @@ int main(int argc, char** argv) {
         sa.status = status;
         sa.progress = progress;
         sa.drift = drift;
+        sa.drift_mask = (getenv("DRIFT_EVERY") ? atoi(getenv("DRIFT_EVERY")) : 1) - 1;
         sa.epoch = epoch = epoch % 4095 + 1;
         sa.shadow = shadow;
         sa.qhat = qhat;
