@@ -140,7 +140,6 @@ struct mi355dr_index {
     int screen_rq_split_tests = 1;  // k_screen_rq: a block test's maxima ride the MFMAs of the other row half (0: in one piece; d = 768 only, A/B; option "screen_rq_split_tests")
     int64_t debug_park = 0;     // diagnostic (option "debug_park_thresholds" = rows): k_screen_rq launches of at least that many rows run with every threshold at +inf -- what such a launch costs without hits; results are wrong while it is set
     float* park_thr = nullptr;
-    int screen_drift_every = 1;  // ... checked on every n-th tile (1, 2, 4, 8; option "screen_drift_every")
     int screen_drift = 3;   // k_screen_rq: tiles a workgroup may run ahead of its slowest sibling (0 = no limiter; option "screen_drift")
     int* rq_progress = nullptr;  // [kRqProgressWords] the limiter's progress words
     int rq_epoch = 0;            // launch stamp of the last k_screen_rq launch (1 ... 4095)

@@ -47,7 +47,6 @@ struct ScreenArgs2 : ScreenArgs {
     int* progress = nullptr;  // [kRqProgressWords] tile counters of the persistent workgroups, 8 words per row-tile slot
     int epoch = 0;            // launch stamp (12 bits) in the words' high bits: words of other launches are ignored
     int drift = 0;            // tiles a workgroup may run ahead of the slowest workgroup on the same row tiles
-    int drift_mask = 0;       // the limiter acts on tiles with (tile counter & drift_mask) == 0 (0: every tile, 1: every other, 3: ...)
 };
 
 // ---- one 1-KiB piece (U = 0,1) of half-tile type S into ring parity `par`; src = the half-tile's first row + K offset

@@ -301,14 +301,15 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
             __hip_atomic_fetch_or(&a.status[q_lane], kStOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             lq_ovf = 0;
         }
-        // drift limiter, wave 0, every (drift_mask + 1)-th tile.  Here -- not behind a barrier: measured behind the first K-step's
-        // hand-over, where the words could be read under the wait for the fragments, the same work cost +4.7 % (zeros: +13.7 %):
-        // right behind a barrier all eight waves start together and the one that has extra work is late at the next; at a
-        // tile's start the waves are staggered (the last barrier is a K-step back) and most of it is absorbed.
-        if (lim && (tc & a.drift_mask) == 0) {
+        // drift limiter, wave 0, every tile.  Here -- not behind a barrier: measured behind the first K-step's hand-over, where the
+        // words could be read under the wait for the fragments, the same work cost +4.7 % (zeros: +13.7 %): right behind a
+        // barrier all eight waves start together and the one that has extra work is late at the next; at a tile's start the
+        // waves are staggered (the last barrier is a K-step back) and most of it is absorbed.  (Acting on every 2nd / 4th tile
+        // only was SLOWER, +0.8 / +2.9 % per step: profiles/r05_drift_limiter.txt.)
+        if (lim) {
             const int mine = stamp | (tc + 1);
             if (lane == 0) asm volatile("global_store_dword %0, %1, %2 sc1" ::"v"(qt * 4), "v"(mine), "s"(prog_base) : "memory");
-            if (tc > 0) {  // the words fetched at the last check (landed: younger pieces have been issued and waited down to 8 since)
+            if (tc > 0) {  // the words fetched one tile ago (landed: twelve younger pieces have been issued and waited down to 8)
                 int w = *(const int*)(smem + rq_prog_off(KS) + (lane & 7) * 4);
                 if (__builtin_amdgcn_ballot_w64((w >> 20) == a.epoch && (w & kRqDoneTiles) + a.drift < tc + 1)) {
                     int spins = 0;

@@ -332,7 +332,6 @@ int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t 
         sa.progress = idx->rq_progress;  // sibling drift limiter: words of older launches carry another stamp and are ignored
         sa.epoch = idx->rq_epoch = idx->rq_epoch % 4095 + 1;
         sa.drift = idx->screen_drift;
-        sa.drift_mask = idx->screen_drift_every - 1;
         if (sa.ksteps == 6 && !idx->screen_rq_split_tests) {  // (A/B form, d = 768 only: every block test in one piece)
             hipLaunchKernelGGL((k_screen_rq<6, 8192, true>), dim3(g2), dim3(512), rq_lds(6), s, sa);
         } else {
@@ -1174,9 +1173,6 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
         idx->debug_park = value;
     } else if (k == "screen_rq_split_tests") {
         idx->screen_rq_split_tests = value != 0;
-    } else if (k == "screen_drift_every") {
-        if (value != 1 && value != 2 && value != 4 && value != 8) return fail(idx, MI355DR_E_INVALID, "screen_drift_every: 1, 2, 4 or 8 tiles");
-        idx->screen_drift_every = (int)value;
     } else if (k == "screen_drift") {
         if (value < 0 || value > 1024) return fail(idx, MI355DR_E_INVALID, "screen_drift: 0 ... 1024 tiles");
         idx->screen_drift = (int)value;

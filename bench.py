@@ -72,7 +72,6 @@ def parse_args():
     ap.add_argument("--screen-rq-split-tests", type=int, default=None, help="k_screen_rq: 0 = every block test in one piece (A/B)")
     ap.add_argument("--debug-park", type=int, default=0, help="diagnostic: k_screen_rq launches of at least this many rows run with every "
                     "threshold at +inf (what such a launch costs without hits; the results of such a run are WRONG)")
-    ap.add_argument("--screen-drift-every", type=int, default=None, help="k_screen_rq: the limiter acts on every n-th tile (1, 2, 4, 8; A/B)")
     ap.add_argument("--screen-drift", type=int, default=None, help="k_screen_rq: tiles a workgroup may lead its siblings by (0 = no limiter; A/B)")
     ap.add_argument("--round-a", type=int, default=None, help="k_prune: rows re-scored before the cut is known (tuning)")
     ap.add_argument("--prefilter16", type=int, default=None, help="0/1: bf16 second screen inside the prune (default: library default)")
@@ -164,8 +163,6 @@ def main() -> None:
         idx.set_option("screen_rq", args.screen_rq)
     if args.screen_drift is not None:
         idx.set_option("screen_drift", args.screen_drift)
-    if args.screen_drift_every is not None:
-        idx.set_option("screen_drift_every", args.screen_drift_every)
     if args.debug_park:
         idx.set_option("debug_park_thresholds", args.debug_park)
     if args.screen_rq_split_tests is not None:
@@ -712,8 +709,6 @@ def main() -> None:
             sub += ["--screen-rq", args.screen_rq]
         if args.screen_drift is not None:
             sub += ["--screen-drift", args.screen_drift]
-        if args.screen_drift_every is not None:
-            sub += ["--screen-drift-every", args.screen_drift_every]
         per_launch, n_prof, note = pmc_fetch_subrun(sub, dom)
         rl = result["roofline"]
         if per_launch is not None:

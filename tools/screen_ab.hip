@@ -149,7 +149,6 @@ int main(int argc, char** argv) {
         sa.status = status;
         sa.progress = progress;
         sa.drift = drift;
-        sa.drift_mask = (getenv("DRIFT_EVERY") ? atoi(getenv("DRIFT_EVERY")) : 1) - 1;
         sa.epoch = epoch = epoch % 4095 + 1;
         sa.shadow = shadow;
         sa.qhat = qhat;
