@@ -20,6 +20,7 @@
 #include "dev_common.h"
 #include "k_screen256c.h"
 #include "k_screen_rq.h"
+#include "k_screen_rq1.h"  // (tools/: the one-wave-per-SIMD experiment, not part of the library)
 
 using namespace mi355;
 
@@ -135,6 +136,9 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)k_screen_rq<6, A, true>, hipFuncAttributeMaxDynamicSharedMemorySize, rq_lds(6)));     \
     CK(hipFuncSetAttribute((const void*)k_screen_rq<3, A, true>, hipFuncAttributeMaxDynamicSharedMemorySize, rq_lds(3)));
     RQ_FORMS(RQ_ATTR)
+#define RQ1_FORMS(X) X(0) X(1) X(4) X(16) X(4096)
+#define RQ1_ATTR(A) CK(hipFuncSetAttribute((const void*)k_screen_rq1<6, A, true>, hipFuncAttributeMaxDynamicSharedMemorySize, rq_lds(6)));
+    RQ1_FORMS(RQ1_ATTR)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
@@ -170,6 +174,14 @@ int main(int argc, char** argv) {
             sa.n_ctiles = (int)((N + 255) / 256);
             hipLaunchKernelGGL((k_screen256c<kScreen256cAbl, true>), dim3(screen256_grid(sa.n_ctiles, sa.n_qtiles)), dim3(512),
                                kScreen256Lds, 0, sa);
+        } else if (variant >= 200 && variant < 100000 && (variant - 200 == 0 || variant - 200 == 1 || variant - 200 == 4 || variant - 200 == 16 || variant - 200 == 4096)) {
+            // k_screen_rq1 (one wave per SIMD, 4 waves x 64 queries; d = 768 only)
+            const int abl = variant - 200;
+            sa.n_ctiles = (int)((N + 127) / 128);
+            const unsigned grid = screen_rq_grid(sa.n_ctiles, sa.n_qtiles);
+            if (ks != 6) { fprintf(stderr, "rq1: d = 768 only\n"); exit(1); }
+#define RQ1_LAUNCH(A) if (abl == A) hipLaunchKernelGGL((k_screen_rq1<6, A, true>), dim3(grid), dim3(256), rq_lds(6), 0, sa);
+            RQ1_FORMS(RQ1_LAUNCH)
         } else {
             const int abl = variant - 100;
             sa.n_ctiles = (int)((N + 127) / 128);
@@ -265,7 +277,7 @@ int main(int argc, char** argv) {
     std::vector<std::vector<Cand>> sets;
     std::vector<int> set_variant;
     for (int variant : variants) {
-        if (variant != 0 && variant != 100 && variant != 164 && variant != 612 && variant != 868 && variant != 2148 && variant != 4196 && variant != 8292) continue;
+        if (variant != 0 && variant != 100 && variant != 164 && variant != 612 && variant != 868 && variant != 2148 && variant != 4196 && variant != 8292 && variant != 200) continue;
         const float T0 = 4.6f / sqrtf((float)d);
         hipLaunchKernelGGL(k_fillf, dim3((Bpad + 255) / 256), dim3(256), 0, 0, thr, Bpad, INFINITY);
         hipLaunchKernelGGL(k_fillf, dim3((Bpad + 255) / 256), dim3(256), 0, 0, thr, B, T0);
