@@ -57,8 +57,22 @@ bench)
   python bench.py > $OUT/bench_default.log 2>&1; tail -1 $OUT/bench_default.log > $OUT/bench_default_line.json; cut -c1-400 $OUT/bench_default_line.json
   python bench.py --screen bf16 $BENCH_QUICK > $OUT/bench_bf16.log 2>&1; tail -1 $OUT/bench_bf16.log > $OUT/bench_bf16_line.json; cut -c1-200 $OUT/bench_bf16_line.json ;;
 stats)
-  rm -rf $OUT/stats; MI355DR_BENCH_PMC=0 rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o stats -- python bench.py --steps 5 --warmup 2 $BENCH_QUICK > $OUT/stats.log 2>&1
-  find $OUT/stats -name "*kernel_stats.csv" | head -1 | xargs -r head -8 ;;
+  # the default command's steps / warm-up (10 / 2), without its untimed extras (they launch the same kernel on other workloads);
+  # the profiled run's own line is kept next to the summary: its roofline.avg_launch_ms is the HIP-event figure of the very launches
+  # the kernel_stats row averages (+ the 2 warm-up steps, whose first launch runs at cold clocks)
+  rm -rf $OUT/stats; MI355DR_BENCH_PMC=0 rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o stats -- python bench.py --steps 10 --warmup 2 $BENCH_QUICK > $OUT/stats.log 2>&1
+  grep '^{"metric"' $OUT/stats.log | tail -1 > $OUT/stats_line.json   # (rocprofv3 prints behind the bench line)
+  find $OUT/stats -name "*kernel_stats.csv" | head -1 | xargs -r head -4
+  python - $OUT <<'PY'
+import csv, glob, json, sys
+out = sys.argv[1]
+line = json.loads(open(out + "/stats_line.json").read())
+f = glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True)[0]
+row = [r for r in csv.DictReader(open(f)) if "k_screen_rq" in r["Name"] or "k_screen256c" in r["Name"]][0]
+print("rocprofv3 average", round(float(row["AverageNs"]) / 1e6, 4), "ms over", row["Calls"], "launches | the same run's HIP events:",
+      line["roofline"]["avg_launch_ms"], "ms over", line["roofline"]["launches"], "timed launches")
+PY
+  ;;
 traffic)
   T=$OUT/traffic; rm -rf $T; mkdir -p $T; ARGS="--steps 3 --warmup 1 $BENCH_QUICK"
   MI355DR_BENCH_PMC=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $T -o fetch -- python bench.py $ARGS > $T/fetch.log 2>&1
