@@ -28,9 +28,9 @@
 // Restrictions: row_bytes = 128 KS with KS a template parameter (the fragments are indexed at compile time); instantiated
 // for the int8 shadow at d <= 768 (the bf16 shadow of d = 768 would need 192 query registers).  Everything else keeps
 // k_screen256c.  ct0 / n_ctiles of the arguments count 128-ROW tiles here.
-// Measured (tools/screen_ab, interleaved with k_screen256c on the same operands, profiles/r05_kstep_ab.txt): Gaussian int8
-// -6 ... -15 % per launch (both kernels run at the socket power cap: the gain is the energy of the L2 -> LDS bytes no longer
-// moved), zeros -24 % (4.2 POP/s = 0.85 of the int8 peak: in cycles the staging no longer shows).
+// Measured (tools/screen_ab, interleaved with k_screen256c on the same operands, 10 M rows x 1024 queries, profiles/r05_kstep_ab.txt):
+// true Gaussian int8 -17 % per launch, -8 % sustained (both kernels run at the socket power cap: the gain is the energy of the
+// L2 -> LDS bytes no longer moved), zeros -26 % (4.3 POP/s = 0.86 of the int8 peak: in cycles the staging no longer shows).
 #pragma once
 #include "k_screen256_common.h"
 
