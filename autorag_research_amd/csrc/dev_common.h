@@ -16,6 +16,7 @@ constexpr int kWave = 64;
 constexpr int kQBlockMax = 1024;  // queries scored per corpus pass (one internal block)
 constexpr int kKMax = 1024;       // largest k served
 constexpr int kCandCap = 2048;    // candidate slots per query between two prunes
+constexpr int kCandCapWide = 4096;  // ... of a pass whose prunes take the two-wave form (k_prune_wide.h: 33 <= k <= 128); the lists are allocated for it
 constexpr int kSortMax = 4096;    // LDS sort capacity (>= kKMax + kCandCap, power of two)
 constexpr int kIrrCap = 1024;     // irregular (zero / non-finite / extreme-norm) rows the screen path tolerates
 constexpr uint64_t kKeyNaN = 0xFFFFFFFFFFFFFFFFull;

@@ -132,6 +132,10 @@ struct mi355dr_index {
     int chunk_growth_set = 0;  // the option was set by the caller: no small-block override
     int64_t small_chunk_rows = 16384;  // chunks up to this many rows go through the 128x128 kernel (dense hits: per-lane appends)
     int cap = mi355::kCandCap;
+    int cap_set = 0;          // option "cand_cap" was set by the caller: every pass uses it (else wide-prune passes use kCandCapWide)
+    // 33 <= k <= 128: the two-wave prune (k_prune_wide.h: 4096 entries, round A of up to 128 rows, no companion launch), the
+    // starter over a 64 k-row sample and chunk ratios up to 4 (option "prune_wide"; 0 = the round-5 schedule, A/B and tests)
+    int prune_wide = 1;
 
     // stats
     int64_t s_screen_launches = 0, s_screen_ns = 0, s_screen_rows = 0, s_fallback_queries = 0, s_chunks = 0,

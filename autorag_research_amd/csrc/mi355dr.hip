@@ -13,6 +13,7 @@
 inline bool screen_rq_has(int ksteps) { return ksteps >= 1 && ksteps <= 6; }
 #include "k_screen_stream.h"
 #include "k_select.h"
+#include "k_prune_wide.h"
 
 using namespace mi355;
 
@@ -115,8 +116,8 @@ int ensure_qstate(mi355dr_index* idx) {
     HIPCHECK(idx, hipMalloc(&idx->st.qhat8, B * idx->dpad8));
     HIPCHECK(idx, hipMalloc(&idx->st.carry, B * sizeof(int)));
     HIPCHECK(idx, hipMalloc(&idx->qdev, B * idx->dim * sizeof(float)));
-    HIPCHECK(idx, hipMalloc(&idx->cand_row, B * kCandCap * sizeof(int32_t)));
-    HIPCHECK(idx, hipMalloc(&idx->cand_val, B * kCandCap * sizeof(float)));
+    HIPCHECK(idx, hipMalloc(&idx->cand_row, B * kCandCapWide * sizeof(int32_t)));
+    HIPCHECK(idx, hipMalloc(&idx->cand_val, B * kCandCapWide * sizeof(float)));
     HIPCHECK(idx, hipMalloc(&idx->qlist_dev, 2 * B * sizeof(int)));  // second half: overflow re-runs
     HIPCHECK(idx, hipHostMalloc(&idx->status_host, (B + 1) * sizeof(int)));
     HIPCHECK(idx, hipMalloc(&idx->out_dist_dev, B * kKMax * sizeof(double)));
@@ -133,6 +134,8 @@ int ensure_qstate(mi355dr_index* idx) {
     HIPCHECK(idx, hipFuncSetAttribute((const void*)k_prune<kPruneSmallThreads, kPruneSmallSort>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)prune_lds_bytes(idx->dim, kPruneSmallThreads, kPruneSmallSort, idx->dpad)));
+    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_prune_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)prune_wide_lds_bytes(idx->dim)));
     {
         int per = kScanQ;
         while (per > 1 && scan_lds_bytes(idx->dim, per) > 150 * 1024) per >>= 1;
@@ -205,7 +208,21 @@ void drain_events(mi355dr_index* idx) {  // the pairs whose launch has finished 
 // Gaussian data.  The chunk growth is capped so that this stays inside what one prune of the one-wave kernel holds.
 constexpr double kInflationBf16 = 5.0, kInflationI8 = 16.0;
 constexpr double kSmallBlockBudget = 1.6;  // (the measured inflations are ~4 and ~9-10: the budget above carries that much slack)
+// Round 6: passes at 33 <= k <= 128 prune with the two-wave form (k_prune_wide.h).  Its 4096 entries hold a chunk's appends
+// AND the survivors carried from the chunk before; the first chunk behind the starter screens its rows from row 0, so it
+// appends ~ k * inflation * ratio.  The inflation of the int8 bound at these k: 5.5 (k-th best of 64 k rows) ... 9.6 (of 10 M)
+// by the Gaussian tail ratio, ~6 measured over the round-5 pass at k = 100 -- budgeted as 10 with a quarter of the entries spare.
+constexpr double kInflationI8Wide = 10.0, kInflationBf16Wide = 4.0;
+inline bool wide_ok(const mi355dr_index* idx, int k) { return idx->prune_wide && k >= kWideKMin && k <= kWideKMax; }
+// the prunes of the search in progress take the two-wave form (the exact scan keeps the general form and its 2048-slot lists)
+inline bool wide_now(const mi355dr_index* idx) { return wide_ok(idx, idx->k_now) && idx->path != MI355DR_PATH_SCAN; }
+// candidate slots per query (= the lists' stride) of the search in progress
+inline int cap_now(const mi355dr_index* idx) { return !idx->cap_set && wide_now(idx) ? kCandCapWide : idx->cap; }
 inline double growth_budget(const mi355dr_index* idx, int k, bool i8) {
+    if (wide_ok(idx, k) && idx->path != MI355DR_PATH_SCAN) {
+        const int room = std::min(kWideEntries, idx->cap_set ? idx->cap : kCandCapWide);
+        return 0.75 * room / ((double)k * (i8 ? kInflationI8Wide : kInflationBf16Wide)) - 1.0;  // (1 + growth = the chunk ratio)
+    }
     const int room = k < kPruneSmallSort / 2 ? kPruneSmallSort - k : idx->cap;  // (large k: the general prune, whole buffer)
     return 0.6 * std::min(room, idx->cap) / ((double)k * (i8 ? kInflationI8 : kInflationBf16));
 }
@@ -237,7 +254,7 @@ int launch_prune(mi355dr_index* idx, hipStream_t s, int nblocks, const int* qlis
     pa.cand_val = idx->cand_val;
     pa.qlist = qlist;
     pa.stat = idx->stat_dev;
-    pa.cap = idx->cap;
+    pa.cap = cap_now(idx);
     pa.d = idx->dim;
     pa.k = k;
     pa.metric = idx->metric;
@@ -252,6 +269,12 @@ int launch_prune(mi355dr_index* idx, hipStream_t s, int nblocks, const int* qlis
     pa.dpad = idx->dpad;
     pa.round_a = idx->round_a;
     // the general form walks the (usually empty) list of queries the one-wave form left, on a small grid
+    if (!exact && wide_now(idx)) {  // 33 <= k <= 128: the two-wave form alone (what it cannot hold is flagged for the re-screen)
+        pa.shadow16 = nullptr;
+        hipLaunchKernelGGL(k_prune_wide, dim3(nblocks), dim3(kWideThreads), prune_wide_lds_bytes(idx->dim), s, pa);
+        HIPCHECK(idx, hipGetLastError());
+        return MI355DR_OK;
+    }
     const bool list_mode = qlist == nullptr;
     pa.skip_list = list_mode ? idx->prune_skip : nullptr;
     pa.skip_parity = list_mode ? (idx->prune_parity ^= 1) : 0;
@@ -331,6 +354,9 @@ int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t 
         }
         sa.progress = idx->rq_progress;  // sibling drift limiter: words of older launches carry another stamp and are ignored
         sa.epoch = idx->rq_epoch = idx->rq_epoch % 4095 + 1;
+        // (the stamp has 12 bits: when it wraps, words left by launches 4095 stamps ago are cleared so that none of them can
+        // pass for a sibling of this launch -- a stale word could only cost a capped wait, never a result)
+        if (sa.epoch == 1) HIPCHECK(idx, hipMemsetAsync(idx->rq_progress, 0, kRqProgressWords * sizeof(int), s));
         sa.drift = idx->screen_drift;
         if (sa.ksteps == 6 && !idx->screen_rq_split_tests) {  // (A/B form, d = 768 only: every block test in one piece)
             hipLaunchKernelGGL((k_screen_rq<6, 8192, true>), dim3(g2), dim3(512), rq_lds(6), s, sa);
@@ -384,6 +410,7 @@ int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t 
 //    re-screened -- measured slower: see index.h.)
 constexpr int kStarterKMax = 32;          // the starter's round A re-scores max(32, 2k) <= 64 rows: one batch of the one-wave form
 constexpr int64_t kStarterRows = 16384;   // sample size (256 slabs); a corpus must hold at least 4 samples
+constexpr int64_t kStarterRowsWide = 65536;  // ... of a pass at 33 <= k <= 128 (1024 slabs)
 struct PassPlan {
     int64_t sample = 0;          // > 0: starter over rows [0, sample)
     std::vector<int64_t> ends;   // chunk ends, ascending, last = n; the first chunk starts at 0 (starter) or is the emit-all one
@@ -399,15 +426,19 @@ PassPlan plan_pass(const mi355dr_index* idx, int B, int k, double growth) {
     // would be flagged for a re-screen), and the sample must offer at least k of them, else its prune publishes no threshold
     // and the first regular chunk would run at thr = -inf WITHOUT the emit-all epilogue -- correct, pathologically slow
     // (4096 <= n < 8192 with k in 17..32).  Either way: the emit-all ladder.
-    const int64_t starter_rows = std::min<int64_t>(kStarterRows, n / 4) / kTileM * kTileM;
+    // Round 6, 33 <= k <= 128 (two-wave prune): the same estimator over a 64 k-row sample -- 1024 slab maxima per query, of
+    // which the prune re-scores the 128 best-looking; their k-th best exact score is (about) the k-th best of the sample.
+    const bool wide = wide_now(idx);
+    const int cap = cap_now(idx);
+    const int64_t starter_rows = std::min<int64_t>(wide ? kStarterRowsWide : kStarterRows, n / 4) / kTileM * kTileM;
     const int64_t starter_slabs = (starter_rows + kSlabRows - 1) / kSlabRows;
-    if (idx->starter && k <= kStarterKMax && idx->retry_level == 0 && idx->chunk0_set == 0 && n >= 4 * 1024 &&
-        starter_slabs <= idx->cap && starter_slabs >= k) {
+    if (idx->starter && (k <= kStarterKMax || wide) && idx->retry_level == 0 && idx->chunk0_set == 0 && n >= 4 * 1024 &&
+        starter_slabs <= cap && starter_slabs >= k) {
         p.sample = starter_rows;
         seen = p.sample;
     } else {
-        const int64_t c0 = std::min<int64_t>(n, round_up(std::max<int64_t>(tile, std::min<int64_t>(idx->chunk0_rows, idx->cap)), tile));
-        p.emit_all_first = c0 <= idx->cap;
+        const int64_t c0 = std::min<int64_t>(n, round_up(std::max<int64_t>(tile, std::min<int64_t>(idx->chunk0_rows, cap)), tile));
+        p.emit_all_first = c0 <= cap;
         p.ends.push_back(c0);
         seen = c0;
         if (c0 >= n) return p;
@@ -486,7 +517,7 @@ int run_screen(mi355dr_index* idx, hipStream_t s, int B, int k, const PassPlan& 
         return MI355DR_OK;
     };
     if (plan.sample > 0) {
-        CHECK(timed(false, plan.sample, [&] { return launch_screen(idx, s, B, 0, plan.sample, idx->cap, kEmitSlabMax); }));
+        CHECK(timed(false, plan.sample, [&] { return launch_screen(idx, s, B, 0, plan.sample, cap_now(idx), kEmitSlabMax); }));
         CHECK(launch_prune(idx, s, B, nullptr, k, /*exact=*/0, /*thr_only=*/true, /*one_wave_only=*/true));
         idx->s_starters++;
     }
@@ -497,13 +528,13 @@ int run_screen(mi355dr_index* idx, hipStream_t s, int B, int k, const PassPlan& 
         if (emit_all) kept_all_below = end;
         // the first chunk has no threshold yet: it keeps every row (direct stores) as long as it fits the buffer
         const bool big = !emit_all && end - done > idx->small_chunk_rows && screen_tile(B) == kT2;
-        CHECK(timed(big, end - done, [&] { return launch_screen(idx, s, B, done, end, idx->cap, emit_all ? kEmitAll : 0); }));
+        CHECK(timed(big, end - done, [&] { return launch_screen(idx, s, B, done, end, cap_now(idx), emit_all ? kEmitAll : 0); }));
         idx->s_chunks++;
         if (end >= idx->n && side_n > 0 && side_n <= kSideMerge) {
             // rows this screen cannot see (irregular; for int8 also loose): a handful of them ride the LAST chunk's prune
             // as "no bound" candidates instead of costing a prune pass of their own (0.12 ms per block at N = 10 M)
             hipLaunchKernelGGL(k_emit_irregular, dim3(B), dim3(64), 0, s, i8 ? idx->irr8_rows : idx->irr_rows, side_n, idx->st,
-                               idx->cand_row, idx->cand_val, idx->cap, (int)kept_all_below);
+                               idx->cand_row, idx->cand_val, cap_now(idx), (int)kept_all_below);
             HIPCHECK(idx, hipGetLastError());
             side_done = true;
         }
@@ -514,7 +545,7 @@ int run_screen(mi355dr_index* idx, hipStream_t s, int B, int k, const PassPlan& 
     }
     if (side_n > 0 && !side_done) {
         hipLaunchKernelGGL(k_emit_irregular, dim3(B), dim3(64), 0, s, i8 ? idx->irr8_rows : idx->irr_rows, side_n, idx->st,
-                           idx->cand_row, idx->cand_val, idx->cap, (int)kept_all_below);
+                           idx->cand_row, idx->cand_val, cap_now(idx), (int)kept_all_below);
         HIPCHECK(idx, hipGetLastError());
         CHECK(launch_prune(idx, s, B, nullptr, k, 0, false, lean));
     }
@@ -545,7 +576,7 @@ int scan_range(mi355dr_index* idx, hipStream_t s, int off, int nq, int k, int64_
     sa.cand_val = idx->cand_val;
     sa.qlist = idx->qlist_dev + off;
     sa.nq = nq;
-    sa.cap = idx->cap;
+    sa.cap = cap_now(idx);
     sa.d = idx->dim;
     sa.metric = idx->metric;
     sa.row0 = r0;
@@ -570,11 +601,12 @@ int run_scan(mi355dr_index* idx, hipStream_t s, const std::vector<int>& qs, int 
     for (int off = 0; off < nq_all; off += per) {
         const int nq = std::min(per, nq_all - off);
         int64_t done = 0;
-        int64_t chunk = std::min<int64_t>(idx->chunk0_rows, idx->cap);
+        const int cap = cap_now(idx);
+        int64_t chunk = std::min<int64_t>(idx->chunk0_rows, cap);
         while (done < idx->n) {
             const int64_t end = std::min<int64_t>(idx->n, done + chunk);
             CHECK(scan_range(idx, s, off, nq, k, done, end));
-            if (end - done > idx->cap) {  // only a chunk larger than the buffer can overflow
+            if (end - done > cap) {  // only a chunk larger than the buffer can overflow
                 HIPCHECK(idx, hipMemcpyAsync(idx->status_host, idx->st.status, kQBlockMax * sizeof(int),
                                              hipMemcpyDeviceToHost, s));
                 HIPCHECK(idx, hipStreamSynchronize(s));
@@ -592,8 +624,8 @@ int run_scan(mi355dr_index* idx, hipStream_t s, const std::vector<int>& qs, int 
                     for (int q : redo)
                         HIPCHECK(idx, hipMemcpyAsync(idx->st.status + q, idx->status_host + q, sizeof(int),
                                                      hipMemcpyHostToDevice, s));
-                    for (int64_t p = done; p < end; p += idx->cap)
-                        CHECK(scan_range(idx, s, roff, (int)redo.size(), k, p, std::min<int64_t>(end, p + idx->cap)));
+                    for (int64_t p = done; p < end; p += cap)
+                        CHECK(scan_range(idx, s, roff, (int)redo.size(), k, p, std::min<int64_t>(end, p + cap)));
                 }
             }
             done = end;
@@ -1187,6 +1219,9 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
     } else if (k == "cand_cap") {
         if (value < 16 || value > kCandCap) return fail(idx, MI355DR_E_INVALID, "cand_cap must be in [16,2048]");
         idx->cap = (int)value;
+        idx->cap_set = 1;
+    } else if (k == "prune_wide") {
+        idx->prune_wide = value != 0;
     } else {
         return fail(idx, MI355DR_E_INVALID, "unknown option: " + k);
     }

@@ -292,7 +292,8 @@ class TorchLateInteractionEmbeddings(MultiVectorBaseEmbedding):
     def __init__(self, model: Any, tokenizer: Any, proj: Any | None = None, device: str = "cuda:0",
                  batch_size: int = 64, max_length: int = 180, model_name: str = "late-interaction",
                  query_marker_id: int | None = None, doc_marker_id: int | None = None, query_pad_to: int = 0,
-                 query_pad_token_id: int | None = None):
+                 query_pad_token_id: int | None = None, attend_to_mask_tokens: bool = False,
+                 doc_skip_token_ids: Any | None = None):
         import torch
 
         init_multivector_base(self, model_name, batch_size)
@@ -305,15 +306,21 @@ class TorchLateInteractionEmbeddings(MultiVectorBaseEmbedding):
         self.max_length = max_length
         self.model_name = model_name
         # ColBERT's input conventions (Khattab & Zaharia 2020; Santhanam et al. 2022), all optional:
-        #   a marker token right behind [CLS] -- [Q] = [unused0] for queries, [D] = [unused1] for documents --, and queries
-        #   padded to a fixed length with [MASK] tokens that ARE attended and kept ("query augmentation", 32 in ColBERTv2)
+        #   a marker token right behind [CLS] -- [Q] = [unused0] for queries, [D] = [unused1] for documents --; queries padded
+        #   to a fixed length with [MASK] tokens whose OUTPUT vectors are kept ("query augmentation", 32 in ColBERTv2) while the
+        #   attention mask stays 0 on them (upstream `attend_to_mask_tokens=False`, what colbertv2.0 was trained with; True =
+        #   they are attended as well); document vectors of punctuation tokens dropped (upstream `mask_punctuation`: the
+        #   skiplist, `doc_skip_token_ids`)
         self.query_marker_id, self.doc_marker_id = query_marker_id, doc_marker_id
         self.query_pad_to, self.query_pad_token_id = int(query_pad_to), query_pad_token_id
+        self.attend_to_mask_tokens = bool(attend_to_mask_tokens)
+        self.doc_skip_token_ids = sorted({int(t) for t in doc_skip_token_ids}) if doc_skip_token_ids else []
 
     @classmethod
     def from_pretrained(cls, model_name_or_path: str, dim: int | None = 128, proj_key: str = "linear.weight", device: str = "cuda:0",
                         dtype: Any = "float32", batch_size: int = 64, max_length: int = 180, query_marker: str | None = None,
                         doc_marker: str | None = None, query_pad_to: int = 0, query_pad_token: str = "[MASK]",
+                        attend_to_mask_tokens: bool = False, mask_punctuation: bool = False,
                         local_files_only: bool = True, trust_remote_code: bool = False):
         """`AutoModel` + `AutoTokenizer` + the per-token projection of a ColBERT checkpoint: the state-dict tensor `proj_key`
         ([dim, hidden], bias-free `linear` in colbert-ir/colbertv2.0), read from the local checkpoint directory because
@@ -348,29 +355,49 @@ class TorchLateInteractionEmbeddings(MultiVectorBaseEmbedding):
                 raise ValueError(f"token {t!r} is not in the checkpoint's vocabulary")
             return int(i)
 
+        skip = None
+        if mask_punctuation:   # upstream: every symbol of string.punctuation and its tokenisation (colbert/modeling/colbert.py skiplist)
+            import string  # noqa: PLC0415
+
+            skip = set()
+            for sym in string.punctuation:
+                i = tok.convert_tokens_to_ids(sym)
+                if i is not None and i != tok.unk_token_id:
+                    skip.add(int(i))
         return cls(model, tok, proj=proj, device=device, batch_size=batch_size, max_length=max_length,
                    model_name=str(model_name_or_path), query_marker_id=tid(query_marker), doc_marker_id=tid(doc_marker),
-                   query_pad_to=query_pad_to, query_pad_token_id=tid(query_pad_token) if query_pad_to else None)
+                   query_pad_to=query_pad_to, query_pad_token_id=tid(query_pad_token) if query_pad_to else None,
+                   attend_to_mask_tokens=attend_to_mask_tokens, doc_skip_token_ids=skip)
 
     def _encode(self, texts: list[str], query: bool) -> dict:
+        """-> model inputs + "keep": which output rows become vectors (not passed to the model)."""
         torch = self._torch
         marker = self.query_marker_id if query else self.doc_marker_id
-        room = self.max_length - (1 if marker is not None else 0)
+        padded_query = bool(query and self.query_pad_to and self.query_pad_token_id is not None)
+        limit = self.query_pad_to if padded_query else self.max_length
+        # truncation happens INSIDE the tokenizer (one slot left for the marker), so a long text keeps its [SEP]
+        room = limit - (1 if marker is not None else 0)
         enc = self.tokenizer(texts, padding=True, truncation=True, max_length=room, return_tensors="pt")
         ids, mask = enc["input_ids"], enc["attention_mask"]
         if marker is not None:  # [CLS] marker tokens...
             ids = torch.cat([ids[:, :1], torch.full_like(ids[:, :1], marker), ids[:, 1:]], dim=1)
             mask = torch.cat([mask[:, :1], torch.ones_like(mask[:, :1]), mask[:, 1:]], dim=1)
-        if query and self.query_pad_to and self.query_pad_token_id is not None:
+        keep = mask.clone()
+        if padded_query:
             L = self.query_pad_to
             if ids.shape[1] < L:
                 pad = L - ids.shape[1]
                 ids = torch.cat([ids, ids.new_zeros((ids.shape[0], pad))], dim=1)
                 mask = torch.cat([mask, mask.new_zeros((mask.shape[0], pad))], dim=1)
-            ids, mask = ids[:, :L].clone(), mask[:, :L].clone()
-            ids[mask == 0] = self.query_pad_token_id   # [MASK] fill: attended and kept
-            mask[:] = 1
-        out = {"input_ids": ids, "attention_mask": mask}
+            ids, mask = ids.clone(), mask.clone()
+            ids[mask == 0] = self.query_pad_token_id   # [MASK] fill: every output row is kept ...
+            keep = torch.ones_like(mask)
+            if self.attend_to_mask_tokens:             # ... and attended only on request (upstream default: not)
+                mask = torch.ones_like(mask)
+        elif not query and self.doc_skip_token_ids:
+            skip = torch.isin(ids, torch.tensor(self.doc_skip_token_ids, dtype=ids.dtype))
+            keep = keep * (~skip).to(keep.dtype)
+        out = {"input_ids": ids, "attention_mask": mask, "keep": keep}
         if "token_type_ids" in enc:
             out["token_type_ids"] = torch.zeros_like(ids)
         return out
@@ -378,14 +405,14 @@ class TorchLateInteractionEmbeddings(MultiVectorBaseEmbedding):
     def _forward(self, texts: list[str], query: bool = False) -> list[MultiVectorEmbedding]:
         torch = self._torch
         enc = {k: v.to(self.device) for k, v in self._encode(texts, query).items()}
+        keep = enc.pop("keep").bool()
         with torch.no_grad():
             out = self.model(**enc)
             h = out.last_hidden_state if hasattr(out, "last_hidden_state") else out
             if self.proj is not None:
                 h = self.proj(h)
             h = torch.nn.functional.normalize(h.float(), dim=-1)
-        mask = enc["attention_mask"].bool()
-        return [h[i][mask[i]].cpu().tolist() for i in range(h.shape[0])]
+        return [h[i][keep[i]].cpu().tolist() for i in range(h.shape[0])]
 
     def embed_query(self, query: str) -> MultiVectorEmbedding:
         return self._forward([query], query=True)[0]

@@ -7,7 +7,9 @@ run over a fake Unit of Work):
   embed_all_queries / embed_all_chunks / ..._multi_vector          base_ingestion.py:542-624
   TextEmbeddingDataIngestor.embed_all, MultiModalEmbeddingDataIngestor.embed_all / embed_all_late_interaction
       autorag_research/data/base.py:57-72, 95-125
-What the reference does and this does too: rows lacking the column are fetched `batch_size` at a time, EXCLUDING the ids that
+What the reference does and this does too: chunk and query rows get their `bm25_tokens` from the repository's
+`batch_update_bm25_tokens` right behind the loop (base_ingestion.py:429-430, 497-540; default tokenizer "bert", None skips it;
+`UowTarget` only -- the in-memory tables have no such column); rows lacking the column are fetched `batch_size` at a time, EXCLUDING the ids that
 already failed in this run; image chunks whose content is NULL are skipped and counted (never handed to the model); an item
 whose embedding raised or came back as None is remembered for the run and the rest of its batch is still stored; the loop ends
 when a fetch comes back empty or a batch made no progress; the return value is the number of rows stored.  Queries AND chunks
@@ -55,6 +57,7 @@ class IngestReport:
     failed_ids: list = field(default_factory=list)      # embedding raised / returned None; not retried in this run
     skipped_none_content: int = 0                         # image chunks with NULL content
     skipped_ids: list = field(default_factory=list)
+    bm25_updated: int = 0                                 # rows whose bm25_tokens the repository filled behind the loop
 
 
 # ---- targets ---------------------------------------------------------------------------------------------------------
@@ -64,40 +67,82 @@ class StoreTarget:
     def __init__(self, store: InMemoryStore):
         self.store = store
         self._pending_mv: dict[str, dict[int, np.ndarray]] = {"chunk": {}, "image_chunk": {}}
+        self._cursor: dict[tuple[str, str], list] = {}   # (entity, embedding type) -> [positions lacking the column, next to serve]
 
     def _table(self, entity: str) -> ChunkTable:
         return self.store.image_chunks if entity == "image_chunk" else self.store.chunks
 
-    def _missing(self, entity: str, emb_type: str):
-        """(id, data) of every row lacking the column, in table order."""
+    def _is_null(self, entity: str, emb_type: str, i: int) -> bool:
+        """row i of the table (or query i of `query_order`) still lacks the column"""
+        if entity == "query":
+            q = self.store.queries[self.store.query_order[i]]
+            return getattr(q, "embedding" if emb_type == "single" else "embeddings") is None
+        t = self._table(entity)
+        if emb_type == "single":
+            return t.embedding is None or bool(np.isnan(t.embedding[i]).all())
+        return i not in self._pending_mv[entity] and (t.mv_offsets is None or t.mv_offsets[i + 1] == t.mv_offsets[i])
+
+    def _missing_positions(self, entity: str, emb_type: str) -> list[int]:
+        """positions (table order) of every row lacking the column: ONE vectorised pass over the table"""
         if entity == "query":
             attr = "embedding" if emb_type == "single" else "embeddings"
-            for qid in self.store.query_order:
-                q = self.store.queries[qid]
-                if getattr(q, attr) is None:
-                    yield qid, q.contents
-            return
+            qs = self.store.queries
+            return [i for i, qid in enumerate(self.store.query_order) if getattr(qs[qid], attr) is None]
         t = self._table(entity)
+        n = len(t.ids)
+        if emb_type == "single":
+            if t.embedding is None:
+                return list(range(n))
+            return np.flatnonzero(np.isnan(t.embedding).all(axis=1)).tolist()
+        null = np.ones(n, dtype=bool) if t.mv_offsets is None else (np.diff(t.mv_offsets) == 0)
         pend = self._pending_mv[entity]
-        for i, pk in enumerate(t.ids):
-            if emb_type == "single":
-                null = t.embedding is None or bool(np.isnan(t.embedding[i]).all())
-            else:
-                null = i not in pend and (t.mv_offsets is None or t.mv_offsets[i + 1] == t.mv_offsets[i])
-            if null:
-                yield pk, t.contents[i]
+        return [int(i) for i in np.flatnonzero(null) if int(i) not in pend]
+
+    def _row(self, entity: str, i: int) -> tuple[Any, Any]:
+        if entity == "query":
+            qid = self.store.query_order[i]
+            return qid, self.store.queries[qid].contents
+        t = self._table(entity)
+        return t.ids[i], t.contents[i]
 
     def count_without(self, entity: str, emb_type: str) -> int:
-        return sum(1 for _ in self._missing(entity, emb_type))
+        return len(self._missing_positions(entity, emb_type))
 
     def fetch_without(self, entity: str, emb_type: str, limit: int, excluded: set) -> list[tuple[Any, Any]]:
-        out = []
-        for pk, data in self._missing(entity, emb_type):
-            if pk not in excluded:
-                out.append((pk, data))
-                if len(out) >= limit:
+        """The next `limit` rows lacking the column, table order, `excluded` left out.  The list of candidates is computed once
+        and served from a cursor (a row handed out is stored or excluded by the caller, so nothing behind the cursor can come
+        back during a run); every candidate is re-checked when served, and an exhausted list is rebuilt ONCE per call -- a
+        second run over the same target sees the rows the first one failed on.  (Round 5 rescanned from row 0 per batch with a
+        Python-level test per row: O(n^2 / batch) -- hours at 1 M rows.)"""
+        key = (entity, emb_type)
+        cur = self._cursor.get(key)
+        if cur is None:
+            cur = self._cursor[key] = [self._missing_positions(entity, emb_type), 0]
+        out: list[tuple[Any, Any]] = []
+        rebuilt = False
+        while len(out) < limit:
+            if cur[1] >= len(cur[0]):
+                if rebuilt:
                     break
+                taken = {pk for pk, _ in out}   # (handed out by this very call and therefore still NULL)
+                cur[0] = [i for i in self._missing_positions(entity, emb_type)
+                          if self._row(entity, i)[0] not in excluded and self._row(entity, i)[0] not in taken]
+                cur[1] = 0
+                rebuilt = True
+                if not cur[0]:
+                    break
+                continue
+            i = cur[0][cur[1]]
+            cur[1] += 1
+            pk, data = self._row(entity, i)
+            if pk in excluded or not self._is_null(entity, emb_type, i):
+                continue
+            out.append((pk, data))
         return out
+
+    def populate_bm25_tokens(self, entity: str, tokenizer: str, batch_size: int) -> int:
+        """The in-memory tables have no `bm25_tokens` column (BM25 is the reference's own SQL: out of scope); nothing to do."""
+        return 0
 
     def set_embeddings(self, entity: str, emb_type: str, ids: list, embeddings: list) -> int:
         if len(ids) != len(embeddings):
@@ -196,6 +241,22 @@ class UowTarget:
             uow.commit()
         return n
 
+    def populate_bm25_tokens(self, entity: str, tokenizer: str, batch_size: int) -> int:
+        """`_populate_bm25_tokens` (base_ingestion.py:497-540): the repository's own batch update; a failure (VectorChord-BM25
+        not installed) is a warning and 0, like the reference."""
+        repo_attr = "chunks" if entity == "chunk" else "queries"
+        with self._svc._create_uow() as uow:
+            repo = getattr(uow, repo_attr, None)
+            if repo is None:
+                raise RuntimeError(f"Repository '{repo_attr}' is not supported by {type(uow).__name__}")
+            try:
+                updated = repo.batch_update_bm25_tokens(tokenizer=tokenizer, batch_size=batch_size)
+            except Exception as e:  # noqa: BLE001 - the reference swallows exactly this
+                logger.warning(f"Failed to generate BM25 tokens for {entity}s (extension may not be installed): {e}")
+                return 0
+            logger.info(f"Generated BM25 tokens for {updated} {entity}s using tokenizer '{tokenizer}'")
+            return updated
+
     def finish(self) -> None:
         pass
 
@@ -226,6 +287,15 @@ class BatchEmbedder:
 
     def _batch(self, items: list) -> list:
         m = self.model
+        # image / document forwards are ONE padded batch in the wrappers (like the reference's): cut an ingest batch by the
+        # model's own `embed_batch_size` so that 128 page images do not go through a VLM in one forward
+        step = int(getattr(m, "embed_batch_size", 0) or 0)
+        if self.kind in ("image", "document") and step > 0 and len(items) > step:
+            fn = m.embed_images if self.kind == "image" else m.embed_documents
+            out: list = []
+            for i in range(0, len(items), step):
+                out.extend(fn(items[i: i + step]))
+            return out
         if self.kind == "image":
             return list(m.embed_images(items))
         if self.kind == "document":
@@ -247,8 +317,8 @@ class BatchEmbedder:
             out = self._batch(items)
             if len(out) == len(items):
                 return [None if e is None else _to_lists(e) for e in out]
-        except Exception:  # noqa: BLE001 - isolate the failing item(s) below
-            pass
+        except Exception as e:  # noqa: BLE001 - isolate the failing item(s) below
+            logger.warning(f"{error_msg}: a batch of {len(items)} raised {type(e).__name__}: {e}; retrying its items one by one")
         res = []
         for it in items:
             try:
@@ -285,7 +355,7 @@ def _run_embed(embed: Any, items: list, max_concurrency: int, error_msg: str) ->
 
 # ---- the loop (base_ingestion.py:326-437, 461-495) ---------------------------------------------------------------------
 def embed_entities_report(where: Any, entity_type: str, embedding_type: str, embed: Any, batch_size: int = 128,
-                          max_concurrency: int = 16) -> IngestReport:
+                          max_concurrency: int = 16, bm25_tokenizer: str | None = "bert") -> IngestReport:
     if entity_type not in ENTITY_CONFIG:
         raise KeyError(entity_type)
     if embedding_type not in ("single", "multi_vector"):
@@ -328,15 +398,19 @@ def embed_entities_report(where: Any, entity_type: str, embedding_type: str, emb
                 break
     finally:
         target.finish()
+    # base_ingestion.py:429-430: chunk and query rows get their `bm25_tokens` right behind the embeddings (the reference's BM25
+    # and hybrid pipelines read nothing else); a target without the column does nothing
+    if entity_type in ("chunk", "query") and bm25_tokenizer is not None and hasattr(target, "populate_bm25_tokens"):
+        rep.bm25_updated = target.populate_bm25_tokens(entity_type, bm25_tokenizer, batch_size)
     logger.info(f"Total {display} embedded{suffix}: {rep.total_embedded} (skipped_failed={len(rep.failed_ids)}, "
                 f"skipped_empty_content={rep.skipped_none_content})")
     return rep
 
 
 def embed_entities(where: Any, entity_type: str, embedding_type: str, embed: Any, batch_size: int = 128,
-                   max_concurrency: int = 16) -> int:
+                   max_concurrency: int = 16, bm25_tokenizer: str | None = "bert") -> int:
     """`BaseIngestionService._embed_entities`: the number of rows embedded and stored."""
-    return embed_entities_report(where, entity_type, embedding_type, embed, batch_size, max_concurrency).total_embedded
+    return embed_entities_report(where, entity_type, embedding_type, embed, batch_size, max_concurrency, bm25_tokenizer).total_embedded
 
 
 def _embedder(model_or_func: Any, kind: str):
@@ -353,13 +427,14 @@ def _emb_type(model_or_func: Any, embedding_type: str | None) -> str:
 
 
 def embed_all_queries(where: Any, model: Any, batch_size: int = 128, max_concurrency: int = 16,
-                      embedding_type: str | None = None) -> int:
+                      embedding_type: str | None = None, bm25_tokenizer: str | None = "bert") -> int:
     """embed_all_queries / embed_all_queries_multi_vector (base_ingestion.py:542-582): by the model's kind unless told."""
-    return embed_entities(where, "query", _emb_type(model, embedding_type), _embedder(model, "query"), batch_size, max_concurrency)
+    return embed_entities(where, "query", _emb_type(model, embedding_type), _embedder(model, "query"), batch_size, max_concurrency,
+                          bm25_tokenizer)
 
 
 def embed_all_chunks(where: Any, model: Any, batch_size: int = 128, max_concurrency: int = 16, unit: str = "chunk",
-                     side: str = "query", embedding_type: str | None = None) -> int:
+                     side: str = "query", embedding_type: str | None = None, bm25_tokenizer: str | None = "bert") -> int:
     """embed_all_chunks[_multi_vector] (base_ingestion.py:584-624) and, with `unit="image_chunk"`, embed_all_image_chunks
     [_multi_vector]: text chunks through the model's QUERY side like the reference (data/base.py:68-72; `side="document"` is an
     explicit deviation for passage-side vectors), image chunks' bytes through the image embedder (data/base.py:110-124)."""
@@ -368,7 +443,8 @@ def embed_all_chunks(where: Any, model: Any, batch_size: int = 128, max_concurre
     if unit == "image_chunk":
         return embed_entities(where, "image_chunk", _emb_type(model, embedding_type), _embedder(model, "image"), batch_size,
                               max_concurrency)
-    return embed_entities(where, "chunk", _emb_type(model, embedding_type), _embedder(model, side), batch_size, max_concurrency)
+    return embed_entities(where, "chunk", _emb_type(model, embedding_type), _embedder(model, side), batch_size, max_concurrency,
+                          bm25_tokenizer)
 
 
 def embed_all(where: Any, model: Any, max_concurrency: int = 16, batch_size: int = 128, unit: str = "chunk") -> None:

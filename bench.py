@@ -103,6 +103,8 @@ def parse_args():
     ap.add_argument("--data", choices=["gaussian", "anisotropic"], default="gaussian",
                     help="gaussian = BASELINE headline; anisotropic = power-law spectrum + near-duplicate clusters (the offline "
                          "stand-in for bge-base on BEIR nq, config C2: use with --metric ip --k 100)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="library option passed to mi355dr_set_option verbatim (developer A/B; repeatable)")
     ap.add_argument("--cpu-sample-rows", type=int, default=2_500_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=3072, help="CPU baseline: queries timed (whole blocks of the pool)")
     return ap.parse_args()
@@ -179,6 +181,9 @@ def main() -> None:
         idx.set_option("prune_companion", args.prune_companion)
     if args.defer_b is not None:
         idx.set_option("defer_round_b", args.defer_b)
+    for kv in args.opt:
+        key, _, val = kv.partition("=")
+        idx.set_option(key, int(val))
     aniso = synth.Anisotropic(torch, d, device) if args.data == "anisotropic" else None
 
     def gen_chunk(c: int, rows: int):

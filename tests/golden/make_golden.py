@@ -952,11 +952,12 @@ def make_ingest() -> dict:
     logging.getLogger("AutoRAG-Research").setLevel(logging.CRITICAL)
     out: dict = {"cases": []}
 
-    def run(entity, emb_type, rows, batch_size, bad_raise=(), bad_none=()):
+    def run(entity, emb_type, rows, batch_size, bad_raise=(), bad_none=(), bm25=None, bm25_raises=False):
         table = [_Obj(id=r["id"], contents=r["contents"], embedding=r.get("embedding"), embeddings=r.get("embeddings")) for r in rows]
         col = "embedding" if emb_type == "single" else "embeddings"
         calls: list = []
         fetches: list = []
+        bm25_calls: list = []
 
         class _Repo:
             session = object()
@@ -987,6 +988,13 @@ def make_ingest() -> dict:
                         setattr(e, vector_column, emb)
                         n += 1
                 return n
+
+            def batch_update_bm25_tokens(self, tokenizer="bert", batch_size=1000):   # orm/repository/chunk.py, query.py
+                bm25_calls.append({"tokenizer": tokenizer, "batch_size": batch_size,
+                                   "rows_embedded_at_call": sum(1 for e in table if getattr(e, col) is not None)})
+                if bm25_raises:
+                    raise RuntimeError("function tokenize(text, unknown) does not exist")
+                return len(table)
 
         repo = _Repo()
 
@@ -1021,9 +1029,10 @@ def make_ingest() -> dict:
                 return {}
 
         svc = _Svc.__new__(_Svc)
-        n = svc._embed_entities(entity, emb_type, embed, batch_size=batch_size, max_concurrency=3, bm25_tokenizer=None)
+        n = svc._embed_entities(entity, emb_type, embed, batch_size=batch_size, max_concurrency=3, bm25_tokenizer=bm25)
         out["cases"].append({
             "entity_type": entity, "embedding_type": emb_type, "batch_size": batch_size,
+            "bm25_tokenizer": bm25, "bm25_raises": bm25_raises, "bm25_calls": bm25_calls,
             "rows": [{k: (v.decode() if isinstance(v, bytes) else v) for k, v in r.items()} | {"bytes": isinstance(r["contents"], bytes)}
                      for r in rows],
             "bad_raise": list(bad_raise), "bad_none": list(bad_none), "returned": n, "embed_calls": sorted(calls),
@@ -1049,6 +1058,15 @@ def make_ingest() -> dict:
     run("chunk", "single", [{"id": 1, "contents": "RAISE"}, {"id": 2, "contents": "NONE"}], batch_size=8,
         bad_raise=("RAISE",), bad_none=("NONE",))                      # nothing can be embedded: the loop still ends
     run("chunk", "multi_vector", [{"id": 1, "contents": "x", "embeddings": [pre]}], batch_size=4)   # nothing to do: returns 0
+    # bm25_tokens (base_ingestion.py:429-430, 497-540): one repository call behind the loop for chunk / query rows, none for
+    # image chunks, a failing call (extension not installed) swallowed; and -- what the early return at :383-386 means -- NOT
+    # made when nothing lacked an embedding
+    run("chunk", "single", [{"id": 1, "contents": "alpha"}, {"id": 2, "contents": "NONE"}, {"id": 3, "contents": "gamma"}],
+        batch_size=2, bad_none=("NONE",), bm25="bert")
+    run("query", "single", [{"id": "q1", "contents": "one"}, {"id": "q2", "contents": "two"}], batch_size=8, bm25="wiki_tocken",
+        bm25_raises=True)
+    run("image_chunk", "single", [{"id": "i1", "contents": b"png-bytes-1"}], batch_size=2, bm25="bert")
+    run("chunk", "single", [{"id": 1, "contents": "x", "embedding": pre}], batch_size=4, bm25="bert")
     return out
 
 

@@ -120,11 +120,35 @@ def test_colbert_yaml_reads_the_projection_and_applies_the_input_conventions(tmp
     ref = torch.nn.functional.normalize(h @ W.T, dim=-1).numpy()
     assert np.abs(np.asarray(docs[0]) - ref).max() < 1e-5
     qids = [tok.cls_token_id, col.query_marker_id] + tok.convert_tokens_to_ids("what is late interaction".split()) + [tok.sep_token_id]
+    n_real = len(qids)
     qids = qids + [tok.mask_token_id] * (32 - len(qids))
+    # upstream ColBERTv2 (attend_to_mask_tokens = False): the [MASK] positions are NOT attended, their output vectors are kept
+    att = torch.tensor([[1] * n_real + [0] * (32 - n_real)], dtype=torch.long)
     with torch.no_grad():
-        hq = model(input_ids=torch.tensor([qids]), attention_mask=torch.ones((1, 32), dtype=torch.long)).last_hidden_state[0]
+        hq = model(input_ids=torch.tensor([qids]), attention_mask=att).last_hidden_state[0]
     assert np.abs(np.asarray(q) - torch.nn.functional.normalize(hq @ W.T, dim=-1).numpy()).max() < 1e-5
     assert col.embed_queries(["what is late interaction", "a b"])[0] == q or np.allclose(col.embed_queries(["what is late interaction"])[0], q, atol=1e-6)
+    # ... and attended on request (the round-5 behaviour)
+    col_att = E.TorchLateInteractionEmbeddings.from_pretrained(str(ck), device="cpu", query_marker="[unused0]", doc_marker="[unused1]",
+                                                               query_pad_to=32, attend_to_mask_tokens=True)
+    with torch.no_grad():
+        hq1 = model(input_ids=torch.tensor([qids]), attention_mask=torch.ones((1, 32), dtype=torch.long)).last_hidden_state[0]
+    assert np.abs(np.asarray(col_att.embed_query("what is late interaction")) -
+                  torch.nn.functional.normalize(hq1 @ W.T, dim=-1).numpy()).max() < 1e-5
+    assert np.abs(np.asarray(col_att.embed_query("what is late interaction")) - np.asarray(q)).max() > 1e-4
+    # a query longer than 32 tokens is cut by the TOKENIZER: [CLS] [Q] 29 words [SEP], the [SEP] survives
+    words = " ".join(["late", "interaction", "dense", "retrieval"] * 10)
+    enc = col._encode([words], query=True)
+    assert enc["input_ids"].shape == (1, 32) and int(enc["input_ids"][0, -1]) == tok.sep_token_id and int(enc["attention_mask"].sum()) == 32
+    # the punctuation skiplist (upstream mask_punctuation): "." and "," are attended but yield no document vector
+    assert set(col.doc_skip_token_ids) >= {tok.convert_tokens_to_ids("."), tok.convert_tokens_to_ids(",")}
+    dp = col.embed_documents(["dense retrieval , on one gpu ."])[0]
+    pids = [tok.cls_token_id, col.doc_marker_id] + tok.convert_tokens_to_ids("dense retrieval , on one gpu .".split()) + [tok.sep_token_id]
+    with torch.no_grad():
+        hp = model(input_ids=torch.tensor([pids]), attention_mask=torch.ones((1, len(pids)), dtype=torch.long)).last_hidden_state[0]
+    keep = [i for i, t in enumerate(pids) if t not in col.doc_skip_token_ids]
+    assert len(dp) == len(pids) - 2 == len(keep)
+    assert np.abs(np.asarray(dp) - torch.nn.functional.normalize(hp @ W.T, dim=-1).numpy()[keep]).max() < 1e-5
     # a plain encoder directory has no projection: a clear error, or dim=None
     plain = tmp_path / "plain"
     _write_checkpoint(plain, colbert=False)

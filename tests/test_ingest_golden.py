@@ -28,6 +28,7 @@ def _fake_service(case):
     col = "embedding" if case["embedding_type"] == "single" else "embeddings"
     table = [_Obj(id=r["id"], contents=_payload(r), embedding=r.get("embedding"), embeddings=r.get("embeddings")) for r in case["rows"]]
     fetches = []
+    bm25_calls = []
 
     class Repo:
         def _missing(self):
@@ -57,6 +58,13 @@ def _fake_service(case):
                     n += 1
             return n
 
+        def batch_update_bm25_tokens(self, tokenizer="bert", batch_size=1000):
+            bm25_calls.append({"tokenizer": tokenizer, "batch_size": batch_size,
+                               "rows_embedded_at_call": sum(1 for e in table if getattr(e, col) is not None)})
+            if case.get("bm25_raises"):
+                raise RuntimeError("function tokenize(text, unknown) does not exist")
+            return len(table)
+
     repo = Repo()
     commits = []
 
@@ -73,7 +81,7 @@ def _fake_service(case):
         def commit(self):
             commits.append(1)
 
-    return _Obj(_create_uow=lambda: Uow()), table, fetches, col, commits
+    return _Obj(_create_uow=lambda: Uow(), bm25_calls=bm25_calls), table, fetches, col, commits
 
 
 def _vectors(case, col):
@@ -114,8 +122,11 @@ def test_uow_target_with_the_reference_call_shape(ci):
         return vec[k]
 
     rep = embed_entities_report(UowTarget(svc), case["entity_type"], case["embedding_type"], embed, batch_size=case["batch_size"],
-                                max_concurrency=3)
+                                max_concurrency=3, bm25_tokenizer=case.get("bm25_tokenizer"))
     assert rep.total_embedded == case["returned"]
+    # bm25_tokens: the repository call the reference makes behind the loop (tokenizer, batch size, and only after every row is stored)
+    assert svc.bm25_calls == case.get("bm25_calls", [])
+    assert rep.bm25_updated == (0 if case.get("bm25_raises") or not case.get("bm25_calls") else len(case["rows"]))
     assert sorted(calls) == case["embed_calls"] and len(calls) == case["n_embed_calls"]
     assert fetches == case["fetches"]
     _check_final(case, col, [{"id": e.id, col: getattr(e, col)} for e in table])
@@ -164,9 +175,11 @@ def test_batched_model_path_has_the_reference_outcome(ci, target_kind):
     model = _Model(case, _vectors(case, col), emb_type == "multi_vector")
     embedder = BatchEmbedder(model, "image" if entity == "image_chunk" else "query")
     if target_kind == "uow":
-        rep = embed_entities_report(UowTarget(svc), entity, emb_type, embedder, batch_size=case["batch_size"])
+        rep = embed_entities_report(UowTarget(svc), entity, emb_type, embedder, batch_size=case["batch_size"],
+                                    bm25_tokenizer=case.get("bm25_tokenizer"))
         final = [{"id": e.id, col: getattr(e, col)} for e in table]
         assert fetches == case["fetches"]
+        assert svc.bm25_calls == case.get("bm25_calls", [])
     else:
         store = InMemoryStore()
         ids = [r["id"] for r in case["rows"]]
@@ -213,6 +226,55 @@ def test_batched_model_path_has_the_reference_outcome(ci, target_kind):
     assert model.batches == n_batches
     assert (model.singles > 0) == any(any(next(r for r in case["rows"] if r["id"] == pk)["contents"] in case["bad_raise"] for pk in f)
                                       for f in case["fetches"])
+
+
+def test_default_tokenizer_is_the_references_and_a_repository_without_the_method_is_a_warning():
+    """`bm25_tokenizer` defaults to "bert" (base_ingestion.py:336); a repository whose `batch_update_bm25_tokens` is missing or
+    raises costs a warning, not the run (:529-537)."""
+    from autorag_research_amd.ingest import UowTarget, embed_entities_report
+
+    case = next(c for c in GOLDEN["cases"] if c.get("bm25_tokenizer") == "bert" and c["bm25_calls"])
+    svc, table, _, col, _ = _fake_service(case)
+    vec = _vectors(case, col)
+
+    async def embed(data):
+        return None if data in case["bad_none"] else vec[data]
+
+    rep = embed_entities_report(UowTarget(svc), case["entity_type"], case["embedding_type"], embed, batch_size=case["batch_size"])
+    assert rep.total_embedded == case["returned"] and [c["tokenizer"] for c in svc.bm25_calls] == ["bert"]
+
+
+def test_store_target_fetches_in_linear_time():
+    """`fetch_without` rescanned the table from row 0 for every batch (O(n^2 / batch): 20 k rows took 3.6 s).  The
+    cursor serves 60 k rows in well under a second, skips excluded ids, and a second run over the same target sees what the
+    first one left."""
+    import time
+
+    from autorag_research_amd.ingest import StoreTarget
+    from autorag_research_amd.store import InMemoryStore
+
+    n, d = 60_000, 8
+    store = InMemoryStore()
+    emb = np.full((n, d), np.nan, np.float32)
+    emb[::7] = 1.0                                    # every 7th row already embedded
+    store.set_chunks(list(range(n)), [f"t{i}" for i in range(n)], embedding=emb)
+    tgt = StoreTarget(store)
+    assert tgt.count_without("chunk", "single") == n - len(range(0, n, 7))
+    t0 = time.perf_counter()
+    seen, failed = [], {5, 6, 8}
+    while True:
+        items = tgt.fetch_without("chunk", "single", 128, failed)
+        if not items:
+            break
+        seen.extend(pk for pk, _ in items)
+        keep = [pk for pk, _ in items if pk % 1000 != 1]          # some rows "fail": excluded from then on
+        failed.update(pk for pk, _ in items if pk % 1000 == 1)
+        tgt.set_embeddings("chunk", "single", keep, [np.zeros(d, np.float32)] * len(keep))
+    dt = time.perf_counter() - t0
+    expect = [i for i in range(n) if i % 7 != 0 and i not in (5, 6, 8)]
+    assert seen == expect and dt < 2.0, dt
+    again = tgt.fetch_without("chunk", "single", 10_000, set())        # a new run: the rows left NULL come back, in table order
+    assert [pk for pk, _ in again] == sorted({5, 6, 8} | {i for i in expect if i % 1000 == 1})
 
 
 def test_rejects_what_the_reference_rejects():

@@ -48,7 +48,7 @@ def check_single(rng, case):
     d = int(rng.choice([5, 16, 64, 100, 128, 256, 384, 768, 1000]))
     Bmax = max(1, int(4e10 / (n * d)))
     B = int(min(Bmax, rng.choice([1, 3, 33, 128, 129, 300, 777, 1024, 1500])))
-    k = int(rng.choice([1, 3, 10, 24, 25, 64, 100, 300, 1024]))
+    k = int(rng.choice([1, 3, 10, 24, 25, 33, 50, 64, 100, 128, 129, 300, 1024]))  # (33 ... 128: the two-wave prune)
     mode = str(rng.choice(["gauss", "scaled", "clustered", "dups", "spiky", "dirty"]))
     metric = "ip" if rng.random() < IP_PROB else "cosine"
     C = corpus(rng, n, d, mode)
@@ -72,6 +72,8 @@ def check_single(rng, case):
         opts["prune_companion"] = 1
     if rng.random() < 0.15:
         opts["defer_round_b"] = 0
+    if rng.random() < 0.15:
+        opts["prune_wide"] = 0
     row_offset = int(rng.choice([0, 0, 12345, 2**33]))
     desc = f"single n={n} d={d} B={B} k={k} mode={mode} metric={metric} opts={opts} row_offset={row_offset}"
     import hashlib
@@ -148,7 +150,7 @@ def check_session(rng, case):
                 desc += f" | {key}={val}"
                 continue
             B = int(rng.choice([1, 2, 8])) if big else int(rng.choice([1, 5, 64, 130, 400, 1100]))
-            k = int(rng.choice([1, 10, 24, 30, 100]))
+            k = int(rng.choice([1, 10, 24, 30, 40, 100, 128]))
             Q = rng.standard_normal((B, d)).astype(np.float32)
             if mode in ("clustered", "dups"):
                 Q[: max(1, B // 2)] = C[rng.integers(0, C.shape[0], size=max(1, B // 2))] + (
