@@ -24,13 +24,17 @@ ABI_SYMBOLS = [
     "mi355dr_search", "mi355dr_search_device", "mi355dr_search_device_async", "mi355dr_search_wait", "mi355dr_add_multivec", "mi355dr_size_multivec",
     "mi355dr_search_maxsim", "mi355dr_search_maxsim_device", "mi355dr_maxsim_subset", "mi355dr_maxsim_subset_ex", "mi355dr_add_multivec_device", "mi355dr_gqr_refine", "mi355dr_gqr_refine_maxsim",
     "mi355dr_gqr_refine_scores", "mi355dr_merge_topk_device", "mi355dr_pack_topk_device",
-    "mi355dr_merge_topk_packed_device", "mi355dr_comm_unique_id", "mi355dr_comm_init", "mi355dr_comm_world", "mi355dr_comm_count",
+    "mi355dr_merge_topk_packed_device", "mi355dr_comm_unique_id", "mi355dr_comm_init", "mi355dr_comm_world", "mi355dr_comm_count", "mi355dr_comm_init_custom",
     "mi355dr_search_sharded_device", "mi355dr_set_option", "mi355dr_get_stat",
     "mi355dr_reset_stats", "mi355dr_timer_start", "mi355dr_timer_stop", "mi355dr_synchronize",
     "mi355dr_dev_alloc", "mi355dr_dev_free", "mi355dr_dev_upload", "mi355dr_dev_download",
     "mi355dr_diag_mfma_stream",
     "mi355dr_debug_screen_dense", "mi355dr_debug_screen_bound", "mi355dr_debug_i8_state", "mi355dr_debug_rescore",
 ]
+
+
+# mi355dr_allgather_fn (include/mi355dr.h): (send_dev, recv_dev, bytes_per_rank, stream, user) -> 0 on success
+ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p)
 
 
 class NativeError(RuntimeError):
@@ -141,6 +145,8 @@ def load() -> ctypes.CDLL:
     L.mi355dr_comm_unique_id.argtypes = [vp, ctypes.c_size_t]
     L.mi355dr_comm_init.restype = c_int
     L.mi355dr_comm_init.argtypes = [vp, c_int, c_int, vp, ctypes.c_size_t]
+    L.mi355dr_comm_init_custom.restype = c_int
+    L.mi355dr_comm_init_custom.argtypes = [vp, c_int, c_int, ALLGATHER_FN, vp]
     L.mi355dr_comm_world.restype = c_int
     L.mi355dr_comm_world.argtypes = [vp]
     L.mi355dr_comm_count.restype = c_int

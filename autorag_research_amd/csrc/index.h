@@ -136,6 +136,7 @@ struct mi355dr_index {
     // 33 <= k <= 128: the two-wave prune (k_prune_wide.h: 4096 entries, round A of up to 128 rows, no companion launch), the
     // starter over a 64 k-row sample and chunk ratios up to 4 (option "prune_wide"; 0 = the round-5 schedule, A/B and tests)
     int prune_wide = 1;
+    int64_t starter_rows_wide = 65536;  // the starter's sample at 33 <= k <= 128 (option "starter_rows_wide", tuning: 4096 ... 262144)
 
     // stats
     int64_t s_screen_launches = 0, s_screen_ns = 0, s_screen_rows = 0, s_fallback_queries = 0, s_chunks = 0,
@@ -160,6 +161,8 @@ struct mi355dr_index {
     // RCCL communicator of a row-sharded index (mi355dr_comm.hip)
     void* comm = nullptr;
     int comm_rank = 0, comm_world = 0;
+    mi355dr_allgather_fn comm_custom = nullptr;  // the host's own all-gather instead of RCCL (mi355dr_comm_init_custom)
+    void* comm_custom_user = nullptr;
     // two of each: block i's all-gather + merge run on comm_stream under block i + 1's search (mi355dr_search_sharded_device)
     int64_t* comm_packed[2] = {nullptr, nullptr};      // [2, kQBlockMax, k] this rank's packed block
     int64_t* comm_packed_all[2] = {nullptr, nullptr};  // [world, 2, kQBlockMax, k]

@@ -118,18 +118,9 @@ __global__ __launch_bounds__(kWideThreads) void k_prune_wide(PruneArgs a) {
 
     // ---- the candidates' screen values as order keys: entry e lives in slot e / T of thread e % T ---------------------------
     uint32_t key[PER];
+    int32_t rowv[PER];  // ... and their rows (lists and the carried survivors are written from registers: no second trip to memory)
     uint32_t in_a = 0;  // bit j: the candidate of slot j went through round A
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const int e = j * T + tid;
-        uint32_t kk = 0;  // 0 = no candidate (below every real key)
-        if (e < n_new) {
-            const float v = cval[e];
-            if (v != v) kk = 0xFFFFFFFFu;  // "no bound": always re-scored
-            else if (!(a.flag8 && a.flag8[crow[e]])) kk = f32_order_key(v);  // (else: stale zero of a loose row)
-        }
-        key[j] = kk;
-    }
+    load_candidate_keys<PER, T, true>(key, cval, crow, a.flag8, n_new, tid, rowv);
     for (int k = tid; k < a.d; k += T) qs[k] = a.q[(int64_t)q * a.d + k];
     auto count_ge = [&](uint32_t x) __attribute__((always_inline)) -> int {
         int c = 0;
@@ -159,7 +150,7 @@ __global__ __launch_bounds__(kWideThreads) void k_prune_wide(PruneArgs a) {
             const unsigned long long bal = __builtin_amdgcn_ballot_w64(w);
             const int pos = n + mbcnt(bal) - off;
             if (w && pos >= 0 && pos < room) {
-                RL[pos] = crow[j * T + tid];
+                RL[pos] = rowv[j];
                 if (mark) in_a |= 1u << j;
             }
             n += __builtin_popcountll(bal);
@@ -196,10 +187,11 @@ __global__ __launch_bounds__(kWideThreads) void k_prune_wide(PruneArgs a) {
         return x;
     };
     // the k best of SK / SR[0, n) under (key, row), sorted, in K2 / R2[0 ...); returns how many (<= max(k, ties)) were sorted.
+    // Up to 2 T entries (kept U round A: every prune but a pass's last) are sorted whole -- no selection in front of the sort.
     // Callers have passed a barrier since SK / SR were last written; K2 / R2 are complete (barrier) on return.
     auto select_sort = [&](int n) __attribute__((always_inline)) -> int {
         int n_sel = n;
-        if (n > a.k) {
+        if (n > a.k && n > 2 * T) {
             uint32_t sk[KS];
             const uint32_t xs = exact_kth_image(sk, n, a.k, true);  // (every real similarity ranks above the NaN class 1 and "absent" 0)
             int c = 0;
@@ -268,26 +260,24 @@ __global__ __launch_bounds__(kWideThreads) void k_prune_wide(PruneArgs a) {
         SR[i] = brow[i];
     }
     __syncthreads();
-    const int n1 = n_best + nA;
-    int n_tot = n1, carried = 0, nB_rescored = 0;
+    const int n1 = n_best + nA;  // <= 2 T: sorted whole, once -- the cut reads its k-th entry, a deferring prune publishes it as it is
+    int n_sel = select_sort(n1);
+    int carried = 0, nB_rescored = 0;
     if (n_cand > nA && !a.thr_only) {
-        // ---- cut = (k-th largest exact similarity over kept U round A) - E: as float, rounded down (k_select.h, same expressions)
+        // ---- cut = (k-th best exact similarity over kept U round A) - E: as float, rounded down (k_select.h, same expressions)
         float cut = -__builtin_inff();
         uint32_t keep_x = 0;  // an exact score must reach this float image to enter the exact buffer (0: anything does)
-        if (n1 >= a.k) {
-            uint32_t sk[KS];
-            const uint32_t xs = exact_kth_image(sk, n1, a.k, false);
-            if (xs != 0) {
-                const float kth = __uint_as_float((xs & 0x80000000u) ? (xs & 0x7FFFFFFFu) : ~xs);  // invert the key
-                const float ku = a.metric == 0 ? kth : kth * inv_qn;
-                cut = ku - fabsf(ku) * (a.metric == 0 ? 0.0f : 4e-6f) - E * 1.001f - 2e-6f * a.cscale;
-                keep_x = xs;
-            }
+        if (n1 >= a.k && K2[a.k - 1] != kKeyNaN) {  // (NaN distances sort last: a NaN here = fewer than k real scores)
+            const float kth = sim_of_dist(a.metric, key_to_dist(K2[a.k - 1]));
+            const float ku = a.metric == 0 ? kth : kth * inv_qn;
+            cut = ku - fabsf(ku) * (a.metric == 0 ? 0.0f : 4e-6f) - E * 1.001f - 2e-6f * a.cscale;
+            keep_x = f32_order_key(kth);
         }
         const uint32_t xB = cut == -__builtin_inff() ? 1u : f32_order_key(cut);
         auto wantB = [&](int j) { return key[j] >= xB && key[j] != 0 && !((in_a >> j) & 1u); };
         if (a.defer_b && cut != -__builtin_inff()) {  // (no cut yet -- fewer than k exact scores --: full round B)
-            // carry the survivors to the head of the list: all loads, barrier, then all stores (a slot may be another survivor's source)
+            // carry the survivors to the head of the list, from registers.  A slot may be another survivor's source, but every
+            // source was read when the keys were loaded: only the barrier between the counting pass and the stores remains.
             int32_t* crow_w = a.cand_row + (int64_t)q * a.cap;
             float* cval_w = a.cand_val + (int64_t)q * a.cap;
             int c = 0;
@@ -298,14 +288,6 @@ __global__ __launch_bounds__(kWideThreads) void k_prune_wide(PruneArgs a) {
             }
             int pos0 = 0;
             carried = wg_scan(c, pos0);
-            int32_t cr[PER];
-#pragma unroll
-            for (int j = 0; j < PER; ++j) {
-                if (j * T >= n_new) break;
-                cr[j] = wantB(j) ? crow[j * T + tid] : 0;
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
                 if (j * T >= n_new) break;
@@ -313,7 +295,7 @@ __global__ __launch_bounds__(kWideThreads) void k_prune_wide(PruneArgs a) {
                 const unsigned long long bal = __builtin_amdgcn_ballot_w64(w);
                 const int pos = pos0 + mbcnt(bal);
                 if (w) {
-                    crow_w[pos] = cr[j];
+                    crow_w[pos] = rowv[j];
                     cval_w[pos] = f32_from_order_key(key[j]);
                 }
                 pos0 += __builtin_popcountll(bal);
@@ -321,11 +303,16 @@ __global__ __launch_bounds__(kWideThreads) void k_prune_wide(PruneArgs a) {
         } else {
             // ---- round B: everything that can still reach the top-k, in windows of kWideList rows; an exact score enters the
             // buffer only if it reaches the k-th best known so far, and the buffer is re-selected before a batch could overflow it
-            if (tid == 0) scal[4] = n1;
+            const int n_keepA = min(a.k, n_sel);
+            for (int i = tid; i < n_keepA; i += T) {  // the sorted best of kept U A back into the exact buffer (K2 / R2 are the stage tiles)
+                SK[i] = K2[i];
+                SR[i] = R2[i];
+            }
+            if (tid == 0) scal[4] = n_keepA;
             int totB = 0;
             for (int off = 0; off == 0 || off < totB; off += kWideList) {  // uniform
                 totB = list_rows(wantB, off, kWideList, false);
-                __syncthreads();  // RL complete, scal[4] visible
+                __syncthreads();  // RL complete, scal[4] visible, K2 / R2 read
                 const int m = min(kWideList, totB - off);
                 for (int base = 0; base < m; base += T) {  // uniform
                     const int e = base + tid;
@@ -354,27 +341,26 @@ __global__ __launch_bounds__(kWideThreads) void k_prune_wide(PruneArgs a) {
                     __syncthreads();
                     const int fill = __builtin_amdgcn_readfirstlane(scal[4]);
                     if (fill + T > kWideKeep) {  // uniform: the next batch might not fit -- keep the k best, tighten the filter
-                        const int n_sel = select_sort(fill);
-                        const int n_keep = min(a.k, n_sel);
-                        for (int i = tid; i < n_keep; i += T) {
+                        const int ns = select_sort(fill);
+                        const int nk = min(a.k, ns);
+                        for (int i = tid; i < nk; i += T) {
                             SK[i] = K2[i];
                             SR[i] = R2[i];
                         }
-                        if (n_keep >= a.k && K2[a.k - 1] != kKeyNaN)
+                        if (nk >= a.k && K2[a.k - 1] != kKeyNaN)
                             keep_x = max(keep_x, f32_order_key(sim_of_dist(a.metric, key_to_dist(K2[a.k - 1]))));
                         __syncthreads();  // K2 / R2 (the stage tiles) read, SK / SR rewritten
-                        if (tid == 0) scal[4] = n_keep;
+                        if (tid == 0) scal[4] = nk;
                         __syncthreads();
                     }
                 }
                 nB_rescored += m;
             }
-            n_tot = __builtin_amdgcn_readfirstlane(scal[4]);
+            // ---- final: the k best of kept U A U B under (key, row)
+            n_sel = select_sort(__builtin_amdgcn_readfirstlane(scal[4]));
         }
     }
     if (tid == 0) a.stat[2 * q + 1] += (unsigned long long)(nA + nB_rescored);
-    // ---- final: the k best of kept U A U B under (key, row) ---------------------------------------------------------------
-    const int n_sel = select_sort(n_tot);
     const int n_keep = min(a.k, n_sel);
     if (!a.thr_only)
         for (int i = tid; i < n_keep; i += T) {

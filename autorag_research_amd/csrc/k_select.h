@@ -82,6 +82,56 @@ __host__ __device__ inline size_t prune_lds_bytes(int d, int threads, int sortma
     return (size_t)sortmax * 8 + (size_t)sortmax * 4 + x + (size_t)sortmax * 4 + prune_qs_floats(d) * 4 + (size_t)dpad16 * 4;
 }
 
+// The candidates' screen values as order keys, entry e in slot e / T of thread e % T: 0 = no candidate (below every real key),
+// 0xFFFFFFFF = "no bound" (NaN value: always re-scored); int8 screen (flag8 != nullptr): a finite value on a row outside the
+// int8 shadow is a stale zero -> dropped (that row comes through k_emit_irregular with NaN instead).
+// All loads of a phase are issued before the first is waited for -- values, then (flag8 only) rows, then flags: three memory
+// round trips per prune.  (Round 5 loaded slot by slot inside `if (e < n_new)`: one to three round trips PER SLOT, ~0.7 us each
+// -- a third of a 45 us prune at the headline's ~6 slots with loose rows in the corpus.)  Indices are clamped, not predicated.
+template <int PER, int T, bool ROWS = false>
+__device__ __forceinline__ void load_candidate_keys(uint32_t (&key)[PER], const float* __restrict__ cval,
+                                                    const int32_t* __restrict__ crow, const uint8_t* __restrict__ flag8,
+                                                    int n_new, int tid, int32_t* rows_out = nullptr) {
+    float v[PER];
+    int32_t r[PER];
+    const int last = n_new - 1;  // (callers return before this when n_new == 0)
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        v[j] = 0.0f;
+        r[j] = 0;
+        if (j * T >= n_new) continue;  // uniform: the list ends before this slot
+        v[j] = cval[min(j * T + tid, last)];
+        if (ROWS) r[j] = crow[min(j * T + tid, last)];
+    }
+    uint8_t f[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) f[j] = 0;
+    if (flag8 != nullptr) {
+        if (!ROWS) {
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                if (j * T >= n_new) continue;
+                r[j] = crow[min(j * T + tid, last)];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            if (j * T >= n_new) continue;
+            f[j] = flag8[r[j]];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        uint32_t kk = 0;
+        if (j * T + tid < n_new) {
+            if (v[j] != v[j]) kk = 0xFFFFFFFFu;
+            else if (!f[j]) kk = f32_order_key(v[j]);
+        }
+        key[j] = kk;
+        if (ROWS) rows_out[j] = r[j];
+    }
+}
+
 template <int THREADS, int SORT>
 __device__ __forceinline__ void prune_body(const PruneArgs& a, char* smem);
 
@@ -188,17 +238,7 @@ __device__ __forceinline__ void prune_body(const PruneArgs& a, char* smem) {
             float* tile = tiles;
             uint32_t key[kSelPerLane];
             unsigned in_a = 0;  // bit j: candidate j*64+lane went through round A
-#pragma unroll
-            for (int j = 0; j < kSelPerLane; ++j) {
-                const int e = j * kWave + lane;
-                uint32_t kk = 0;  // 0 = no candidate (below every real key)
-                if (e < n_new) {
-                    const float v = cval[e];
-                    if (v != v) kk = 0xFFFFFFFFu;  // "no bound": always re-scored
-                    else if (!(a.flag8 && a.flag8[crow[e]])) kk = f32_order_key(v);  // (else: stale zero of a loose row)
-                }
-                key[j] = kk;
-            }
+            load_candidate_keys<kSelPerLane, kWave>(key, cval, crow, a.flag8, n_new, lane);
             for (int k = lane; k < a.d; k += kWave) qs[k] = a.q[(int64_t)q * a.d + k];
             if (a.shadow16 != nullptr)
                 for (int k = lane; k < a.dpad; k += kWave) q16[k] = bf16_bits_to_f32(a.st.qhat[(int64_t)q * a.dpad + k]);

@@ -410,7 +410,7 @@ int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t 
 //    re-screened -- measured slower: see index.h.)
 constexpr int kStarterKMax = 32;          // the starter's round A re-scores max(32, 2k) <= 64 rows: one batch of the one-wave form
 constexpr int64_t kStarterRows = 16384;   // sample size (256 slabs); a corpus must hold at least 4 samples
-constexpr int64_t kStarterRowsWide = 65536;  // ... of a pass at 33 <= k <= 128 (1024 slabs)
+// (a pass at 33 <= k <= 128 samples idx->starter_rows_wide rows: 65536 = 1024 slabs by default)
 struct PassPlan {
     int64_t sample = 0;          // > 0: starter over rows [0, sample)
     std::vector<int64_t> ends;   // chunk ends, ascending, last = n; the first chunk starts at 0 (starter) or is the emit-all one
@@ -430,7 +430,7 @@ PassPlan plan_pass(const mi355dr_index* idx, int B, int k, double growth) {
     // which the prune re-scores the 128 best-looking; their k-th best exact score is (about) the k-th best of the sample.
     const bool wide = wide_now(idx);
     const int cap = cap_now(idx);
-    const int64_t starter_rows = std::min<int64_t>(wide ? kStarterRowsWide : kStarterRows, n / 4) / kTileM * kTileM;
+    const int64_t starter_rows = std::min<int64_t>(wide ? idx->starter_rows_wide : kStarterRows, n / 4) / kTileM * kTileM;
     const int64_t starter_slabs = (starter_rows + kSlabRows - 1) / kSlabRows;
     if (idx->starter && (k <= kStarterKMax || wide) && idx->retry_level == 0 && idx->chunk0_set == 0 && n >= 4 * 1024 &&
         starter_slabs <= cap && starter_slabs >= k) {
@@ -1222,6 +1222,9 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
         idx->cap_set = 1;
     } else if (k == "prune_wide") {
         idx->prune_wide = value != 0;
+    } else if (k == "starter_rows_wide") {
+        if (value < 4096 || value > 262144) return fail(idx, MI355DR_E_INVALID, "starter_rows_wide must be in [4096, 262144]");
+        idx->starter_rows_wide = value;
     } else {
         return fail(idx, MI355DR_E_INVALID, "unknown option: " + k);
     }

@@ -76,6 +76,8 @@ void comm_destroy(mi355dr_index* idx) {
         if (r.comm_destroy) (void)r.comm_destroy(idx->comm);
         idx->comm = nullptr;
     }
+    idx->comm_custom = nullptr;
+    idx->comm_custom_user = nullptr;
     for (int i = 0; i < 2; ++i) {
         if (idx->comm_packed[i]) (void)hipFree(idx->comm_packed[i]);
         if (idx->comm_packed_all[i]) (void)hipFree(idx->comm_packed_all[i]);
@@ -123,11 +125,29 @@ int mi355dr_comm_init(mi355dr_index* idx, int rank, int world, const void* nccl_
     return MI355DR_OK;
 }
 
-int mi355dr_comm_world(const mi355dr_index* idx) { return idx && idx->comm ? idx->comm_world : 0; }
+int mi355dr_comm_init_custom(mi355dr_index* idx, int rank, int world, mi355dr_allgather_fn fn, void* user) {
+    if (!idx) return mi355::fail(nullptr, MI355DR_E_INVALID, "null index");
+    if (world < 1 || rank < 0 || rank >= world) return mi355::fail(idx, MI355DR_E_INVALID, "need 0 <= rank < world");
+    if (!fn) return mi355::fail(idx, MI355DR_E_INVALID, "all-gather function is null");
+    std::lock_guard<std::mutex> g(idx->mu);
+    HIPCHECK(idx, hipSetDevice(idx->device));
+    mi355::comm_destroy(idx);
+    idx->comm_custom = fn;
+    idx->comm_custom_user = user;
+    idx->comm_rank = rank;
+    idx->comm_world = world;
+    return MI355DR_OK;
+}
+
+int mi355dr_comm_world(const mi355dr_index* idx) { return idx && (idx->comm || idx->comm_custom) ? idx->comm_world : 0; }
 
 int mi355dr_comm_count(mi355dr_index* idx, int* out) {
     if (!idx || !out) return mi355::fail(idx, MI355DR_E_INVALID, "null argument");
     *out = 0;
+    if (idx->comm_custom) {
+        *out = idx->comm_world;
+        return MI355DR_OK;
+    }
     if (!idx->comm) return MI355DR_OK;
     RcclApi& r = rccl();
     if (!r.comm_count) return mi355::fail(idx, MI355DR_E_UNSUPPORTED, "librccl lacks ncclCommCount");
@@ -146,7 +166,8 @@ int mi355dr_comm_count(mi355dr_index* idx, int* out) {
 int mi355dr_search_sharded_device(mi355dr_index* idx, const float* queries_dev, int B, int k, double* out_dist_dev,
                                   int64_t* out_rows_dev, void* stream) {
     if (!idx) return mi355::fail(nullptr, MI355DR_E_INVALID, "null index");
-    if (!idx->comm) return mi355::fail(idx, MI355DR_E_INVALID, "mi355dr_comm_init has not been called on this index");
+    if (!idx->comm && !idx->comm_custom)
+        return mi355::fail(idx, MI355DR_E_INVALID, "mi355dr_comm_init has not been called on this index");
     if (B < 0 || k <= 0 || k > mi355::kKMax) return mi355::fail(idx, MI355DR_E_INVALID, "bad B / k");
     if ((int64_t)idx->comm_world * k > mi355::kSortMax) return mi355::fail(idx, MI355DR_E_UNSUPPORTED, "world*k exceeds 4096");
     if (B == 0) return MI355DR_OK;
@@ -185,9 +206,15 @@ int mi355dr_search_sharded_device(mi355dr_index* idx, const float* queries_dev, 
         // complete on the host (the library re-does the rare flagged queries here): the packed block is final and visible
         CHECK(mi355dr_search_wait(idx, p.ticket));
         const size_t plane = (size_t)p.nb * k;
-        const int rc = r.all_gather(idx->comm_packed[p.buf], idx->comm_packed_all[p.buf], 2 * plane, kNcclInt64, idx->comm,
-                                    idx->comm_stream);
-        if (rc != 0) return nccl_fail(idx, "ncclAllGather", rc);
+        if (idx->comm_custom) {   // the host's transport (ordered on the communication stream, or complete on return)
+            const int rc = idx->comm_custom(idx->comm_packed[p.buf], idx->comm_packed_all[p.buf], 2 * plane * sizeof(int64_t),
+                                            (void*)idx->comm_stream, idx->comm_custom_user);
+            if (rc != 0) return mi355::fail(idx, MI355DR_E_HIP, "the host's all-gather failed with code " + std::to_string(rc));
+        } else {
+            const int rc = r.all_gather(idx->comm_packed[p.buf], idx->comm_packed_all[p.buf], 2 * plane, kNcclInt64, idx->comm,
+                                        idx->comm_stream);
+            if (rc != 0) return nccl_fail(idx, "ncclAllGather", rc);
+        }
         CHECK(mi355dr_merge_topk_packed_device(idx, idx->comm_packed_all[p.buf], world, p.nb, k, out_dist_dev + (int64_t)p.b0 * k,
                                                out_rows_dev + (int64_t)p.b0 * k, idx->comm_stream));
         HIPCHECK(idx, hipEventRecord(idx->comm_done[p.buf], idx->comm_stream));

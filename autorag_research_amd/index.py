@@ -148,6 +148,26 @@ class Mi355Index:
         buf = ctypes.create_string_buffer(bytes(unique_id), 128)
         check(self._h, self._lib.mi355dr_comm_init(self._h, int(rank), int(world), ctypes.cast(buf, ctypes.c_void_p), 128))
 
+    def comm_init_custom(self, rank: int, world: int, all_gather) -> None:
+        """The sharded search over the HOST's own all-gather instead of RCCL (mi355dr_comm_init_custom).
+        `all_gather(send_ptr, recv_ptr, bytes_per_rank, stream_handle) -> None` moves device memory: every rank's
+        `bytes_per_rank` bytes at `send_ptr` into `recv_ptr`, rank-major, complete on return (or ordered on the stream).
+        An exception inside it becomes error code 1 of the search that called it."""
+        from ._native import ALLGATHER_FN
+
+        def thunk(send, recv, nbytes, stream, _user):
+            try:
+                all_gather(int(send or 0), int(recv or 0), int(nbytes), int(stream or 0))
+            except Exception:  # noqa: BLE001 - must not unwind through the C frame
+                import traceback
+
+                traceback.print_exc()
+                return 1
+            return 0
+
+        self._allgather_thunk = ALLGATHER_FN(thunk)   # (kept alive as long as the index may call it)
+        check(self._h, self._lib.mi355dr_comm_init_custom(self._h, int(rank), int(world), self._allgather_thunk, None))
+
     def comm_world(self) -> int:
         return int(self._lib.mi355dr_comm_world(self._h))
 

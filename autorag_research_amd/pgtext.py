@@ -15,6 +15,11 @@ and the two bulk paths around them:
   * `results_to_copy_text`: a page of ranked results -> `COPY chunk_retrieved_result (query_id, pipeline_id, chunk_id,
     rel_score) FROM STDIN` rows, the bulk form of `bulk_insert` of the reference's row dicts
     (orm/service/retrieval_pipeline.py:171-181, orm/repository/chunk_retrieved_result.py:116-127).
+  * `restore_script_rows`: a published pre-embedded dataset is a pg_dump CUSTOM-format archive (`DBConnection.restore_database`,
+    orm/connection.py:298; data/hf_storage.py downloads it).  `pg_restore -f -` turns such an archive into a plain SQL script
+    WITHOUT a server; the table's data is its `COPY <schema>.<table> (<every column>) FROM stdin;` block.  This reads that block
+    out of the script and projects it onto (id, contents, embedding, embeddings), whatever the column order:
+        pg_restore -f - --data-only -t chunk dataset.dump | python -m autorag_research_amd.pgtext --table chunk --out shards/chunk
 Fixtures: tests/golden/pgtext_golden.json (strings produced / parsed by the imported reference converters).
 """
 
@@ -154,6 +159,37 @@ def copy_text_to_shard(lines: Iterable[str], directory: str | Path, id_type: str
     return write_shard(directory, copy_text_to_table(lines, id_type, has_contents))
 
 
+_COPY_HEAD = re.compile(r'^COPY\s+(?:(?:"[^"]+"|\w+)\.)?(?:"([^"]+)"|(\w+))\s*\((.*)\)\s+FROM\s+stdin;\s*$', re.IGNORECASE)
+
+
+def restore_script_rows(lines: Iterable[str], table: str = "chunk",
+                        columns: tuple[str, ...] = ("id", "contents", "embedding", "embeddings")) -> Iterable[str]:
+    """The data rows of `table` in a `pg_restore -f -` / `pg_dump --format=plain` script, re-projected onto `columns`
+    (tab-separated COPY text, in that order): what `copy_text_to_table` / `copy_text_to_shard` read.  The block runs from
+    `COPY [schema.]table (col, ...) FROM stdin;` to the `\\.` line; a script without the table, or a table without one of the
+    columns, is an error (for `image_chunk` pass columns=("id", "embedding", "embeddings") and has_contents=False downstream)."""
+    it = iter(lines)
+    for line in it:
+        m = _COPY_HEAD.match(line.rstrip("\n"))
+        if not m or (m.group(1) or m.group(2)) != table:
+            continue
+        cols = [c.strip().strip('"') for c in m.group(3).split(",")]
+        missing = [c for c in columns if c not in cols]
+        if missing:
+            raise ValueError(f"table {table!r} has no column(s) {missing} (its COPY block lists {cols})")
+        take = [cols.index(c) for c in columns]
+        for row in it:
+            row = row.rstrip("\n")
+            if row == r"\.":
+                return
+            f = row.split("\t")   # (COPY text escapes a tab inside a value as \t: a raw split is the field split)
+            if len(f) != len(cols):
+                raise ValueError(f"expected {len(cols)} fields in the COPY block of {table!r}, got {len(f)}: {row[:60]!r}")
+            yield "\t".join(f[i] for i in take)
+        raise ValueError(f"the COPY block of {table!r} does not end with a \\. line (truncated script?)")
+    raise ValueError(f"no `COPY ... {table} (...) FROM stdin;` block in the script")
+
+
 def table_to_copy_text(table: ChunkTable) -> list[str]:
     """The inverse (id, contents, embedding, embeddings) rows: what a pre-embedded dataset dump carries."""
     out = []
@@ -179,5 +215,25 @@ def results_to_copy_text(pipeline_id: int | str, query_ids: list, results: list,
     return rows
 
 
+def _main(argv: list[str] | None = None) -> int:
+    """`pg_restore -f - --data-only -t chunk dataset.dump | python -m autorag_research_amd.pgtext --table chunk --out DIR`"""
+    import argparse  # noqa: PLC0415
+    import sys  # noqa: PLC0415
+
+    ap = argparse.ArgumentParser(description="pg_restore / pg_dump plain script (stdin) -> shard directory of one table")
+    ap.add_argument("--table", default="chunk", help="chunk | image_chunk")
+    ap.add_argument("--out", required=True, help="shard directory to write (shards.py format)")
+    ap.add_argument("--id-type", choices=["int", "str"], default="int", help="primary-key type of the schema (bigint | string)")
+    a = ap.parse_args(argv)
+    has_contents = a.table != "image_chunk"   # (image_chunk.contents is the image itself: not exported to the index side)
+    cols = ("id", "contents", "embedding", "embeddings") if has_contents else ("id", "embedding", "embeddings")
+    shard = copy_text_to_shard(restore_script_rows(sys.stdin, a.table, cols), a.out, a.id_type, has_contents)
+    print(shard)
+    return 0
+
+
 __all__ = ["format_vector", "format_vector_array", "format_vector_array_sql", "parse_vector", "parse_vector_array",
-           "copy_text_to_table", "copy_text_to_shard", "table_to_copy_text", "results_to_copy_text"]
+           "copy_text_to_table", "copy_text_to_shard", "restore_script_rows", "table_to_copy_text", "results_to_copy_text"]
+
+if __name__ == "__main__":
+    raise SystemExit(_main())

@@ -141,6 +141,12 @@ class ShardedSearcher:
         self.device = device
         self.row_offset = 0
         self.force_pipeline = False  # tests: run the gather + merge pipeline at world size 1 too
+        # gloo with a GPU-resident index (ranks that cannot meet in RCCL -- e.g. two ranks on ONE device, which RCCL refuses --
+        # or a node without xGMI between them): the shard's packed lists and the merge stay on the device exactly as under
+        # nccl, only the exchange takes a host hop (D2H, gloo all-gather, H2D).  Off for index stand-ins without device entry
+        # points (tests/helpers.OracleIndex): they take the host pipeline.
+        self.host_hop = bool(self.backend == "gloo" and hasattr(self.index, "search_device_async")
+                             and hasattr(self.index, "merge_topk_packed_device"))
         self.overlapped_blocks = 0   # blocks whose gather ran under the next block's search (host pipeline; tests)
 
     def add_local(self, rows, global_row0: int) -> None:
@@ -163,7 +169,7 @@ class ShardedSearcher:
             q = q[None, :]
         if self.world == 1 and not self.force_pipeline:
             return self.index.search(q, k)
-        if self.backend == "nccl" and hasattr(self.index, "search_device"):
+        if (self.backend == "nccl" or self.host_hop) and hasattr(self.index, "search_device"):
             return self._search_device_pipelined(q, k, block)
         return self._search_host_pipelined(q, k, block)
 
@@ -192,11 +198,21 @@ class ShardedSearcher:
             if ticket is not None:
                 self.index.search_wait(ticket)
             pk = packed[buf][: 2 * nb * k]
+            ga_host = None
+            if self.host_hop:   # the block is final (search_wait / the synchronize below): host hop of the exchange
+                if ticket is None:
+                    compute.synchronize()
+                pk_host = pk.cpu()
+                ga_host = torch.empty((self.world * pk_host.numel(),), dtype=torch.int64)
+                dist.all_gather_into_tensor(ga_host, pk_host, group=self.group)
             with torch.cuda.stream(comm):
                 if ticket is None:
                     comm.wait_stream(compute)
                 ga = gathered[buf][: self.world * 2 * nb * k]
-                dist.all_gather_into_tensor(ga, pk, group=self.group)
+                if ga_host is not None:
+                    ga.copy_(ga_host)
+                else:
+                    dist.all_gather_into_tensor(ga, pk, group=self.group)
                 self.index.merge_topk_packed_device(ga.data_ptr(), self.world, nb, k, out_d[b0:b0 + nb].data_ptr(),
                                                     out_r[b0:b0 + nb].data_ptr(), comm.cuda_stream)
                 done[buf] = torch.cuda.Event()
@@ -267,7 +283,7 @@ class ShardedSearcher:
             return self.index.search_maxsim(qtok, q_offsets, k)
         import torch
 
-        on_gpu = self.backend == "nccl"
+        on_gpu = self.backend == "nccl" or self.host_hop
         if on_gpu and hasattr(self.index, "search_maxsim_device"):
             # nccl: the shard's lists stay in HBM from the MaxSim kernels to the merge -- mi355dr_search_maxsim_device writes
             # them to device buffers, fp32 -> float8 (exact, order-preserving) and the packing are device ops, one
@@ -287,7 +303,12 @@ class ShardedSearcher:
             self.index.search_maxsim_device(qd.data_ptr(), q_offsets, k, d32.data_ptr(), packed[1].data_ptr(), cur.cuda_stream)
             packed[0].view(torch.float64).copy_(d32)
             gathered = torch.empty((self.world, 2, B, k), dtype=torch.int64, device=dev)
-            self._dist.all_gather_into_tensor(gathered.view(-1), packed.view(-1), group=self.group)
+            if self.host_hop:
+                g_host = torch.empty((self.world * packed.numel(),), dtype=torch.int64)
+                self._dist.all_gather_into_tensor(g_host, packed.view(-1).cpu(), group=self.group)
+                gathered.view(-1).copy_(g_host)
+            else:
+                self._dist.all_gather_into_tensor(gathered.view(-1), packed.view(-1), group=self.group)
             out_d = torch.empty((B, k), dtype=torch.float64, device=dev)
             out_r = torch.empty((B, k), dtype=torch.int64, device=dev)
             self.index.merge_topk_packed_device(gathered.data_ptr(), self.world, B, k, out_d.data_ptr(), out_r.data_ptr(),

@@ -103,6 +103,8 @@ def parse_args():
     ap.add_argument("--data", choices=["gaussian", "anisotropic"], default="gaussian",
                     help="gaussian = BASELINE headline; anisotropic = power-law spectrum + near-duplicate clusters (the offline "
                          "stand-in for bge-base on BEIR nq, config C2: use with --metric ip --k 100)")
+    ap.add_argument("--traffic", action="store_true", help="run the PMC sub-run (rocprofv3 --pmc FETCH_SIZE of this workload, 3 steps) "
+                                                           "that fills roofline.traffic even with --no-extras")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="library option passed to mi355dr_set_option verbatim (developer A/B; repeatable)")
     ap.add_argument("--cpu-sample-rows", type=int, default=2_500_000)
@@ -351,19 +353,10 @@ def main() -> None:
     alg_bytes = float(screen_rows) * d * 4            # algorithmic HBM bytes: N*d*4 per pass
     shadow_bytes = float(screen_rows) * dpad * (1 if i8 else 2)  # bytes the screen really streams (shadow rows)
     screen_s = screen_ns * 1e-9
-    # HBM traffic of the dominant kernel from the committed PMC pass of this same command (rocprofv3 cannot run
-    # inside the timed region): bytes per screened row x rows per launch.  See tools/collect_traffic.sh.
+    # HBM traffic of the dominant kernel: measured by a PMC sub-run of this very workload behind the timed region (below) or
+    # absent -- nothing is replayed from an earlier round's profile (rocprofv3 cannot run inside the timed region)
     traffic = None
-    traffic_src = None
-    for tname in (("r04_traffic_i8.json", "r03_traffic_i8.json", "r02_traffic_i8.json") if i8 else ("r02_traffic.json", "r01_traffic.json")):
-        tfile = ROOT / "profiles" / tname
-        if tfile.exists() and B > 128 and d == 768 and launches:
-            per_row = json.loads(tfile.read_text())["hbm_read_bytes_per_screened_row"]
-            traffic = round(per_row * screen_rows / launches)
-            traffic_src = f"REPLAYED, not measured in this run: {per_row:.0f} B per screened row from profiles/{tname} " \
-                          "(rocprofv3 --pmc FETCH_SIZE pass of this same command, x1024 x2 gfx950 correction; " \
-                          "tools/collect_traffic.sh) x the rows one launch screened here"
-            break
+    traffic_src = "not measured (run without --no-extras, or with --traffic, for the in-run rocprofv3 --pmc FETCH_SIZE sub-run)"
     ubench = (MFMA_I8_UBENCH_TOPS["32x32x32"] if i8 else MFMA_BF16_UBENCH_TF)
     roof = {
         "bound": "mfma",
@@ -705,7 +698,7 @@ def main() -> None:
             result["extra"]["replicated"] = leg
     if have_pg:
         dist.destroy_process_group()
-    if rank == 0 and world == 1 and not args.no_extras and B > 128:
+    if rank == 0 and world == 1 and (not args.no_extras or args.traffic) and B > 128:
         # (every index of this process is closed by now: the sub-run builds its own copy of the corpus)
         sub = ["--rows", n_total, "--dim", d, "--block", B, "--k", k, "--metric", args.metric, "--data", args.data,
                "--screen", args.screen]
@@ -714,17 +707,18 @@ def main() -> None:
             sub += ["--screen-rq", args.screen_rq]
         if args.screen_drift is not None:
             sub += ["--screen-drift", args.screen_drift]
+        for kv in args.opt:
+            sub += ["--opt", kv]
         per_launch, n_prof, note = pmc_fetch_subrun(sub, dom)
         rl = result["roofline"]
         if per_launch is not None:
-            rl["traffic_replayed"] = rl.get("traffic")
             rl["traffic"] = round(per_launch)
             rl["traffic_source"] = (
                 f"MEASURED in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE sub-run of this workload (3 steps, {n_prof} "
                 f"{dom} launches; KiB x 1024 x 2: the gfx950 correction of MI355X_MICROARCH.md), mean per launch -- the "
                 "launches of a pass differ in size exactly as in the timed region")
         else:
-            rl["traffic_source"] = (rl.get("traffic_source") or "") + f" [live PMC sub-run: {note}]"
+            rl["traffic_source"] = f"not measured [live PMC sub-run: {note}]"
     if rank == 0 and world == 1 and not args.no_extras and "maxsim" in result:
         # the MaxSim screens' HBM traffic, measured like the single-vector kernel's: a PMC sub-run of the same store + steps
         for key, tokens, docs in (("colbert_like", "text", 1_000_000), ("colpali_like", "page", 100_000)):

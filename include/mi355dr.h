@@ -189,6 +189,15 @@ int mi355dr_comm_world(const mi355dr_index* idx);  /* 0 before mi355dr_comm_init
 /* the rank count RCCL itself reports for the communicator (ncclCommCount): what a caller logs to show that the collective
  * really spans N ranks; 0 before mi355dr_comm_init */
 int mi355dr_comm_count(mi355dr_index* idx, int* out);
+/* Transport plug-in: the same sharded search over an all-gather the HOST provides instead of RCCL -- MPI / UCX hosts, a node
+ * whose ranks cannot meet in one RCCL communicator (RCCL refuses two ranks on one device: the two-ranks-on-one-GPU parity test
+ * of tests/test_gpu_world2.py runs mi355dr_search_sharded_device through this entry).  `fn` gathers `bytes_per_rank` bytes from
+ * every rank's `send_dev` into `recv_dev` (rank-major, device memory), either ordered on `stream` or complete on return, and
+ * returns 0 on success; it is called from the thread that calls mi355dr_search_sharded_device, once per block, in the same
+ * order on every rank.  Replaces a communicator set by mi355dr_comm_init (and vice versa); mi355dr_comm_count then reports
+ * `world` as given. */
+typedef int (*mi355dr_allgather_fn)(const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* stream, void* user);
+int mi355dr_comm_init_custom(mi355dr_index* idx, int rank, int world, mi355dr_allgather_fn fn, void* user);
 /* device buffers in / out like mi355dr_search_device; every rank passes the same queries and receives the same result.
  * Blocks of 1024 queries are software-pipelined: block i + 1 is searched while block i's all-gather + merge run on the
  * index's communication stream (two packed / gathered buffers).  Asynchronous on `stream` (NULL = the index's own stream):

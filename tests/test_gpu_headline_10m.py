@@ -1,5 +1,5 @@
 """GPU: the BASELINE headline corpus at FULL size inside the test suite -- N = 10 M rows, d = 768, L2-normalised Gaussian rows
-generated on the device chunk by chunk (bench.py's generator: synth.gaussian_chunk), 1024-query blocks, k = 10.  The oracle
+generated on the device chunk by chunk (bench.py's generator: synth.gaussian_chunk), 1024-query blocks, k = 10 and k = 100.  The oracle
 cannot finish at this size, so the checks are the size-independent ones: planted answers at recorded rows come back first with
 their exact distances (oracle on the planted rows only), every list sorted by (distance, row) with rows unique and in range,
 the guaranteed exact-scan path reproduces the screen path bit for bit on a query subset, the two halves of the index searched
@@ -62,7 +62,7 @@ def test_ten_million_rows(native_built, oracle):
     # planted answers: the easy ones (sigma <= 1: cosine >= 0.7, far above any Gaussian neighbour) lead their query's list in
     # order of their exact distances, which are the oracle's on those very rows
     Qh, Ph = Q.cpu().numpy(), p_vec.cpu().numpy()
-    for b in range(0, B, 7):
+    for b in range(B):   # (every query; round 5 looked at every 7th)
         mine = [i for i in np.nonzero(p_owner == b)[0] if p_sigma[i] <= 1.0]
         if not mine:
             continue
@@ -71,10 +71,35 @@ def test_ten_million_rows(native_built, oracle):
         assert np.array_equal(rows[b, :len(mine)], want_rows)
         assert np.array_equal(dist[b, :len(mine)].view(np.uint64), od[0].view(np.uint64))
     # the guaranteed exact path on a subset == the screen path, bit for bit
+    n_scan = 128   # (round 5: 24)
     whole.set_option("path", "scan")
-    ds, rs = run(whole, Q, 24)
+    ds, rs = run(whole, Q, n_scan)
     whole.set_option("path", "auto")
-    assert np.array_equal(rs, rows[:24]) and np.array_equal(ds.view(np.uint64), dist[:24].view(np.uint64))
+    assert np.array_equal(rs, rows[:n_scan]) and np.array_equal(ds.view(np.uint64), dist[:n_scan].view(np.uint64))
+    # k = 100 (BASELINE config 2's limit; the two-wave prune behind the 64 k-row starter) at the same full size: lists sorted and
+    # unique, the planted rows first with the oracle's distances, the exact-scan path bit for bit on 64 queries, and the first
+    # ten entries of every list = the k = 10 list
+    k100 = 100
+
+    def run100(ix, q, nb):
+        od = torch.empty((nb, k100), dtype=torch.float64, device=dev)
+        orr = torch.empty((nb, k100), dtype=torch.int64, device=dev)
+        ix.search_device(q.data_ptr(), nb, k100, od.data_ptr(), orr.data_ptr(), s)
+        torch.cuda.synchronize()
+        return od.cpu().numpy(), orr.cpu().numpy()
+
+    whole.reset_stats()
+    dist100, rows100 = run100(whole, Q, B)
+    assert whole.stat("fallback_queries") == 0 and whole.stat("retry_queries") == 0 and whole.stat("starters") == 1
+    assert whole.stat("chunks") <= 7, whole.stat("chunks")     # (thirty in round 5)
+    assert rows100.min() >= 0 and rows100.max() < n and (np.diff(dist100, axis=1) >= 0).all()
+    assert (np.diff(rows100, axis=1)[np.diff(dist100, axis=1) == 0] > 0).all()
+    assert all(len(set(r)) == k100 for r in rows100.tolist())
+    assert np.array_equal(rows100[:, :k], rows) and np.array_equal(dist100[:, :k].view(np.uint64), dist.view(np.uint64))
+    whole.set_option("path", "scan")
+    ds, rs = run100(whole, Q, 64)
+    whole.set_option("path", "auto")
+    assert np.array_equal(rs, rows100[:64]) and np.array_equal(ds.view(np.uint64), dist100[:64].view(np.uint64))
     # halves (row offsets) + merge by (distance, row) == the whole
     d1, r1 = run(lo, Q, B)
     d2, r2 = run(hi, Q, B)

@@ -76,3 +76,46 @@ def test_copy_dump_to_shard_to_search_and_write_back(tmp_path, monkeypatch, orac
     assert len(rows) == 6
     f = rows[0].split("\t")
     assert f[0] == "qa" and f[1] == "5" and int(f[2]) == res[0][0]["doc_id"] and float(f[3]) == res[0][0]["score"]
+
+
+def test_pg_restore_script_to_shard(tmp_path):
+    """A published dataset is a pg_dump custom-format archive (orm/connection.py:298); `pg_restore -f -` prints it as a script
+    whose `COPY public.chunk (<every column>) FROM stdin;` block carries the rows.  The block is found among the other tables',
+    projected onto (id, contents, embedding, embeddings) whatever the column order, and lands in a shard directory -- by the
+    function and by the `python -m autorag_research_amd.pgtext` one-liner of INTEGRATION.md."""
+    import subprocess
+    import sys
+
+    from autorag_research_amd import pgtext as pt
+    from autorag_research_amd.shards import read_shard
+
+    rng = np.random.default_rng(9)
+    n, d = 12, 8
+    emb = rng.standard_normal((n, d)).astype(np.float32)
+    toks = [rng.standard_normal((int(t), d)).astype(np.float32) for t in rng.integers(0, 4, size=n)]
+    rows = []
+    for i in range(n):
+        e = r"\N" if i == 4 else pt.format_vector(emb[i])
+        mv = pt.format_vector_array(toks[i]) if toks[i].shape[0] else (r"\N" if i % 2 else "{}")
+        # the reference's column order (orm/schema_factory.py:148-154) with the two vector columns swapped and a text with a tab
+        rows.append("\t".join([str(100 + i), f"passage\\t{i}" if i == 2 else f"passage {i}", mv, e, r"\N", "f", r"\N"]))
+    script = ["--", "-- PostgreSQL database dump", "--", "SET statement_timeout = 0;", "",
+              "COPY public.query (id, contents, embedding) FROM stdin;", "1\tq\t[1,2]", r"\.", "",
+              "COPY public.chunk (id, contents, embeddings, embedding, bm25_tokens, is_table, table_type) FROM stdin;", *rows, r"\.", "",
+              "COPY public.image_chunk (id, parent_page, contents, mimetype, embedding, embeddings) FROM stdin;", r"\.", ""]
+    t = pt.copy_text_to_table(pt.restore_script_rows(script, "chunk"))
+    assert t.ids == list(range(100, 100 + n)) and t.contents[2] == "passage\t2"
+    live = [i for i in range(n) if i != 4]
+    assert np.isnan(t.embedding[4]).all() and np.array_equal(t.embedding[live], emb[live])
+    assert np.array_equal(np.diff(t.mv_offsets), [x.shape[0] for x in toks]) and np.array_equal(t.mv_tokens, np.concatenate(toks))
+    with pytest.raises(ValueError, match="no `COPY"):
+        list(pt.restore_script_rows(script, "caption"))
+    with pytest.raises(ValueError, match="no column"):
+        list(pt.restore_script_rows(script, "query", ("id", "embeddings")))
+    with pytest.raises(ValueError, match="does not end"):
+        list(pt.restore_script_rows(script[:12], "chunk"))
+    r = subprocess.run([sys.executable, "-m", "autorag_research_amd.pgtext", "--table", "chunk", "--out", str(tmp_path / "chunk")],
+                       input="\n".join(script) + "\n", capture_output=True, text=True, cwd=str(GOLDEN.parent.parent), timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    back = read_shard(tmp_path / "chunk")
+    assert back.ids == t.ids and np.array_equal(back.mv_tokens, t.mv_tokens) and np.array_equal(back.embedding[live], emb[live])
