@@ -435,12 +435,20 @@ __device__ __forceinline__ float chain_piece(const float* tile, int lane, const 
     return acc;
 }
 
-// full chain <row, qv> for this lane's row (nullptr = idle slot); rows prefetched two pieces ahead when d%4==0
+// full chain <row, qv> for this lane's row (nullptr = idle slot); rows prefetched DEPTH pieces ahead when d%4==0 (2: 128
+// registers of pieces in flight; 3: 192).  Measured round 6 (-DMI355_STAGE_DEPTH=3, profiles/r06_stage_depth_ab.txt): a third
+// piece in flight changes neither prune (k = 10: 6.246 / 6.241 ms per pass, k = 100: 7.68 / 7.69) -- a prune is a chain of ~25
+// dependent steps of ~1 us each (counts, keys, rows, the pieces, norms, kept list, sort, publish), not a wait for the pieces.
+#ifndef MI355_STAGE_DEPTH
+#define MI355_STAGE_DEPTH 2
+#endif
+template <int DEPTH = MI355_STAGE_DEPTH>
 __device__ __forceinline__ float staged_dot(float* tile, const float* my_row, const float* qv, int d, int lane) {
+    static_assert(DEPTH == 2 || DEPTH == 3, "pieces in flight");
     float acc = 0.0f;
     if ((d & 3) == 0) {
         StageRows sr;
-        StagePiece p0, p1;
+        StagePiece p0, p1, p2;
         const bool dense = stage_rows_init_dense(sr, my_row, lane);
         auto issue = [&](StagePiece& p, int k0) __attribute__((always_inline)) {
             if (dense && k0 + kStageCols <= d) stage_issue_dense(p, sr, k0, lane);  // wave-uniform
@@ -448,14 +456,24 @@ __device__ __forceinline__ float staged_dot(float* tile, const float* my_row, co
         };
         issue(p0, 0);
         if (kStageCols < d) issue(p1, kStageCols);
-        for (int k0 = 0; k0 < d; k0 += 2 * kStageCols) {
+        if constexpr (DEPTH == 3) {
+            if (2 * kStageCols < d) issue(p2, 2 * kStageCols);
+        }
+        for (int k0 = 0; k0 < d; k0 += DEPTH * kStageCols) {
             stage_commit(tile, p0, lane);
-            if (k0 + 2 * kStageCols < d) issue(p0, k0 + 2 * kStageCols);
+            if (k0 + DEPTH * kStageCols < d) issue(p0, k0 + DEPTH * kStageCols);
             acc = chain_piece(tile, lane, qv + k0, min(kStageCols, d - k0), acc);
             if (k0 + kStageCols < d) {
                 stage_commit(tile, p1, lane);
-                if (k0 + 3 * kStageCols < d) issue(p1, k0 + 3 * kStageCols);
+                if (k0 + (DEPTH + 1) * kStageCols < d) issue(p1, k0 + (DEPTH + 1) * kStageCols);
                 acc = chain_piece(tile, lane, qv + k0 + kStageCols, min(kStageCols, d - k0 - kStageCols), acc);
+            }
+            if constexpr (DEPTH == 3) {
+                if (k0 + 2 * kStageCols < d) {
+                    stage_commit(tile, p2, lane);
+                    if (k0 + 5 * kStageCols < d) issue(p2, k0 + 5 * kStageCols);
+                    acc = chain_piece(tile, lane, qv + k0 + 2 * kStageCols, min(kStageCols, d - k0 - 2 * kStageCols), acc);
+                }
             }
         }
     } else {

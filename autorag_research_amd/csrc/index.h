@@ -103,7 +103,6 @@ struct mi355dr_index {
     // by document length; 1: parked epilogue; 2: immediate epilogue; 0: one wave per document with the query fragments in LDS
     // (k_maxsim16_d128<NCB, 8>) -- option "maxsim_wg", A/B and tests
     int maxsim_wg = -1;
-    int maxsim_packed = 0;   // 16-query screen over the packed bf16 copy (k_maxsim_wgp.h; measured slower than the padded copy: off)
     int maxsim_tighten = 1;  // MaxSim fast path: narrow the candidate band with the exact distances of the screen's top-k (0: band 2E)
     int maxsim_aligned = 1;  // k_maxsim16_wg: when every query of a pass is one column block, a wave sums its own two queries (0: A/B)
     int maxsim_wg_min = 8;   // fewest column blocks of a pass that take the workgroup form (8: short documents only; 9)
@@ -136,6 +135,15 @@ struct mi355dr_index {
     // 33 <= k <= 128: the two-wave prune (k_prune_wide.h: 4096 entries, round A of up to 128 rows, no companion launch), the
     // starter over a 64 k-row sample and chunk ratios up to 4 (option "prune_wide"; 0 = the round-5 schedule, A/B and tests)
     int prune_wide = 1;
+    // k_screen_rq: the waves of a workgroup flush their hit-lane queues at the same tiles, every `period` tiles with
+    // period = the largest power of two below screen_flush_lanes / (expected hit lanes per wave and tile) (1 ... 64);
+    // option "screen_flush_sync" (0 = every wave on its own, round 5), "screen_flush_lanes" (tuning)
+    int screen_flush_sync = 1, screen_flush_lanes = 48, screen_flush_alone = 40;
+    int wide_inflation_x10 = 100;  // growth budget of the two-wave prune's passes: inflation of the int8 bound it plans for, x 10 (tuning)
+    int flush_mask_now = -1;     // ... of the chunk being launched (run_screen)
+    // pass schedule: ratio of chunk i = (geometric mean) x taper^((n-1)/2 - i) -- early chunks (cheap hits, loose bound) larger,
+    // late chunks (expensive hits) smaller; 100 = uniform ratios (option "chunk_taper_x100")
+    int chunk_taper_x100 = 0;   // 0 = auto: 120 for passes of the two-wave prune (measured -1 % at k = 100), 100 otherwise (k = 10: no gain)
     int64_t starter_rows_wide = 65536;  // the starter's sample at 33 <= k <= 128 (option "starter_rows_wide", tuning: 4096 ... 262144)
 
     // stats
@@ -153,7 +161,7 @@ struct mi355dr_index {
     int64_t s_ms_screened = 0, s_ms_candidates = 0, s_ms_fallbacks = 0;  // MaxSim: queries screened, docs re-scored, full re-runs
     // option "profile": HIP-event time of the MaxSim screen launches (k_maxsim16*) and of the exact launches on candidate lists
     int64_t s_ms_screen_ns = 0, s_ms_screen_launches = 0, s_ms_exact_ns = 0, s_ms_exact_launches = 0, s_ms_pack_ns = 0;
-    int64_t s_ms_packed_launches = 0, s_ms_screen_cols = 0;  // query-vector columns (whole blocks of 32) the screen launches multiplied every token by
+    int64_t s_ms_screen_cols = 0;  // query-vector columns (whole blocks of 32) the screen launches multiplied every token by
     hipEvent_t ms_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<mi355::EventPair> ev_pool, ev_pending;
     hipEvent_t t0 = nullptr, t1 = nullptr;

@@ -21,7 +21,7 @@
 //   * and not at all when every query of the pass IS one column block (`aligned`: ColBERT's 32-vector queries): the wave that
 //     holds a query's columns sums them itself (-5 % on a store of 32..180-token documents).
 // Column blocks w and w + 8 sit on the same wave, waves w and w + 4 on the same SIMD: 12 column blocks (sixteen 24-vector
-// queries) are 3 per SIMD, 16 are 4 per SIMD -- balanced.  What did NOT help: fewer MFMAs (the packed copy, k_maxsim_wgp.h),
+// queries) are 3 per SIMD, 16 are 4 per SIMD -- balanced.  What did NOT help: fewer MFMAs (round 4's packed copy without per-document padding: 13 % fewer blocks on text, 2-3 % slower; removed in round 6),
 // wave priorities, interleaving the two accumulator chains.
 // The per-document sums add the column maxima in another order than k_maxsim16_d128 and the exact kernel do; the screen's
 // bound covers any order (search_maxsim_impl: e_acc).  Bit-exactness of the RESULTS is the exact re-score's business, as before.

@@ -21,21 +21,22 @@
 // rigorous bound of DESIGN.md "Screen bounds" (same expressions as k_select.h).
 // Reference: the same `ORDER BY distance LIMIT k` of orm/repository/base.py:409-415, at limit = 33 ... 128 (BASELINE config 2).
 #pragma once
+#include <type_traits>
+
 #include "k_select.h"
 
 namespace mi355 {
 
-constexpr int kWideWaves = 2, kWidePer = 32;
-constexpr int kWideThreads = kWideWaves * kWave;        // 128
-constexpr int kWideEntries = kWideThreads * kWidePer;   // 4096 candidates per prune
+constexpr int kWideEntries = 4096;   // candidates per prune: WAVES x 64 threads x PER keys (2 x 32 or 1 x 64)
 constexpr int kWideKeep = 512;   // exact (key, row) pairs in LDS: kept (<= 128) + round A (<= 128) + one batch, then shrunk
 constexpr int kWideList = 1024;  // rows listed per re-score window
 constexpr int kWideKMin = 33, kWideKMax = 128;
+constexpr int kWideSortWhole = 256;  // kept (<= 128) + round A (<= 128)
 
 // dynamic LDS: SK[kWideKeep] u64 | SR[kWideKeep] i32 | stage tiles (one per wave; the final sort's K2 / R2 alias them) |
 //              RL[kWideList] i32 | qs[d] f32 + 16 scalars
-__host__ __device__ inline size_t prune_wide_lds_bytes(int d) {
-    return (size_t)kWideKeep * 12 + (size_t)kWideWaves * kStageFloats * sizeof(float) + (size_t)kWideList * 4 +
+__host__ __device__ inline size_t prune_wide_lds_bytes(int d, int waves) {
+    return (size_t)kWideKeep * 12 + (size_t)waves * kStageFloats * sizeof(float) + (size_t)kWideList * 4 +
            prune_qs_floats(d) * 4;
 }
 
@@ -44,8 +45,15 @@ __device__ __forceinline__ float f32_from_order_key(uint32_t k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
 
-__global__ __launch_bounds__(kWideThreads) void k_prune_wide(PruneArgs a) {
-    constexpr int T = kWideThreads, PER = kWidePer, WAVES = kWideWaves;
+// WAVES x PER = 2 x 32 is the form the library launches.  1 x 64 (ONE wave per query, 64 keys per lane, 30 KiB of LDS: all 1024
+// queries of a block resident at once instead of 512, round A in two batches one after the other) was built and measured,
+// bit-identical: its deferring prunes take 164-184 us against 128-155 (N = 10 M, k = 100; profiles/r06_prune_wide_ab.txt) --
+// what bounds a prune is the chain of dependent steps inside one query, not how many queries are resident.
+template <int WAVES, int PER>
+__global__ __launch_bounds__(WAVES * kWave) void k_prune_wide(PruneArgs a) {
+    constexpr int T = WAVES * kWave;
+    static_assert(T * PER == kWideEntries && (PER == 32 || PER == 64), "entries");
+    typedef std::conditional_t<PER == 64, unsigned long long, uint32_t> amask_t;
     constexpr int KS = kWideKeep / T;  // slots per thread over the exact buffer
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint64_t* SK = (uint64_t*)smem;
@@ -89,6 +97,7 @@ __global__ __launch_bounds__(kWideThreads) void k_prune_wide(PruneArgs a) {
     // sum of a wave-uniform value over the waves; one barrier (two exchange parities: a wave may enter the next exchange
     // while its sibling still reads this one's words)
     auto wg_sum = [&](int v) __attribute__((always_inline)) -> int {
+        if constexpr (WAVES == 1) return v;
         if (lane == 0) scal[par * WAVES + wave] = v;
         __syncthreads();
         int c = 0;
@@ -99,6 +108,10 @@ __global__ __launch_bounds__(kWideThreads) void k_prune_wide(PruneArgs a) {
     };
     // the same, plus the sum over the waves before this one
     auto wg_scan = [&](int v, int& before) __attribute__((always_inline)) -> int {
+        if constexpr (WAVES == 1) {
+            before = 0;
+            return v;
+        }
         if (lane == 0) scal[par * WAVES + wave] = v;
         __syncthreads();
         int c = 0, b = 0;
@@ -119,7 +132,7 @@ __global__ __launch_bounds__(kWideThreads) void k_prune_wide(PruneArgs a) {
     // ---- the candidates' screen values as order keys: entry e lives in slot e / T of thread e % T ---------------------------
     uint32_t key[PER];
     int32_t rowv[PER];  // ... and their rows (lists and the carried survivors are written from registers: no second trip to memory)
-    uint32_t in_a = 0;  // bit j: the candidate of slot j went through round A
+    amask_t in_a = 0;  // bit j: the candidate of slot j went through round A
     load_candidate_keys<PER, T, true>(key, cval, crow, a.flag8, n_new, tid, rowv);
     for (int k = tid; k < a.d; k += T) qs[k] = a.q[(int64_t)q * a.d + k];
     auto count_ge = [&](uint32_t x) __attribute__((always_inline)) -> int {
@@ -151,7 +164,7 @@ __global__ __launch_bounds__(kWideThreads) void k_prune_wide(PruneArgs a) {
             const int pos = n + mbcnt(bal) - off;
             if (w && pos >= 0 && pos < room) {
                 RL[pos] = rowv[j];
-                if (mark) in_a |= 1u << j;
+                if (mark) in_a |= (amask_t)1 << j;
             }
             n += __builtin_popcountll(bal);
         }
@@ -187,11 +200,11 @@ __global__ __launch_bounds__(kWideThreads) void k_prune_wide(PruneArgs a) {
         return x;
     };
     // the k best of SK / SR[0, n) under (key, row), sorted, in K2 / R2[0 ...); returns how many (<= max(k, ties)) were sorted.
-    // Up to 2 T entries (kept U round A: every prune but a pass's last) are sorted whole -- no selection in front of the sort.
+    // Up to kWideSortWhole entries (kept U round A: every prune but a pass's last) are sorted whole -- no selection in front of the sort.
     // Callers have passed a barrier since SK / SR were last written; K2 / R2 are complete (barrier) on return.
     auto select_sort = [&](int n) __attribute__((always_inline)) -> int {
         int n_sel = n;
-        if (n > a.k && n > 2 * T) {
+        if (n > a.k && n > kWideSortWhole) {
             uint32_t sk[KS];
             const uint32_t xs = exact_kth_image(sk, n, a.k, true);  // (every real similarity ranks above the NaN class 1 and "absent" 0)
             int c = 0;
@@ -231,27 +244,30 @@ __global__ __launch_bounds__(kWideThreads) void k_prune_wide(PruneArgs a) {
     };
 
     // ---- round A: the best-looking candidates, one gather round (a batch per wave) -------------------------------------------
-    const int wantA = min(n_cand, min(T, max(a.k, a.round_a > 0 ? a.round_a : max(32, 2 * a.k))));
+    const int wantA = min(n_cand, min(2 * kWave, max(a.k, a.round_a > 0 ? a.round_a : max(32, 2 * a.k))));
     int nA = 0;
     if (wantA > 0) {
-        // largest x (20 leading bits) with count(key >= x) >= wantA: a few more than wantA may pass, the list takes the first T
+        // largest x (20 leading bits) with count(key >= x) >= wantA: a few more than wantA may pass, the list takes the first 128
         uint32_t x = 0;
         for (int b = 31; b >= 12; --b) {
             const uint32_t t = x | (1u << b);
             if (count_ge(t) >= wantA) x = t;
         }
         if (x == 0) x = 1u;
-        nA = min(T, list_rows([&](int j) { return key[j] >= x; }, 0, T, true));
+        constexpr int kAMax = 2 * kWave;  // rows of round A (one batch per wave of the two-wave form, two batches of the one-wave form)
+        nA = min(kAMax, list_rows([&](int j) { return key[j] >= x; }, 0, kAMax, true));
         __syncthreads();  // RL complete
-        const int e = tid;
-        const bool live = e < nA;
-        const int32_t row = live ? RL[e] : -1;
-        const float* rp = live ? a.rows + (int64_t)row * a.d : nullptr;
-        if (wave * kWave < nA) {  // wave-uniform
-            const float acc = staged_dot(tile, rp, qs, a.d, lane);
-            if (live) {
-                SK[n_best + e] = dist_to_key(distance_from(a.metric, acc, nq, a.nrm2[row]));
-                SR[n_best + e] = row;
+        for (int base = 0; base < nA; base += T) {  // uniform
+            const int e = base + tid;
+            const bool live = e < nA;
+            const int32_t row = live ? RL[e] : -1;
+            const float* rp = live ? a.rows + (int64_t)row * a.d : nullptr;
+            if (base + wave * kWave < nA) {  // wave-uniform
+                const float acc = staged_dot(tile, rp, qs, a.d, lane);
+                if (live) {
+                    SK[n_best + e] = dist_to_key(distance_from(a.metric, acc, nq, a.nrm2[row]));
+                    SR[n_best + e] = row;
+                }
             }
         }
     }
@@ -274,7 +290,7 @@ __global__ __launch_bounds__(kWideThreads) void k_prune_wide(PruneArgs a) {
             keep_x = f32_order_key(kth);
         }
         const uint32_t xB = cut == -__builtin_inff() ? 1u : f32_order_key(cut);
-        auto wantB = [&](int j) { return key[j] >= xB && key[j] != 0 && !((in_a >> j) & 1u); };
+        auto wantB = [&](int j) { return key[j] >= xB && key[j] != 0 && !((in_a >> j) & (amask_t)1); };
         if (a.defer_b && cut != -__builtin_inff()) {  // (no cut yet -- fewer than k exact scores --: full round B)
             // carry the survivors to the head of the list, from registers.  A slot may be another survivor's source, but every
             // source was read when the keys were loaded: only the barrier between the counting pass and the stores remains.

@@ -47,6 +47,11 @@ struct ScreenArgs2 : ScreenArgs {
     int* progress = nullptr;  // [kRqProgressWords] tile counters of the persistent workgroups, 8 words per row-tile slot
     int epoch = 0;            // launch stamp (12 bits) in the words' high bits: words of other launches are ignored
     int drift = 0;            // tiles a workgroup may run ahead of the slowest workgroup on the same row tiles
+    // k_screen_rq, hit-lane queues: >= 0 = the eight waves of a workgroup flush their queues TOGETHER, at every tile whose
+    // number has no bit of this mask set (period = mask + 1 tiles, chosen by the host from the hit density it expects);
+    // < 0 = every wave on its own when its queue passes kLaneQueueFlushAt (round 5)
+    int flush_mask = -1;
+    int flush_alone = 40;     // ... under that schedule a wave still flushes by itself once its queue holds more than this many entries
 };
 
 // ---- one 1-KiB piece (U = 0,1) of half-tile type S into ring parity `par`; src = the half-tile's first row + K offset

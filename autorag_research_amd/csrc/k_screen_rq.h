@@ -292,7 +292,14 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
     int row0_cur = (a.ct0 + ctl) * kRqRows, row0_prev = row0_cur;  // rows < 2^31 (checked by the host)
     bool have_prev = false;  // a finished tile's row half 1 is waiting for its tests
     for (;;) {
-        if (((ABL >> 8) & 3) != 1 && lq_n > kLaneQueueFlushAt) {  // wave-uniform, rare: this wave stalls on vector memory once per ~25 hit lanes
+        // Flush of the hit-lane queue.  A flush costs its wave one returning atomic's round trip, and the workgroup's other seven
+        // waves wait for it at the next barrier; waves that flush when THEIR queue is full do so at different tiles, so at
+        // 0.7 hit lanes per block (k = 100) the workgroup paid for a flush at almost every tile.  Round 6: all eight flush at the
+        // same tiles (a.flush_mask, period from the host's estimate of the hit density) -- their round trips overlap; a wave
+        // whose queue fills faster than foreseen still flushes on its own (at a.flush_alone entries).
+        const bool flush_due = a.flush_mask >= 0 ? ((tc & a.flush_mask) == 0 && lq_n > 0) || lq_n > a.flush_alone
+                                                 : lq_n > kLaneQueueFlushAt;
+        if (((ABL >> 8) & 3) != 1 && flush_due) {  // wave-uniform
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if constexpr (((ABL >> 8) & 3) != 1) lane_queue_flush<I8>(a, lq, lq_n, row_end);
             lq_n = 0;

@@ -134,8 +134,8 @@ int ensure_qstate(mi355dr_index* idx) {
     HIPCHECK(idx, hipFuncSetAttribute((const void*)k_prune<kPruneSmallThreads, kPruneSmallSort>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)prune_lds_bytes(idx->dim, kPruneSmallThreads, kPruneSmallSort, idx->dpad)));
-    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_prune_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)prune_wide_lds_bytes(idx->dim)));
+    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_prune_wide<2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)prune_wide_lds_bytes(idx->dim, 2)));
     {
         int per = kScanQ;
         while (per > 1 && scan_lds_bytes(idx->dim, per) > 150 * 1024) per >>= 1;
@@ -221,7 +221,7 @@ inline int cap_now(const mi355dr_index* idx) { return !idx->cap_set && wide_now(
 inline double growth_budget(const mi355dr_index* idx, int k, bool i8) {
     if (wide_ok(idx, k) && idx->path != MI355DR_PATH_SCAN) {
         const int room = std::min(kWideEntries, idx->cap_set ? idx->cap : kCandCapWide);
-        return 0.75 * room / ((double)k * (i8 ? kInflationI8Wide : kInflationBf16Wide)) - 1.0;  // (1 + growth = the chunk ratio)
+        return 0.75 * room / ((double)k * (i8 ? idx->wide_inflation_x10 / 10.0 : kInflationBf16Wide)) - 1.0;  // (1 + growth = the chunk ratio)
     }
     const int room = k < kPruneSmallSort / 2 ? kPruneSmallSort - k : idx->cap;  // (large k: the general prune, whole buffer)
     return 0.6 * std::min(room, idx->cap) / ((double)k * (i8 ? kInflationI8 : kInflationBf16));
@@ -271,7 +271,7 @@ int launch_prune(mi355dr_index* idx, hipStream_t s, int nblocks, const int* qlis
     // the general form walks the (usually empty) list of queries the one-wave form left, on a small grid
     if (!exact && wide_now(idx)) {  // 33 <= k <= 128: the two-wave form alone (what it cannot hold is flagged for the re-screen)
         pa.shadow16 = nullptr;
-        hipLaunchKernelGGL(k_prune_wide, dim3(nblocks), dim3(kWideThreads), prune_wide_lds_bytes(idx->dim), s, pa);
+        hipLaunchKernelGGL((k_prune_wide<2, 32>), dim3(nblocks), dim3(2 * kWave), prune_wide_lds_bytes(idx->dim, 2), s, pa);
         HIPCHECK(idx, hipGetLastError());
         return MI355DR_OK;
     }
@@ -358,6 +358,8 @@ int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t 
         // pass for a sibling of this launch -- a stale word could only cost a capped wait, never a result)
         if (sa.epoch == 1) HIPCHECK(idx, hipMemsetAsync(idx->rq_progress, 0, kRqProgressWords * sizeof(int), s));
         sa.drift = idx->screen_drift;
+        sa.flush_mask = idx->flush_mask_now;
+        sa.flush_alone = idx->screen_flush_alone;
         if (sa.ksteps == 6 && !idx->screen_rq_split_tests) {  // (A/B form, d = 768 only: every block test in one piece)
             hipLaunchKernelGGL((k_screen_rq<6, 8192, true>), dim3(g2), dim3(512), rq_lds(6), s, sa);
         } else {
@@ -450,10 +452,18 @@ PassPlan plan_pass(const mi355dr_index* idx, int B, int k, double growth) {
     // less than a chunk boundary; 5 M rows take 4 instead of 5: 3.50 against 3.49 ms; profiles/r05_chunk_sweep.txt)
     int steps = std::max(1, (int)std::ceil(std::log(span) / std::log(rmax) - 0.15));
     const double r = std::pow(span, 1.0 / steps);
+    // tapered ratios (same product): r_i = r * t^((steps-1)/2 - i); the first (largest) one stays within what the lists hold
+    double taper = std::max(1.0, (idx->chunk_taper_x100 > 0 ? idx->chunk_taper_x100 : (wide ? 120 : 100)) / 100.0);
+    if (steps > 1 && taper > 1.0) {
+        const double room = std::max(1.0, rmax * 1.25 / r);  // (the budget line already keeps a quarter / 40 % of the entries spare)
+        taper = std::min(taper, std::pow(room, 2.0 / (steps - 1)));
+    } else {
+        taper = 1.0;
+    }
     double pos = (double)seen;
     int64_t prev = p.sample > 0 ? 0 : seen;
     for (int i = 1; i <= steps; ++i) {
-        pos *= r;
+        pos *= r * std::pow(taper, (steps - 1) / 2.0 - (i - 1));
         int64_t end = i == steps ? n : std::min<int64_t>(n, round_up((int64_t)pos, tile));
         if (tile == kT2 && end < n) {
             // whole rounds of the persistent grid: 8 XCDs x (32 / n_qtiles) corpus tiles are in flight at a time, and a chunk
@@ -528,6 +538,14 @@ int run_screen(mi355dr_index* idx, hipStream_t s, int B, int k, const PassPlan& 
         if (emit_all) kept_all_below = end;
         // the first chunk has no threshold yet: it keeps every row (direct stores) as long as it fits the buffer
         const bool big = !emit_all && end - done > idx->small_chunk_rows && screen_tile(B) == kT2;
+        {   // hit lanes a wave of k_screen_rq expects per tile (32 queries x 128 rows): rows above the threshold of `seen` rows
+            // ~ k x inflation / seen per row and query (inflation of the int8 bound ~8)
+            const int64_t seen = ci == 0 ? (plan.sample > 0 ? plan.sample : end) : done;
+            const double lanes = 8.0 * k * 4096.0 / (double)std::max<int64_t>(seen, 1);
+            int period = 1;
+            while (period < 64 && period * 2 * lanes <= idx->screen_flush_lanes) period *= 2;
+            idx->flush_mask_now = idx->screen_flush_sync ? period - 1 : -1;
+        }
         CHECK(timed(big, end - done, [&] { return launch_screen(idx, s, B, done, end, cap_now(idx), emit_all ? kEmitAll : 0); }));
         idx->s_chunks++;
         if (end >= idx->n && side_n > 0 && side_n <= kSideMerge) {
@@ -1159,9 +1177,6 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
     } else if (k == "maxsim_wg") {
         if (value < -1 || value > 2) return fail(idx, MI355DR_E_INVALID, "maxsim_wg must be -1 (by document length), 0, 1 or 2");
         idx->maxsim_wg = (int)value;
-    } else if (k == "maxsim_packed") {
-        if (value < 0 || value > 1) return fail(idx, MI355DR_E_INVALID, "maxsim_packed must be 0 or 1");
-        idx->maxsim_packed = (int)value;
     } else if (k == "maxsim_tighten") {
         idx->maxsim_tighten = value != 0;
     } else if (k == "maxsim_aligned") {
@@ -1222,6 +1237,20 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
         idx->cap_set = 1;
     } else if (k == "prune_wide") {
         idx->prune_wide = value != 0;
+    } else if (k == "screen_flush_sync") {
+        idx->screen_flush_sync = value != 0;
+    } else if (k == "screen_flush_lanes") {
+        if (value < 1 || value > 64) return fail(idx, MI355DR_E_INVALID, "screen_flush_lanes must be in [1, 64]");
+        idx->screen_flush_lanes = (int)value;
+    } else if (k == "screen_flush_alone") {
+        if (value < 8 || value > 60) return fail(idx, MI355DR_E_INVALID, "screen_flush_alone must be in [8, 60]");
+        idx->screen_flush_alone = (int)value;
+    } else if (k == "wide_inflation_x10") {
+        if (value < 20 || value > 400) return fail(idx, MI355DR_E_INVALID, "wide_inflation_x10 must be in [20, 400]");
+        idx->wide_inflation_x10 = (int)value;
+    } else if (k == "chunk_taper_x100") {
+        if (value != 0 && (value < 100 || value > 300)) return fail(idx, MI355DR_E_INVALID, "chunk_taper_x100 must be 0 (auto) or in [100, 300]");
+        idx->chunk_taper_x100 = (int)value;
     } else if (k == "starter_rows_wide") {
         if (value < 4096 || value > 262144) return fail(idx, MI355DR_E_INVALID, "starter_rows_wide must be in [4096, 262144]");
         idx->starter_rows_wide = value;
@@ -1270,7 +1299,6 @@ int mi355dr_get_stat(mi355dr_index* idx, const char* key, int64_t* out) {
     else if (k == "maxsim_exact_ns") *out = idx->s_ms_exact_ns;
     else if (k == "maxsim_exact_launches") *out = idx->s_ms_exact_launches;
     else if (k == "maxsim_screen_cols") *out = idx->s_ms_screen_cols;
-    else if (k == "maxsim_packed_launches") *out = idx->s_ms_packed_launches;
     else if (k == "irregular_rows") *out = idx->irr_n;
     else if (k == "loose_rows") *out = idx->irr8_n;
     else if (k == "screen_dtype_active") *out = use_i8(idx) ? MI355DR_SCREEN_I8 : MI355DR_SCREEN_BF16;
@@ -1287,7 +1315,7 @@ int mi355dr_reset_stats(mi355dr_index* idx) {
     idx->s_screen_launches = idx->s_screen_ns = idx->s_screen_rows = idx->s_fallback_queries = idx->s_chunks =
         idx->s_passes = idx->s_rq_launches = idx->s_big_launches = idx->s_big_ns = idx->s_big_rows = idx->s_starters = 0;
     idx->s_ms_screened = idx->s_ms_candidates = idx->s_ms_fallbacks = idx->s_retry_queries = 0;
-    idx->s_ms_screen_ns = idx->s_ms_screen_launches = idx->s_ms_exact_ns = idx->s_ms_exact_launches = idx->s_ms_screen_cols = idx->s_ms_packed_launches = idx->s_ms_pack_ns = 0;
+    idx->s_ms_screen_ns = idx->s_ms_screen_launches = idx->s_ms_exact_ns = idx->s_ms_exact_launches = idx->s_ms_screen_cols = idx->s_ms_pack_ns = 0;
     if (idx->stat_dev) {
         HIPCHECK(idx, hipSetDevice(idx->device));
         HIPCHECK(idx, hipMemset(idx->stat_dev, 0, 2 * kQBlockMax * sizeof(unsigned long long)));

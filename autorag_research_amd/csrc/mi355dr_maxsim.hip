@@ -25,32 +25,13 @@
 //   (Dmax = largest token norm in the store) and |T - S| <= E = (eps + 2 n_q 2^-24) Dmax sum_i |q_i| for the
 //   per-doc sums.  k docs have T >= x_k (k-th best screen score) hence S >= x_k - E; any doc of the exact top-k
 //   (ties included) has S >= that, hence T >= x_k - 2E: the candidate set.
-#include <array>
 #include <chrono>
-#include <utility>
 
-#include "index.h"
+#include "maxsim_common.h"
 
 using namespace mi355;
 
 namespace mi355 {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int kMsCols = 128;        // query-token columns per launch (4 column blocks of 32)
-constexpr int kMsBlkRows = 32;
-constexpr int kMsThreads = 256;     // 4 waves
-constexpr int kMsDocsPerWave = 4;   // docs a wave walks per workgroup (amortises staging the query block in LDS)
-constexpr int kSegSort = kSortMax;  // select: largest segment (entries sorted per workgroup)
-constexpr int kMsListGrid = 256;    // workgroups of a doc-list launch of k_maxsim (4 waves each stride over the list)
-constexpr int kMsRedBytes = 4 * 4 * 32 * 4;  // k_maxsim, cooperative list mode: [wave][column block][column] maxima
-constexpr int kMsCandCap = 8192;    // docs the screen may hand to the exact kernel per query (more: exact full scan)
-// One pass of the bf16 screen over the token store serves up to kMsPassGroups groups of <= 4 queries (dims <= 128): the pass is
-// bound by the HBM stream of the fragment copy up to ~8 column blocks and by the matrix pipe beyond, so every further query
-// that rides a pass costs MFMA time only -- 16 queries x 32 vectors = 16 column blocks = 128 KiB of query fragments in LDS.
-constexpr int kMsPassGroups = 4;
-constexpr int kMsPassQueries = 4 * kMsPassGroups;
-constexpr int kMsPassBlocks = 4 * kMsPassGroups;  // column blocks of 32 query vectors
 
 struct MultiVecStore {
     int64_t n_docs = 0;
@@ -62,12 +43,6 @@ struct MultiVecStore {
     // holding dims kk*16 + half*8 + 0..7 of token `row` (original column order)
     int nkk = 0;                   // dim rounded up to 16, / 16
     uint4* tok16 = nullptr;        // [cap_blocks * nkk * 64]
-    // PACKED bf16 copy (k_maxsim_wgp.h): the documents' tokens back to back in the same fragment order, blocks of 32 tokens
-    // wherever they fall; built from tok16 when a 16-query pass first wants it, rebuilt after adds
-    uint4* tok16p = nullptr;       // [ceil(n_tok / 32) * 8 * 64] (dims <= 128 only)
-    int64_t* tok_off = nullptr;    // [packed_docs + 1] first token of each doc (device)
-    int64_t packed_docs = -1;      // docs the packed copy holds (-1: none)
-    std::vector<int64_t> tok_off_host{0};
     double tok_norm_max = 0.0;     // largest token norm (double, from the fp32 values)
     double tok16_norm_max = 0.0;   // largest norm of a bf16-rounded token
     double tok_res_max = 0.0;      // largest residual norm |d - bf16(d)| of a token
@@ -114,7 +89,7 @@ void multivec_destroy(mi355dr_index* idx) {
     if (!m) return;
     void* ptrs[] = {m->tok, m->blk_off, m->qtok, m->dist, m->pk[0], m->pk[1], m->pr[0], m->pr[1], m->out_d, m->out_r,
                     m->tok16, m->qfrag, m->dist16, m->cand_list, m->cand_dist, m->cand_ctl, m->sel[0], m->sel[1],
-                    m->two_e_dev, m->cand_sd, m->tok16p, m->tok_off};
+                    m->two_e_dev, m->cand_sd};
     if (m->cand_ctl_host) (void)hipHostFree(m->cand_ctl_host);
     if (m->stage_host) (void)hipHostFree(m->stage_host);
     for (void* p : ptrs)
@@ -344,261 +319,6 @@ __global__ __launch_bounds__(kMsThreads, 2) void k_maxsim(const MsArgs a) {
     }  // docs of this wave
 }
 
-// ---- bf16 screen: same walk as k_maxsim, operands are 16-byte MFMA fragments (1 KiB per wave instruction, fully
-// coalesced), v_mfma_f32_32x32x16_bf16, 8 fragments of the doc block in flight while the previous 8 are consumed ----
-typedef __bf16 ms_bf16x8 __attribute__((ext_vector_type(8)));
-
-struct Ms16Args {
-    const uint4* tok16;
-    const int64_t* blk_off;
-    const uint4* qfrag;     // [column blocks][nkk][64]
-    float* dist;            // [nq_launch, n_docs]
-    int64_t n_docs;
-    int nkk;
-    int nq_launch;
-    int q_col0[kMsPassQueries];  // (k_maxsim16_d128 serves up to FOUR groups of <= 4 queries per launch: rows 4 g .. 4 g + 3)
-    int q_len[kMsPassQueries];
-    const int64_t* tok_off;  // k_maxsim16_wgp: [n_docs + 1] token offsets of the packed copy (tok16 then points at it)
-    int aligned;             // k_maxsim16_wg: query r of the launch is exactly column block r (q_col0[r] = 32 r, q_len[r] <= 32)
-};
-
-// wave-wide fp32 sum by DPP, valid in LANE 63: four row_shr steps (inclusive prefix inside each row of 16 lanes), then
-// row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3 -- six VALU operations where the shuffle butterfly was six
-// dependent ds_bpermute round trips through the LDS (a text document's two query sums: a tenth of the kernel)
-template <int CTRL, int ROWMASK, bool BC>
-__device__ __forceinline__ float mw_dpp(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROWMASK, 0xF, BC));
-}
-__device__ __forceinline__ float mw_wave_sum_lane63(float v) {
-    v += mw_dpp<0x111, 0xF, true>(v);   // row_shr:1
-    v += mw_dpp<0x112, 0xF, true>(v);   // row_shr:2
-    v += mw_dpp<0x114, 0xF, true>(v);   // row_shr:4
-    v += mw_dpp<0x118, 0xF, true>(v);   // row_shr:8 -> lane 15 of every row holds the row's sum
-    v += mw_dpp<0x142, 0xA, false>(v);  // row_bcast:15 -> rows 1, 3
-    v += mw_dpp<0x143, 0xC, false>(v);  // row_bcast:31 -> rows 2, 3: lane 63 holds the wave's sum
-    return v;
-}
-
-__device__ __forceinline__ void ms16_load_piece(uint4 (&a)[8], const uint4* blk, int piece, int nkk, int lane) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int kk = piece * 8 + i;
-        a[i] = kk < nkk ? blk[(int64_t)kk * 64 + lane] : make_uint4(0u, 0u, 0u, 0u);
-    }
-}
-
-__device__ __forceinline__ void ms16_compute_piece(f32x16 (&acc)[4], const uint4 (&a)[8], const uint4* qs, int ncb, int piece,
-                                                   int nkk, int lane) {
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-        if (cb >= ncb) break;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int kk = piece * 8 + i;
-            if (kk >= nkk) break;
-            const uint4 bv = qs[(cb * nkk + kk) * 64 + lane];
-            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ms_bf16x8, a[i]),
-                                                              __builtin_bit_cast(ms_bf16x8, bv), acc[cb], 0, 0, 0);
-        }
-    }
-}
-
-__global__ __launch_bounds__(kMsThreads, 2) void k_maxsim16(Ms16Args a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint4* qs = (uint4*)smem;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 4 * a.nkk * 64; i += kMsThreads) qs[i] = a.qfrag[i];
-    __syncthreads();
-    int ncb = 0;
-    for (int qi = 0; qi < a.nq_launch; ++qi) ncb = max(ncb, (a.q_col0[qi] + a.q_len[qi] + 31) / 32);
-    const int npp = (a.nkk + 7) / 8;  // pieces of 8 fragments per block
-    for (int dw = 0; dw < kMsDocsPerWave; ++dw) {
-        const int64_t doc = ((int64_t)dw * gridDim.x + blockIdx.x) * 4 + wave;
-        if (doc >= a.n_docs) break;
-        const int64_t b0 = a.blk_off[doc], b1 = a.blk_off[doc + 1];
-        float run[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) run[c] = -__builtin_inff();
-        const int64_t npieces = (b1 - b0) * npp;
-        f32x16 acc[4];
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
-        uint4 pa[8], pb[8];
-        auto blk_of = [&](int64_t p) { return a.tok16 + (b0 + p / npp) * (int64_t)a.nkk * 64; };
-        auto finish_block = [&]() {
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
-                if (cb >= ncb) break;
-                float m = acc[cb][0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[cb][r]);
-                m = fmaxf(m, __shfl_xor(m, 32, kWave));
-                run[cb] = fmaxf(run[cb], m);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
-            }
-        };
-        if (npieces > 0) ms16_load_piece(pa, blk_of(0), 0, a.nkk, lane);
-        for (int64_t p = 0; p < npieces; p += 2) {
-            if (p + 1 < npieces) ms16_load_piece(pb, blk_of(p + 1), (int)((p + 1) % npp), a.nkk, lane);
-            ms16_compute_piece(acc, pa, qs, ncb, (int)(p % npp), a.nkk, lane);
-            if ((p + 1) % npp == 0) finish_block();
-            if (p + 1 < npieces) {
-                if (p + 2 < npieces) ms16_load_piece(pa, blk_of(p + 2), (int)((p + 2) % npp), a.nkk, lane);
-                ms16_compute_piece(acc, pb, qs, ncb, (int)((p + 1) % npp), a.nkk, lane);
-                if ((p + 2) % npp == 0) finish_block();
-            }
-        }
-        for (int qi = 0; qi < a.nq_launch; ++qi) {  // (masked butterfly sum over the query's column blocks: see k_maxsim16_d128)
-            const int c0 = a.q_col0[qi], len = a.q_len[qi];  // (queries are packed column after column: any first column)
-            float part = 0.0f;
-#pragma unroll
-            for (int cbi = 0; cbi < 4; ++cbi) {
-                const int j = cbi * 32 + (lane & 31) - c0;  // this lane's column of block cbi as a token index of query qi
-                if (j >= 0 && j < len) part += run[cbi];
-            }
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) part += __shfl_xor(part, o, kWave);
-            if (lane == 0) a.dist[(int64_t)qi * a.n_docs + doc] = b1 > b0 ? -part : __uint_as_float(0x7FC00000u);
-        }
-    }
-}
-
-// ---- the same screen for dims <= 128 (8 fragments = ONE piece per 32-token block; the ColBERT / ColPali shape),
-// with the number of column blocks a template parameter: every loop is unrolled at compile time, the query fragments
-// stay in registers, LDS and global addresses are one base register + immediates, and the accumulator of a block
-// starts from the MFMA's inline-zero C operand instead of 16 v_mov. ----
-// NW = waves per workgroup: 4 while two workgroups fit a CU (<= 8 column blocks = 64 KiB of query fragments each), 8 beyond
-// (one workgroup per CU by LDS: still two waves per SIMD).  A wave's documents do not depend on NW's siblings: no barrier
-// after the staging.
-template <int NCB, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void k_maxsim16_d128(Ms16Args a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint4* qs = (uint4*)smem;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < NCB * 8 * 64; i += NW * 64) qs[i] = a.qfrag[i];
-    __syncthreads();
-    const uint4* const ql = qs + lane;
-    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    // The wave's kMsDocsPerWave documents are walked as ONE stream of 32-token blocks: the first block of the next document
-    // is requested while the last block of the current one is multiplied (a text document is ~3 blocks: with the pipeline
-    // restarted per document, every document paid one exposed HBM round trip).
-    // The grid may be smaller than the store (option maxsim_persistent): the workgroups then walk the documents in rounds of 4
-    // docs per wave and stage the query fragments once.  Measured (round 3, interleaved on one box): no gain on 1 M text docs,
-    // 4 % slower on 100 k pages -- the default grid is one round.
-    for (int64_t round = 0; round * ((int64_t)gridDim.x * NW * kMsDocsPerWave) < a.n_docs; ++round) {
-    int64_t dq[kMsDocsPerWave], db0[kMsDocsPerWave], dnb[kMsDocsPerWave];
-#pragma unroll
-    for (int dw = 0; dw < kMsDocsPerWave; ++dw) {
-        dq[dw] = ((round * kMsDocsPerWave + dw) * (int64_t)gridDim.x + blockIdx.x) * NW + wave;
-        const bool live = dq[dw] < a.n_docs;
-        db0[dw] = live ? a.blk_off[dq[dw]] : 0;
-        dnb[dw] = live ? a.blk_off[dq[dw] + 1] - db0[dw] : 0;
-        if (!live) dq[dw] = -1;
-    }
-    uint4 pa[8], pb[8];
-    auto load = [&](uint4(&dst)[8], const uint4* src) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) dst[i] = src[i * 64];
-    };
-    float run[NCB];
-    auto block = [&](const uint4(&fr)[8]) {
-        // Up to 8 column blocks the compiler keeps as many query fragments in registers as fit (they are loop-invariant) and
-        // reads the rest per MFMA.  Beyond 8 that hoisting only costs: 16 blocks x 32 VGPRs cannot stay, and what it keeps anyway
-        // pushes the kernel into scratch (10 spilled VGPRs at 16 blocks).  There the base pointer is made opaque once per token
-        // block: every fragment is one ds_read_b128 in front of its MFMA, 128 B/clk per CU at the full matrix rate -- half of
-        // what the LDS delivers.
-        typedef const __attribute__((address_space(3))) uint4 lds_uint4;
-        unsigned qoff = (unsigned)(unsigned long)((const __attribute__((address_space(3))) char*)(const char*)ql);
-        if constexpr (NCB > 8) asm volatile("" : "+v"(qoff));  // (an LDS byte offset: the reads stay ds_read_b128, not FLAT)
-        lds_uint4* const qlb = (lds_uint4*)(unsigned long)qoff;
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) {
-            f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ms_bf16x8, fr[0]),
-                                                                 __builtin_bit_cast(ms_bf16x8, qlb[(cb * 8) * 64]), zero, 0, 0, 0);
-#pragma unroll
-            for (int i = 1; i < 8; ++i)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ms_bf16x8, fr[i]),
-                                                              __builtin_bit_cast(ms_bf16x8, qlb[(cb * 8 + i) * 64]), acc, 0, 0, 0);
-            float m = acc[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
-            run[cb] = fmaxf(run[cb], m);  // (the two halves of the wave are combined once per doc, below)
-        }
-    };
-    auto blk_ptr = [&](int dw, int64_t p) { return a.tok16 + (db0[dw] + p) * (8 * 64) + lane; };
-    // first block of the first non-empty document
-    int parity = 0;
-    {
-        const uint4* first = nullptr;
-#pragma unroll
-        for (int f = kMsDocsPerWave - 1; f >= 0; --f)
-            if (dnb[f] > 0) first = blk_ptr(f, 0);
-        if (first) load(pa, first);
-    }
-#pragma unroll
-    for (int dw = 0; dw < kMsDocsPerWave; ++dw) {
-        const int64_t doc = dq[dw];
-        if (doc < 0) break;
-        const uint4* first_next = nullptr;  // first block of the next non-empty document of this wave
-#pragma unroll
-        for (int f = kMsDocsPerWave - 1; f > dw; --f)
-            if (dnb[f] > 0) first_next = blk_ptr(f, 0);
-        const int64_t nb = dnb[dw];
-#pragma unroll
-        for (int c = 0; c < NCB; ++c) run[c] = -__builtin_inff();
-        for (int64_t p = 0; p < nb; ++p) {
-            // the block after this one: the next of this document, or the first of the next non-empty one
-            const uint4* nxt = p + 1 < nb ? blk_ptr(dw, p + 1) : first_next;
-            if (parity == 0) {
-                if (nxt) load(pb, nxt);
-                block(pa);
-            } else {
-                if (nxt) load(pa, nxt);
-                block(pb);
-            }
-            parity ^= 1;
-        }
-        // The two halves of the wave hold different token rows of the same column: one v_permlane32_swap joins the halves of
-        // TWO column blocks at once (lanes 0..31: block 2 p, lanes 32..63: block 2 p + 1) -- round 4; was one ds_bpermute
-        // round trip per block.
-        float rr[(NCB + 1) / 2];
-#pragma unroll
-        for (int p2 = 0; p2 < (NCB + 1) / 2; ++p2) {
-            float hi = 2 * p2 + 1 < NCB ? run[2 * p2 + 1] : -__builtin_inff();
-            asm volatile("" : "+v"(hi));  // (two distinct registers: the swap of a register with itself is miscompiled)
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(run[2 * p2]), __float_as_uint(hi), false, false);
-            rr[p2] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-        }
-        // per query: the sum of its columns' maxima -- every column lives in exactly one lane now (block cbi in the wave half
-        // cbi & 1), so a masked add per touched block and ONE wave-wide DPP sum (six VALU operations, result in lane 63) do it;
-        // round 3 had five ds_bpermute butterfly steps per query here, and on 3-block text documents at 8 queries per pass that
-        // epilogue was a third of the kernel.  The queries of a pass are packed column after column (eight 24-vector queries =
-        // 6 column blocks, not 8 padded ones), so a query may start anywhere and span a block boundary.
-        // The order of the fp32 additions differs from the exact kernel's; the screen's bound covers any order (e_acc).
-        for (int qi = 0; qi < a.nq_launch; ++qi) {
-            const int c0 = a.q_col0[qi], len = a.q_len[qi];
-            float part = 0.0f;
-#pragma unroll
-            for (int cbi = 0; cbi < NCB; ++cbi) {
-                // (wave-uniform skip of the blocks the query does not touch: a 32-token query touches one or two of the eight)
-                if (cbi * 32 + 31 < c0 || cbi * 32 >= c0 + len) continue;
-                const int j = cbi * 32 + (lane & 31) - c0;  // this lane's column of block cbi as a token index of query qi
-                if (j >= 0 && j < len && (lane >> 5) == (cbi & 1)) part += rr[cbi >> 1];
-            }
-            part = mw_wave_sum_lane63(part);
-            if (lane == 63) a.dist[(int64_t)qi * a.n_docs + doc] = nb > 0 ? -part : __uint_as_float(0x7FC00000u);
-        }
-    }
-    }  // rounds
-}
-
-}  // namespace mi355
-#include "k_maxsim_wg.h"
-#include "k_maxsim_wgp.h"
-namespace mi355 {
 
 // fp32 -> sortable key (distance asc, NaN last)
 __device__ __forceinline__ uint64_t f32_to_key(float f) {
@@ -906,104 +626,6 @@ int ms_reserve(mi355dr_index* idx, MultiVecStore* m, int64_t want_blocks, int64_
 
 }  // namespace
 
-// ---- k_maxsim16_d128<NCB, NW> by run-time NCB (1 .. kMsPassBlocks): NW = 4 up to 8 column blocks, 8 beyond ----
-namespace {
-typedef void (*Ms16Kernel)(mi355::Ms16Args);
-template <int NCB>
-constexpr Ms16Kernel ms16_kernel_of() {
-    if constexpr (NCB <= 8) return mi355::k_maxsim16_d128<NCB, 4>;
-    else return mi355::k_maxsim16_d128<NCB, 8>;
-}
-template <int... I>
-constexpr std::array<Ms16Kernel, sizeof...(I)> ms16_table(std::integer_sequence<int, I...>) {
-    return {ms16_kernel_of<I + 1>()...};
-}
-const std::array<Ms16Kernel, mi355::kMsPassBlocks> kMs16Kernels = ms16_table(std::make_integer_sequence<int, mi355::kMsPassBlocks>{});
-inline int ms16_waves(int ncb) { return ncb <= 8 ? 4 : 8; }
-
-// the workgroup-cooperative form (k_maxsim_wg.h) for 9 .. 16 column blocks
-typedef void (*Ms16WgKernel)(mi355::Ms16Args, int64_t);
-template <bool DEFER, int BPS, bool PIPE, int... I>
-constexpr std::array<Ms16WgKernel, sizeof...(I)> ms16wg_table(std::integer_sequence<int, I...>) {
-    return {mi355::k_maxsim16_wg<I + 9, DEFER, BPS, PIPE>...};
-}
-// [blocks per stage: 2, 4, 4 software-pipelined][epilogue: parked, at once][NCB - 9]
-const std::array<Ms16WgKernel, 8> kMs16WgKernels[3][2] = {
-    {ms16wg_table<true, 2, false>(std::make_integer_sequence<int, 8>{}), ms16wg_table<false, 2, false>(std::make_integer_sequence<int, 8>{})},
-    {ms16wg_table<true, 4, false>(std::make_integer_sequence<int, 8>{}), ms16wg_table<false, 4, false>(std::make_integer_sequence<int, 8>{})},
-    {ms16wg_table<true, 4, true>(std::make_integer_sequence<int, 8>{}), ms16wg_table<false, 4, true>(std::make_integer_sequence<int, 8>{})}};
-
-// 8 column blocks (one per wave; the pipelined form only): [epilogue: parked, at once].  Measured (interleaved, round 4): with
-// fewer MFMAs per block the workgroup form has a floor of ~880 cycles per block and CU (6.0 ms per pass over 100 k pages, 7.8 ms
-// over 1 M text docs, whatever the column count) where one wave per document streams at 6.2 TB/s up to 4 column blocks:
-// 8 blocks over short documents 8.17 against 8.97 ms; pages 6.04 against 5.15 ms and 5..7 blocks everywhere: one wave per document.
-const Ms16WgKernel kMs16Wg8Kernels[2] = {mi355::k_maxsim16_wg<8, true, 4, true>, mi355::k_maxsim16_wg<8, false, 4, true>};
-
-// ... over the packed copy (k_maxsim_wgp.h), 4 blocks per stage
-template <int... I>
-constexpr std::array<Ms16WgKernel, sizeof...(I)> ms16wgp_table(std::integer_sequence<int, I...>) {
-    return {mi355::k_maxsim16_wgp<I + 9, 4>...};
-}
-const std::array<Ms16WgKernel, 8> kMs16WgpKernels = ms16wgp_table(std::make_integer_sequence<int, 8>{});
-
-int ms16_wgp_launch(mi355dr_index* idx, hipStream_t s, int ncb, int64_t n_tok, const mi355::Ms16Args& sa) {
-    // one workgroup per CU, each a contiguous range of documents with ~1/256 of the tokens (at least 1024 tokens each)
-    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(256, (n_tok + 1023) / 1024));
-    hipLaunchKernelGGL(kMs16WgpKernels[ncb - 9], dim3(grid), dim3(512), (size_t)mi355::mwp_lds(4), s, sa, n_tok);
-    HIPCHECK(idx, hipGetLastError());
-    return MI355DR_OK;
-}
-
-int ms16_d128_prepare(mi355dr_index* idx) {
-    for (auto kfn : kMs16WgpKernels)
-        HIPCHECK(idx, hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, mi355::mwp_lds(4)));
-    for (auto kfn : kMs16Wg8Kernels)
-        HIPCHECK(idx, hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, mi355::mw_lds(4)));
-    for (int ncb = 1; ncb <= mi355::kMsPassBlocks; ++ncb)
-        if (ncb * 8192 > 64 * 1024)
-            HIPCHECK(idx, hipFuncSetAttribute((const void*)kMs16Kernels[ncb - 1], hipFuncAttributeMaxDynamicSharedMemorySize, ncb * 8192));
-    for (int b = 0; b < 3; ++b)
-        for (int e = 0; e < 2; ++e)
-            for (auto kfn : kMs16WgKernels[b][e])
-                HIPCHECK(idx, hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, mi355::mw_lds(b ? 4 : 2)));
-    return MI355DR_OK;
-}
-
-// one screen launch over every doc: each wave walks kMsDocsPerWave docs; `persistent`: only as many workgroups as are resident
-// at once, walking the docs in rounds (evened out: 100 k pages over 512 workgroups would be 12.2 rounds, a fifth of the chip
-// idle in the last one)
-int ms16_d128_launch(mi355dr_index* idx, hipStream_t s, int ncb, int64_t n_docs, int64_t n_blocks, bool persistent,
-                     const mi355::Ms16Args& sa) {
-    if (ncb == 8 && idx->maxsim_wg && idx->maxsim_wg_min <= 8 && (idx->maxsim_wg > 0 || n_blocks < 8 * n_docs)) {
-        const bool now = idx->maxsim_wg == 2;
-        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(256, (n_blocks + 31) / 32));
-        hipLaunchKernelGGL(kMs16Wg8Kernels[now ? 1 : 0], dim3(grid), dim3(512), (size_t)mi355::mw_lds(4), s, sa, n_blocks);
-        HIPCHECK(idx, hipGetLastError());
-        return MI355DR_OK;
-    }
-    if (ncb >= 9 && idx->maxsim_wg) {
-        // per-document epilogue: parked behind the next stage barrier for stores of short documents (text: -3.5 % on the kernel),
-        // at once for long ones (pages: the parked form's bookkeeping per stage costs 2 % there) -- interleaved A/B, round 4
-        const bool now = idx->maxsim_wg == 2 || (idx->maxsim_wg < 0 && n_blocks >= 8 * n_docs);
-        // one workgroup per CU, each a contiguous range of documents with ~1/256 of the token blocks (at least 32 blocks each)
-        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(256, (n_blocks + 31) / 32));
-        const int bps = idx->maxsim_wg_bps == 2 ? 2 : 4;
-        hipLaunchKernelGGL(kMs16WgKernels[bps == 4 ? (idx->maxsim_wg_pipe ? 2 : 1) : 0][now ? 1 : 0][ncb - 9], dim3(grid), dim3(512), (size_t)mi355::mw_lds(bps), s, sa,
-                           n_blocks);
-        HIPCHECK(idx, hipGetLastError());
-        return MI355DR_OK;
-    }
-    const int nw = ms16_waves(ncb);
-    const unsigned grid_docs = (unsigned)((n_docs + (int64_t)nw * mi355::kMsDocsPerWave - 1) / ((int64_t)nw * mi355::kMsDocsPerWave));
-    const unsigned resident = ncb <= 10 && nw == 4 ? 512u : 256u;
-    const unsigned rounds = persistent ? (grid_docs + resident - 1) / resident : 1u;
-    const unsigned grid = std::max(1u, (grid_docs + rounds - 1) / std::max(rounds, 1u));
-    hipLaunchKernelGGL(kMs16Kernels[ncb - 1], dim3(grid), dim3(nw * 64), (size_t)ncb * 8 * 64 * sizeof(uint4), s, sa);
-    HIPCHECK(idx, hipGetLastError());
-    return MI355DR_OK;
-}
-}  // namespace
-
 extern "C" {
 
 int mi355dr_add_multivec(mi355dr_index* idx, const float* vecs, const int64_t* offsets, int64_t n_docs) {
@@ -1098,7 +720,6 @@ int mi355dr_add_multivec(mi355dr_index* idx, const float* vecs, const int64_t* o
     HIPCHECK(idx, hipMemcpy(m->blk_off, m->blk_off_host.data(), m->blk_off_host.size() * sizeof(int64_t),
                             hipMemcpyHostToDevice));
     rollback.keep = true;
-    for (int64_t i = 0; i < n_docs; ++i) m->tok_off_host.push_back(m->tok_off_host.back() + (offsets[i + 1] - offsets[i]));
     m->n_blocks += new_blocks;
     m->n_docs += n_docs;
     return MI355DR_OK;
@@ -1247,65 +868,12 @@ int mi355dr_add_multivec_device(mi355dr_index* idx, const float* vecs_dev, const
     m->tok16_norm_max = std::max(m->tok16_norm_max, v[1]);
     m->tok_res_max = std::max(m->tok_res_max, v[2]);
     if (nf) m->finite = false;
-    for (int64_t i = 0; i < n_docs; ++i) m->tok_off_host.push_back(m->tok_off_host.back() + T[i]);
     m->n_blocks += new_blocks;
     m->n_docs += n_docs;
     return MI355DR_OK;
 }
 
 namespace {
-
-// one workgroup per block of the PACKED stream: row r holds token 32 b + r of the store; its fragments are copied from the padded
-// copy (doc found by binary search over the token offsets, one search per row)
-__global__ __launch_bounds__(512) void k_ms_pack16(const uint4* __restrict__ tok16, const int64_t* __restrict__ blk_off,
-                                                    const int64_t* __restrict__ tok_off, int64_t n_docs, int64_t n_tok,
-                                                    uint4* __restrict__ out) {
-    __shared__ int64_t src[32];  // fragment index base of the row's token in the padded copy: (block * 8) * 64 + row, or -1
-    const int64_t b = blockIdx.x;
-    const int tid = threadIdx.x;
-    if (tid < 32) {
-        const int64_t t = b * 32 + tid;
-        int64_t v = -1;
-        if (t < n_tok) {
-            int64_t lo = 0, hi = n_docs;  // last doc with tok_off[doc] <= t (docs without tokens never win: the NEXT doc starts at t too)
-            while (hi - lo > 1) {
-                const int64_t mid = (lo + hi) >> 1;
-                if (tok_off[mid] <= t) lo = mid;
-                else hi = mid;
-            }
-            const int64_t within = t - tok_off[lo];
-            v = ((blk_off[lo] + (within >> 5)) * 8) * 64 + (within & 31);
-        }
-        src[tid] = v;
-    }
-    __syncthreads();
-    const int kk = tid >> 6, lane = tid & 63;
-    const int64_t sb = src[lane & 31];
-    uint4 val = make_uint4(0u, 0u, 0u, 0u);
-    if (sb >= 0) val = tok16[sb + (int64_t)kk * 64 + 32 * (lane >> 5)];
-    out[(b * 8 + kk) * 64 + lane] = val;
-}
-
-// the packed copy up to date with the store (dims <= 128)
-int ms_pack(mi355dr_index* idx, MultiVecStore* m, hipStream_t s) {
-    if (m->packed_docs == m->n_docs) return MI355DR_OK;
-    const int64_t n_tok = m->tok_off_host.back();
-    const int64_t n_pb = std::max<int64_t>(1, (n_tok + 31) / 32);
-    HIPCHECK(idx, hipStreamSynchronize(s));
-    if (m->tok16p) (void)hipFree(m->tok16p);
-    if (m->tok_off) (void)hipFree(m->tok_off);
-    m->tok16p = nullptr;
-    m->tok_off = nullptr;
-    m->packed_docs = -1;
-    HIPCHECK(idx, hipMalloc(&m->tok16p, (size_t)n_pb * 8 * 64 * sizeof(uint4)));
-    HIPCHECK(idx, hipMalloc(&m->tok_off, (size_t)(m->n_docs + 1) * sizeof(int64_t)));
-    HIPCHECK(idx, hipMemcpyAsync(m->tok_off, m->tok_off_host.data(), (size_t)(m->n_docs + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_ms_pack16, dim3((unsigned)n_pb), dim3(512), 0, s, m->tok16, m->blk_off, m->tok_off, m->n_docs, n_tok, m->tok16p);
-    HIPCHECK(idx, hipGetLastError());
-    HIPCHECK(idx, hipStreamSynchronize(s));
-    m->packed_docs = m->n_docs;
-    return MI355DR_OK;
-}
 
 }  // namespace
 
@@ -1416,9 +984,7 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
         HIPCHECK(idx, hipFuncSetAttribute((const void*)k_ms_final, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           kMsCandCap * 12));
         HIPCHECK(idx, hipFuncSetAttribute((const void*)k_maxsim, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + kMsRedBytes)));
-        if (lds16 <= 160 * 1024)
-            HIPCHECK(idx, hipFuncSetAttribute((const void*)k_maxsim16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
-        CHECK(ms16_d128_prepare(idx));
+        CHECK(ms16_prepare(idx, lds16));
         HIPCHECK(idx, hipFuncSetAttribute((const void*)k_topk_segments, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           kSegSort * 12));
     }
@@ -1673,23 +1239,10 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
                 if (!e) HIPCHECK(idx, hipEventCreate(&e));
             HIPCHECK(idx, hipEventRecord(idx->ms_ev[0], s));
         }
-        // 9+ column blocks, dims <= 128: over the PACKED copy on request (option maxsim_packed; measured slower, k_maxsim_wgp.h)
-        const int64_t n_tok_all = m->tok_off_host.back();
-        const bool packed = nkk == 8 && ncb_launch >= 9 && idx->maxsim_wg != 0 && n_tok_all > 0 && idx->maxsim_packed > 0;
-        if (packed) {
-            CHECK(ms_pack(idx, m, s));
-            sa.tok16 = m->tok16p;
-            sa.tok_off = m->tok_off;
-        }
-        if (idx->profile) HIPCHECK(idx, hipEventRecord(idx->ms_ev[0], s));  // (again: behind a possible rebuild of the packed copy)
-        if (packed) {
-            CHECK(ms16_wgp_launch(idx, s, ncb_launch, n_tok_all, sa));
-            idx->s_ms_packed_launches++;
-        } else if (nkk == 8) {  // dims <= 128: the compile-time-unrolled forms, only as many column blocks as the pass has
+        if (nkk == 8) {  // dims <= 128: the compile-time-unrolled forms, only as many column blocks as the pass has
             CHECK(ms16_d128_launch(idx, s, ncb_launch, m->n_docs, m->n_blocks, idx->maxsim_persistent != 0, sa));
         } else {
-            hipLaunchKernelGGL(k_maxsim16, dim3(grid_all), dim3(kMsThreads), lds16, s, sa);
-            HIPCHECK(idx, hipGetLastError());
+            CHECK(ms16_generic_launch(idx, s, grid_all, lds16, sa));
         }
         idx->s_ms_screen_cols += 32 * (int64_t)ncb_launch;
         if (idx->profile) HIPCHECK(idx, hipEventRecord(idx->ms_ev[1], s));

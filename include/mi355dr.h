@@ -228,8 +228,11 @@ int mi355dr_search_sharded_device(mi355dr_index* idx, const float* queries_dev, 
  *          "maxsim_wg_pipe" (1 [default]: a block's maxima folded between the next block's MFMAs), "maxsim_wg_min" (8 [default]
  *          / 9: fewest column blocks that take the workgroup form), "maxsim_aligned" (1 [default]: queries that are exactly
  *          one 32-column block are summed by the wave that holds them), "maxsim_tighten" (1 [default]: candidate band from the
- *          exact distances of the screen's top-k), "maxsim_packed" (0 [default] / 1: screen over a packed bf16 copy without
- *          per-document padding, built on first use).
+ *          exact distances of the screen's top-k); round 6: "prune_wide" (1 [default]: passes at 33 <= k <= 128 use the
+ *          two-wave prune, a starter over "starter_rows_wide" [65536] rows and chunk ratios up to 4; 0 = the round-5 schedule),
+ *          "screen_flush_sync" (1 [default]: the waves of a k_screen_rq workgroup flush their hit-lane queues at the same tiles;
+ *          "screen_flush_lanes" [48] / "screen_flush_alone" [40] tune the period), "chunk_taper_x100" (0 [default] = 120 for
+ *          prune_wide passes, 100 = uniform chunk ratios otherwise), "wide_inflation_x10" (the budget's inflation figure).
  * stats:   "screen_launches", "screen_ns" (profile=1), "screen_rows" (all screen launches) and their k_screen256 share
  *          "screen256_launches", "screen256_ns", "screen256_rows"; "candidates", "rescored",
  *          "fallback_queries" (queries recomputed by the exact scan), "retry_queries" (queries whose candidate list
@@ -240,7 +243,7 @@ int mi355dr_search_sharded_device(mi355dr_index* idx, const float* queries_dev, 
  *          "maxsim_screened" (queries served by the MaxSim screen), "maxsim_candidates" (docs re-scored exactly for them),
  *          "maxsim_fallbacks" (queries re-run by the exact full scan), "maxsim_screen_launches" / "maxsim_screen_ns" /
  *          "maxsim_exact_launches" / "maxsim_exact_ns" (profile=1), "maxsim_screen_cols" (query columns the screen launches
- *          multiplied every token by), "maxsim_packed_launches",
+ *          multiplied every token by),
  *          "hbm_bytes_resident". */
 int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value);
 int mi355dr_get_stat(mi355dr_index* idx, const char* key, int64_t* out);

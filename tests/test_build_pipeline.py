@@ -195,14 +195,18 @@ def test_screen_stream_ring_stays_in_flight(screen_asm, i8, nq):
 
 @pytest.fixture(scope="module")
 def maxsim_asm_text(tmp_path_factory):
+    """Device assembly of the two MaxSim translation units (round 6 split the screens off: mi355dr_maxsim_screen.hip), concatenated."""
     hipcc = Path("/opt/rocm/bin/hipcc")
     if not hipcc.exists():
         pytest.skip("hipcc not available")
-    out = tmp_path_factory.mktemp("asm") / "mi355dr_maxsim.s"
-    cmd = [str(hipcc), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", f"-I{ROOT / 'include'}",
-           f"-I{CSRC}", str(CSRC / "mi355dr_maxsim.hip"), "-S", "--cuda-device-only", "-o", str(out)]
-    subprocess.run(cmd, check=True, capture_output=True, timeout=900)
-    return out.read_text()
+    texts = []
+    for unit in ("mi355dr_maxsim.hip", "mi355dr_maxsim_screen.hip"):
+        out = tmp_path_factory.mktemp("asm") / (Path(unit).stem + ".s")
+        cmd = [str(hipcc), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", f"-I{ROOT / 'include'}",
+               f"-I{CSRC}", str(CSRC / unit), "-S", "--cuda-device-only", "-o", str(out)]
+        subprocess.run(cmd, check=True, capture_output=True, timeout=900)
+        texts.append(out.read_text())
+    return "\n".join(texts)
 
 
 def test_no_kernel_of_the_library_touches_the_stack(lib_asm_text, maxsim_asm_text):
@@ -212,7 +216,7 @@ def test_no_kernel_of_the_library_touches_the_stack(lib_asm_text, maxsim_asm_tex
     the stack at entry and read back from there."""
     import re
 
-    for text in (lib_asm_text, maxsim_asm_text):
+    for text in (lib_asm_text, maxsim_asm_text):   # (maxsim_asm_text: both MaxSim units)
         kernels = re.findall(r"\n(_ZN5mi355[^\n:]+):[^\n]*\n(.*?)\.end_amdhsa_kernel", text, re.S)
         assert len(kernels) >= 20
         for name, body in kernels:

@@ -295,7 +295,6 @@ def test_sixteen_queries_ride_one_screen_pass(pkg, oracle, tmin, tmax, n_docs):
         idx.add_multivec(tok, off)
         for groups, wg, bps in ((4, -1, 4), (1, -1, 4), (3, 1, 2), (2, 0, 4), (4, 2, 4), (4, 0, 4), (4, 1, 4), (4, 2, 2), (4, 1, 2)):
             idx.set_option("maxsim_tighten", int(bps == 4))   # the candidate band narrowed by the starter's exact distances / the 2E band
-            idx.set_option("maxsim_packed", int(groups == 4 and bps == 4 and wg != 1))   # the screen over the packed / the padded bf16 copy
             idx.set_option("maxsim_wg_pipe", int(wg != 2))   # the software-pipelined form / the plain one
             idx.set_option("maxsim_pass_groups", groups)
             idx.set_option("maxsim_wg", wg)   # -1 by document length / 1 parked / 2 immediate epilogue / 0 one wave per document
@@ -342,11 +341,12 @@ def test_sixteen_queries_ride_one_screen_pass(pkg, oracle, tmin, tmax, n_docs):
 
 
 @pytest.mark.parametrize("shape", ["tiny_docs", "ragged", "long"])
-def test_packed_screen_equals_oracle(pkg, oracle, shape):
-    """The 16-query screen over the PACKED bf16 copy (k_maxsim_wgp.h): blocks of 32 tokens wherever they fall, so a block may
-    hold many short documents (more documents ending between two ring barriers than parking slots: the lot's own barrier), the
-    end of one and the start of the next, documents without vectors, and -- after an add -- a rebuilt copy.  Same answers as the
-    oracle, bit for bit, and the packed launches are counted."""
+def test_sixteen_query_screen_over_hard_document_shapes(pkg, oracle, shape):
+    """The 16-query workgroup screen over document shapes that stress its per-document bookkeeping: thousands of documents of
+    0..5 tokens (a document ends at almost every block: more documents between two ring barriers than the usual store has),
+    ragged documents with a tenth of them empty, 1000-token pages -- and a store grown by a second add between two searches.
+    Same answers as the oracle, bit for bit.  (These shapes were written for round 4's packed bf16 copy, k_maxsim_wgp.h: measured
+    2-3 % slower than the padded copy then, removed in round 6; the shapes stay.)"""
     rng = np.random.default_rng({"tiny_docs": 11, "ragged": 12, "long": 13}[shape])
     d = 128
     if shape == "tiny_docs":
@@ -365,21 +365,18 @@ def test_packed_screen_equals_oracle(pkg, oracle, shape):
     rd, rr = oracle.maxsim_topk(tok, off, qtok, qoff, k)
     half = len(lens) // 2
     with pkg.Mi355Index(d) as idx:
-        idx.set_option("maxsim_packed", 1)
         idx.add_multivec(tok[:off[half]], off[:half + 1])
-        d0, r0 = idx.search_maxsim(qtok, qoff, k)             # (packs the first half)
+        d0, r0 = idx.search_maxsim(qtok, qoff, k)
         rd0, rr0 = oracle.maxsim_topk(tok[:off[half]], off[:half + 1], qtok, qoff, k)
         assert np.array_equal(r0, rr0)
         idx.add_multivec(tok[off[half]:], off[half:] - off[half])
         idx.reset_stats()
-        dist, rows = idx.search_maxsim(qtok, qoff, k)         # (the copy is rebuilt)
-        assert idx.stat("maxsim_packed_launches") >= 1
+        dist, rows = idx.search_maxsim(qtok, qoff, k)
+        assert idx.stat("maxsim_screened") >= len(qlens) - 1 and idx.stat("maxsim_fallbacks") == 0
         assert np.array_equal(rows, rr)
         ok = ~np.isnan(rd)
         assert np.array_equal(np.isnan(dist), np.isnan(rd))
         assert np.array_equal(dist[ok].view(np.uint32), rd[ok].view(np.uint32))
-        idx.set_option("maxsim_packed", 0)
-        idx.reset_stats()
+        idx.set_option("maxsim_wg", 0)                        # one wave per document: the same lists
         dist2, rows2 = idx.search_maxsim(qtok, qoff, k)
-        assert idx.stat("maxsim_packed_launches") == 0
         assert np.array_equal(rows2, rows) and np.array_equal(dist2.view(np.uint32), dist.view(np.uint32))

@@ -135,7 +135,7 @@ print("WORLD2_OK", rank)
 """
 
 
-def test_two_ranks_on_one_gpu_equal_one_gpu_and_the_oracle(native_built, oracle):
+def _run_pair():
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = str(sk.getsockname()[1])
@@ -153,6 +153,17 @@ def test_two_ranks_on_one_gpu_equal_one_gpu_and_the_oracle(native_built, oracle)
             for pp in procs:
                 pp.kill()
             raise
-    for rank, (p, (so, se)) in enumerate(zip(procs, outs)):
-        if p.returncode != 0 or f"WORLD2_OK {rank}" not in so:
-            pytest.fail(f"rank {rank}: exit code {p.returncode}\n--- stdout\n{so[-1500:]}\n--- stderr\n{se[-6000:]}")
+    bad = [rank for rank, (p, (so, _)) in enumerate(zip(procs, outs)) if p.returncode != 0 or f"WORLD2_OK {rank}" not in so]
+    # (the rank that failed FIRST is the one to read: its peer then dies in the next collective)
+    return "\n".join(f"rank {rank}: exit code {procs[rank].returncode}\n--- stdout\n{outs[rank][0][-800:]}\n--- stderr\n"
+                     f"{outs[rank][1][-3500:]}" for rank in bad)
+
+
+def test_two_ranks_on_one_gpu_equal_one_gpu_and_the_oracle(native_built, oracle):
+    report = _run_pair()
+    if report and "AssertionError" not in report and "NativeError" not in report:
+        # a rank lost to the rendezvous / the transport (seen once in 8 runs, at the end of a 20-minute suite: the peer's gloo pair
+        # was closed) is not a verdict on the search: one more attempt; a parity failure (an assert, a library error) never retries
+        report = _run_pair()
+    if report:
+        pytest.fail(report)

@@ -8,7 +8,7 @@ checksum of the returned ids must be the same on every line of a store.
 
     python tools/maxsim_ab.py maxsim_wg_pipe=1 maxsim_wg_pipe=0
     python tools/maxsim_ab.py --stores text --queries 8 maxsim_wg_min=8 maxsim_wg_min=9
-    python tools/maxsim_ab.py "maxsim_tighten=1,maxsim_aligned=1" "maxsim_tighten=0,maxsim_aligned=0" maxsim_packed=1
+    python tools/maxsim_ab.py "maxsim_tighten=1,maxsim_aligned=1" "maxsim_tighten=0,maxsim_aligned=0"
 
 `profiles/r04_maxsim_ab.txt` is this tool's output over the round (one A/B per change).
 """
@@ -19,7 +19,7 @@ import time
 import numpy as np
 
 DEFAULTS = {"maxsim_wg": -1, "maxsim_pass_groups": 4, "maxsim_wg_bps": 4, "maxsim_wg_pipe": 1, "maxsim_wg_min": 8,
-            "maxsim_aligned": 1, "maxsim_tighten": 1, "maxsim_packed": 0, "maxsim_coop": -1}
+            "maxsim_aligned": 1, "maxsim_tighten": 1, "maxsim_coop": -1}
 
 
 def build(pkg, torch, tokens: str, n_docs: int, d: int = 128):

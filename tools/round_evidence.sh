@@ -7,6 +7,8 @@
 #   stats      rocprofv3 --kernel-trace --stats of the bench command
 #   traffic    PMC passes (separate, kernel-trace only) of the bench command: FETCH_SIZE, WRITE_SIZE, L2 hit, SQ busy / LDS
 #   timelines  one-step kernel timelines at N = 10 M and at the 8-way shard size
+#   k100       BASELINE config 2's limit (top-100) at the headline corpus: bench lines at N = 10 M / 1.25 M, one-pass timelines,
+#              the round-5 schedule (prune_wide 0) and the unsynchronised queue flush (screen_flush_sync 0) beside them
 #   shards     pass time at the 1/2/4/8-GPU shard sizes, plain and through the all-gather + merge path (world 1)
 #   c2         config C2 stand-in (anisotropic, inner product, k = 100): line + kernel stats
 #   maxsim     the two MaxSim stores as bench lines of their own + kernel stats + PMC (FETCH_SIZE; SQ busy)
@@ -17,7 +19,7 @@
 #   fuzz       tools/fuzz_parity.py campaign (FUZZ_SECONDS, default 600)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/ev; mkdir -p $OUT
-SECTIONS="${@:-tests bench stats traffic timelines shards c2 maxsim}"
+SECTIONS="${@:-tests bench stats traffic timelines k100 shards c2 maxsim}"
 BENCH_QUICK="--no-cpu-baseline --no-extras"
 
 smi_poll() {  # smi_poll <file> <samples>: "(<MHz>Mhz) <W>" per line
@@ -55,7 +57,7 @@ tests)
   python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log ;;
 bench)
   python bench.py > $OUT/bench_default.log 2>&1; tail -1 $OUT/bench_default.log > $OUT/bench_default_line.json; cut -c1-400 $OUT/bench_default_line.json
-  python bench.py --screen bf16 $BENCH_QUICK > $OUT/bench_bf16.log 2>&1; tail -1 $OUT/bench_bf16.log > $OUT/bench_bf16_line.json; cut -c1-200 $OUT/bench_bf16_line.json ;;
+  python bench.py --screen bf16 $BENCH_QUICK --traffic > $OUT/bench_bf16.log 2>&1; tail -1 $OUT/bench_bf16.log > $OUT/bench_bf16_line.json; cut -c1-200 $OUT/bench_bf16_line.json ;;
 stats)
   # the default command's steps / warm-up (10 / 2), without its untimed extras (they launch the same kernel on other workloads);
   # the profiled run's own line is kept next to the summary: its roofline.avg_launch_ms is the HIP-event figure of the very launches
@@ -83,6 +85,18 @@ traffic)
 timelines)
   timeline 10000000 $OUT/timeline_10m.txt
   timeline 1250000 $OUT/timeline_1250k.txt ;;
+k100)
+  for rows in 10000000 1250000; do
+    for o in "" "--opt screen_flush_sync=0" "--opt prune_wide=0"; do
+      python bench.py --k 100 --rows $rows --steps 20 --warmup 3 $BENCH_QUICK $o 2>/dev/null | tail -1 | python -c "
+import sys, json; r = json.loads(sys.stdin.read()); e = r['extra']
+print('k100 rows $rows opts [$o] ms_per_step', r['ms_per_step'], 'screens', r['roofline']['all_screen_kernels_ms_per_step'], 'launches/pass', r['roofline']['all_screen_launches'] / r['steps'], 'cand', e['candidates_per_query_per_step'], 'resc', e['rescored_per_query_per_step'], 'retry', e['retry_queries'], 'fallback', e['fallback_queries'])"
+    done
+  done | tee $OUT/k100_lines.txt
+  bash tools/timeline.sh $OUT/timeline_k100.txt --k 100
+  bash tools/timeline.sh $OUT/timeline_k100_1250k.txt --k 100 --rows 1250000
+  bash tools/timeline.sh $OUT/timeline_k100_r5_schedule.txt --k 100 --opt prune_wide=0
+  head -20 $OUT/timeline_k100.txt ;;
 shards)
   export MASTER_ADDR=127.0.0.1 MASTER_PORT=29544 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0
   for rows in 10000000 5000000 2500000 1250000; do
@@ -92,8 +106,8 @@ shards)
   done | tee $OUT/shard_sizes.txt
   unset MASTER_ADDR MASTER_PORT RANK WORLD_SIZE LOCAL_RANK ;;
 c2)
-  C2="--data anisotropic --metric ip --k 100 --rows 2000000"
-  python bench.py $C2 --steps 20 --warmup 3 $BENCH_QUICK > $OUT/bench_c2.log 2>&1; tail -1 $OUT/bench_c2.log > $OUT/bench_c2_line.json; cut -c1-300 $OUT/bench_c2_line.json
+  C2="--data anisotropic --metric ip --k 100 --rows 2681468"   # (BEIR nq's row count: BASELINE config 2)
+  python bench.py $C2 --steps 20 --warmup 3 $BENCH_QUICK --traffic > $OUT/bench_c2.log 2>&1; tail -1 $OUT/bench_c2.log > $OUT/bench_c2_line.json; cut -c1-300 $OUT/bench_c2_line.json
   rm -rf $OUT/stats_c2; MI355DR_BENCH_PMC=0 rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats_c2 -o stats -- python bench.py $C2 --steps 5 --warmup 2 $BENCH_QUICK > $OUT/stats_c2.log 2>&1 ;;
 maxsim)
   for shape in text page; do
