@@ -152,15 +152,15 @@ int ensure_qstate(mi355dr_index* idx) {
         HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen_stream<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, stream_lds));
         HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen_stream<true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, stream_lds));
     }
-    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen256c<kScreen256cAbl, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen256c<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kScreen256Lds));
-    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen256c<kScreen256cAbl, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen256c<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kScreen256Lds));
 #define MI355_RQ_ATTR(KS)                                                                                              \
-    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen_rq<KS, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, rq_lds(KS)));
+    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen_rq<KS, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, rq_lds(KS)));
     MI355_RQ_FORMS(MI355_RQ_ATTR)
 #undef MI355_RQ_ATTR
-    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen_rq<6, 8192, true>, hipFuncAttributeMaxDynamicSharedMemorySize, rq_lds(6)));
+    HIPCHECK(idx, hipFuncSetAttribute((const void*)k_screen_rq<6, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, rq_lds(6)));
     HIPCHECK(idx, hipFuncSetAttribute((const void*)k_merge_topk, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kSortMax * 12));
     idx->qstate_ready = true;
@@ -361,19 +361,19 @@ int launch_screen(mi355dr_index* idx, hipStream_t s, int B, int64_t r0, int64_t 
         sa.flush_mask = idx->flush_mask_now;
         sa.flush_alone = idx->screen_flush_alone;
         if (sa.ksteps == 6 && !idx->screen_rq_split_tests) {  // (A/B form, d = 768 only: every block test in one piece)
-            hipLaunchKernelGGL((k_screen_rq<6, 8192, true>), dim3(g2), dim3(512), rq_lds(6), s, sa);
+            hipLaunchKernelGGL((k_screen_rq<6, false, true>), dim3(g2), dim3(512), rq_lds(6), s, sa);
         } else {
             switch (sa.ksteps) {
 #define MI355_RQ_LAUNCH(KS) \
-    case KS: hipLaunchKernelGGL((k_screen_rq<KS, 0, true>), dim3(g2), dim3(512), rq_lds(KS), s, sa); break;
+    case KS: hipLaunchKernelGGL((k_screen_rq<KS, true, true>), dim3(g2), dim3(512), rq_lds(KS), s, sa); break;
                 MI355_RQ_FORMS(MI355_RQ_LAUNCH)
 #undef MI355_RQ_LAUNCH
             }
         }
     } else if (tile == kT2) {
         const unsigned g2 = screen256_grid(sa.n_ctiles, sa.n_qtiles);  // persistent: <= one workgroup per CU
-        if (i8) hipLaunchKernelGGL((k_screen256c<kScreen256cAbl, true>), dim3(g2), dim3(512), kScreen256Lds, s, sa);
-        else hipLaunchKernelGGL((k_screen256c<kScreen256cAbl, false>), dim3(g2), dim3(512), kScreen256Lds, s, sa);
+        if (i8) hipLaunchKernelGGL((k_screen256c<true>), dim3(g2), dim3(512), kScreen256Lds, s, sa);
+        else hipLaunchKernelGGL((k_screen256c<false>), dim3(g2), dim3(512), kScreen256Lds, s, sa);
     } else if (!emit_all && idx->screen_stream && B <= 64 && sa.ksteps >= 1 &&
                (B <= 32 ? 32 : 64) * sa.row_bytes <= kStreamQueryBytesMax) {
         // small query blocks: the streaming form (resident query block, deep row ring, one persistent workgroup per CU)

@@ -75,7 +75,7 @@ def test_screen256c_structure(screen_asm, i8):
     """Third form (the one the library launches): free-running waves -- one workgroup barrier per K-step, every fragment read
     issued two micro-steps ahead under counted LDS waits, nine (int8: + the row-group records) LDS-DMA pieces per K-step spread
     over the micro-steps, the append path out of line (one copy, reached by a call), no scratch."""
-    names = [n for n in screen_asm if "k_screen256cILi" in n and n.endswith(f"ELb{int(i8)}EEEvNS_11ScreenArgs2E")]
+    names = [n for n in screen_asm if f"k_screen256cILb{int(i8)}EEEvNS_11ScreenArgs2E" in n]
     assert len(names) == 1, sorted(screen_asm)
     ops = screen_asm[names[0]]
     want = "v_mfma_i32_32x32x32_i8" if i8 else "v_mfma_f32_32x32x16_bf16"
@@ -111,7 +111,7 @@ def test_screen_rq_structure(screen_asm, ks):
     wait + barrier) in every K-step but a tile's last (KS >= 2: the four block tests of a tile then sit between two barriers),
     no full vmcnt(0) between the first and the last MFMA outside the flush of the hit-lane queue, the hit path INLINE (five
     inline-asm ds_write_b128 per test site behind a wave-uniform branch; no call anywhere), no scratch."""
-    names = [n for n in screen_asm if f"k_screen_rqILi{ks}ELi0ELb1E" in n]
+    names = [n for n in screen_asm if f"k_screen_rqILi{ks}ELb1ELb1E" in n]   # <KS, SPLIT = true, int8>
     assert len(names) == 1, sorted(screen_asm)
     ops = screen_asm[names[0]]
     stages = {4: 4, 5: 5}.get(ks, 6)
@@ -260,3 +260,13 @@ def test_maxsim_workgroup_screen_keeps_its_ring_in_flight(maxsim_asm_text, ncb, 
         gaps = [sum(o.startswith("v_max3_f32") for o in ops[mf[i]:mf[i + 7]]) for i in range(0, len(mf) - 7, 8)]
         assert max(gaps) >= 6, gaps
     assert any(o.startswith("s_load_dwordx2") for o in loop)
+
+
+def test_the_product_kernels_carry_no_timing_builds():
+    """the screens' ablation forms (template parameter ABL: no fragment reads / tests / barrier / LDS-DMA, ...)
+    live in tools/k_screen_rq_abl.h / tools/k_screen256c_abl.h for tools/screen_ab.hip; the library's headers carry the kernels
+    alone, and the packed MaxSim copy (measured slower in round 4) is gone."""
+    for h in ("k_screen_rq.h", "k_screen256c.h", "k_screen256_common.h", "k_prune_wide.h"):
+        assert "ABL" not in (CSRC / h).read_text(), h
+    assert not (CSRC / "k_maxsim_wgp.h").exists()
+    assert (ROOT / "tools" / "k_screen_rq_abl.h").exists() and "ABL" in (ROOT / "tools" / "k_screen_rq_abl.h").read_text()

@@ -1,3 +1,5 @@
+// tools/k_screen256c_abl.h -- the ABLATION build of csrc/k_screen256c.h: the same kernel with its timing forms (template parameter ABL) for
+// tools/screen_ab.hip.  Not part of the library: the product header carries the kernel alone (round 6).  Keep in step by hand.
 // k_screen256c.h -- third form of the large-block screen: same tile (256 corpus rows x 256 queries, 8 waves, persistent),
 // same LDS image, same epilogue as k_screen256b -- but NO ping-pong.
 //
@@ -29,14 +31,15 @@
 
 namespace mi355 {
 
-// LDS-DMA pieces per micro-step slot {5, 6, 7 | 0, 1, 2, 3, 4}.  (Three other spreads were the A/B of round 2, interleaved:
-// +1.5 ... +5 %.  More pieces right behind the hand-over, or a thinner, longer spread: both lose.  The kernel's timing builds
-// live in tools/k_screen256c_abl.h with tools/screen_ab.hip.)
-__host__ __device__ constexpr int kc_sched(int slot) {
-    constexpr int t[8] = {2, 2, 0, 2, 2, 1, 0, 0};
-    return t[slot];
+constexpr int kScreen256cAbl = 1024;  // SADDR (the only staging form this kernel has)
+
+// LDS-DMA pieces per micro-step slot {5, 6, 7 | 0, 1, 2, 3, 4} for schedule id (0 = what the library runs; the others are the
+// A/B of round 2 (interleaved): +1.5 ... +5 %.  More pieces right behind the hand-over, or a thinner, longer spread: both lose.)
+__host__ __device__ constexpr int kc_sched(int id, int slot) {
+    constexpr int t[4][8] = {{2, 2, 0, 2, 2, 1, 0, 0}, {2, 2, 0, 1, 1, 1, 1, 1}, {1, 1, 1, 1, 1, 2, 2, 0}, {2, 2, 0, 2, 1, 1, 1, 0}};
+    return t[id][slot];
 }
-template <bool I8>
+template <int ABL, bool I8>
 __global__ __launch_bounds__(512, 2) void k_screen256c(ScreenArgs2 a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(512, 2) void k_screen256c(ScreenArgs2 a) {
 // (-1.6 % against A0 B0 | B1 A1).  
 #define KC_PIECE(PAR, P, RECPOS)                                                                      \
     do {                                                                                              \
-        {                                                                                             \
+        if constexpr ((ABL & 16) == 0) {                                                              \
             const int c__ = (P);                                                                      \
             if (c__ == 0 || c__ == 1) kb_stage<0, true>(smem, wave, PAR, c_base + c_k, voffA, c__ & 1);            \
             else if (c__ == 2 || c__ == 3) kb_stage<3, true>(smem, wave, PAR, c_base + half_A + c_k, voffA, c__ & 1); \
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(512, 2) void k_screen256c(ScreenArgs2 a) {
 // reads for micro-step M2 (0..9; 8, 9 = micro-steps 0, 1 of the next K-step, other ring parity)
 #define KC_PREFETCH(M2)                                                                               \
     do {                                                                                              \
-        {                                                                                             \
+        if constexpr ((ABL & 1) == 0) {  /* (bit 0: timing build without fragment reads) */            \
             constexpr int m2__ = (M2) & 7;                                                            \
             const int rp__ = (M2) >= 8 ? (par ^ 1) : par;                                             \
             if (m2__ < 4) KC_RD_B(rp__, m2__ & 3);                                                    \
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(512, 2) void k_screen256c(ScreenArgs2 a) {
 // test block (I, RB, J) of the tile whose first row is ROW0, records slot RSLOT
 #define KC_TEST1(I, RB, J, ROW0, RSLOT)                                                               \
     do {                                                                                              \
-        {                                                                                             \
+        if constexpr ((ABL & 4) == 0) {                                                               \
             int lane_e = lane;                                                                        \
             asm volatile("" : "+v"(lane_e));                                                          \
             const int q__ = q0 + 64 * wc + 32 * (J) + (lane_e & 31);                                  \
@@ -188,7 +191,10 @@ __global__ __launch_bounds__(512, 2) void k_screen256c(ScreenArgs2 a) {
                 const I8Group g__ = ((const I8Group*)(smem + kRecOff + ((RSLOT) & 3) * 256))[4 * wr + 2 * (I) + (RB)]; \
                 blk__ = i8_blk(g__, scq[J], kqq[J]);                                                  \
             }                                                                                         \
-            screen_test_block<I8>(a.status, acc[I][RB][J], q__, rbase__, row_end, th[J], blk__, que, que_n); \
+            if constexpr ((ABL & 4096) != 0)                                                          \
+                screen_test_block_cold<I8>(a.status, acc[I][RB][J], q__, rbase__, row_end, th[J], blk__, que, que_n); \
+            else                                                                                      \
+                screen_test_block<I8>(a.status, acc[I][RB][J], q__, rbase__, row_end, th[J], blk__, que, que_n); \
         }                                                                                             \
     } while (0)
 // one micro-step: [reads for M + 2] [4 MFMAs] [DMA pieces P0, P0 + 1 (NP of them)] [one block test]
@@ -202,13 +208,20 @@ __global__ __launch_bounds__(512, 2) void k_screen256c(ScreenArgs2 a) {
         KC_PIN();                                                                                     \
     } while (0)
 
-    // pieces per micro-step 5, 6, 7 (behind the hand-over) | 0, 1, 2, 3, 4 (next K-step)
-    constexpr int kN5 = kc_sched(0), kN6 = kc_sched(1), kN7 = kc_sched(2), kN0 = kc_sched(3),
-                  kN1 = kc_sched(4), kN2 = kc_sched(5), kN3 = kc_sched(6), kN4 = kc_sched(7);
+    // pieces per micro-step 5, 6, 7 (behind the hand-over) | 0, 1, 2, 3, 4 (next K-step); bits 7, 8: the schedule id
+    constexpr int kSched = (ABL >> 7) & 3;
+    constexpr int kN5 = kc_sched(kSched, 0), kN6 = kc_sched(kSched, 1), kN7 = kc_sched(kSched, 2), kN0 = kc_sched(kSched, 3),
+                  kN1 = kc_sched(kSched, 4), kN2 = kc_sched(kSched, 5), kN3 = kc_sched(kSched, 6), kN4 = kc_sched(kSched, 7);
     constexpr int kNLate = kN5 + kN6 + kN7;
     static_assert(kNLate + kN0 + kN1 + kN2 + kN3 + kN4 == 9, "nine pieces per K-step");
-    constexpr int kPF = 3;  // fragment reads run this many micro-steps ahead (3: -1.7 % against 2)
+    constexpr int kPF = (ABL & 2048) ? 2 : 3;  // fragment reads run this many micro-steps ahead (3: -1.7 % against 2, bit 11)
     bf16x8 fAq[4][2], fBk[4][2];
+    if constexpr ((ABL & 1) != 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" : "=v"(fAq[i][j]), "=v"(fBk[i][j]));
+    }
     // ---- prologue: K-step 0 completely into parity 0, the first four pieces of K-step 1 into parity 1; K-step 0 landed
     // and visible; fragments of micro-steps 0 and 1
 #pragma unroll
@@ -223,7 +236,7 @@ __global__ __launch_bounds__(512, 2) void k_screen256c(ScreenArgs2 a) {
     int par = 0, t = 0;
     KC_PREFETCH(0);
     KC_PREFETCH(1);
-    KC_PREFETCH(2);
+    if constexpr (kPF == 3) KC_PREFETCH(2);
 
     const int row_end = (int)a.row_end;
     int row0_cur = (a.ct0 + ctl) * kT2, row0_prev = row0_cur;  // rows < 2^31 (checked by the host)
@@ -261,19 +274,20 @@ __global__ __launch_bounds__(512, 2) void k_screen256c(ScreenArgs2 a) {
         if (last) KC_TEST1(0, 0, 0, row0_cur, gpos);
 #define KC_HANDOVER()                                                                                 \
     do {                                                                                              \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  /* this wave's pieces of K-step g+1 have landed */ \
+        if constexpr ((ABL & 32) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  /* this wave's pieces of K-step g+1 have landed */ \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  /* ... and its last fragments of K-step g are in registers */ \
-        MI355_BARRIER();                                                                              \
+        if constexpr ((ABL & 8) == 0) MI355_BARRIER();                                                \
         KC_PIN();                                                                                     \
     } while (0)
         // ---- hand-over of the ring: every read of K-step g has been issued (the last ones kPF micro-steps before the end)
         KC_ADVANCE();
-        KC_HANDOVER();
-        KC_MICRO(5, false, par, 0, kN5, gpos + 2);
+        if constexpr (kPF == 3) KC_HANDOVER();
+        KC_MICRO(5, false, par, 0, kPF == 3 ? kN5 : 0, gpos + 2);
         if (last) KC_TEST1(0, 0, 1, row0_cur, gpos);
-        KC_MICRO(6, false, par, kN5, kN6, gpos + 2);
+        if constexpr (kPF == 2) KC_HANDOVER();
+        KC_MICRO(6, false, par, kPF == 3 ? kN5 : 0, kPF == 3 ? kN6 : 2, gpos + 2);
         if (last) KC_TEST1(0, 1, 0, row0_cur, gpos);
-        KC_MICRO(7, false, par, kN5 + kN6, kN7, gpos + 2);
+        KC_MICRO(7, false, par, kPF == 3 ? kN5 + kN6 : 2, kPF == 3 ? kN7 : 2, gpos + 2);
 #undef KC_HANDOVER
         if (last) KC_TEST1(0, 1, 1, row0_cur, gpos);
         par ^= 1;

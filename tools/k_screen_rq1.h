@@ -6,7 +6,7 @@
 // everything not said here.  Measured against k_screen_rq in tools/screen_ab (variant 200 + ABL): profiles/r05_rq1_ab.txt.
 // NOT launched by the library.
 #pragma once
-#include "k_screen_rq.h"
+#include "k_screen_rq_abl.h"
 
 namespace mi355 {
 

@@ -1,3 +1,5 @@
+// tools/k_screen_rq_abl.h -- the ABLATION build of csrc/k_screen_rq.h: the same kernel with its timing forms (template parameter ABL) for
+// tools/screen_ab.hip.  Not part of the library: the product header carries the kernel alone (round 6).  Keep in step by hand.
 // k_screen_rq.h -- the large-block screen with the QUERY operand resident in registers ("rq"): rows are the only operand
 // that goes through the LDS.
 //
@@ -61,12 +63,10 @@ static_assert(rq_lds(6) <= 160 * 1024, "LDS per workgroup");
 // persistent grid in 128-row tiles: 8 XCDs x L workgroups (same rule as screen256_grid)
 __host__ __device__ inline unsigned screen_rq_grid(int n_ctiles, int n_qtiles) { return screen256_grid(n_ctiles, n_qtiles); }
 
-// SPLIT (the library's option "screen_rq_split_tests"; false only at KS = 6, for the A/B): a block test's maxima ride the MFMAs of
-// the other row half (screen_block_max_part) instead of being taken in one piece at the test.  The kernel's timing builds (no
-// fragment reads / tests / barrier / LDS-DMA, per-K-step hand-over, ...) live in tools/k_screen_rq_abl.h with tools/screen_ab.hip.
-// (Cache policies nt / sc0 / sc1 on the row pieces, measured in round 5: +1 ... +3 % on Gaussian operands,
-// profiles/r05_kstep_ab.txt -- the default policy stays.)
-template <int KS, bool SPLIT, bool I8>
+// ABL (timing builds for the A/B table; 0 = the kernel): 1 no fragment reads, 4 no tests, 8 no barrier, 16 no LDS-DMA in the
+// loop, 32 no vmcnt at the hand-over, 64 every test reads its own row-group record (the form before RQ_LOAD_REC); 2048 a hand-over in EVERY K-step (the form before kSkipLast); 4096 no drift limiter; 8192 every test in one piece (the form before the maxima rode the MFMAs); bits 8, 9: the hit path without its stores (256) / its stores ALWAYS issued under EXEC = hit lanes instead of behind a branch (512: measured +15 % with thresholds parked -- stores under an empty EXEC are not free).  (Cache policies nt / sc0 / sc1 on the row pieces, measured in round 5:
+// +1 ... +3 % on Gaussian operands, profiles/r05_kstep_ab.txt -- the default policy stays.)
+template <int KS, int ABL, bool I8>
 __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
     constexpr int NST = rq_stages(KS);
     static_assert(NST % KS == 0, "a tile never wraps the ring");
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
     const unsigned rec_lds = lds0 + rq_rec_off(KS);
     const unsigned rec_voff = (unsigned)((lane & 7) * 4);  // the tile's 4 records = 8 dwords, eight copies per slot
     // drift limiter (wave 0): the slot's 8 progress words, this workgroup's is word qt
-    bool lim = a.drift > 0 && a.progress != nullptr && a.n_qtiles > 1 && a.n_qtiles <= 8 && wave == 0;
+    bool lim = (ABL & 4096) == 0 && a.drift > 0 && a.progress != nullptr && a.n_qtiles > 1 && a.n_qtiles <= 8 && wave == 0;
     const char* const prog_base = (const char*)(a.progress + (cslot * 8 + xcd) * 8);
     const unsigned prog_lds = lds0 + rq_prog_off(KS);
     const unsigned prog_voff = (unsigned)(((lane & 7) < a.n_qtiles ? (lane & 7) : 0) * 4);
@@ -147,11 +147,11 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
     unsigned c_dst = lds0 + (unsigned)(2 * wave) * 1024u;  // LDS address of this wave's first piece in the cursor's stage
 #define RQ_PIECE(U)                                                                                   \
     do {                                                                                              \
-        glds16_saddr(c_base + c_k, voff[U], c_dst + (U) * 1024u);                                     \
+        if constexpr ((ABL & 16) == 0) glds16_saddr(c_base + c_k, voff[U], c_dst + (U) * 1024u);       \
     } while (0)
 #define RQ_REC()                                                                                      \
     do {                                                                                              \
-        if constexpr (I8)                                                                             \
+        if constexpr (I8 && (ABL & 16) == 0)                                                          \
             if (c_n == 0)                                                                             \
                 glds4_saddr((const char*)a.grp + (int64_t)(a.ct0 + c_ctl) * (kRqRows / kI8GroupRows * (int)sizeof(I8Group)), \
                             rec_voff, rec_lds + (unsigned)(c_tc & (kRqRecSlots - 1)) * 256u);         \
@@ -175,13 +175,21 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
     // ---- row fragments: ring of four micro-steps x 2 blocks, read kPF micro-steps ahead
     constexpr int kPF = 3;
     bf16x8 fAq[4][2];
+    if constexpr ((ABL & 1) != 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" : "=v"(fAq[i][j]));
+    }
 // reads of micro-step M2 (0..7 this K-step, 8..10 = micro-steps 0..2 of the next one) from stage byte offsets SB / SBN
 #define RQ_PREFETCH(M2, SB, SBN)                                                                      \
     do {                                                                                              \
-        constexpr int m2__ = (M2) & 7;                                                                \
-        const char* r__ = smem + ((M2) >= 8 ? (SBN) : (SB)) + (2 * (m2__ >> 2)) * 4096;               \
-        _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                              \
-            fAq[m2__ & 3][rb] = __builtin_bit_cast(bf16x8, *(const uint4*)(r__ + rb * 4096 + (offA ^ ((m2__ & 3) * 32)))); \
+        if constexpr ((ABL & 1) == 0) {                                                               \
+            constexpr int m2__ = (M2) & 7;                                                            \
+            const char* r__ = smem + ((M2) >= 8 ? (SBN) : (SB)) + (2 * (m2__ >> 2)) * 4096;           \
+            _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                          \
+                fAq[m2__ & 3][rb] = __builtin_bit_cast(bf16x8, *(const uint4*)(r__ + rb * 4096 + (offA ^ ((m2__ & 3) * 32)))); \
+        }                                                                                             \
     } while (0)
 #define RQ_MM(M, TT, ZERO)                                                                            \
     do {                                                                                              \
@@ -190,11 +198,11 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
                                                        (ZERO) ? zero16 : acc[2 * ((M) >> 2) + rb]);   \
     } while (0)
 // ... the same with the running maximum of finished block TB folded in behind the two MFMAs (parts 2 (M & 1), 2 (M & 1) + 1 of
-// screen_block_max_part: a block's four parts ride two consecutive micro-steps).  SPLIT = false: the test in one piece (the form
+// screen_block_max_part: a block's four parts ride two consecutive micro-steps).  ABL bit 13: the test in one piece (the form
 // before, A/B).
 #define RQ_MM_T(M, TT, ZERO, TB)                                                                      \
     do {                                                                                              \
-        if constexpr (!SPLIT) {                                                                       \
+        if constexpr ((ABL & 4) != 0 || (ABL & 8192) != 0) {                                          \
             RQ_MM(M, TT, ZERO);                                                                       \
         } else {                                                                                      \
             acc[2 * ((M) >> 2)] = screen_mfma<I8>(fAq[(M) & 3][0], fB[4 * (TT) + ((M) & 3)], (ZERO) ? zero16 : acc[2 * ((M) >> 2)]); \
@@ -209,10 +217,10 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
 // The four blocks' constants (m = S_g S_q, ek = e_g kq) of the tile under test, read from the records ring ONE micro-step
 // before the tile's first test instead of inside each test: a test that reads its record itself waits with lgkmcnt(0) for a
 // read queued BEHIND the six to eight fragment reads in flight (LDS returns in order) -- ~150 cycles of this wave, four times
-// per tile.
+// per tile.  (ABL bit 6: the old form, for the A/B.)
 #define RQ_LOAD_REC(TC)                                                                               \
     do {                                                                                              \
-        if constexpr (I8) {                                                                           \
+        if constexpr (I8 && (ABL & 4) == 0 && (ABL & 64) == 0) {                                      \
             const float4* rp__ = (const float4*)(smem + rq_rec_off(KS) + ((TC) & (kRqRecSlots - 1)) * 256); \
             const float4 r0__ = rp__[0], r1__ = rp__[1];                                              \
             rec_m[0] = r0__.x * scq, rec_e[0] = r0__.y * kqq, rec_m[1] = r0__.z * scq, rec_e[1] = r0__.w * kqq; \
@@ -222,16 +230,23 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
 // test row block RB of the tile whose first row is ROW0 (records slot of tile counter TC)
 #define RQ_TEST(RB, ROW0, TC)                                                                         \
     do {                                                                                              \
-        int lane_e = lane;                                                                            \
-        asm volatile("" : "+v"(lane_e));                                                              \
-        const int q__ = q0 + (lane_e & 31);                                                           \
-        const int rbase__ = (ROW0) + 32 * (RB) + 4 * (lane_e >> 5);                                   \
-        I8Blk blk__{1.0f, 0.0f};                                                                      \
-        if constexpr (I8) blk__ = I8Blk{rec_m[RB], rec_e[RB]};                                        \
-        if constexpr (!SPLIT)                                                                         \
-            screen_test_block_lq<I8, 0>(a, a.status, row_end, acc[RB], q__, rbase__, th, blk__, lq, lq_n, lq_ovf); \
-        else                                                                                          \
-            screen_test_block_lq_max<I8, 0>(a, a.status, row_end, acc[RB], tg, q__, rbase__, th, blk__, lq, lq_n, lq_ovf); \
+        if constexpr ((ABL & 4) == 0) {                                                               \
+            int lane_e = lane;                                                                        \
+            asm volatile("" : "+v"(lane_e));                                                          \
+            const int q__ = q0 + (lane_e & 31);                                                       \
+            const int rbase__ = (ROW0) + 32 * (RB) + 4 * (lane_e >> 5);                               \
+            I8Blk blk__{1.0f, 0.0f};                                                                  \
+            if constexpr (I8 && (ABL & 64) != 0) {                                                    \
+                const I8Group g__ = ((const I8Group*)(smem + rq_rec_off(KS) + ((TC) & (kRqRecSlots - 1)) * 256))[RB]; \
+                blk__ = i8_blk(g__, scq, kqq);                                                        \
+            } else if constexpr (I8) {                                                                \
+                blk__ = I8Blk{rec_m[RB], rec_e[RB]};                                                  \
+            }                                                                                         \
+            if constexpr ((ABL & 8192) != 0)                                                          \
+                screen_test_block_lq<I8, (ABL >> 8) & 3>(a, a.status, row_end, acc[RB], q__, rbase__, th, blk__, lq, lq_n, lq_ovf); \
+            else                                                                                      \
+                screen_test_block_lq_max<I8, (ABL >> 8) & 3>(a, a.status, row_end, acc[RB], tg, q__, rbase__, th, blk__, lq, lq_n, lq_ovf); \
+        }                                                                                             \
     } while (0)
 #define RQ_MICRO(M, TT, ZERO, SB, SBN)                                                                \
     do {                                                                                              \
@@ -248,13 +263,13 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
         RQ_PIN();                                                                                     \
     } while (0)
 
-    // Hand-over schedule.  kSkipLast (KS >= 2): NO hand-over in a tile's LAST K-step -- the
+    // Hand-over schedule.  kSkipLast (KS >= 2; ABL bit 11 = the per-K-step form, A/B): NO hand-over in a tile's LAST K-step -- the
     // ring stage it reads is handed over together with the next K-step's, in the next tile's first K-step.  The four block tests
     // of a tile sit in its last K-step (row half 0) and in the next tile's first (row half 1), i.e. now BETWEEN two consecutive
     // barriers: a wave with hits is late once per tile instead of once per test site, and the delays of different waves overlap
     // instead of adding up (the eight waves meet at every barrier: whatever a hit costs one wave is paid by all -- with one hit
     // per 3 ... 30 blocks some wave of the eight has one at most test sites; profiles/r05_hit_path.txt).
-    constexpr bool kSkipLast = KS >= 2;
+    constexpr bool kSkipLast = KS >= 2 && (ABL & 2048) == 0;
     constexpr int kPrologueSteps = kSkipLast ? NST - 1 : NST;  // (the first hand-over then frees two stages like every tile's first)
     // ---- prologue: K-steps 0 .. kPrologueSteps-1 into the ring; K-step 0 landed and visible; fragments of micro-steps 0..2
 #pragma unroll
@@ -264,8 +279,10 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
         RQ_REC();
         RQ_ADVANCE();
     }
-    // this wave's pieces of K-step 0 (the oldest) have landed: at most the younger ones (+ records) are out
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (kPrologueSteps - 1)) : "memory");
+    if constexpr ((ABL & 16) == 0) {
+        // this wave's pieces of K-step 0 (the oldest) have landed: at most the younger ones (+ records) are out
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (kPrologueSteps - 1)) : "memory");
+    }
     MI355_BARRIER();
     int s0b = 0;  // ring byte offset of the tile's first K-step (compile-time 0 when a tile is the whole ring)
     int tc = 0;   // tile counter of this workgroup (records slot)
@@ -284,10 +301,14 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
         // whose queue fills faster than foreseen still flushes on its own (at a.flush_alone entries).
         const bool flush_due = a.flush_mask >= 0 ? ((tc & a.flush_mask) == 0 && lq_n > 0) || lq_n > a.flush_alone
                                                  : lq_n > kLaneQueueFlushAt;
-        if (flush_due) {  // wave-uniform
+        if (((ABL >> 8) & 3) != 1 && flush_due) {  // wave-uniform
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            lane_queue_flush<I8>(a, lq, lq_n, row_end);
+            if constexpr (((ABL >> 8) & 3) != 1) lane_queue_flush<I8>(a, lq, lq_n, row_end);
             lq_n = 0;
+        }
+        if (((ABL >> 8) & 3) == 2 && lq_ovf) {  // (branch-free A/B form only) a burst did not fit the queue -- this wave's queries are re-screened by the host
+            __hip_atomic_fetch_or(&a.status[q_lane], kStOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lq_ovf = 0;
         }
         // drift limiter, wave 0, every tile.  Here -- not behind a barrier: measured behind the first K-step's hand-over, where the
         // words could be read under the wait for the fragments, the same work cost +4.7 % (zeros: +13.7 %): right behind a
@@ -345,13 +366,15 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
                 // (t = KS - 2).  In flight before this K-step's issue: through K-step g + NST - 1 (g + NST - 2 in a tile's first
                 // K-step: the previous one issued nothing).  Record pieces only make the wait stricter.
                 const int allowed = 2 * (NST - 2 - ((kSkipLast && first) ? 1 : 0) - ((kSkipLast && t == KS - 2) ? 1 : 0));
-                if (allowed >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else if (allowed == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else if (allowed == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else if (allowed == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if constexpr ((ABL & 48) == 0) {
+                    if (allowed >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else if (allowed == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else if (allowed == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else if (allowed == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and the last fragments of this one are in registers
-                MI355_BARRIER();
+                if constexpr ((ABL & 8) == 0) MI355_BARRIER();
             }
             RQ_PIN();
             if (last) RQ_MICRO_T(5, t, false, sb, sbn, 0);
@@ -390,7 +413,7 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
     // the last tile's row half 1 (no MFMAs left to hide under: the maxima in one piece)
 #define RQ_TEST_WHOLE(RB)                                                                             \
     do {                                                                                              \
-        if constexpr (SPLIT) {                                                                        \
+        if constexpr ((ABL & 4) == 0 && (ABL & 8192) == 0) {                                          \
             tg = screen_block_max_part<I8, 0>(acc[RB], tg);                                           \
             tg = screen_block_max_part<I8, 1>(acc[RB], tg);                                           \
             tg = screen_block_max_part<I8, 2>(acc[RB], tg);                                           \
@@ -402,9 +425,13 @@ __global__ __launch_bounds__(512, 2) void k_screen_rq(ScreenArgs2 a) {
     RQ_TEST_WHOLE(3);
 #undef RQ_TEST_WHOLE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the dummy prefetches must land before the LDS is freed
-    if (a.drift > 0 && a.progress != nullptr && wave == 0 && lane == 0)  // done: nobody waits for this one
+    if ((ABL & 4096) == 0 && a.drift > 0 && a.progress != nullptr && wave == 0 && lane == 0)  // done: nobody waits for this one
         __hip_atomic_store((int*)prog_base + qt, stamp | kRqDoneTiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     lane_queue_flush<I8>(a, lq, lq_n, row_end);
+    if constexpr ((ABL & 4) != 0) {  // timing build without tests: the accumulators stay live
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(acc[i]));
+    }
 
 #undef RQ_PIN
 #undef RQ_PIECE

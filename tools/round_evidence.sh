@@ -139,7 +139,7 @@ mx)
     for c in 7000 700 100; do /tmp/mfma_power_probe gather 10000000 1024 $c | tail -1; done; } 2>&1 | tee $OUT/mx_probe.txt ;;
 kstep)
   # the A/B of the two large-block int8 screens + the timing builds of the new one, each with power / clock next to a sustained run
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -Iautorag_research_amd/csrc tools/screen_ab.hip -o /tmp/screen_ab || exit 1
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -Iautorag_research_amd/csrc -Itools tools/screen_ab.hip -o /tmp/screen_ab || exit 1
   { echo "# k_screen256c (variant 0: 256 x 256 tile, both operands through the LDS) against k_screen_rq (variant 100: 128 rows x 256"
     echo "# queries, query operand resident in registers), int8, ${KROWS:-10000000} rows x 1024 queries x d 768, thresholds parked; timing builds of"
     echo "# k_screen_rq: 101 no fragment reads | 104 no tests | 108 no barrier | 116 no LDS-DMA | 117 no LDS-DMA, no fragment reads"

@@ -2,7 +2,7 @@
 //   variant 0          k_screen256c<int8>   (256 rows x 256 queries, both operands through the LDS)
 //   variant 100 + ABL  k_screen_rq<KS, ABL, int8>  (128 rows x 256 queries, query operand resident in registers);
 //                      ABL = timing builds (1 no fragment reads, 4 no tests, 8 no barrier, 16 no LDS-DMA)
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -Iautorag_research_amd/csrc tools/screen_ab.hip -o tools/bin/screen_ab
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -Iautorag_research_amd/csrc -Itools tools/screen_ab.hip -o tools/bin/screen_ab
 // Run:   screen_ab [rows] [queries] [dim] ;  env ROUNDS (interleaved timing rounds, default 12), VARIANTS=0,100,..., DATA (1 =
 //        Gaussian sigma 29 -- what the library's shadows hold --, 2 = zeros), SECONDS (sustained run of the FIRST variant, for power)
 // Output: per variant median / mean ms and TOP/s with thresholds parked (+inf), then the candidate sets of every non-timing
@@ -18,8 +18,8 @@
 #include <vector>
 
 #include "dev_common.h"
-#include "k_screen256c.h"
-#include "k_screen_rq.h"
+#include "k_screen256c_abl.h"  // (tools/: the kernels WITH their timing forms; the library's headers carry the kernels alone)
+#include "k_screen_rq_abl.h"
 #include "k_screen_rq1.h"  // (tools/: the one-wave-per-SIMD experiment, not part of the library)
 
 using namespace mi355;
