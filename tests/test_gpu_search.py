@@ -641,3 +641,48 @@ def test_bf16_second_screen_inside_the_prune_keeps_results_exact(pkg, oracle, mo
         m = ~np.isnan(rd)
         assert np.array_equal(np.isnan(dist), ~m) and np.array_equal(dist[m].view(np.uint64), rd[m].view(np.uint64))
     assert rescored[1] <= rescored[0]
+
+
+@pytest.mark.parametrize("k", [40, 100, 128])
+@pytest.mark.parametrize("order", ["ascending", "ties", "descending"])
+def test_two_wave_prune_on_adversarial_row_orders(pkg, oracle, k, order):
+    """k_prune_wide (33 <= k <= 128) where its bookkeeping is stressed instead of its common case:
+    * `ascending`: the rows' similarity to the queries GROWS with the row index, so every chunk's candidates beat everything kept
+      (round A cannot hold the entrants, round B passes its filter by the hundred: the 512-entry exact buffer is re-selected
+      again and again, thresholds lag the data);
+    * `ties`: a third of the corpus are exact copies of 50 rows (float-image ties far beyond k: selections by image return more
+      than k, the (key, row) sort decides);
+    * `descending`: the best rows first (the starter's sample already holds the final top-k; later chunks append almost nothing).
+    Also with every prune re-scoring its survivors at once (defer_round_b = 0: round B and the shrink path in EVERY prune) and with the
+    round-5 schedule (prune_wide = 0).  All against the oracle, bit for bit."""
+    rng = np.random.default_rng(900 + k)
+    n, d, B = 220_000, 128, 96
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    C = rng.standard_normal((n, d)).astype(np.float32)
+    axis = Q[:48].mean(axis=0)
+    axis /= np.linalg.norm(axis)
+    if order in ("ascending", "descending"):
+        w = np.linspace(0.0, 3.0, n, dtype=np.float32)   # the component along the queries' common direction grows with the row
+        if order == "descending":
+            w = w[::-1].copy()
+        C += w[:, None] * axis[None, :]
+    else:
+        base = rng.standard_normal((50, d)).astype(np.float32) + 2.0 * axis[None, :]
+        pos = rng.choice(n, size=n // 3, replace=False)
+        C[pos] = base[rng.integers(0, 50, size=pos.size)]
+    rd, rr = oracle.topk_search(C, Q, k)
+    small_steps = {"chunk_growth": 1, "starter_rows_wide": 4096, "defer_round_b": 0}   # nine chunks, round B in every prune
+    for opts in ({}, {"defer_round_b": 0}, small_steps, {"prune_wide": 0}):
+        with pkg.Mi355Index(d) as idx:
+            for key, val in opts.items():
+                idx.set_option(key, val)
+            idx.add(C)
+            idx.reset_stats()
+            dist, rows = idx.search(Q, k)
+            assert np.array_equal(rows, rr), (order, k, opts)
+            assert np.array_equal(dist.view(np.uint64), rd.view(np.uint64)), (order, k, opts)
+            assert idx.stat("fallback_queries") == 0
+            if order == "ties" and k >= 100 and opts is small_steps:
+                # ~1 460 copies of the best row tie at the k-th place: round B re-scores them by the hundred and every one passes the
+                # buffer's filter (equal images), so the 512-entry exact buffer is re-selected several times per prune
+                assert idx.stat("rescored") / B > 1000, idx.stat("rescored") / B
