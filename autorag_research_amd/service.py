@@ -42,6 +42,21 @@ class _World:
     def __init__(self, dist: Any):
         self.dist = dist
         self.rank, self.size = dist.get_rank(), dist.get_world_size()
+        # The plugin's own collectives can be given a deadline: MI355DR_COLLECTIVE_TIMEOUT_S = seconds makes every rank create
+        # (together: `new_group` is itself a collective, and `detect()` runs on every rank when the pipeline is constructed) a
+        # group over the whole world with that timeout, and every collective below -- and the sharded searchers' -- uses it.
+        # A rank that died or left through a rank-local error while its peers are inside a collective then costs them that many
+        # seconds and a RuntimeError instead of the launcher's default (30 min under gloo, 10 under nccl) -- `agree` reconciles
+        # failures OUTSIDE collectives only.  Unset / 0: the default group, as before.
+        self.group = None
+        try:
+            t = float(os.environ.get("MI355DR_COLLECTIVE_TIMEOUT_S", "0") or 0)
+        except ValueError:
+            t = 0.0
+        if t > 0:
+            import datetime  # noqa: PLC0415
+
+            self.group = dist.new_group(ranks=list(range(self.size)), timeout=datetime.timedelta(seconds=t))
 
     @classmethod
     def detect(cls) -> "_World | None":
@@ -65,7 +80,7 @@ class _World:
                 box[0] = (True, make())
             except Exception as e:  # noqa: BLE001 - re-raised below, on every rank
                 box[0] = (False, self._portable(e))
-        self.dist.broadcast_object_list(box, src=0)
+        self.dist.broadcast_object_list(box, src=0, group=self.group)
         ok, value = box[0]
         if not ok:
             raise value
@@ -87,7 +102,7 @@ class _World:
         """True iff `ok` on every rank: ranks settle the outcome of a rank-local step BEFORE any of them branches into a
         different sequence of collectives (block answer vs per-query fallback vs retry)."""
         flags: list[Any] = [None] * self.size
-        self.dist.all_gather_object(flags, bool(ok))
+        self.dist.all_gather_object(flags, bool(ok), group=self.group)
         return all(flags)
 
     def same_everywhere(self, what: str, digest: str) -> None:
@@ -95,7 +110,7 @@ class _World:
         global row ids are positions in that order, so two ranks that saw different orders would silently map each other's
         rows to the wrong primary keys)."""
         seen: list[Any] = [None] * self.size
-        self.dist.all_gather_object(seen, digest)
+        self.dist.all_gather_object(seen, digest, group=self.group)
         if any(d != seen[0] for d in seen):
             raise RuntimeError(f"{what}: the ranks exported different tables ({len(set(seen))} distinct digests over "
                                f"{self.size} ranks) -- the table changed during the export or the keys are not totally "
@@ -153,7 +168,7 @@ class _UnitIndex:
             not_null = ~np.isnan(emb).all(axis=1)
             self.single_rows = np.nonzero(not_null)[0]
             lo, hi = shard_bounds(int(self.single_rows.shape[0]), world.size, world.rank)
-            s = ShardedSearcher(emb.shape[1], "cosine", self.device, index_factory=Mi355Index)
+            s = ShardedSearcher(emb.shape[1], "cosine", self.device, index_factory=Mi355Index, group=world.group)
             s.add_local(emb[self.single_rows[lo:hi]], lo)
             self.single_sharded = s
         return self.single_sharded
@@ -167,7 +182,7 @@ class _UnitIndex:
             if tok is None or off is None:
                 raise ValueError("table has no multi-vector embeddings")
             lo, hi = shard_bounds_by_tokens(off, world.size, world.rank)
-            s = ShardedSearcher(tok.shape[1], "cosine", self.device, index_factory=Mi355Index)
+            s = ShardedSearcher(tok.shape[1], "cosine", self.device, index_factory=Mi355Index, group=world.group)
             s.add_local_multivec(tok[off[lo]:off[hi]], off[lo:hi + 1] - off[lo], lo)
             self.multi_sharded = s
             self.multi_rows = np.arange(off.shape[0] - 1)
@@ -289,7 +304,7 @@ class Mi355RetrievalService:
                 box[0] = (True, await make())
             except Exception as e:  # noqa: BLE001
                 box[0] = (False, _World._portable(e))
-        self._world.dist.broadcast_object_list(box, src=0)
+        self._world.dist.broadcast_object_list(box, src=0, group=self._world.group)
         ok, value = box[0]
         if not ok:
             raise value

@@ -395,3 +395,52 @@ def test_hyde_generates_on_rank_zero_only_and_survives_rank_local_llm_faults(tmp
     od, orow = oracle.topk_search(g["C"], v[None, :], 3)
     assert [d["doc_id"] for d in r0["by_id"]] == [g["ids"][int(i)] for i in orow[0]]
     assert [d["score"] for d in r0["by_id"]] == [1.0 - float(x) for x in od[0]]
+
+
+def _deadline_worker(rank: int, world: int, port: int, out_dir: str):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), MI355DR_COLLECTIVE_TIMEOUT_S="3")
+    import time
+
+    import torch.distributed as dist
+
+    import autorag_research_amd.service as svc
+    from helpers import OracleIndex, build_golden_stores
+
+    svc.Mi355Index = OracleIndex
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    store, _ = build_golden_stores()
+    s = svc.Mi355RetrievalService(lambda: store)            # (every rank: creates the deadline group together)
+    w = s._world
+    assert w is not None and w.group is not None
+    assert w.agree(True) and not w.agree(rank == 0)          # the plugin's collectives work over the group
+    res = s.vector_search(["q1", "q2"], 3)                   # ... and so does the sharded search behind it
+    assert len(res) == 2 and len(res[0]) == 3
+    out = {"rank": rank}
+    if rank == 0:
+        t0 = time.time()
+        try:
+            w.agree(True)                                     # rank 1 never comes: a deadline, not a hang
+            out["outcome"] = "returned"
+        except Exception as e:  # noqa: BLE001
+            out["outcome"] = type(e).__name__
+        out["waited_s"] = time.time() - t0
+    else:
+        time.sleep(8.0)                                       # "died" outside the collective its peer is in
+    (Path(out_dir) / f"deadline{rank}.json").write_text(json.dumps(out))
+    os._exit(0)   # (the group is poisoned by the timeout: no orderly destroy)
+
+
+def test_collective_deadline_turns_a_lost_rank_into_an_error(tmp_path, oracle):
+    """`_World.agree` cannot reconcile a rank that is lost while its peers are inside a collective.  With
+    MI355DR_COLLECTIVE_TIMEOUT_S the plugin's collectives (and its sharded searchers') run over a group of their own with that
+    deadline: the waiting rank gets an exception after ~3 s instead of the launcher's default of 30 minutes."""
+    import torch.multiprocessing as mp
+
+    world, port = 2, _free_port()
+    mp.spawn(_deadline_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = json.loads((tmp_path / "deadline0.json").read_text())
+    assert r0["outcome"] != "returned" and 2.0 < r0["waited_s"] < 7.5, r0
+    assert json.loads((tmp_path / "deadline1.json").read_text())["rank"] == 1
