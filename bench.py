@@ -48,6 +48,33 @@ from bench_support import (HBM_PEAK_GBS, MFMA_BF16_PEAK_TF, MFMA_BF16_POWER_LIMI
                            replicated_leg, row_sharded_leg, run_maxsim, small_corpus_line)
 
 
+class _HostHopDist:
+    """torch.distributed with its device collectives taken through the host (--rehearse-one-gpu: gloo between ranks that share
+    ONE GPU).  Everything else is the module itself."""
+
+    def __init__(self, dist, torch):
+        self._d, self._t = dist, torch
+
+    def __getattr__(self, name):
+        return getattr(self._d, name)
+
+    def all_gather_into_tensor(self, out, inp, group=None):
+        self._t.cuda.current_stream().synchronize()
+        host = self._t.empty(out.shape, dtype=out.dtype)
+        self._d.all_gather_into_tensor(host, inp.cpu(), group=group)
+        out.copy_(host)
+
+    def all_reduce(self, t, op=None, group=None):
+        host = t.cpu()
+        self._d.all_reduce(host, op=op if op is not None else self._d.ReduceOp.SUM, group=group)
+        t.copy_(host)
+
+    def broadcast(self, t, src, group=None):
+        host = t.cpu()
+        self._d.broadcast(host, src=src, group=group)
+        t.copy_(host)
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,6 +130,10 @@ def parse_args():
     ap.add_argument("--data", choices=["gaussian", "anisotropic"], default="gaussian",
                     help="gaussian = BASELINE headline; anisotropic = power-law spectrum + near-duplicate clusters (the offline "
                          "stand-in for bge-base on BEIR nq, config C2: use with --metric ip --k 100)")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="developer / test: run the N > 1 leg with every rank on cuda:0 (one-GPU boxes; RCCL refuses two ranks on one "
+                         "device): gloo process group, device collectives take a host hop.  The line says so in config.collective; "
+                         "its value is NOT a multi-GPU measurement")
     ap.add_argument("--traffic", action="store_true", help="run the PMC sub-run (rocprofv3 --pmc FETCH_SIZE of this workload, 3 steps) "
                                                            "that fills roofline.traffic even with --no-extras")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
@@ -128,6 +159,8 @@ def main() -> None:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the search path)")
+    if args.rehearse_one_gpu:
+        local_rank = 0   # every rank on the one device
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -144,7 +177,11 @@ def main() -> None:
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
+        if args.rehearse_one_gpu:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            dist = _HostHopDist(dist, torch)         # device tensors of the collectives travel through the host
+        else:
+            dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
         row_group = layout.make_row_group(dist)      # None: the whole world (or a single rank)
 
     n_chunks = (n_total + CHUNK_ROWS - 1) // CHUNK_ROWS
@@ -419,7 +456,8 @@ def main() -> None:
             "layout": {"row_shards": R, "query_groups": QG, "rule": args.layout},
             "parallelism": f"{layout.describe()}" + ((" + one packed RCCL all-gather of the per-shard top-k + k_merge_topk per step, inside the timed loop (" + ("library RCCL communicator" if args.comm == "lib"
                             else "torch.distributed, on a second stream under the next step's search") + ")") if use_dist else ""),
-            "collective": ({"transport": "library RCCL communicator (ncclAllGather)" if args.comm == "lib"
+            "collective": ({"transport": "REHEARSAL on one GPU: gloo, device tensors through the host (not a multi-GPU measurement)"
+                            if args.rehearse_one_gpu else "library RCCL communicator (ncclAllGather)" if args.comm == "lib"
                             else "torch.distributed backend nccl (= RCCL)",
                             "ranks_in_all_gather": int(dist.get_world_size(row_group)),
                             "rccl_comm_count": idx.comm_count() if args.comm == "lib" else None,
