@@ -107,6 +107,9 @@ struct mi355dr_index {
     int maxsim_aligned = 1;  // k_maxsim16_wg: when every query of a pass is one column block, a wave sums its own two queries (0: A/B)
     int maxsim_wg_min = 8;   // fewest column blocks of a pass that take the workgroup form (8: short documents only; 9)
     int maxsim_wg_pipe = 1;  // k_maxsim16_wg, 4 blocks per stage: fold block j under the MFMAs of block j + 1 (0: the unpipelined form, A/B)
+    // MaxSim screen, aligned passes that take the workgroup form: the granule-packed bf16 copy (k_maxsim_wg8.h; a second shadow,
+    // built on first use).  -1 (default): when it removes at least 5 % of the padded copy's blocks and its memory is there; 1: always; 0: never
+    int maxsim_pack8 = -1;
     int maxsim_wg_bps = 4;  // k_maxsim16_wg: 32-token blocks per ring stage (2: 7 stages of 16 KiB, 4: 4 stages of 32 KiB); option, A/B
     int maxsim_pass_groups = 4;  // groups of <= 4 queries one pass of the MaxSim screen serves (1 .. 4; option "maxsim_pass_groups", A/B and tests)
     int maxsim_screen = 1; // 1: bf16 MFMA screen + exact re-score of the candidates, 0: exact kernel over every doc
@@ -161,6 +164,8 @@ struct mi355dr_index {
     int64_t s_ms_screened = 0, s_ms_candidates = 0, s_ms_fallbacks = 0;  // MaxSim: queries screened, docs re-scored, full re-runs
     // option "profile": HIP-event time of the MaxSim screen launches (k_maxsim16*) and of the exact launches on candidate lists
     int64_t s_ms_screen_ns = 0, s_ms_screen_launches = 0, s_ms_exact_ns = 0, s_ms_exact_launches = 0, s_ms_pack_ns = 0;
+    int64_t s_ms_packed_launches = 0;  // screen launches that took the granule-packed copy (k_maxsim_wg8.h)
+    int64_t s_ms_packed_blocks = 0;    // ... and the 32-token blocks of that copy (0: none built)
     int64_t s_ms_screen_cols = 0;  // query-vector columns (whole blocks of 32) the screen launches multiplied every token by
     hipEvent_t ms_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<mi355::EventPair> ev_pool, ev_pending;

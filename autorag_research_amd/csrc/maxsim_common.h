@@ -45,12 +45,23 @@ struct Ms16Args {
     int aligned;             // k_maxsim16_wg: query r of the launch is exactly column block r (q_col0[r] = 32 r, q_len[r] <= 32)
 };
 
+// the granule-packed bf16 copy (k_maxsim_wg8.h): documents rounded up to whole 8-token granules, the stream cut into 32-token blocks
+struct Ms16Pack {
+    const uint4* tok16p;   // [n_pblocks][nkk = 8][64] fragments, the padded copy's order inside a block
+    const int64_t* goff;   // [n_docs + 1] first granule of each doc (device)
+    int64_t n_gran;        // goff[n_docs]
+    int64_t n_pblocks;     // ceil(n_gran / 4)
+};
+
 // ---- mi355dr_maxsim_screen.hip ----
 // dynamic-LDS attributes of every screen kernel (lds16 = the generic form's query-fragment bytes; > 160 KiB: that form is not used)
 int ms16_prepare(mi355dr_index* idx, size_t lds16);
 // one screen launch over every doc, dims <= 128 (compile-time column-block count): one wave per document, or the
 // workgroup-cooperative form from 8 / 9 column blocks up (options maxsim_wg*, maxsim_persistent)
-int ms16_d128_launch(mi355dr_index* idx, hipStream_t s, int ncb, int64_t n_docs, int64_t n_blocks, bool persistent, const Ms16Args& sa);
+// `pk` (may be null): the packed copy; taken when the pass is aligned and the workgroup form serves it (ms16_takes_wg)
+int ms16_d128_launch(mi355dr_index* idx, hipStream_t s, int ncb, int64_t n_docs, int64_t n_blocks, bool persistent, const Ms16Args& sa,
+                     const Ms16Pack* pk = nullptr);
+bool ms16_takes_wg(const mi355dr_index* idx, int ncb, int64_t n_docs, int64_t n_blocks);
 // ... dims > 128: the generic form (k_maxsim16)
 int ms16_generic_launch(mi355dr_index* idx, hipStream_t s, unsigned grid, size_t lds16, const Ms16Args& sa);
 

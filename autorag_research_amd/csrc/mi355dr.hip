@@ -1186,6 +1186,9 @@ int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value) {
         idx->maxsim_wg_min = (int)value;
     } else if (k == "maxsim_wg_pipe") {
         idx->maxsim_wg_pipe = value != 0;
+    } else if (k == "maxsim_pack8") {
+        if (value < -1 || value > 1) return fail(idx, MI355DR_E_INVALID, "maxsim_pack8 must be -1 (when it pays), 0 or 1");
+        idx->maxsim_pack8 = (int)value;
     } else if (k == "maxsim_wg_bps") {
         if (value != 2 && value != 4) return fail(idx, MI355DR_E_INVALID, "maxsim_wg_bps must be 2 or 4");
         idx->maxsim_wg_bps = (int)value;
@@ -1299,6 +1302,8 @@ int mi355dr_get_stat(mi355dr_index* idx, const char* key, int64_t* out) {
     else if (k == "maxsim_exact_ns") *out = idx->s_ms_exact_ns;
     else if (k == "maxsim_exact_launches") *out = idx->s_ms_exact_launches;
     else if (k == "maxsim_screen_cols") *out = idx->s_ms_screen_cols;
+    else if (k == "maxsim_packed_launches") *out = idx->s_ms_packed_launches;
+    else if (k == "maxsim_packed_blocks") *out = idx->s_ms_packed_blocks;
     else if (k == "irregular_rows") *out = idx->irr_n;
     else if (k == "loose_rows") *out = idx->irr8_n;
     else if (k == "screen_dtype_active") *out = use_i8(idx) ? MI355DR_SCREEN_I8 : MI355DR_SCREEN_BF16;
@@ -1315,7 +1320,7 @@ int mi355dr_reset_stats(mi355dr_index* idx) {
     idx->s_screen_launches = idx->s_screen_ns = idx->s_screen_rows = idx->s_fallback_queries = idx->s_chunks =
         idx->s_passes = idx->s_rq_launches = idx->s_big_launches = idx->s_big_ns = idx->s_big_rows = idx->s_starters = 0;
     idx->s_ms_screened = idx->s_ms_candidates = idx->s_ms_fallbacks = idx->s_retry_queries = 0;
-    idx->s_ms_screen_ns = idx->s_ms_screen_launches = idx->s_ms_exact_ns = idx->s_ms_exact_launches = idx->s_ms_screen_cols = idx->s_ms_pack_ns = 0;
+    idx->s_ms_screen_ns = idx->s_ms_screen_launches = idx->s_ms_exact_ns = idx->s_ms_exact_launches = idx->s_ms_screen_cols = idx->s_ms_pack_ns = idx->s_ms_packed_launches = 0;
     if (idx->stat_dev) {
         HIPCHECK(idx, hipSetDevice(idx->device));
         HIPCHECK(idx, hipMemset(idx->stat_dev, 0, 2 * kQBlockMax * sizeof(unsigned long long)));

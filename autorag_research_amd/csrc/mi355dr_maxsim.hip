@@ -62,6 +62,14 @@ struct MultiVecStore {
     size_t stage_bytes = 0;
     int64_t* blk_off = nullptr;    // [cap_docs+1] first block of each doc (device)
     std::vector<int64_t> blk_off_host;
+    std::vector<int32_t> tok_cnt_host;  // [n_docs] token vectors of each doc (the padded copies do not keep it)
+    // the granule-packed bf16 copy of k_maxsim_wg8.h: a second shadow, built on first use (ms_pack8_ensure), stale after an add
+    uint4* tok16p = nullptr;       // [pack_cap_blocks * nkk * 64]
+    int64_t* goff = nullptr;       // [pack_cap_docs + 1] first 8-token granule of each doc (device)
+    int64_t pack_docs = -1;        // n_docs the copy was built (or judged) for; -1: never
+    int64_t pack_gran = 0, pack_blocks = 0, pack_cap_blocks = 0, pack_cap_docs = 0;
+    bool pack_use = false;         // the copy exists for pack_docs docs and pays (or is forced)
+    int pack_mode = 0;             // option maxsim_pack8 at the time of that decision
     // search scratch
     float* qtok = nullptr;         // [kMsCols, dpad] per launch
     float* dist = nullptr;         // [max queries per launch (4), cap_docs]
@@ -89,7 +97,7 @@ void multivec_destroy(mi355dr_index* idx) {
     if (!m) return;
     void* ptrs[] = {m->tok, m->blk_off, m->qtok, m->dist, m->pk[0], m->pk[1], m->pr[0], m->pr[1], m->out_d, m->out_r,
                     m->tok16, m->qfrag, m->dist16, m->cand_list, m->cand_dist, m->cand_ctl, m->sel[0], m->sel[1],
-                    m->two_e_dev, m->cand_sd};
+                    m->two_e_dev, m->cand_sd, m->tok16p, m->goff};
     if (m->cand_ctl_host) (void)hipHostFree(m->cand_ctl_host);
     if (m->stage_host) (void)hipHostFree(m->stage_host);
     for (void* p : ptrs)
@@ -720,6 +728,7 @@ int mi355dr_add_multivec(mi355dr_index* idx, const float* vecs, const int64_t* o
     HIPCHECK(idx, hipMemcpy(m->blk_off, m->blk_off_host.data(), m->blk_off_host.size() * sizeof(int64_t),
                             hipMemcpyHostToDevice));
     rollback.keep = true;
+    for (int64_t i = 0; i < n_docs; ++i) m->tok_cnt_host.push_back((int32_t)(offsets[i + 1] - offsets[i]));
     m->n_blocks += new_blocks;
     m->n_docs += n_docs;
     return MI355DR_OK;
@@ -868,12 +877,100 @@ int mi355dr_add_multivec_device(mi355dr_index* idx, const float* vecs_dev, const
     m->tok16_norm_max = std::max(m->tok16_norm_max, v[1]);
     m->tok_res_max = std::max(m->tok_res_max, v[2]);
     if (nf) m->finite = false;
+    for (int64_t i = 0; i < n_docs; ++i) m->tok_cnt_host.push_back((int32_t)T[i]);
     m->n_blocks += new_blocks;
     m->n_docs += n_docs;
     return MI355DR_OK;
 }
 
 namespace {
+
+// ---- the granule-packed bf16 copy (k_maxsim_wg8.h) ----
+// one wave per PACKED block: lane = (row = lane & 31, half = lane >> 5) copies its 16-byte fragment of every k-group from the padded
+// copy -- same bf16 values, so the two copies screen to bit-identical distances.  Row r of packed block p is token
+// min(8 (granule - goff[doc]) + r % 8, T - 1) of the doc that owns granule 4 p + r / 8; rows past the last granule repeat the
+// stream's last token (no workgroup ever folds them).
+__global__ __launch_bounds__(64) void k_ms_pack8(const uint4* __restrict__ tok16, const int64_t* __restrict__ blk_off,
+                                                 const int32_t* __restrict__ tok_cnt, const int64_t* __restrict__ goff,
+                                                 int64_t n_docs, int64_t n_gran, int nkk, uint4* __restrict__ out) {
+    const int64_t p = blockIdx.x;
+    const int lane = threadIdx.x, r = lane & 31, hf = lane >> 5;
+    int64_t gi = p * 4 + (r >> 3);
+    int rr = r & 7;
+    if (gi >= n_gran) {
+        gi = n_gran - 1;
+        rr = 7;
+    }
+    int64_t lo = 0, hi = n_docs - 1;  // the doc with goff[doc] <= gi < goff[doc + 1]
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (goff[mid + 1] > gi) hi = mid;
+        else lo = mid + 1;
+    }
+    const int64_t t = min((gi - goff[lo]) * 8 + rr, (int64_t)tok_cnt[lo] - 1);
+    const uint4* src = tok16 + ((blk_off[lo] + (t >> 5)) * nkk) * 64 + (int)(t & 31) + 32 * hf;
+    uint4* dst = out + (p * nkk) * 64 + lane;
+    for (int kk = 0; kk < nkk; ++kk) dst[(int64_t)kk * 64] = src[(int64_t)kk * 64];
+}
+
+// Makes the packed copy current for the store's docs, or decides it is not to be used (m->pack_use).  Called with the index lock
+// held, before a screen launch on stream `s` that could take it.  A failed allocation is not an error: the padded copy serves.
+int ms_pack8_ensure(mi355dr_index* idx, MultiVecStore* m, hipStream_t s) {
+    if (m->pack_docs == m->n_docs && (m->pack_use || m->pack_mode == idx->maxsim_pack8)) return MI355DR_OK;
+    m->pack_docs = m->n_docs;
+    m->pack_mode = idx->maxsim_pack8;
+    m->pack_use = false;
+    if (m->nkk != 8 || (int64_t)m->tok_cnt_host.size() != m->n_docs || m->n_blocks == 0) return MI355DR_OK;
+    std::vector<int64_t> goff((size_t)m->n_docs + 1);
+    goff[0] = 0;
+    for (int64_t i = 0; i < m->n_docs; ++i) goff[i + 1] = goff[i] + (m->tok_cnt_host[i] + 7) / 8;
+    const int64_t n_gran = goff[m->n_docs], n_pb = (n_gran + 3) / 4;
+    if (n_gran == 0) return MI355DR_OK;
+    if (idx->maxsim_pack8 < 0 && (double)n_pb > 0.95 * (double)m->n_blocks) return MI355DR_OK;  // (long documents: nothing to gain)
+    if (n_pb > m->pack_cap_blocks) {
+        if (m->tok16p) (void)hipFree(m->tok16p);
+        m->tok16p = nullptr;
+        m->pack_cap_blocks = 0;
+        const int64_t want = std::max<int64_t>(n_pb, std::min<int64_t>(m->cap_blocks, n_pb + n_pb / 2));
+        if (hipMalloc(&m->tok16p, (size_t)want * m->nkk * 64 * sizeof(uint4)) != hipSuccess) {
+            (void)hipGetLastError();
+            m->tok16p = nullptr;
+            return MI355DR_OK;
+        }
+        m->pack_cap_blocks = want;
+    }
+    if (m->n_docs > m->pack_cap_docs) {
+        if (m->goff) (void)hipFree(m->goff);
+        m->goff = nullptr;
+        m->pack_cap_docs = 0;
+        if (hipMalloc(&m->goff, (size_t)(m->cap_docs + 1) * sizeof(int64_t)) != hipSuccess) {
+            (void)hipGetLastError();
+            m->goff = nullptr;
+            return MI355DR_OK;
+        }
+        m->pack_cap_docs = m->cap_docs;
+    }
+    int32_t* cnt = nullptr;
+    if (hipMalloc(&cnt, (size_t)m->n_docs * sizeof(int32_t)) != hipSuccess) {
+        (void)hipGetLastError();
+        return MI355DR_OK;
+    }
+    struct Free {
+        void* p;
+        ~Free() { (void)hipFree(p); }
+    } free_cnt{cnt};
+    HIPCHECK(idx, hipMemcpyAsync(cnt, m->tok_cnt_host.data(), (size_t)m->n_docs * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIPCHECK(idx, hipMemcpyAsync(m->goff, goff.data(), goff.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_ms_pack8, dim3((unsigned)n_pb), dim3(64), 0, s, m->tok16, m->blk_off, cnt, m->goff, m->n_docs, n_gran, m->nkk,
+                       m->tok16p);
+    HIPCHECK(idx, hipGetLastError());
+    HIPCHECK(idx, hipStreamSynchronize(s));  // (the host vectors above are the copies' sources)
+    m->pack_gran = n_gran;
+    m->pack_blocks = n_pb;
+    m->pack_use = true;
+    idx->s_ms_packed_blocks = n_pb;
+    return MI355DR_OK;
+}
 
 }  // namespace
 
@@ -1240,7 +1337,20 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
             HIPCHECK(idx, hipEventRecord(idx->ms_ev[0], s));
         }
         if (nkk == 8) {  // dims <= 128: the compile-time-unrolled forms, only as many column blocks as the pass has
-            CHECK(ms16_d128_launch(idx, s, ncb_launch, m->n_docs, m->n_blocks, idx->maxsim_persistent != 0, sa));
+            Ms16Pack pk{};
+            bool packed = false;
+            if (sa.aligned && idx->maxsim_pack8 != 0 && ms16_takes_wg(idx, ncb_launch, m->n_docs, m->n_blocks)) {
+                CHECK(ms_pack8_ensure(idx, m, s));
+                if (m->pack_use) {
+                    pk.tok16p = m->tok16p;
+                    pk.goff = m->goff;
+                    pk.n_gran = m->pack_gran;
+                    pk.n_pblocks = m->pack_blocks;
+                    packed = true;
+                }
+            }
+            idx->s_ms_packed_launches += packed ? 1 : 0;
+            CHECK(ms16_d128_launch(idx, s, ncb_launch, m->n_docs, m->n_blocks, idx->maxsim_persistent != 0, sa, packed ? &pk : nullptr));
         } else {
             CHECK(ms16_generic_launch(idx, s, grid_all, lds16, sa));
         }

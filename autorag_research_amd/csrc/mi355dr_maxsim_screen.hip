@@ -242,6 +242,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_maxsim16_d128(Ms16Args a) {
 
 }  // namespace mi355
 #include "k_maxsim_wg.h"
+#include "k_maxsim_wg8.h"
 
 // ---- k_maxsim16_d128<NCB, NW> by run-time NCB (1 .. kMsPassBlocks): NW = 4 up to 8 column blocks, 8 beyond ----
 namespace mi355 {
@@ -284,6 +285,7 @@ int ms16_prepare(mi355dr_index* idx, size_t lds16) {
         HIPCHECK(idx, hipFuncSetAttribute((const void*)k_maxsim16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
     for (auto kfn : kMs16Wg8Kernels)
         HIPCHECK(idx, hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, mi355::mw_lds(4)));
+    HIPCHECK(idx, hipFuncSetAttribute((const void*)mi355::k_maxsim16_wg8, hipFuncAttributeMaxDynamicSharedMemorySize, mi355::mw_lds(4)));
     for (int ncb = 1; ncb <= mi355::kMsPassBlocks; ++ncb)
         if (ncb * 8192 > 64 * 1024)
             HIPCHECK(idx, hipFuncSetAttribute((const void*)kMs16Kernels[ncb - 1], hipFuncAttributeMaxDynamicSharedMemorySize, ncb * 8192));
@@ -297,8 +299,20 @@ int ms16_prepare(mi355dr_index* idx, size_t lds16) {
 // one screen launch over every doc: each wave walks kMsDocsPerWave docs; `persistent`: only as many workgroups as are resident
 // at once, walking the docs in rounds (evened out: 100 k pages over 512 workgroups would be 12.2 rounds, a fifth of the chip
 // idle in the last one)
+bool ms16_takes_wg(const mi355dr_index* idx, int ncb, int64_t n_docs, int64_t n_blocks) {
+    if (ncb == 8) return idx->maxsim_wg && idx->maxsim_wg_min <= 8 && (idx->maxsim_wg > 0 || n_blocks < 8 * n_docs);
+    return ncb >= 9 && idx->maxsim_wg;
+}
+
 int ms16_d128_launch(mi355dr_index* idx, hipStream_t s, int ncb, int64_t n_docs, int64_t n_blocks, bool persistent,
-                     const Ms16Args& sa) {
+                     const Ms16Args& sa, const Ms16Pack* pk) {
+    if (pk && sa.aligned && ms16_takes_wg(idx, ncb, n_docs, n_blocks)) {
+        // the granule-packed copy (k_maxsim_wg8.h): one workgroup per CU, each a contiguous range of documents with ~1/256 of the granules
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(256, (pk->n_pblocks + 31) / 32));
+        hipLaunchKernelGGL(mi355::k_maxsim16_wg8, dim3(grid), dim3(512), (size_t)mi355::mw_lds(4), s, sa, *pk, ncb);
+        HIPCHECK(idx, hipGetLastError());
+        return MI355DR_OK;
+    }
     if (ncb == 8 && idx->maxsim_wg && idx->maxsim_wg_min <= 8 && (idx->maxsim_wg > 0 || n_blocks < 8 * n_docs)) {
         const bool now = idx->maxsim_wg == 2;
         const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(256, (n_blocks + 31) / 32));

@@ -232,7 +232,11 @@ int mi355dr_search_sharded_device(mi355dr_index* idx, const float* queries_dev, 
  *          two-wave prune, a starter over "starter_rows_wide" [65536] rows and chunk ratios up to 4; 0 = the round-5 schedule),
  *          "screen_flush_sync" (1 [default]: the waves of a k_screen_rq workgroup flush their hit-lane queues at the same tiles;
  *          "screen_flush_lanes" [48] / "screen_flush_alone" [40] tune the period), "chunk_taper_x100" (0 [default] = 120 for
- *          prune_wide passes, 100 = uniform chunk ratios otherwise), "wide_inflation_x10" (the budget's inflation figure).
+ *          prune_wide passes, 100 = uniform chunk ratios otherwise), "wide_inflation_x10" (the budget's inflation figure);
+ *          "maxsim_pack8" (MaxSim screen, passes of 32-vector queries in the workgroup form: a second bf16 shadow whose documents are
+ *          rounded up to 8-token granules instead of 32-token blocks, built on the first such pass and after every add -- -1
+ *          [default]: when it has at least 5 % fewer blocks than the padded copy and its memory is there, 1: always, 0: never;
+ *          identical results).
  * stats:   "screen_launches", "screen_ns" (profile=1), "screen_rows" (all screen launches) and their k_screen256 share
  *          "screen256_launches", "screen256_ns", "screen256_rows"; "candidates", "rescored",
  *          "fallback_queries" (queries recomputed by the exact scan), "retry_queries" (queries whose candidate list
@@ -242,7 +246,8 @@ int mi355dr_search_sharded_device(mi355dr_index* idx, const float* queries_dev, 
  *          irregular ones included), "screen_dtype_active" (MI355DR_SCREEN_BF16 / _I8: what AUTO resolves to now),
  *          "maxsim_screened" (queries served by the MaxSim screen), "maxsim_candidates" (docs re-scored exactly for them),
  *          "maxsim_fallbacks" (queries re-run by the exact full scan), "maxsim_screen_launches" / "maxsim_screen_ns" /
- *          "maxsim_exact_launches" / "maxsim_exact_ns" (profile=1), "maxsim_screen_cols" (query columns the screen launches
+ *          "maxsim_exact_launches" / "maxsim_exact_ns" (profile=1), "maxsim_packed_launches" / "maxsim_packed_blocks" (screen launches over the
+ *          granule-packed copy / its 32-token blocks), "maxsim_screen_cols" (query columns the screen launches
  *          multiplied every token by),
  *          "hbm_bytes_resident". */
 int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value);

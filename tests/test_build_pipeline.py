@@ -262,6 +262,33 @@ def test_maxsim_workgroup_screen_keeps_its_ring_in_flight(maxsim_asm_text, ncb, 
     assert any(o.startswith("s_load_dwordx2") for o in loop)
 
 
+def test_maxsim_packed_screen_folds_and_sums_in_the_mfma_shadow(maxsim_asm_text):
+    """k_maxsim16_wg8 (round 6: the granule-packed copy).  Pinned on the generated code: the ring discipline of k_maxsim16_wg's
+    pipelined form (one counted wait per stage loop, no full vector-memory wait inside, the stage one ring ahead staged by LDS-DMA,
+    token fragments only from LDS), the granule maxima folded BETWEEN the MFMAs of the next block (v_max3 only: no canonicalising
+    v_max_f32 x, x, x of raw MFMA results), the deferred per-document sums (the DPP chain) between MFMAs too, and a document cursor
+    that is scalar: no v_readfirstlane and no 64-bit VALU compare between the prologue's wait and the loops' last MFMA."""
+    name = "_ZN5mi35514k_maxsim16_wg8ENS_8Ms16ArgsENS_8Ms16PackEi"
+    ops, desc = _whole_kernel(maxsim_asm_text, name)
+    assert ".amdhsa_private_segment_fixed_size 0" in desc and not any(o.startswith("scratch_") for o in ops)
+    w12 = [i for i, o in enumerate(ops) if o.startswith("s_waitcnt") and "vmcnt(12)" in o]
+    wl = [i for i, o in enumerate(ops) if o.startswith("s_waitcnt") and "vmcnt(8)" in o]
+    assert len(w12) == 1 and len(wl) == 2 and w12[0] < wl[0]
+    mf = [i for i, o in enumerate(ops) if o.startswith("v_mfma_f32_32x32x16_bf16")]
+    assert len(mf) == 96    # 4 blocks per stage x (8 MFMAs in the one-column-block loop + 16 in the other)
+    loop = ops[w12[0] + 1:max(mf) + 1]
+    assert not any(_is_vm0(o) for o in loop), [o for o in loop if "vmcnt" in o]
+    assert sum(o.startswith("global_load_lds_dwordx4") for o in loop) == 8
+    assert not any(o.startswith(("global_load_dword", "flat_load")) for o in loop)
+    assert sum(o.startswith("ds_read_b128") for o in ops) == 16 + 8 * 4 * 2
+    assert any(o.startswith("s_load_dwordx2") for o in loop)            # granule offsets through the scalar cache
+    assert not any(o.startswith(("v_readfirstlane", "v_cmp_ge_i64", "v_cmp_gt_i64", "v_cmp_lt_i64", "v_cmp_le_i64")) for o in loop)
+    bursts = [ops[mf[i]:mf[i + 7] + 1] for i in range(0, len(mf) - 7, 8)]
+    assert max(sum(o.startswith("v_max3_f32") for o in b) for b in bursts) >= 6
+    assert max(sum(o.startswith("v_add_f32_dpp") for o in b) for b in bursts) >= 3
+    assert not any(o.startswith("v_max_f32") and len(set(o.replace(",", " ").split()[1:])) == 1 for b in bursts for o in b)
+
+
 def test_the_product_kernels_carry_no_timing_builds():
     """the screens' ablation forms (template parameter ABL: no fragment reads / tests / barrier / LDS-DMA, ...)
     live in tools/k_screen_rq_abl.h / tools/k_screen256c_abl.h for tools/screen_ab.hip; the library's headers carry the kernels

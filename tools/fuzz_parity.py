@@ -207,7 +207,8 @@ def check_maxsim(rng, case):
         idx.set_option("maxsim_wg_pipe", int(rng.random() < 0.7))
         idx.set_option("maxsim_wg_min", int(rng.integers(8, 10)))
         idx.set_option("maxsim_aligned", int(rng.random() < 0.8))
-        rng.integers(0, 2)   # (round 4-5 drew the packed-copy switch here: the draw stays so that seeds replay the same cases)
+        # (round 4-5 drew the token-packed copy's switch here; round 6: the granule-packed copy -- when it pays / always)
+        idx.set_option("maxsim_pack8", 1 if int(rng.integers(0, 2)) else -1)
         tighten = int(rng.random() < 0.7)
         idx.set_option("maxsim_tighten", tighten)
         desc += f" groups={groups} wg={wg} bps={bps} tighten={tighten}"

@@ -19,7 +19,7 @@ import time
 import numpy as np
 
 DEFAULTS = {"maxsim_wg": -1, "maxsim_pass_groups": 4, "maxsim_wg_bps": 4, "maxsim_wg_pipe": 1, "maxsim_wg_min": 8,
-            "maxsim_aligned": 1, "maxsim_tighten": 1, "maxsim_coop": -1}
+            "maxsim_aligned": 1, "maxsim_tighten": 1, "maxsim_coop": -1, "maxsim_pack8": -1}
 
 
 def build(pkg, torch, tokens: str, n_docs: int, d: int = 128):
