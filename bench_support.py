@@ -175,6 +175,8 @@ def run_maxsim(args, n_docs: int, tokens: str, nq: int, steps: int, warmup: int,
     scr_n, scr_ns = idx.stat("maxsim_screen_launches"), idx.stat("maxsim_screen_ns")
     ex_n, ex_ns = idx.stat("maxsim_exact_launches"), idx.stat("maxsim_exact_ns")
     cols_issued = idx.stat("maxsim_screen_cols") / max(scr_n, 1)  # query columns per launch, whole blocks of 32
+    # the granule-packed copy (csrc/k_maxsim_wg8.h; default: taken when it has >= 5 % fewer blocks): what the launches multiplied
+    packed_n, packed_blocks = idx.stat("maxsim_packed_launches"), idx.stat("maxsim_packed_blocks")
     probe_out = None
     if probe:  # socket power / shader clock next to ~2 s of the same steps (not timed)
         try:
@@ -182,6 +184,10 @@ def run_maxsim(args, n_docs: int, tokens: str, nq: int, steps: int, warmup: int,
         except Exception as e:  # noqa: BLE001
             probe_out = {"error": f"{type(e).__name__}: {e}"}
     blocks = int(((lens + 31) // 32).sum())
+    packed = bool(scr_n) and packed_n == scr_n and packed_blocks > 0
+    padded_blocks = blocks
+    if packed:
+        blocks = int(packed_blocks)
     n_tok = float(lens.sum())
     alg_bytes = n_tok * d * 4                                    # fp32 token rows read once per pass
     streamed = float(blocks) * 32 * d * 2                        # bf16 fragment store the screen streams, per pass
@@ -198,7 +204,9 @@ def run_maxsim(args, n_docs: int, tokens: str, nq: int, steps: int, warmup: int,
         "queries_per_s": round(steps * qblock / el, 2), "ms_per_step": round(el * 1e3 / steps, 3), "steps": steps,
         "queries_per_pass": qblock,
         "includes": "H2D of the query block, D2H of results",
-        "roofline": {"bound": "mfma", "kernel": (lambda ncb: f"k_maxsim16_wg<{ncb}>" if ncb > 8 else f"k_maxsim16_d128<{ncb}>")((qblock * nq + 31) // 32),
+        "roofline": {"bound": "mfma", "kernel": "k_maxsim16_wg8" if packed else (lambda ncb: f"k_maxsim16_wg<{ncb}>" if ncb > 8 else f"k_maxsim16_d128<{ncb}>")((qblock * nq + 31) // 32),
+                     "token_copy": (f"granule-packed bf16 copy: {blocks} blocks of 32 tokens (documents rounded up to 8 tokens; the padded "
+                                    f"copy has {padded_blocks})" if packed else f"padded bf16 copy: {blocks} blocks of 32 tokens"),
                      "op": "bf16 flops (v_mfma_f32_32x32x16_bf16)",
                      "achieved": round(alg_flops / scr_s / 1e12, 2) if scr_n else None,
                      "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
