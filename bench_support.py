@@ -132,6 +132,9 @@ def run_maxsim(args, n_docs: int, tokens: str, nq: int, steps: int, warmup: int,
     idx = pkg.Mi355Index(d, "cosine", device=dev.index)
     if os.environ.get("MI355DR_MAXSIM_PERSISTENT") is not None:   # developer A/B
         idx.set_option("maxsim_persistent", int(os.environ["MI355DR_MAXSIM_PERSISTENT"]))
+    for kv in getattr(args, "opt", []):   # (library options as KEY=VALUE, like the single-vector workload: A/B runs and tests)
+        key, _, val = kv.partition("=")
+        idx.set_option(key, int(val))
     g = torch.Generator(device=dev)
     g.manual_seed(777)
     t_build = time.perf_counter()

@@ -96,7 +96,15 @@ def test_maxsim_leg_reports_the_mfma_roofline_from_the_timed_steps(native_built)
     d = _bench("--workload", "maxsim", "--tokens", "text", "--docs", "60000", "--steps", "6", "--warmup", "1", "--no-cpu-baseline")
     assert d["metric"] == "queries/sec" and d["value"] > 0 and "workload" in d["config"]
     r = d["roofline"]
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["kernel"].startswith("k_maxsim16_wg<16>")
+    # (round 6: a store of passages is screened over its granule-packed copy -- the line names the kernel and the copy it multiplied)
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["kernel"] == "k_maxsim16_wg8" and "granule-packed" in r["token_copy"]
     assert r["launches"] == 6 and 0 < r["achieved"] <= r["issued_tflops"] * 1.001 < r["peak"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac_of_power_limited_stream"] < 1.3
     assert d["extra"]["exact_full_scan_fallbacks"] == 0 and 0 < d["extra"]["candidates_per_query"] < 2000
+    # the padded copy on request: the same algorithmic flops over more issued ones, the same answers' statistics
+    d0 = _bench("--workload", "maxsim", "--tokens", "text", "--docs", "60000", "--steps", "6", "--warmup", "1", "--no-cpu-baseline",
+                "--no-extras", "--opt", "maxsim_pack8=0")
+    r0 = d0["roofline"]
+    assert r0["kernel"].startswith("k_maxsim16_wg<16>") and r0["token_copy"].startswith("padded")
+    assert r0["launches"] == 6 and r0["issued_tflops"] / r0["achieved"] > r["issued_tflops"] / r["achieved"] * 1.05
+    assert d0["extra"]["candidates_per_query"] == d["extra"]["candidates_per_query"]
