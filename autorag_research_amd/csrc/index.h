@@ -166,6 +166,7 @@ struct mi355dr_index {
     int64_t s_ms_screen_ns = 0, s_ms_screen_launches = 0, s_ms_exact_ns = 0, s_ms_exact_launches = 0, s_ms_pack_ns = 0;
     int64_t s_ms_packed_launches = 0;  // screen launches that took the granule-packed copy (k_maxsim_wg8.h)
     int64_t s_ms_packed_blocks = 0;    // ... and the 32-token blocks of that copy (0: none built)
+    int64_t s_ms_packed_built = 0;     // blocks k_ms_pack8 has written since the index was created (a store that grows is packed from its new granules on)
     int64_t s_ms_screen_cols = 0;  // query-vector columns (whole blocks of 32) the screen launches multiplied every token by
     hipEvent_t ms_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<mi355::EventPair> ev_pool, ev_pending;

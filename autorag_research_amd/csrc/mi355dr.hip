@@ -1304,6 +1304,7 @@ int mi355dr_get_stat(mi355dr_index* idx, const char* key, int64_t* out) {
     else if (k == "maxsim_screen_cols") *out = idx->s_ms_screen_cols;
     else if (k == "maxsim_packed_launches") *out = idx->s_ms_packed_launches;
     else if (k == "maxsim_packed_blocks") *out = idx->s_ms_packed_blocks;
+    else if (k == "maxsim_packed_built") *out = idx->s_ms_packed_built;
     else if (k == "irregular_rows") *out = idx->irr_n;
     else if (k == "loose_rows") *out = idx->irr8_n;
     else if (k == "screen_dtype_active") *out = use_i8(idx) ? MI355DR_SCREEN_I8 : MI355DR_SCREEN_BF16;

@@ -892,8 +892,8 @@ namespace {
 // stream's last token (no workgroup ever folds them).
 __global__ __launch_bounds__(64) void k_ms_pack8(const uint4* __restrict__ tok16, const int64_t* __restrict__ blk_off,
                                                  const int32_t* __restrict__ tok_cnt, const int64_t* __restrict__ goff,
-                                                 int64_t n_docs, int64_t n_gran, int nkk, uint4* __restrict__ out) {
-    const int64_t p = blockIdx.x;
+                                                 int64_t n_docs, int64_t n_gran, int nkk, uint4* __restrict__ out, int64_t p0) {
+    const int64_t p = p0 + blockIdx.x;
     const int lane = threadIdx.x, r = lane & 31, hf = lane >> 5;
     int64_t gi = p * 4 + (r >> 3);
     int rr = r & 7;
@@ -917,6 +917,10 @@ __global__ __launch_bounds__(64) void k_ms_pack8(const uint4* __restrict__ tok16
 // held, before a screen launch on stream `s` that could take it.  A failed allocation is not an error: the padded copy serves.
 int ms_pack8_ensure(mi355dr_index* idx, MultiVecStore* m, hipStream_t s) {
     if (m->pack_docs == m->n_docs && (m->pack_use || m->pack_mode == idx->maxsim_pack8)) return MI355DR_OK;
+    // a store that grew since the copy was built is packed from the block its new granules start in (an ingest loop that searches
+    // between its adds pays for the new documents only); a copy that was never built, was judged not to pay, or must move is
+    // packed whole
+    int64_t first_block = m->pack_use && m->pack_docs >= 0 && m->pack_docs < m->n_docs ? m->pack_gran / 4 : 0;
     m->pack_docs = m->n_docs;
     m->pack_mode = idx->maxsim_pack8;
     m->pack_use = false;
@@ -928,6 +932,7 @@ int ms_pack8_ensure(mi355dr_index* idx, MultiVecStore* m, hipStream_t s) {
     if (n_gran == 0) return MI355DR_OK;
     if (idx->maxsim_pack8 < 0 && (double)n_pb > 0.95 * (double)m->n_blocks) return MI355DR_OK;  // (long documents: nothing to gain)
     if (n_pb > m->pack_cap_blocks) {
+        first_block = 0;
         if (m->tok16p) (void)hipFree(m->tok16p);
         m->tok16p = nullptr;
         m->pack_cap_blocks = 0;
@@ -961,9 +966,12 @@ int ms_pack8_ensure(mi355dr_index* idx, MultiVecStore* m, hipStream_t s) {
     } free_cnt{cnt};
     HIPCHECK(idx, hipMemcpyAsync(cnt, m->tok_cnt_host.data(), (size_t)m->n_docs * sizeof(int32_t), hipMemcpyHostToDevice, s));
     HIPCHECK(idx, hipMemcpyAsync(m->goff, goff.data(), goff.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_ms_pack8, dim3((unsigned)n_pb), dim3(64), 0, s, m->tok16, m->blk_off, cnt, m->goff, m->n_docs, n_gran, m->nkk,
-                       m->tok16p);
-    HIPCHECK(idx, hipGetLastError());
+    if (n_pb > first_block) {  // (new documents without vectors add no granule)
+        hipLaunchKernelGGL(k_ms_pack8, dim3((unsigned)(n_pb - first_block)), dim3(64), 0, s, m->tok16, m->blk_off, cnt, m->goff, m->n_docs,
+                           n_gran, m->nkk, m->tok16p, first_block);
+        HIPCHECK(idx, hipGetLastError());
+        idx->s_ms_packed_built += n_pb - first_block;
+    }
     HIPCHECK(idx, hipStreamSynchronize(s));  // (the host vectors above are the copies' sources)
     m->pack_gran = n_gran;
     m->pack_blocks = n_pb;

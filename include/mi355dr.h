@@ -246,8 +246,8 @@ int mi355dr_search_sharded_device(mi355dr_index* idx, const float* queries_dev, 
  *          irregular ones included), "screen_dtype_active" (MI355DR_SCREEN_BF16 / _I8: what AUTO resolves to now),
  *          "maxsim_screened" (queries served by the MaxSim screen), "maxsim_candidates" (docs re-scored exactly for them),
  *          "maxsim_fallbacks" (queries re-run by the exact full scan), "maxsim_screen_launches" / "maxsim_screen_ns" /
- *          "maxsim_exact_launches" / "maxsim_exact_ns" (profile=1), "maxsim_packed_launches" / "maxsim_packed_blocks" (screen launches over the
- *          granule-packed copy / its 32-token blocks), "maxsim_screen_cols" (query columns the screen launches
+ *          "maxsim_exact_launches" / "maxsim_exact_ns" (profile=1), "maxsim_packed_launches" / "maxsim_packed_blocks" / "maxsim_packed_built" (screen launches over the
+ *          granule-packed copy / its 32-token blocks / blocks written into it so far: a store that grows is packed from its new granules on), "maxsim_screen_cols" (query columns the screen launches
  *          multiplied every token by),
  *          "hbm_bytes_resident". */
 int mi355dr_set_option(mi355dr_index* idx, const char* key, int64_t value);

@@ -104,6 +104,23 @@ def test_pack8_follows_the_store_and_the_pass_shape(pkg, oracle):
         off_all = np.concatenate([off, off[-1] + off2[1:]])
         _same(idx.search_maxsim(qa, oa, k), oracle.maxsim_topk(tok_all, off_all, qa, oa, k))
         assert idx.stat("maxsim_packed_launches") == 2 and idx.stat("maxsim_packed_blocks") > b1
+        # documents without vectors add no granule (nothing to pack)
+        empty = np.zeros((0, 128), np.float32)
+        idx.add_multivec(empty, np.zeros(4, np.int64))
+        off_all = np.concatenate([off_all, np.full(3, off_all[-1])])
+        built0, blocks0 = idx.stat("maxsim_packed_built"), idx.stat("maxsim_packed_blocks")
+        _same(idx.search_maxsim(qa, oa, k), oracle.maxsim_topk(tok_all, off_all, qa, oa, k))
+        assert idx.stat("maxsim_packed_built") - built0 <= 1 and idx.stat("maxsim_packed_blocks") == blocks0
+        # a store that grows is packed from the block its new granules start in (an ingest loop that searches between its adds):
+        # five small adds write their own blocks and the block each shares with what was there, not the copy five times over
+        for i in range(5):
+            t3, o3 = _store(rng, rng.integers(0, 40, size=37))
+            idx.add_multivec(t3, o3)
+            tok_all = np.concatenate([tok_all, t3])
+            off_all = np.concatenate([off_all, off_all[-1] + o3[1:]])
+            _same(idx.search_maxsim(qa, oa, k), oracle.maxsim_topk(tok_all, off_all, qa, oa, k))
+        grown = idx.stat("maxsim_packed_blocks") - blocks0
+        assert 0 < grown and idx.stat("maxsim_packed_built") - built0 <= grown + 7
     tokp, offp = _store(rng, [515] * 60)                   # pages: 16.1 blocks padded to 17 -- the packed copy would save 4 %
     with pkg.Mi355Index(128) as idx:
         idx.add_multivec(tokp, offp)
