@@ -118,8 +118,14 @@ __global__ __launch_bounds__(kMsThreads, 2) void k_maxsim16(Ms16Args a) {
 // NW = waves per workgroup: 4 while two workgroups fit a CU (<= 8 column blocks = 64 KiB of query fragments each), 8 beyond
 // (one workgroup per CU by LDS: still two waves per SIMD).  A wave's documents do not depend on NW's siblings: no barrier
 // after the staging.
-template <int NCB, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void k_maxsim16_d128(Ms16Args a) {
+// PK (round 6): the same walk over the GRANULE-PACKED copy (k_maxsim_wg8.h: documents rounded up to 8 tokens, the stream cut into 32-token
+// blocks wherever they fall).  A document's first and last block may hold a neighbour's granules: their lanes are not loaded (a
+// granule of one k-group half is one 128-byte line: the pass reads the document's own bytes only -- 10 % fewer on a store of
+// passages, and up to ~8 column blocks this form is bound by exactly those bytes), and since register quad j of the accumulator IS
+// granule j of the block (both wave halves), a boundary block's maximum is taken over the document's quads only.  The rows of
+// lanes that were not loaded multiply whatever the registers held: an MFMA's rows do not mix, and their quads are never looked at.
+template <int NCB, int NW, bool PK>
+__global__ __launch_bounds__(NW * 64, 2) void k_maxsim16_d128(Ms16Args a, Ms16Pack pk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4* qs = (uint4*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -135,21 +141,47 @@ __global__ __launch_bounds__(NW * 64, 2) void k_maxsim16_d128(Ms16Args a) {
     // 4 % slower on 100 k pages -- the default grid is one round.
     for (int64_t round = 0; round * ((int64_t)gridDim.x * NW * kMsDocsPerWave) < a.n_docs; ++round) {
     int64_t dq[kMsDocsPerWave], db0[kMsDocsPerWave], dnb[kMsDocsPerWave];
+    int dlo[kMsDocsPerWave], dhi[kMsDocsPerWave];  // (PK) granules of the first block in front of the document, of the last block that are its own
 #pragma unroll
     for (int dw = 0; dw < kMsDocsPerWave; ++dw) {
         dq[dw] = ((round * kMsDocsPerWave + dw) * (int64_t)gridDim.x + blockIdx.x) * NW + wave;
         const bool live = dq[dw] < a.n_docs;
-        db0[dw] = live ? a.blk_off[dq[dw]] : 0;
-        dnb[dw] = live ? a.blk_off[dq[dw] + 1] - db0[dw] : 0;
+        dlo[dw] = 0;
+        dhi[dw] = 4;
+        if constexpr (PK) {
+            const int64_t g0 = live ? pk.goff[dq[dw]] : 0, g1 = live ? pk.goff[dq[dw] + 1] : 0;
+            db0[dw] = g0 >> 2;
+            dnb[dw] = g1 > g0 ? ((g1 + 3) >> 2) - (g0 >> 2) : 0;
+            dlo[dw] = (int)(g0 & 3);
+            dhi[dw] = (int)(g1 - (((g1 + 3) >> 2) - 1) * 4);  // 1..4 (unused when the document is empty)
+        } else {
+            db0[dw] = live ? a.blk_off[dq[dw]] : 0;
+            dnb[dw] = live ? a.blk_off[dq[dw] + 1] - db0[dw] : 0;
+        }
         if (!live) dq[dw] = -1;
     }
     uint4 pa[8], pb[8];
-    auto load = [&](uint4(&dst)[8], const uint4* src) {
+    if constexpr (PK) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) dst[i] = src[i * 64];
+        for (int i = 0; i < 8; ++i) pa[i] = pb[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    // (PK) granule range [jlo, jhi) of a document's block p: all four but in its first and last block
+    auto lo_of = [&](int dw, int64_t p) { return p == 0 ? dlo[dw] : 0; };
+    auto hi_of = [&](int dw, int64_t p) { return p == dnb[dw] - 1 ? dhi[dw] : 4; };
+    auto load = [&](uint4(&dst)[8], const uint4* src, int jlo, int jhi) {
+        if constexpr (PK) {
+            const int gr = (lane & 31) >> 3;  // this lane's granule of the block
+            if (gr >= jlo && gr < jhi) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dst[i] = src[i * 64];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dst[i] = src[i * 64];
+        }
     };
     float run[NCB];
-    auto block = [&](const uint4(&fr)[8]) {
+    auto block = [&](const uint4(&fr)[8], int jlo, int jhi) {
         // Up to 8 column blocks the compiler keeps as many query fragments in registers as fit (they are loop-invariant) and
         // reads the rest per MFMA.  Beyond 8 that hoisting only costs: 16 blocks x 32 VGPRs cannot stay, and what it keeps anyway
         // pushes the kernel into scratch (10 spilled VGPRs at 16 blocks).  There the base pointer is made opaque once per token
@@ -167,42 +199,61 @@ __global__ __launch_bounds__(NW * 64, 2) void k_maxsim16_d128(Ms16Args a) {
             for (int i = 1; i < 8; ++i)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ms_bf16x8, fr[i]),
                                                               __builtin_bit_cast(ms_bf16x8, qlb[(cb * 8 + i) * 64]), acc, 0, 0, 0);
-            float m = acc[0];
+            float m;
+            if (!PK || (jlo == 0 && jhi == 4)) {  // (wave-uniform)
+                m = acc[0];
 #pragma unroll
-            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+            } else {  // a boundary block of the packed copy: the document's own quads
+                m = -__builtin_inff();
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j >= jlo && j < jhi) m = fmaxf(m, fmaxf(fmaxf(acc[4 * j], acc[4 * j + 1]), fmaxf(acc[4 * j + 2], acc[4 * j + 3])));
+            }
             run[cb] = fmaxf(run[cb], m);  // (the two halves of the wave are combined once per doc, below)
         }
     };
-    auto blk_ptr = [&](int dw, int64_t p) { return a.tok16 + (db0[dw] + p) * (8 * 64) + lane; };
+    auto blk_ptr = [&](int dw, int64_t p) { return (PK ? pk.tok16p : a.tok16) + (db0[dw] + p) * (8 * 64) + lane; };
     // first block of the first non-empty document
     int parity = 0;
     {
         const uint4* first = nullptr;
+        int flo = 0, fhi = 4;
 #pragma unroll
         for (int f = kMsDocsPerWave - 1; f >= 0; --f)
-            if (dnb[f] > 0) first = blk_ptr(f, 0);
-        if (first) load(pa, first);
+            if (dnb[f] > 0) {
+                first = blk_ptr(f, 0);
+                flo = lo_of(f, 0);
+                fhi = hi_of(f, 0);
+            }
+        if (first) load(pa, first, flo, fhi);
     }
 #pragma unroll
     for (int dw = 0; dw < kMsDocsPerWave; ++dw) {
         const int64_t doc = dq[dw];
         if (doc < 0) break;
         const uint4* first_next = nullptr;  // first block of the next non-empty document of this wave
+        int fn_lo = 0, fn_hi = 4;
 #pragma unroll
         for (int f = kMsDocsPerWave - 1; f > dw; --f)
-            if (dnb[f] > 0) first_next = blk_ptr(f, 0);
+            if (dnb[f] > 0) {
+                first_next = blk_ptr(f, 0);
+                fn_lo = lo_of(f, 0);
+                fn_hi = hi_of(f, 0);
+            }
         const int64_t nb = dnb[dw];
 #pragma unroll
         for (int c = 0; c < NCB; ++c) run[c] = -__builtin_inff();
         for (int64_t p = 0; p < nb; ++p) {
             // the block after this one: the next of this document, or the first of the next non-empty one
             const uint4* nxt = p + 1 < nb ? blk_ptr(dw, p + 1) : first_next;
+            const int n_lo = p + 1 < nb ? 0 : fn_lo, n_hi = p + 1 < nb ? hi_of(dw, p + 1) : fn_hi;
             if (parity == 0) {
-                if (nxt) load(pb, nxt);
-                block(pa);
+                if (nxt) load(pb, nxt, n_lo, n_hi);
+                block(pa, lo_of(dw, p), hi_of(dw, p));
             } else {
-                if (nxt) load(pa, nxt);
-                block(pb);
+                if (nxt) load(pa, nxt, n_lo, n_hi);
+                block(pb, lo_of(dw, p), hi_of(dw, p));
             }
             parity ^= 1;
         }
@@ -247,17 +298,22 @@ __global__ __launch_bounds__(NW * 64, 2) void k_maxsim16_d128(Ms16Args a) {
 // ---- k_maxsim16_d128<NCB, NW> by run-time NCB (1 .. kMsPassBlocks): NW = 4 up to 8 column blocks, 8 beyond ----
 namespace mi355 {
 namespace {
-typedef void (*Ms16Kernel)(mi355::Ms16Args);
-template <int NCB>
+typedef void (*Ms16Kernel)(mi355::Ms16Args, mi355::Ms16Pack);
+template <int NCB, bool PK>
 constexpr Ms16Kernel ms16_kernel_of() {
-    if constexpr (NCB <= 8) return mi355::k_maxsim16_d128<NCB, 4>;
-    else return mi355::k_maxsim16_d128<NCB, 8>;
+    if constexpr (NCB <= 8) return mi355::k_maxsim16_d128<NCB, 4, PK>;
+    else return mi355::k_maxsim16_d128<NCB, 8, PK>;
 }
-template <int... I>
+template <bool PK, int... I>
 constexpr std::array<Ms16Kernel, sizeof...(I)> ms16_table(std::integer_sequence<int, I...>) {
-    return {ms16_kernel_of<I + 1>()...};
+    return {ms16_kernel_of<I + 1, PK>()...};
 }
-const std::array<Ms16Kernel, mi355::kMsPassBlocks> kMs16Kernels = ms16_table(std::make_integer_sequence<int, mi355::kMsPassBlocks>{});
+const std::array<Ms16Kernel, mi355::kMsPassBlocks> kMs16Kernels = ms16_table<false>(std::make_integer_sequence<int, mi355::kMsPassBlocks>{});
+// ... over the granule-packed copy: ONE or TWO column blocks -- the passes of one or two queries, which are bound by the token stream's
+// bytes (measured, 1 M passages: one query per call 5.00 -> 4.55 ms).  From 3 blocks up the boundary logic's live state on top of the
+// hoisted query fragments spills, and without the hoisting the pass is slower than over the padded copy (4 queries: 5.49 -> 6.07 ms)
+constexpr int kMs16PkMaxNcb = 2;
+const std::array<Ms16Kernel, kMs16PkMaxNcb> kMs16PkKernels = ms16_table<true>(std::make_integer_sequence<int, kMs16PkMaxNcb>{});
 inline int ms16_waves(int ncb) { return ncb <= 8 ? 4 : 8; }
 
 // the workgroup-cooperative form (k_maxsim_wg.h) for 9 .. 16 column blocks
@@ -337,7 +393,9 @@ int ms16_d128_launch(mi355dr_index* idx, hipStream_t s, int ncb, int64_t n_docs,
     const unsigned resident = ncb <= 10 && nw == 4 ? 512u : 256u;
     const unsigned rounds = persistent ? (grid_docs + resident - 1) / resident : 1u;
     const unsigned grid = std::max(1u, (grid_docs + rounds - 1) / std::max(rounds, 1u));
-    hipLaunchKernelGGL(kMs16Kernels[ncb - 1], dim3(grid), dim3(nw * 64), (size_t)ncb * 8 * 64 * sizeof(uint4), s, sa);
+    const bool pk8 = pk && ncb <= kMs16PkMaxNcb;
+    hipLaunchKernelGGL(pk8 ? kMs16PkKernels[ncb - 1] : kMs16Kernels[ncb - 1], dim3(grid), dim3(nw * 64), (size_t)ncb * 8 * 64 * sizeof(uint4), s, sa,
+                       pk8 ? *pk : mi355::Ms16Pack{});
     HIPCHECK(idx, hipGetLastError());
     return MI355DR_OK;
 }

@@ -79,10 +79,36 @@ def test_pack8_equals_padded_and_oracle(pkg, oracle, shape, nq):
         assert idx.stat("maxsim_packed_blocks") > 0
 
 
+@pytest.mark.parametrize("shape", list(SHAPES))
+@pytest.mark.parametrize("qlens", [[32], [20, 7, 32], [24, 24], [1], [64], [31, 0, 5], [9, 20, 0, 30]])
+def test_pack8_small_passes_one_wave_per_document(pkg, oracle, shape, qlens):
+    """A pass of one or two column blocks -- one or two queries per call, the reference's call shape -- takes one wave per document
+    (k_maxsim16_d128) over the packed copy too: a document's first and last block are shared with its neighbours, whose lanes are not
+    loaded and whose accumulator quads are not looked at.  Any query layout (queries packed column after column, a query may straddle
+    the two blocks), every document shape; pack 1 == pack 0 == oracle."""
+    rng = np.random.default_rng(len(shape) * 31 + sum(qlens))
+    tok, off = _store(rng, SHAPES[shape](rng))
+    qtok, qoff = _queries(rng, [t for t in qlens])
+    k = 7
+    want = oracle.maxsim_topk(tok, off, qtok, qoff, k)
+    live = np.asarray(qlens) > 0
+    with pkg.Mi355Index(128) as idx:
+        idx.add_multivec(tok, off)
+        cands = {}
+        for pack in (0, 1):
+            idx.set_option("maxsim_pack8", pack)
+            idx.reset_stats()
+            d, r = idx.search_maxsim(qtok, qoff, k)
+            cands[pack] = idx.stat("maxsim_candidates")
+            assert (idx.stat("maxsim_packed_launches") > 0) == (pack == 1)
+            _same((d[live], r[live]), (want[0][live], want[1][live]))
+        assert cands[0] == cands[1]
+
+
 def test_pack8_follows_the_store_and_the_pass_shape(pkg, oracle):
-    """The packed copy is a shadow of the store: stale after an add (rebuilt on the next aligned pass, device and host adds alike), not
-    taken by passes that are not aligned (24-vector queries) or that take one wave per document (few column blocks), and in the
-    default mode (-1) not built for stores it would not shorten (long documents: pages)."""
+    """The packed copy is a shadow of the store: stale after an add (extended by the next pass that takes it), not taken by passes
+    of the workgroup form that are not aligned (24-vector queries), taken by passes of up to 8 column blocks whatever their queries,
+    and in the default mode (-1) not built for stores it would not shorten (long documents: pages)."""
     rng = np.random.default_rng(8)
     k = 5
     qa, oa = _queries(rng, [32] * 12)
@@ -97,13 +123,16 @@ def test_pack8_follows_the_store_and_the_pass_shape(pkg, oracle):
         assert idx.stat("maxsim_packed_launches") == 1     # default mode: 1..89-token documents lose a fifth of their blocks
         b1 = idx.stat("maxsim_packed_blocks")
         _same(idx.search_maxsim(qn, on, k), oracle.maxsim_topk(tok, off, qn, on, k))
+        assert idx.stat("maxsim_packed_launches") == 1     # 9 column blocks of 24-vector queries: the padded copy
         _same(idx.search_maxsim(q4, o4, k), oracle.maxsim_topk(tok, off, q4, o4, k))
-        assert idx.stat("maxsim_packed_launches") == 1     # neither of the two took it
+        assert idx.stat("maxsim_packed_launches") == 1     # 4 column blocks: one wave per document, over the padded copy (hoisted fragments)
+        _same(idx.search_maxsim(q4[:32], o4[:2], k), oracle.maxsim_topk(tok, off, q4[:32], o4[:2], k))
+        assert idx.stat("maxsim_packed_launches") == 2     # one query: one wave per document, over the packed copy
         idx.add_multivec(tok2, off2)                        # the store grows: the copy is rebuilt for the next aligned pass
         tok_all = np.concatenate([tok, tok2])
         off_all = np.concatenate([off, off[-1] + off2[1:]])
         _same(idx.search_maxsim(qa, oa, k), oracle.maxsim_topk(tok_all, off_all, qa, oa, k))
-        assert idx.stat("maxsim_packed_launches") == 2 and idx.stat("maxsim_packed_blocks") > b1
+        assert idx.stat("maxsim_packed_launches") == 3 and idx.stat("maxsim_packed_blocks") > b1
         # documents without vectors add no granule (nothing to pack)
         empty = np.zeros((0, 128), np.float32)
         idx.add_multivec(empty, np.zeros(4, np.int64))
