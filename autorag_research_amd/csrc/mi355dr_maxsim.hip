@@ -1347,10 +1347,10 @@ static int search_maxsim_impl(mi355dr_index* idx, const float* qtok, const int32
         if (nkk == 8) {  // dims <= 128: the compile-time-unrolled forms, only as many column blocks as the pass has
             Ms16Pack pk{};
             bool packed = false;
-            // the granule-packed copy serves the workgroup form's aligned passes (k_maxsim_wg8.h) and the passes of one or two column
-            // blocks (k_maxsim16_d128<.., PK>: one or two queries per call are bound by the token stream's bytes: 10 % fewer)
+            // the granule-packed copy serves the workgroup form's aligned passes (k_maxsim_wg8.h) and the passes of up to four column
+            // blocks (k_maxsim16_d128<.., PK>: one to four queries per call are bound by the token stream's bytes: 10 % fewer)
             const bool wg_form = ms16_takes_wg(idx, ncb_launch, m->n_docs, m->n_blocks);
-            if (idx->maxsim_pack8 != 0 && (wg_form ? sa.aligned != 0 : ncb_launch <= 2)) {
+            if (idx->maxsim_pack8 != 0 && (wg_form ? sa.aligned != 0 : ncb_launch <= 4)) {
                 CHECK(ms_pack8_ensure(idx, m, s));
                 if (m->pack_use) {
                     pk.tok16p = m->tok16p;

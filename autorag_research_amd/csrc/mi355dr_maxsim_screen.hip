@@ -128,7 +128,10 @@ template <int NCB, int NW, bool PK>
 __global__ __launch_bounds__(NW * 64, 2) void k_maxsim16_d128(Ms16Args a, Ms16Pack pk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4* qs = (uint4*)smem;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // (PK: the wave index said to be uniform -- the documents' block ranges and boundary granules then live in SGPRs, which is what
+    // keeps the packed form's extra state from spilling next to the hoisted query fragments)
+    const int wave = PK ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
     for (int i = tid; i < NCB * 8 * 64; i += NW * 64) qs[i] = a.qfrag[i];
     __syncthreads();
     const uint4* const ql = qs + lane;
@@ -189,7 +192,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_maxsim16_d128(Ms16Args a, Ms16Pa
         // what the LDS delivers.
         typedef const __attribute__((address_space(3))) uint4 lds_uint4;
         unsigned qoff = (unsigned)(unsigned long)((const __attribute__((address_space(3))) char*)(const char*)ql);
-        if constexpr (NCB > 8) asm volatile("" : "+v"(qoff));  // (an LDS byte offset: the reads stay ds_read_b128, not FLAT)
+        // (PK at 4 blocks: what the compiler hoists there on top of the boundary logic's state spills)
+        if constexpr (NCB > 8 || (PK && NCB == 4)) asm volatile("" : "+v"(qoff));  // (an LDS byte offset: the reads stay ds_read_b128, not FLAT)
         lds_uint4* const qlb = (lds_uint4*)(unsigned long)qoff;
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
@@ -309,10 +313,12 @@ constexpr std::array<Ms16Kernel, sizeof...(I)> ms16_table(std::integer_sequence<
     return {ms16_kernel_of<I + 1, PK>()...};
 }
 const std::array<Ms16Kernel, mi355::kMsPassBlocks> kMs16Kernels = ms16_table<false>(std::make_integer_sequence<int, mi355::kMsPassBlocks>{});
-// ... over the granule-packed copy: ONE or TWO column blocks -- the passes of one or two queries, which are bound by the token stream's
-// bytes (measured, 1 M passages: one query per call 5.00 -> 4.55 ms).  From 3 blocks up the boundary logic's live state on top of the
-// hoisted query fragments spills, and without the hoisting the pass is slower than over the padded copy (4 queries: 5.49 -> 6.07 ms)
-constexpr int kMs16PkMaxNcb = 2;
+// ... over the granule-packed copy: up to FOUR column blocks -- the passes of one to four queries, which are bound by the token stream's
+// bytes.  Measured, 1 M passages, 1 / 2 / 3 / 4 / 5 / 6 / 7 queries of 32 vectors per call, padded -> packed: 5.05 -> 4.53, 5.08 -> 4.55,
+// 5.15 -> 4.85, 5.44 -> 5.36, 6.09 -> 6.07, 6.87 -> 6.90, 7.67 -> 9.16 ms (profiles/r06_maxsim_pack8_ab.txt, table 10): beyond four blocks
+// the pass is no longer bound by bytes.  (At 4 and 5 blocks the query fragments are read per MFMA: hoisted on top of the boundary
+// logic's state they spill.)
+constexpr int kMs16PkMaxNcb = 4;
 const std::array<Ms16Kernel, kMs16PkMaxNcb> kMs16PkKernels = ms16_table<true>(std::make_integer_sequence<int, kMs16PkMaxNcb>{});
 inline int ms16_waves(int ncb) { return ncb <= 8 ? 4 : 8; }
 

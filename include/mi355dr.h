@@ -233,7 +233,7 @@ int mi355dr_search_sharded_device(mi355dr_index* idx, const float* queries_dev, 
  *          "screen_flush_sync" (1 [default]: the waves of a k_screen_rq workgroup flush their hit-lane queues at the same tiles;
  *          "screen_flush_lanes" [48] / "screen_flush_alone" [40] tune the period), "chunk_taper_x100" (0 [default] = 120 for
  *          prune_wide passes, 100 = uniform chunk ratios otherwise), "wide_inflation_x10" (the budget's inflation figure);
- *          "maxsim_pack8" (MaxSim screen, passes of 32-vector queries in the workgroup form and passes of one / two column blocks: a second bf16 shadow whose documents are
+ *          "maxsim_pack8" (MaxSim screen, passes of 32-vector queries in the workgroup form and passes of up to four column blocks: a second bf16 shadow whose documents are
  *          rounded up to 8-token granules instead of 32-token blocks, built on the first such pass and extended by the next one after an add -- -1
  *          [default]: when it has at least 5 % fewer blocks than the padded copy and its memory is there, 1: always, 0: never;
  *          identical results).

@@ -80,12 +80,12 @@ def test_pack8_equals_padded_and_oracle(pkg, oracle, shape, nq):
 
 
 @pytest.mark.parametrize("shape", list(SHAPES))
-@pytest.mark.parametrize("qlens", [[32], [20, 7, 32], [24, 24], [1], [64], [31, 0, 5], [9, 20, 0, 30]])
+@pytest.mark.parametrize("qlens", [[32], [20, 7, 32], [24, 24], [1], [64], [31, 0, 5], [9, 20, 0, 30], [32] * 3, [24] * 5, [100, 28], [32, 31, 33, 32]])
 def test_pack8_small_passes_one_wave_per_document(pkg, oracle, shape, qlens):
-    """A pass of one or two column blocks -- one or two queries per call, the reference's call shape -- takes one wave per document
-    (k_maxsim16_d128) over the packed copy too: a document's first and last block are shared with its neighbours, whose lanes are not
+    """A pass of up to four column blocks -- one to four queries per call: the reference's call shape and small batches -- takes one
+    wave per document (k_maxsim16_d128) over the packed copy too: a document's first and last block are shared with its neighbours, whose lanes are not
     loaded and whose accumulator quads are not looked at.  Any query layout (queries packed column after column, a query may straddle
-    the two blocks), every document shape; pack 1 == pack 0 == oracle."""
+    blocks), every document shape; pack 1 == pack 0 == oracle."""
     rng = np.random.default_rng(len(shape) * 31 + sum(qlens))
     tok, off = _store(rng, SHAPES[shape](rng))
     qtok, qoff = _queries(rng, [t for t in qlens])
@@ -125,9 +125,10 @@ def test_pack8_follows_the_store_and_the_pass_shape(pkg, oracle):
         _same(idx.search_maxsim(qn, on, k), oracle.maxsim_topk(tok, off, qn, on, k))
         assert idx.stat("maxsim_packed_launches") == 1     # 9 column blocks of 24-vector queries: the padded copy
         _same(idx.search_maxsim(q4, o4, k), oracle.maxsim_topk(tok, off, q4, o4, k))
-        assert idx.stat("maxsim_packed_launches") == 1     # 4 column blocks: one wave per document, over the padded copy (hoisted fragments)
-        _same(idx.search_maxsim(q4[:32], o4[:2], k), oracle.maxsim_topk(tok, off, q4[:32], o4[:2], k))
-        assert idx.stat("maxsim_packed_launches") == 2     # one query: one wave per document, over the packed copy
+        assert idx.stat("maxsim_packed_launches") == 2     # 4 column blocks: one wave per document, over the packed copy
+        q5, o5 = _queries(rng, [32] * 5)
+        _same(idx.search_maxsim(q5, o5, k), oracle.maxsim_topk(tok, off, q5, o5, k))
+        assert idx.stat("maxsim_packed_launches") == 2     # 5 column blocks: one wave per document, over the padded copy
         idx.add_multivec(tok2, off2)                        # the store grows: the copy is rebuilt for the next aligned pass
         tok_all = np.concatenate([tok, tok2])
         off_all = np.concatenate([off, off[-1] + off2[1:]])
