@@ -129,9 +129,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_maxsim16_d128(Ms16Args a, Ms16Pa
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4* qs = (uint4*)smem;
     const int tid = threadIdx.x, lane = tid & 63;
-    // (PK: the wave index said to be uniform -- the documents' block ranges and boundary granules then live in SGPRs, which is what
-    // keeps the packed form's extra state from spilling next to the hoisted query fragments)
-    const int wave = PK ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
+    // (the wave index said to be uniform: the documents' block ranges -- and the packed form's boundary granules -- then live in
+    // SGPRs.  That is what keeps PK from spilling next to the hoisted query fragments, and the padded form gains from it too:
+    // 5 x 32-vector queries over 1 M passages 6.10 -> 5.74 ms, everything else within noise; profiles/r06_maxsim_pack8_ab.txt, table 11)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < NCB * 8 * 64; i += NW * 64) qs[i] = a.qfrag[i];
     __syncthreads();
     const uint4* const ql = qs + lane;

@@ -291,29 +291,37 @@ class ShardedSearcher:
             dev = torch.device("cuda", self.device)
             q_offsets = np.ascontiguousarray(q_offsets, dtype=np.int32)
             B = q_offsets.shape[0] - 1
-            qd = torch.from_numpy(np.ascontiguousarray(qtok, dtype=np.float32)).to(dev)
-            d32 = torch.empty((B, k), dtype=torch.float32, device=dev)
-            packed = torch.empty((2, B, k), dtype=torch.int64, device=dev)
-            cur = torch.cuda.current_stream(dev)
-            # torch's default stream has handle 0, which the library reads as "no stream to wait for": the upload of `qd` and
-            # the caching allocator's reuse of `d32` / `packed` are then ordered against the index's own stream by the host;
-            # a real stream handle is ordered by the library itself (it makes its stream wait for the caller's)
-            if cur.cuda_stream == 0:
-                cur.synchronize()
-            self.index.search_maxsim_device(qd.data_ptr(), q_offsets, k, d32.data_ptr(), packed[1].data_ptr(), cur.cuda_stream)
-            packed[0].view(torch.float64).copy_(d32)
-            gathered = torch.empty((self.world, 2, B, k), dtype=torch.int64, device=dev)
-            if self.host_hop:
-                g_host = torch.empty((self.world * packed.numel(),), dtype=torch.int64)
-                self._dist.all_gather_into_tensor(g_host, packed.view(-1).cpu(), group=self.group)
-                gathered.view(-1).copy_(g_host)
-            else:
-                self._dist.all_gather_into_tensor(gathered.view(-1), packed.view(-1), group=self.group)
-            out_d = torch.empty((B, k), dtype=torch.float64, device=dev)
-            out_r = torch.empty((B, k), dtype=torch.int64, device=dev)
-            self.index.merge_topk_packed_device(gathered.data_ptr(), self.world, B, k, out_d.data_ptr(), out_r.data_ptr(),
-                                                cur.cuda_stream)
-            return out_d.cpu().numpy().astype(np.float32), out_r.cpu().numpy()
+            # Everything on ONE real (non-default) stream.  The library works on a stream of its own, created non-blocking: torch's
+            # default stream (handle 0, which the library reads as "no stream to wait for") is ordered against it by nothing.  With
+            # the default stream here, the merge could start before the gathered lists' H2D copy had landed and `out_d.cpu()` could
+            # read before the merge had run -- a lost race shows only when the device is contended (two ranks on one GPU: a wrong
+            # list in one run of seven, round 6).  A real handle is ordered by the library itself (its stream waits for the caller's,
+            # the merge is launched ON the caller's), and the host waits for this stream before it reads.
+            if getattr(self, "_ms_stream", None) is None:
+                self._ms_stream = torch.cuda.Stream(dev)
+            side = self._ms_stream
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                qd = torch.from_numpy(np.ascontiguousarray(qtok, dtype=np.float32)).to(dev)
+                d32 = torch.empty((B, k), dtype=torch.float32, device=dev)
+                packed = torch.empty((2, B, k), dtype=torch.int64, device=dev)
+                self.index.search_maxsim_device(qd.data_ptr(), q_offsets, k, d32.data_ptr(), packed[1].data_ptr(), side.cuda_stream)
+                packed[0].view(torch.float64).copy_(d32)
+                gathered = torch.empty((self.world, 2, B, k), dtype=torch.int64, device=dev)
+                if self.host_hop:
+                    g_host = torch.empty((self.world * packed.numel(),), dtype=torch.int64)
+                    self._dist.all_gather_into_tensor(g_host, packed.view(-1).cpu(), group=self.group)
+                    gathered.view(-1).copy_(g_host)
+                else:
+                    self._dist.all_gather_into_tensor(gathered.view(-1), packed.view(-1), group=self.group)
+                out_d = torch.empty((B, k), dtype=torch.float64, device=dev)
+                out_r = torch.empty((B, k), dtype=torch.int64, device=dev)
+                self.index.merge_topk_packed_device(gathered.data_ptr(), self.world, B, k, out_d.data_ptr(), out_r.data_ptr(),
+                                                    side.cuda_stream)
+                side.synchronize()
+                res = out_d.cpu().numpy().astype(np.float32), out_r.cpu().numpy()
+            torch.cuda.current_stream(dev).wait_stream(side)   # (the caching allocator may hand these blocks to the default stream next)
+            return res
         dist_l, rows_l = self.index.search_maxsim(qtok, q_offsets, k)
         B = dist_l.shape[0]
         # fp32 -> float8 is exact and order-preserving, so the float8 merge applies unchanged
