@@ -165,7 +165,10 @@ int mi355dr_gqr_refine_scores(mi355dr_index* idx, const double* primary_scores, 
 
 /* ---- shard merge (multi-GPU): [world, B, k] gathered (dist,row) device buffers -> [B, k] ----
  * The merge functions only enqueue work on `stream` (NULL: the index's stream); synchronise that stream (or call
- * mi355dr_synchronize for the index stream) before reading the outputs on the host. */
+ * mi355dr_synchronize for the index stream) before reading the outputs on the host.  The index's stream is NON-BLOCKING: the
+ * legacy default stream (handle 0 -- what NULL means here, and what a framework's "current stream" often is) is ordered
+ * against it by nothing.  A caller whose inputs were produced on the default stream either passes a real stream of its own
+ * (the merge then runs ON it, behind its producers and in front of its consumers) or synchronises on both sides itself. */
 int mi355dr_merge_topk_device(mi355dr_index* idx, const double* dist_all_dev, const int64_t* rows_all_dev, int world,
                               int B, int k, double* out_dist_dev, int64_t* out_rows_dev, void* stream);
 
